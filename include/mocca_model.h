@@ -1,0 +1,159 @@
+/*
+ * mocca_model.h -- the flat, versioned model blob shared by the HIP stepper
+ * (mocca_envs_amd/csrc), the CPU oracle (oracle/) and the Python model
+ * compiler (mocca_envs_amd/model.py mirrors this struct with ctypes).
+ *
+ * It replaces what the reference obtains from Bullet's importers:
+ *   loadMJCF(walker3d.xml)            /root/reference/mocca_envs/robots.py:102
+ *   getJointInfo limits [8],[9]       /root/reference/mocca_envs/bullet_utils.py:197-199
+ *   power_coef gains                  /root/reference/mocca_envs/robots.py:168,234-256
+ *   World.set_physics_parameters      /root/reference/mocca_envs/bullet_utils.py:343-350
+ *   StadiumScene ground friction      /root/reference/mocca_envs/bullet_utils.py:361-371
+ *
+ * Conventions
+ *   body 0 is the floating base; body b (1..n_joints) hangs off parent[b] by
+ *   one hinge whose value is q[b-1].  Bodies are in topological (DFS) order so
+ *   parent[b] < b, and q order equals the reference's `ordered_joints`.
+ *   A body frame has its origin at the hinge anchor; jpos/jrot give it in the
+ *   parent frame at q = 0; the hinge axis is in the body frame.
+ *   The base frame origin is the point the reference reports as
+ *   `robot_body.pose().xyz()` (bullet_utils.py:104).
+ *   All reals are fp32 so that every implementation starts from identical
+ *   constants; the f64 oracle widens them.
+ */
+#ifndef MOCCA_MODEL_H
+#define MOCCA_MODEL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOCCA_MODEL_MAGIC 0x41434F4Du /* "MOCA" */
+#define MOCCA_MODEL_VERSION 3u
+
+#define MOCCA_MAX_BODIES 24
+#define MOCCA_MAX_GEOMS 32
+#define MOCCA_MAX_PAIRS 192
+#define MOCCA_MAX_FEET 2
+#define MOCCA_MAX_SLOTS 40   /* terrain contact slots (warm-start impulses) */
+#define MOCCA_MAX_PLANKS 3
+#define MOCCA_MAX_TERRAIN_STEPS 20
+
+enum { MOCCA_GEOM_SPHERE = 0, MOCCA_GEOM_CAPSULE = 1 };
+
+/* task ids accepted by mocca_create() */
+enum {
+  MOCCA_TASK_WALKER3D_CUSTOM = 0,  /* env_locomotion.py:37-282  */
+  MOCCA_TASK_WALKER3D_STEPPER = 1, /* env_locomotion.py:330-840 */
+};
+
+typedef struct MoccaModel {
+  uint32_t magic;
+  uint32_t version;
+  int32_t n_bodies; /* 1 + n_joints */
+  int32_t n_joints;
+  int32_t n_geoms;
+  int32_t n_pairs; /* self-collision candidate pairs */
+  int32_t n_feet;
+  int32_t n_slots; /* terrain contact slots = spheres + 2*capsules */
+
+  /* ---- topology ---- */
+  int32_t parent[MOCCA_MAX_BODIES];    /* parent[0] = -1 */
+  uint32_t anc_mask[MOCCA_MAX_BODIES]; /* bit b' set iff body b' (>=1) is b or an ancestor of b */
+  int32_t depth[MOCCA_MAX_BODIES];     /* number of joints between base and b */
+
+  /* ---- joints (index = body, entry 0 unused) ---- */
+  float jpos[MOCCA_MAX_BODIES][3];
+  float jrot[MOCCA_MAX_BODIES][9]; /* row-major, parent <- body at q=0 */
+  float jaxis[MOCCA_MAX_BODIES][3];
+  float jlo[MOCCA_MAX_BODIES];
+  float jhi[MOCCA_MAX_BODIES];
+  float jdamp[MOCCA_MAX_BODIES];
+  float jarm[MOCCA_MAX_BODIES];
+  float gain[MOCCA_MAX_BODIES]; /* torque per unit action, robots.py:168 */
+
+  /* ---- inertial (index = body) ---- */
+  float mass[MOCCA_MAX_BODIES];
+  float com[MOCCA_MAX_BODIES][3];
+  float inertia[MOCCA_MAX_BODIES][6]; /* xx yy zz xy xz yz about com, body axes */
+
+  /* ---- collision geoms ---- */
+  int32_t g_body[MOCCA_MAX_GEOMS];
+  int32_t g_type[MOCCA_MAX_GEOMS];
+  int32_t g_slot[MOCCA_MAX_GEOMS];    /* first terrain slot of this geom */
+  int32_t g_terrain[MOCCA_MAX_GEOMS]; /* 1 if the filter lets it touch static terrain */
+  float g_radius[MOCCA_MAX_GEOMS];
+  float g_p1[MOCCA_MAX_GEOMS][3]; /* body frame; sphere centre / capsule end 1 */
+  float g_p2[MOCCA_MAX_GEOMS][3]; /* capsule end 2 (= p1 for spheres) */
+  float g_friction[MOCCA_MAX_GEOMS];
+
+  int32_t pair_a[MOCCA_MAX_PAIRS];
+  int32_t pair_b[MOCCA_MAX_PAIRS];
+
+  int32_t foot_body[MOCCA_MAX_FEET]; /* robots.py:232 foot_names order: right, left */
+
+  /* ---- physics parameters (bullet_utils.py:340-350, env_base.py:78-83) ---- */
+  float gravity;        /* 9.8 */
+  float dt;             /* substep, 1/240 */
+  int32_t n_substeps;   /* 4 */
+  int32_t n_iters;      /* 5 */
+  float erp;            /* 0.9  setDefaultContactERP */
+  float contact_margin; /* contacts exist below this gap */
+  float lin_damp;       /* base linear damping  */
+  float ang_damp;       /* base angular damping */
+  float max_qd;         /* joint velocity clamp */
+  float warmstart;      /* 0.85; 0 disables */
+  float ground_friction;/* 0.8  bullet_utils.py:371 */
+  float plank_friction; /* 1.0  bullet_objects.py:68 */
+  float plank_stiffness;/* 30000 */
+  float plank_damping;  /* 1000 */
+  float plank_half[3];  /* half extents of the scaled LargePlank slab */
+  float limit_slack;    /* joint-limit rows are built when predicted gap < slack */
+  float plank_com_z;    /* z of the plank base link's inertial frame in the plank frame (bullet_objects.py:62) */
+
+  /* ---- task constants ---- */
+  float init_q[MOCCA_MAX_BODIES]; /* robots.py:296-302 "running_start", index = body */
+  float init_pos[3];              /* robots.py:276 / env_locomotion.py:339 */
+  float control_dt;               /* 1/60, scene.dt (bullet_utils.py:296) */
+  float termination_height;       /* 0.7   env_locomotion.py:44 */
+  float electricity_cost;         /* 4.5   env_locomotion.py:54 */
+  float stall_torque_cost;        /* 0.225 */
+  float joints_at_limit_cost;     /* 0.1   */
+  int32_t max_episode_steps;      /* 1000  __init__.py:55 */
+  int32_t mirror_right[9];        /* robots.py:282-284 (joint indices, 0-based) */
+  int32_t mirror_left[9];         /* robots.py:285-287 */
+  int32_t mirror_neg[2];          /* robots.py:288 */
+  int32_t n_mirror_side;
+  int32_t n_mirror_neg;
+  int32_t pad_[2];
+} MoccaModel;
+
+/* ------------------------------------------------------------------------
+ * Per-env dynamic state record (floats), used by get_state/set_state:
+ *   [0:3] base position  [3:7] base quaternion (x,y,z,w)
+ *   [7:10] base linear velocity (world)  [10:13] base angular velocity (world)
+ *   [13:13+nj] q   [13+nj:13+2nj] qd   then n_slots warm-start normal impulses
+ * ------------------------------------------------------------------------ */
+#define MOCCA_STATE_BASE 13
+#define MOCCA_STATE_DIM(nj, nslots) (13 + 2 * (nj) + (nslots))
+
+/* Per-env task record (32-bit words; f = float, i = int32), get/set_task():
+ *   0 f walk_target.x   1 f walk_target.y   2 f walk_target.z
+ *   3 f linear_potential 4 f angular_potential
+ *   5 i close_count      6 f stop_frames     7 i done (sticky)
+ *   8 i t (steps this episode)  9 i episode  10 i draw counter
+ *  11 i mirrored        12 f feet_contact[0] 13 f feet_contact[1]
+ *  14 f dist            15 f angle
+ *  --- stepper only ---
+ *  16 i next_step_index 17 i target_reached_count 18 i stop_on_next_step
+ *  19 i set_stop_on_next_step 20 i curriculum 21 f applied_gain
+ *  22..23 reserved
+ */
+#define MOCCA_TASK_WORDS 24
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOCCA_MODEL_H */

@@ -1,0 +1,581 @@
+"""Model compiler: robot description -> flat ``MoccaModel`` blob (include/mocca_model.h).
+
+This is the host-side replacement for Bullet's MJCF/SDF/URDF importers that the
+reference reaches through ``loadMJCF`` (/root/reference/mocca_envs/robots.py:102),
+``loadSDF`` (bullet_utils.py:365-368) and ``getJointInfo`` (bullet_utils.py:197-199).
+
+The Walker3D description below is this project's own table of the numbers in
+``data/robots/walker3d.xml`` (line numbers cited per entry); it is data, not a
+copy of the XML.  ``tests/test_model.py`` re-parses the reference XML when it is
+present and checks every number against this table.
+
+Assumptions about how Bullet turns the MJCF into a multibody are listed in
+DESIGN.md ("Model assumptions"); all of them only affect numbers in the blob,
+never the kernels, so a blob dumped from a real PyBullet session
+(``tools/dump_pybullet_model.py``) can be loaded instead of this compiler's output.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+MAX_BODIES = 24
+MAX_GEOMS = 32
+MAX_PAIRS = 192
+MAX_FEET = 2
+MAX_SLOTS = 40
+MAGIC = 0x41434F4D
+VERSION = 3
+
+GEOM_SPHERE, GEOM_CAPSULE = 0, 1
+TASK_WALKER3D_CUSTOM, TASK_WALKER3D_STEPPER = 0, 1
+TASK_WORDS = 24
+STATE_BASE = 13
+TERRAIN_STEPS = 20
+
+
+class MoccaModel(C.Structure):
+    """ctypes mirror of ``struct MoccaModel`` (include/mocca_model.h)."""
+
+    _fields_ = [
+        ("magic", C.c_uint32),
+        ("version", C.c_uint32),
+        ("n_bodies", C.c_int32),
+        ("n_joints", C.c_int32),
+        ("n_geoms", C.c_int32),
+        ("n_pairs", C.c_int32),
+        ("n_feet", C.c_int32),
+        ("n_slots", C.c_int32),
+        ("parent", C.c_int32 * MAX_BODIES),
+        ("anc_mask", C.c_uint32 * MAX_BODIES),
+        ("depth", C.c_int32 * MAX_BODIES),
+        ("jpos", (C.c_float * 3) * MAX_BODIES),
+        ("jrot", (C.c_float * 9) * MAX_BODIES),
+        ("jaxis", (C.c_float * 3) * MAX_BODIES),
+        ("jlo", C.c_float * MAX_BODIES),
+        ("jhi", C.c_float * MAX_BODIES),
+        ("jdamp", C.c_float * MAX_BODIES),
+        ("jarm", C.c_float * MAX_BODIES),
+        ("gain", C.c_float * MAX_BODIES),
+        ("mass", C.c_float * MAX_BODIES),
+        ("com", (C.c_float * 3) * MAX_BODIES),
+        ("inertia", (C.c_float * 6) * MAX_BODIES),
+        ("g_body", C.c_int32 * MAX_GEOMS),
+        ("g_type", C.c_int32 * MAX_GEOMS),
+        ("g_slot", C.c_int32 * MAX_GEOMS),
+        ("g_terrain", C.c_int32 * MAX_GEOMS),
+        ("g_radius", C.c_float * MAX_GEOMS),
+        ("g_p1", (C.c_float * 3) * MAX_GEOMS),
+        ("g_p2", (C.c_float * 3) * MAX_GEOMS),
+        ("g_friction", C.c_float * MAX_GEOMS),
+        ("pair_a", C.c_int32 * MAX_PAIRS),
+        ("pair_b", C.c_int32 * MAX_PAIRS),
+        ("foot_body", C.c_int32 * MAX_FEET),
+        ("gravity", C.c_float),
+        ("dt", C.c_float),
+        ("n_substeps", C.c_int32),
+        ("n_iters", C.c_int32),
+        ("erp", C.c_float),
+        ("contact_margin", C.c_float),
+        ("lin_damp", C.c_float),
+        ("ang_damp", C.c_float),
+        ("max_qd", C.c_float),
+        ("warmstart", C.c_float),
+        ("ground_friction", C.c_float),
+        ("plank_friction", C.c_float),
+        ("plank_stiffness", C.c_float),
+        ("plank_damping", C.c_float),
+        ("plank_half", C.c_float * 3),
+        ("limit_slack", C.c_float),
+        ("plank_com_z", C.c_float),
+        ("init_q", C.c_float * MAX_BODIES),
+        ("init_pos", C.c_float * 3),
+        ("control_dt", C.c_float),
+        ("termination_height", C.c_float),
+        ("electricity_cost", C.c_float),
+        ("stall_torque_cost", C.c_float),
+        ("joints_at_limit_cost", C.c_float),
+        ("max_episode_steps", C.c_int32),
+        ("mirror_right", C.c_int32 * 9),
+        ("mirror_left", C.c_int32 * 9),
+        ("mirror_neg", C.c_int32 * 2),
+        ("n_mirror_side", C.c_int32),
+        ("n_mirror_neg", C.c_int32),
+        ("pad_", C.c_int32 * 2),
+    ]
+
+    def to_bytes(self) -> bytes:
+        return bytes(memoryview(self))
+
+    @classmethod
+    def from_bytes(cls, b: bytes) -> "MoccaModel":
+        if len(b) != C.sizeof(cls):
+            raise ValueError(f"model blob is {len(b)} bytes, expected {C.sizeof(cls)}")
+        m = cls.from_buffer_copy(b)
+        if m.magic != MAGIC or m.version != VERSION:
+            raise ValueError("bad model blob magic/version")
+        return m
+
+    @property
+    def state_dim(self) -> int:
+        return STATE_BASE + 2 * self.n_joints + self.n_slots
+
+
+# --------------------------------------------------------------------------
+# Robot description format (this project's own)
+# --------------------------------------------------------------------------
+DEG = math.pi / 180.0
+DENSITY = 1000.0  # MJCF default geom density; walker3d.xml sets none
+
+
+@dataclass
+class Hinge:
+    name: str
+    axis: Tuple[float, float, float]
+    lo_deg: float
+    hi_deg: float
+    gain: float  # robots.py:234-256 power_coef (base_power = 1.0)
+
+
+@dataclass
+class Geom:
+    name: str
+    kind: int  # GEOM_SPHERE / GEOM_CAPSULE
+    radius: float
+    p1: Tuple[float, float, float]
+    p2: Optional[Tuple[float, float, float]] = None
+    group: int = 3  # MJCF contype   (walker3d.xml:5 default 3)
+    mask: int = 3   # MJCF conaffinity
+    friction: float = 1.2  # walker3d.xml:5 friction="1.2 0.1 0.1" (lateral)
+
+
+@dataclass
+class Body:
+    name: str
+    pos: Tuple[float, float, float]  # in parent body frame
+    anchor: Tuple[float, float, float] = (0.0, 0.0, 0.0)  # hinge anchor(s) in this body frame
+    quat_wxyz: Tuple[float, float, float, float] = (1.0, 0.0, 0.0, 0.0)
+    hinges: List[Hinge] = field(default_factory=list)
+    geoms: List[Geom] = field(default_factory=list)
+    children: List["Body"] = field(default_factory=list)
+
+
+def _leg(side: str, y: float, sx: float) -> Body:
+    """walker3d.xml:32-46 (right) / :48-62 (left).  `sx` flips hip_x / hip_z axes (:49-50)."""
+    foot = Body(
+        f"{side}_foot", (0, 0, -0.49), anchor=(0, 0, 0.07),
+        hinges=[Hinge(f"{side}_ankle", (0, 1, 0), -20, 40, 60)],
+        geoms=[
+            Geom(f"{side}_foot_1", GEOM_CAPSULE, 0.045, (-0.04, 0.02, 0.07), (0.18, 0.03, 0.07)),
+            Geom(f"{side}_foot_2", GEOM_CAPSULE, 0.045, (-0.04, -0.02, 0.07), (0.18, -0.03, 0.07)),
+        ],
+    )
+    shin = Body(
+        f"{side}_shin", (0, 0, -0.363), anchor=(0, 0, 0.02),
+        hinges=[Hinge(f"{side}_knee", (0, -1, 0), -150, 0, 90)],
+        geoms=[Geom(f"{side}_shin1", GEOM_CAPSULE, 0.055, (0, 0, 0), (0, 0, -0.34))],
+        children=[foot],
+    )
+    return Body(
+        f"{side}_thigh", (0, y, -0.04), anchor=(0, 0, 0.06),
+        hinges=[
+            Hinge(f"{side}_hip_x", (sx, 0, 0), -25, 5, 80),
+            Hinge(f"{side}_hip_z", (0, 0, sx), -40, 35, 60),
+            Hinge(f"{side}_hip_y", (0, 1, 0), -100, 20, 100),
+        ],
+        geoms=[
+            Geom(f"{side}_hip", GEOM_SPHERE, 0.08, (0, 0, 0.06)),
+            Geom(f"{side}_thigh1", GEOM_CAPSULE, 0.065, (0, 0, 0), (0, 0, -0.30)),
+        ],
+        children=[shin],
+    )
+
+
+def _arm(side: str, sy: float, sx: float) -> Body:
+    """walker3d.xml:66-78 (right) / :79-91 (left); `sx` flips shoulder_x/z and elbow axes."""
+    hand = Body(f"{side}_hand", (0, sy * 0.30, 0),
+                geoms=[Geom(f"{side}_hand", GEOM_SPHERE, 0.04, (0, 0, 0))])
+    lower = Body(
+        f"{side}_lower_arm", (0, sy * 0.28, 0),
+        hinges=[Hinge(f"{side}_elbow", (0, 0, sx), 0, 120, 60)],
+        geoms=[Geom(f"{side}_larm", GEOM_CAPSULE, 0.035, (0, 0, 0), (0, sy * 0.25, 0))],
+        children=[hand],
+    )
+    return Body(
+        f"{side}_upper_arm", (0, sy * 0.23, 0.08),
+        hinges=[
+            Hinge(f"{side}_shoulder_x", (sx, 0, 0), -60, 100, 60),
+            Hinge(f"{side}_shoulder_z", (0, 0, sx), -35, 120, 60),
+            Hinge(f"{side}_shoulder_y", (0, 1, 0), -60, 60, 50),
+        ],
+        geoms=[Geom(f"{side}_uarm1", GEOM_CAPSULE, 0.035, (0, 0, 0), (0, sy * 0.25, 0))],
+        children=[lower],
+    )
+
+
+def walker3d_description() -> Body:
+    """The Walker3D tree (walker3d.xml:16-92), joint order == robots.py:282-288 indices."""
+    pelvis = Body(
+        "pelvis", (0, 0, -0.16), anchor=(0, 0, 0.1), quat_wxyz=(1.0, 0.0, -0.002, 0.0),  # :29
+        hinges=[Hinge("abdomen_x", (1, 0, 0), -25, 25, 60)],  # :30
+        geoms=[Geom("butt", GEOM_SPHERE, 0.11, (0, 0, 0.1), group=1, mask=1)],  # :31
+        children=[_leg("right", -0.11, 1.0), _leg("left", 0.11, -1.0)],
+    )
+    waist = Body(
+        "waist", (0, 0, -0.240), anchor=(0, 0, 0.065),  # :25-27
+        hinges=[Hinge("abdomen_z", (0, 0, 1), -35, 35, 60), Hinge("abdomen_y", (0, 1, 0), -80, 15, 80)],
+        geoms=[Geom("waist", GEOM_SPHERE, 0.09, (0, 0, 0.07), group=2, mask=2)],  # :28
+        children=[pelvis],
+    )
+    head = Body("head", (0, 0, 0.25), geoms=[Geom("head", GEOM_SPHERE, 0.1, (0, 0, 0))])  # :17-19
+    torso = Body("torso", (0, 0, 0), geoms=[Geom("torso1", GEOM_SPHERE, 0.14, (0, 0, 0), group=1, mask=1)])  # :20-22
+    root = Body(
+        "walker3d", (0, 0, 1.32),  # :16
+        geoms=[
+            Geom("right_shoulder", GEOM_SPHERE, 0.05, (0, -0.15, 0.08)),  # :23
+            Geom("left_shoulder", GEOM_SPHERE, 0.05, (0, 0.15, 0.08)),  # :24
+        ],
+        children=[head, torso, waist, _arm("right", -1.0, 1.0), _arm("left", 1.0, -1.0)],
+    )
+    return root
+
+
+# --------------------------------------------------------------------------
+# geometry helpers
+# --------------------------------------------------------------------------
+def quat_wxyz_to_mat(q: Sequence[float]) -> np.ndarray:
+    w, x, y, z = np.asarray(q, dtype=np.float64) / np.linalg.norm(q)
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+def _geom_inertial(g: Geom) -> Tuple[float, np.ndarray, np.ndarray]:
+    """mass, com, inertia tensor about com (frame of p1/p2) for a solid sphere / capsule."""
+    r = g.radius
+    if g.kind == GEOM_SPHERE:
+        m = DENSITY * 4.0 / 3.0 * math.pi * r ** 3
+        return m, np.asarray(g.p1, float), np.eye(3) * (0.4 * m * r * r)
+    p1, p2 = np.asarray(g.p1, float), np.asarray(g.p2, float)
+    L = float(np.linalg.norm(p2 - p1))
+    u = (p2 - p1) / L
+    m_cyl = DENSITY * math.pi * r * r * L
+    m_hs = DENSITY * 2.0 / 3.0 * math.pi * r ** 3
+    m = m_cyl + 2 * m_hs
+    i_ax = 0.5 * m_cyl * r * r + 2 * (0.4 * m_hs * r * r)
+    i_tr = m_cyl * (L * L / 12.0 + r * r / 4.0) + 2 * (
+        (83.0 / 320.0) * m_hs * r * r + m_hs * (L / 2.0 + 3.0 * r / 8.0) ** 2)
+    uu = np.outer(u, u)
+    return m, 0.5 * (p1 + p2), i_ax * uu + i_tr * (np.eye(3) - uu)
+
+
+def _compose_inertial(parts: List[Tuple[float, np.ndarray, np.ndarray]]):
+    m = sum(p[0] for p in parts)
+    if m == 0.0:
+        return 0.0, np.zeros(3), np.zeros((3, 3))
+    c = sum(p[0] * p[1] for p in parts) / m
+    I = np.zeros((3, 3))
+    for mi, ci, Ii in parts:
+        d = ci - c
+        I += Ii + mi * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+    return m, c, I
+
+
+@dataclass
+class _FlatBody:
+    name: str
+    parent: int
+    jpos: np.ndarray
+    jrot: np.ndarray
+    hinge: Optional[Hinge]
+    geoms: List[Tuple[Geom, np.ndarray, np.ndarray, int]]  # geom, p1, p2 (flat body frame), bullet link id
+    bullet_link: int
+
+
+def _flatten(root: Body, base_ref: str):
+    """Expand multi-hinge bodies into chains, merge hinge-less children into their parent.
+
+    Returns flat bodies plus, for the self-collision filter, the Bullet-style
+    link tree in which hinge-less children stay separate links attached by fixed
+    joints ("jointfix", robots.py:167).
+    """
+    flat: List[_FlatBody] = []
+    bl_parent: List[int] = []  # Bullet-style link parents (index = bullet link id)
+
+    # base reference point: origin of the base frame inside the root body frame
+    own = [_geom_inertial(g) for g in root.geoms]
+    if base_ref == "own_com":
+        base_origin = _compose_inertial(own)[1]
+    elif base_ref == "body_frame":
+        base_origin = np.zeros(3)
+    else:
+        raise ValueError(base_ref)
+
+    def add_geoms(fb: _FlatBody, body: Body, R: np.ndarray, t: np.ndarray, bl: int):
+        for g in body.geoms:
+            p1 = R @ np.asarray(g.p1, float) + t
+            p2 = R @ np.asarray(g.p2 if g.p2 is not None else g.p1, float) + t
+            fb.geoms.append((g, p1, p2, bl))
+
+    def merge_fixed(fi: int, body: Body, R: np.ndarray, t: np.ndarray, bl_par: int):
+        """hinge-less child `body` rigidly attached to flat body `fi`: x_fi = R x + t."""
+        bl_parent.append(bl_par)
+        bl = len(bl_parent) - 1
+        add_geoms(flat[fi], body, R, t, bl)
+        for ch in body.children:
+            Rc = R @ quat_wxyz_to_mat(ch.quat_wxyz)
+            tc = R @ np.asarray(ch.pos, float) + t
+            if ch.hinges:
+                add_hinged(ch, fi, Rc, tc, bl)
+            else:
+                merge_fixed(fi, ch, Rc, tc, bl)
+
+    def add_hinged(body: Body, parent_flat: int, R: np.ndarray, t: np.ndarray, bl_par: int):
+        """`body` frame expressed in the parent flat-body frame: x_par = R x + t (at q = 0)."""
+        anchor = np.asarray(body.anchor, float)
+        last = parent_flat
+        bl = bl_par
+        for k, h in enumerate(body.hinges):
+            if k == 0:
+                jpos, jrot = R @ anchor + t, R
+            else:
+                jpos, jrot = np.zeros(3), np.eye(3)
+            bl_parent.append(bl)
+            bl = len(bl_parent) - 1
+            fb = _FlatBody(h.name, last, jpos, jrot, h, [], bl)
+            flat.append(fb)
+            last = len(flat) - 1
+        fb = flat[last]
+        # the last link of the chain carries the MJCF body: body coords -> link coords = x - anchor
+        add_geoms(fb, body, np.eye(3), -anchor, bl)
+        for ch in body.children:
+            Rc = quat_wxyz_to_mat(ch.quat_wxyz)
+            tc = np.asarray(ch.pos, float) - anchor
+            if ch.hinges:
+                add_hinged(ch, last, Rc, tc, bl)
+            else:
+                merge_fixed(last, ch, Rc, tc, bl)
+
+    bl_parent.append(-1)
+    base = _FlatBody(root.name, -1, np.zeros(3), np.eye(3), None, [], 0)
+    flat.append(base)
+    add_geoms(base, root, np.eye(3), -base_origin, 0)
+    for ch in root.children:
+        Rc = quat_wxyz_to_mat(ch.quat_wxyz)
+        tc = np.asarray(ch.pos, float) - base_origin
+        if ch.hinges:
+            add_hinged(ch, 0, Rc, tc, 0)
+        else:
+            merge_fixed(0, ch, Rc, tc, 0)
+    return flat, bl_parent, base_origin
+
+
+def _bullet_ancestors(bl_parent: List[int], a: int) -> set:
+    out = set()
+    while a >= 0:
+        out.add(a)
+        a = bl_parent[a]
+    return out
+
+
+TERRAIN_GROUP = 2           # btBroadphaseProxy::StaticFilter      [UNVERIFIED-BULLET]
+TERRAIN_MASK = ~2 & 0xFFFF  # AllFilter ^ StaticFilter             [UNVERIFIED-BULLET]
+
+
+def compile_model(
+    root: Body,
+    foot_names: Sequence[str],
+    init_q_by_name: Dict[str, float],
+    init_pos: Sequence[float],
+    mirror_right: Sequence[int],
+    mirror_left: Sequence[int],
+    mirror_neg: Sequence[int],
+    *,
+    base_ref: str = "body_frame",
+    joint_damping: float = 0.0,
+    joint_armature: float = 0.0,
+    self_collision: bool = True,
+) -> MoccaModel:
+    flat, bl_parent, _ = _flatten(root, base_ref)
+    nb = len(flat)
+    assert nb <= MAX_BODIES
+    m = MoccaModel()
+    m.magic, m.version = MAGIC, VERSION
+    m.n_bodies, m.n_joints = nb, nb - 1
+
+    geoms = []
+    for b, fb in enumerate(flat):
+        m.parent[b] = fb.parent
+        if b == 0:
+            m.anc_mask[0], m.depth[0] = 0, 0
+        else:
+            m.anc_mask[b] = m.anc_mask[fb.parent] | (1 << b)
+            m.depth[b] = m.depth[fb.parent] + 1
+            for k in range(3):
+                m.jpos[b][k] = fb.jpos[k]
+                m.jaxis[b][k] = fb.hinge.axis[k]
+            for k in range(9):
+                m.jrot[b][k] = fb.jrot.reshape(-1)[k]
+            m.jlo[b] = fb.hinge.lo_deg * DEG
+            m.jhi[b] = fb.hinge.hi_deg * DEG
+            m.jdamp[b] = joint_damping
+            m.jarm[b] = joint_armature
+            m.gain[b] = fb.hinge.gain
+            m.init_q[b] = init_q_by_name.get(fb.hinge.name, 0.0)
+        parts = []
+        for g, p1, p2, bl in fb.geoms:
+            gg = Geom(g.name, g.kind, g.radius, tuple(p1), tuple(p2), g.group, g.mask, g.friction)
+            parts.append(_geom_inertial(gg))
+            geoms.append((b, gg, bl))
+        mass, com, I = _compose_inertial(parts)
+        m.mass[b] = mass
+        for k in range(3):
+            m.com[b][k] = com[k]
+        for k, (i, j) in enumerate([(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)]):
+            m.inertia[b][k] = I[i, j]
+
+    assert len(geoms) <= MAX_GEOMS
+    m.n_geoms = len(geoms)
+    slot = 0
+    for gi, (b, g, bl) in enumerate(geoms):
+        m.g_body[gi], m.g_type[gi], m.g_radius[gi] = b, g.kind, g.radius
+        m.g_friction[gi] = g.friction
+        for k in range(3):
+            m.g_p1[gi][k] = g.p1[k]
+            m.g_p2[gi][k] = g.p2[k]
+        m.g_slot[gi] = slot
+        slot += 1 if g.kind == GEOM_SPHERE else 2
+        m.g_terrain[gi] = int(bool(g.group & TERRAIN_MASK) and bool(TERRAIN_GROUP & g.mask))
+    assert slot <= MAX_SLOTS
+    m.n_slots = slot
+
+    # self-collision candidate pairs: URDF_USE_SELF_COLLISION |
+    # URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS (robots.py:259-264) + group/mask filter
+    pairs = []
+    if self_collision:
+        for i in range(len(geoms)):
+            for j in range(i + 1, len(geoms)):
+                bi, gi_, li = geoms[i]
+                bj, gj_, lj = geoms[j]
+                if li == lj:
+                    continue
+                if li in _bullet_ancestors(bl_parent, lj) or lj in _bullet_ancestors(bl_parent, li):
+                    continue
+                if not ((gi_.group & gj_.mask) and (gj_.group & gi_.mask)):
+                    continue
+                if bi == bj:
+                    continue  # rigidly attached in our tree (e.g. head vs torso): cannot move relative
+                pairs.append((i, j))
+    assert len(pairs) <= MAX_PAIRS, len(pairs)
+    m.n_pairs = len(pairs)
+    for k, (i, j) in enumerate(pairs):
+        m.pair_a[k], m.pair_b[k] = i, j
+
+    names = [fb.name for fb in flat]
+    last_link_of_body = {}
+    # foot_names are MJCF body names; the link carrying the body is its last hinge
+    def find_body(b: Body, nm: str) -> Optional[Body]:
+        if b.name == nm:
+            return b
+        for ch in b.children:
+            r = find_body(ch, nm)
+            if r is not None:
+                return r
+        return None
+
+    m.n_feet = len(foot_names)
+    for k, fn in enumerate(foot_names):
+        fbdy = find_body(root, fn)
+        m.foot_body[k] = names.index(fbdy.hinges[-1].name)
+
+    # physics parameters
+    m.gravity = 9.8                 # env_base.py:80
+    m.dt = 1.0 / 240.0              # env_base.py:81 with env_locomotion.py:39-41
+    m.n_substeps = 4                # env_locomotion.py:41
+    m.n_iters = 5                   # bullet_utils.py:340
+    m.erp = 0.9                     # bullet_utils.py:345
+    m.contact_margin = 0.02         # [UNVERIFIED-BULLET] contact breaking threshold
+    m.lin_damp = 0.04               # [UNVERIFIED-BULLET] btMultiBody default
+    m.ang_damp = 0.04
+    m.max_qd = 100.0                # [UNVERIFIED-BULLET] maxCoordinateVelocity
+    m.warmstart = 0.85              # [UNVERIFIED-BULLET] m_warmstartingFactor
+    m.ground_friction = 0.8         # bullet_utils.py:371
+    m.plank_friction = 1.0          # bullet_objects.py:68
+    m.plank_stiffness = 30000.0     # bullet_objects.py:70
+    m.plank_damping = 1000.0        # bullet_objects.py:71
+    # plank_large.urdf boxes 1 x 20 x (0.45 + 0.05) scaled by 2*step_radius = 0.5
+    m.plank_half[0], m.plank_half[1], m.plank_half[2] = 0.25, 5.0, 0.125
+    m.limit_slack = 0.05
+    m.plank_com_z = -0.275 * 0.5    # plank_large.urdf:8 scaled by 2*step_radius (bullet_objects.py:62,98-103)
+
+    for k in range(3):
+        m.init_pos[k] = init_pos[k]
+    m.control_dt = 1.0 / 60.0       # env_locomotion.py:39
+    m.termination_height = 0.7      # env_locomotion.py:44
+    m.electricity_cost = 4.5        # env_locomotion.py:54
+    m.stall_torque_cost = 0.225     # env_locomotion.py:55
+    m.joints_at_limit_cost = 0.1    # env_locomotion.py:56
+    m.max_episode_steps = 1000      # __init__.py:55
+    m.n_mirror_side, m.n_mirror_neg = len(mirror_right), len(mirror_neg)
+    for k, v in enumerate(mirror_right):
+        m.mirror_right[k] = v
+    for k, v in enumerate(mirror_left):
+        m.mirror_left[k] = v
+    for k, v in enumerate(mirror_neg):
+        m.mirror_neg[k] = v
+    return m
+
+
+WALKER3D_JOINT_NAMES = [
+    "abdomen_z", "abdomen_y", "abdomen_x",
+    "right_hip_x", "right_hip_z", "right_hip_y", "right_knee", "right_ankle",
+    "left_hip_x", "left_hip_z", "left_hip_y", "left_knee", "left_ankle",
+    "right_shoulder_x", "right_shoulder_z", "right_shoulder_y", "right_elbow",
+    "left_shoulder_x", "left_shoulder_z", "left_shoulder_y", "left_elbow",
+]
+
+
+def walker3d_running_start() -> Dict[str, float]:
+    """robots.py:296-302."""
+    q = np.zeros(21)
+    q[[5, 6]] = -np.pi / 8
+    q[10] = np.pi / 10
+    q[[13, 17]] = np.pi / 3
+    q[14] = -np.pi / 6
+    q[18] = np.pi / 6
+    q[[16, 20]] = np.pi / 3
+    return {n: float(v) for n, v in zip(WALKER3D_JOINT_NAMES, q)}
+
+
+def compile_walker3d(task: int = TASK_WALKER3D_CUSTOM, **kw) -> MoccaModel:
+    """Walker3D blob.  `task` only changes the initial base position (env_locomotion.py:339)."""
+    init_pos = (0.0, 0.0, 1.32) if task == TASK_WALKER3D_CUSTOM else (0.3, 0.0, 1.32)
+    # walker3d.xml:4 <joint armature="0.01" damping=".1">.  The armature is what keeps the
+    # three-hinge shoulder (massless intermediate links, z range up to 120 deg, walker3d.xml:67-69)
+    # away from the gimbal singularity where ABA's D_i -> 0; see DESIGN.md "Model assumptions".
+    kw.setdefault("joint_damping", 0.1)
+    kw.setdefault("joint_armature", 0.01)
+    m = compile_model(
+        walker3d_description(),
+        foot_names=["right_foot", "left_foot"],             # robots.py:232
+        init_q_by_name=walker3d_running_start(),
+        init_pos=init_pos,                                  # robots.py:276
+        mirror_right=[3, 4, 5, 6, 7, 13, 14, 15, 16],       # robots.py:282-284
+        mirror_left=[8, 9, 10, 11, 12, 17, 18, 19, 20],     # robots.py:285-287
+        mirror_neg=[0, 2],                                  # robots.py:288
+        **kw,
+    )
+    return m
+
+
+def joint_limits(m: MoccaModel) -> Tuple[np.ndarray, np.ndarray]:
+    nj = m.n_joints
+    lo = np.array([m.jlo[b] for b in range(1, nj + 1)], dtype=np.float32)
+    hi = np.array([m.jhi[b] for b in range(1, nj + 1)], dtype=np.float32)
+    return lo, hi

@@ -1,0 +1,1262 @@
+/*
+ * mocca_oracle.c -- CPU restatement of the vectorised locomotion stepper.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under mocca_envs_amd/ may import, link or
+ * call this file; it is the checker for the HIP path (tests/, bench.py's
+ * cpu_baseline leg, __graft_entry__.smoke()).
+ *
+ * PARITY STATUS
+ *   task / observation / reward arithmetic : pinned against golden vectors
+ *       captured by importing the reference (tests/golden/, tools/make_golden.py).
+ *   rigid-body physics                     : *** parity unpinned ***.  The
+ *       reference's physics lives in the third-party `pybullet` wheel
+ *       (un-pinned in /root/reference/setup.py:11), which is neither vendored
+ *       nor installable here and for which the reference holds no golden
+ *       vectors.  This file restates the published algorithms Bullet's
+ *       btMultiBodyDynamicsWorld is built from -- Featherstone's articulated
+ *       body algorithm, projected Gauss-Seidel over contact / friction /
+ *       joint-limit rows with Baumgarte (ERP) stabilisation, symplectic Euler --
+ *       at the call sites the reference drives them from:
+ *         setJointMotorControlArray(TORQUE_CONTROL) robots.py:35-40
+ *         stepSimulation()                          bullet_utils.py:352-353
+ *         physics parameters                        bullet_utils.py:340-350, env_base.py:78-83
+ *       and checks them with physical invariants (tests/test_oracle_physics.py).
+ *
+ * Build: compiled twice by oracle/Makefile, -DREAL=float (what the GPU must
+ * match) and -DREAL=double (the reference arithmetic width).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mocca_model.h"
+
+#ifndef REAL
+#define REAL double
+#endif
+typedef REAL real;
+
+#define MB MOCCA_MAX_BODIES
+#define NDOF_MAX (6 + MB)
+#define MAX_CONTACTS 14
+#define MAX_ROWS 64
+
+#if defined(__GNUC__)
+#define API __attribute__((visibility("default")))
+#else
+#define API
+#endif
+
+/* ------------------------------------------------------------------ */
+/* small linear algebra                                                */
+/* ------------------------------------------------------------------ */
+static inline real dot3(const real *a, const real *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void cross3(const real *a, const real *b, real *o) {
+  real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static inline real dot6(const real *a, const real *b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+static inline void matvec3(const real *R, const real *x, real *o) {
+  real a = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
+  real b = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
+  real c = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
+  o[0] = a; o[1] = b; o[2] = c;
+}
+static inline void matmul3(const real *A, const real *B, real *C) {
+  real T[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) T[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+  memcpy(C, T, sizeof(T));
+}
+static void quat_to_mat(const real *q, real *R) { /* q = (x,y,z,w) */
+  real x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+/* rotation about unit axis a by angle th (Rodrigues) */
+static void axis_angle_mat(const real *a, real th, real *R) {
+  real c = cos(th), s = sin(th), t = 1 - c;
+  R[0] = c + t * a[0] * a[0];        R[1] = t * a[0] * a[1] - s * a[2]; R[2] = t * a[0] * a[2] + s * a[1];
+  R[3] = t * a[0] * a[1] + s * a[2]; R[4] = c + t * a[1] * a[1];        R[5] = t * a[1] * a[2] - s * a[0];
+  R[6] = t * a[0] * a[2] - s * a[1]; R[7] = t * a[1] * a[2] + s * a[0]; R[8] = c + t * a[2] * a[2];
+}
+/* spatial motion cross  v x m  (ang;lin) */
+static inline void crm(const real *v, const real *m, real *o) {
+  real a[3], b[3], c[3];
+  cross3(v, m, a);
+  cross3(v, m + 3, b);
+  cross3(v + 3, m, c);
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2];
+  o[3] = b[0] + c[0]; o[4] = b[1] + c[1]; o[5] = b[2] + c[2];
+}
+/* spatial force cross  v x* f */
+static inline void crf(const real *v, const real *f, real *o) {
+  real a[3], b[3], c[3];
+  cross3(v, f, a);
+  cross3(v + 3, f + 3, b);
+  cross3(v, f + 3, c);
+  o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2];
+  o[3] = c[0]; o[4] = c[1]; o[5] = c[2];
+}
+/* Cholesky inverse of a symmetric positive definite 6x6 (row-major full storage) */
+static void spd6_inverse(const real *A, real *Ainv) {
+  real L[36];
+  memset(L, 0, sizeof(L));
+  for (int j = 0; j < 6; ++j) {
+    real s = A[6 * j + j];
+    for (int k = 0; k < j; ++k) s -= L[6 * j + k] * L[6 * j + k];
+    real d = sqrt(s);
+    L[6 * j + j] = d;
+    real id = 1 / d;
+    for (int i = j + 1; i < 6; ++i) {
+      real t = A[6 * i + j];
+      for (int k = 0; k < j; ++k) t -= L[6 * i + k] * L[6 * j + k];
+      L[6 * i + j] = t * id;
+    }
+  }
+  /* invert L (lower) */
+  real Li[36];
+  memset(Li, 0, sizeof(Li));
+  for (int j = 0; j < 6; ++j) {
+    Li[6 * j + j] = 1 / L[6 * j + j];
+    for (int i = j + 1; i < 6; ++i) {
+      real t = 0;
+      for (int k = j; k < i; ++k) t -= L[6 * i + k] * Li[6 * k + j];
+      Li[6 * i + j] = t / L[6 * i + i];
+    }
+  }
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      real t = 0;
+      for (int k = (i > j ? i : j); k < 6; ++k) t += Li[6 * k + i] * Li[6 * k + j];
+      Ainv[6 * i + j] = t;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Philox4x32-10, keyed (seed), counter (block, episode, env, stream)  */
+/* ------------------------------------------------------------------ */
+static void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *out) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+/* d-th uniform in [0,1) of (seed, env, episode): 24-bit mantissa so f32 and f64 agree exactly */
+static real rng_uniform(uint64_t seed, uint32_t env, uint32_t episode, uint32_t d) {
+  uint32_t o[4];
+  philox4x32(d >> 2, episode, env, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  return (real)((o[d & 3] >> 8) * (1.0f / 16777216.0f));
+}
+
+/* ------------------------------------------------------------------ */
+/* environment storage                                                 */
+/* ------------------------------------------------------------------ */
+typedef struct {
+  real pos[3], quat[4], vel[3], omg[3];
+  real q[MB], qd[MB]; /* index = body, [0] unused */
+  real warm[MOCCA_MAX_SLOTS];
+} Dyn;
+
+typedef struct {
+  real walk_target[3];
+  real linear_potential, angular_potential;
+  int32_t close_count;
+  real stop_frames;
+  int32_t done, t, episode, draw, mirrored;
+  real feet_contact[2];
+  real dist, angle;
+  int32_t next_step_index, target_reached_count, stop_on_next_step, set_stop_on_next_step, curriculum;
+  real applied_gain;
+  real prev_body_x;
+} Task;
+
+typedef struct {
+  real terrain[MOCCA_MAX_TERRAIN_STEPS][6];        /* x y z phi x_tilt y_tilt, env_locomotion.py:441 */
+  int32_t plank_info[MOCCA_MAX_PLANKS];            /* terrain row currently shown by plank k */
+} Terrain;
+
+/* per-substep workspace (kept so tests can inspect it) */
+typedef struct {
+  real R[MB][9], r[MB][3], a[MB][3]; /* body orientation, origin rel. base origin, hinge axis (world) */
+  real S[MB][6], v[MB][6], c[MB][6], I[MB][36], pA[MB][6], IA[MB][36];
+  real U[MB][6], d[MB], u[MB], acc[MB][6], qdd[MB];
+  real IA0inv[36];
+  real comw[MB][3]; /* link COM rel. base origin */
+  /* contacts */
+  int nc;
+  int c_a[MAX_CONTACTS], c_b[MAX_CONTACTS], c_slot[MAX_CONTACTS];
+  real c_P[MAX_CONTACTS][3], c_n[MAX_CONTACTS][3], c_depth[MAX_CONTACTS], c_mu[MAX_CONTACTS];
+  real c_erp[MAX_CONTACTS], c_cfm[MAX_CONTACTS];
+  int foot_touch[MOCCA_MAX_FEET];        /* any terrain contact of foot k this substep */
+  int foot_target[MOCCA_MAX_FEET];       /* foot k touches the cover of the target plank */
+  /* rows */
+  int nr;
+  real J[MAX_ROWS][NDOF_MAX], Mi[MAX_ROWS][NDOF_MAX], A[MAX_ROWS][MAX_ROWS];
+  real lam[MAX_ROWS], bias[MAX_ROWS], cfm[MAX_ROWS], w[MAX_ROWS];
+  int row_kind[MAX_ROWS]; /* 0 limit, 1 normal, 2 friction */
+  int row_normal[MAX_ROWS]; /* friction: index of its normal row */
+  real row_mu[MAX_ROWS];
+  int row_slot[MAX_ROWS];
+} Work;
+
+typedef struct {
+  MoccaModel m;
+  int task_id, n_envs;
+  uint64_t seed;
+  int auto_reset, eval_mode, random_pose;
+  Dyn *dyn;
+  Task *task;
+  Terrain *ter;
+  Work wk;
+  real feet_xyz[MOCCA_MAX_FEET][3];
+  real body_rpy[3], body_vel[3];
+  /* optional uniform tape: when set, every random draw pops from it instead of Philox, so the golden
+   * tests can feed the oracle the very numbers a scripted numpy RandomState gave the reference */
+  const double *tape;
+  int tape_n, tape_pos;
+} Oracle;
+
+static real draw_uniform(Oracle *o, int env, Task *tk) {
+  if (o->tape) {
+    real u = o->tape_pos < o->tape_n ? (real)o->tape[o->tape_pos] : (real)0.5;
+    o->tape_pos++;
+    tk->draw++;
+    return u;
+  }
+  return rng_uniform(o->seed, (uint32_t)env, (uint32_t)tk->episode, (uint32_t)tk->draw++);
+}
+
+#define NJ(o) ((o)->m.n_joints)
+
+/* ------------------------------------------------------------------ */
+/* kinematics + ABA                                                    */
+/* ------------------------------------------------------------------ */
+static void kinematics(const MoccaModel *m, const Dyn *s, Work *w) {
+  quat_to_mat(s->quat, w->R[0]);
+  w->r[0][0] = w->r[0][1] = w->r[0][2] = 0;
+  for (int b = 1; b < m->n_bodies; ++b) {
+    int p = m->parent[b];
+    real jr[9], ax[3], jp[3], Rq[9], T[9];
+    for (int k = 0; k < 9; ++k) jr[k] = m->jrot[b][k];
+    for (int k = 0; k < 3; ++k) { ax[k] = m->jaxis[b][k]; jp[k] = m->jpos[b][k]; }
+    axis_angle_mat(ax, s->q[b], Rq);
+    matmul3(w->R[p], jr, T);
+    matvec3(T, ax, w->a[b]);
+    matmul3(T, Rq, w->R[b]);
+    real off[3];
+    matvec3(w->R[p], jp, off);
+    for (int k = 0; k < 3; ++k) w->r[b][k] = w->r[p][k] + off[k];
+  }
+  for (int b = 0; b < m->n_bodies; ++b) {
+    real cl[3] = {m->com[b][0], m->com[b][1], m->com[b][2]}, cw[3];
+    matvec3(w->R[b], cl, cw);
+    for (int k = 0; k < 3; ++k) w->comw[b][k] = w->r[b][k] + cw[k];
+  }
+}
+
+/* spatial inertia about the base origin, world axes */
+static void body_inertia(const MoccaModel *m, const Work *w, int b, real *I) {
+  real Il[9] = {m->inertia[b][0], m->inertia[b][3], m->inertia[b][4],
+                m->inertia[b][3], m->inertia[b][1], m->inertia[b][5],
+                m->inertia[b][4], m->inertia[b][5], m->inertia[b][2]};
+  real T[9], Rt[9], Iw[9];
+  const real *R = w->R[b];
+  matmul3(R, Il, T);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Rt[3 * i + j] = R[3 * j + i];
+  matmul3(T, Rt, Iw);
+  real ms = m->mass[b];
+  const real *c = w->comw[b];
+  real cc = dot3(c, c);
+  memset(I, 0, 36 * sizeof(real));
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) I[6 * i + j] = Iw[3 * i + j] + ms * ((i == j ? cc : 0) - c[i] * c[j]);
+  /* m c^x upper-right, its transpose lower-left */
+  real cx[9] = {0, -c[2], c[1], c[2], 0, -c[0], -c[1], c[0], 0};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      I[6 * i + 3 + j] = ms * cx[3 * i + j];
+      I[6 * (3 + i) + j] = ms * cx[3 * j + i];
+    }
+  for (int i = 0; i < 3; ++i) I[6 * (3 + i) + 3 + i] = ms;
+}
+
+static void matvec6(const real *M, const real *x, real *o) {
+  real t[6];
+  for (int i = 0; i < 6; ++i) t[i] = dot6(M + 6 * i, x);
+  memcpy(o, t, sizeof(t));
+}
+
+/* Featherstone ABA about the (instantaneous) base origin in world axes.
+ * tau[b] : generalised force on hinge b.  Outputs w->qdd, w->acc[0] (spatial). */
+static void aba(const MoccaModel *m, const Dyn *s, const real *tau, Work *w, int with_bias) {
+  int nb = m->n_bodies;
+  /* pass 1 */
+  for (int k = 0; k < 3; ++k) { w->v[0][k] = s->omg[k]; w->v[0][3 + k] = s->vel[k]; }
+  for (int b = 1; b < nb; ++b) {
+    int p = m->parent[b];
+    real ra[3];
+    cross3(w->r[b], w->a[b], ra);
+    for (int k = 0; k < 3; ++k) { w->S[b][k] = w->a[b][k]; w->S[b][3 + k] = ra[k]; }
+    real vJ[6];
+    for (int k = 0; k < 6; ++k) vJ[k] = w->S[b][k] * s->qd[b];
+    crm(w->v[p], vJ, w->c[b]);
+    for (int k = 0; k < 6; ++k) w->v[b][k] = w->v[p][k] + vJ[k];
+  }
+  for (int b = 0; b < nb; ++b) {
+    body_inertia(m, w, b, w->I[b]);
+    memcpy(w->IA[b], w->I[b], 36 * sizeof(real));
+    real Iv[6];
+    matvec6(w->I[b], w->v[b], Iv);
+    if (with_bias) crf(w->v[b], Iv, w->pA[b]);
+    else memset(w->pA[b], 0, 6 * sizeof(real));
+    if (!with_bias) { memset(w->c[b], 0, 6 * sizeof(real)); }
+    /* gravity as an external force through the COM */
+    if (with_bias) {
+      real f[3] = {0, 0, -(real)m->gravity * (real)m->mass[b]}, n[3];
+      cross3(w->comw[b], f, n);
+      for (int k = 0; k < 3; ++k) { w->pA[b][k] -= n[k]; w->pA[b][3 + k] -= f[k]; }
+    }
+  }
+  if (with_bias) {
+    /* base damping: force -k m v through the base origin, torque -k Ic w  [UNVERIFIED-BULLET] */
+    real Il[9] = {m->inertia[0][0], m->inertia[0][3], m->inertia[0][4],
+                  m->inertia[0][3], m->inertia[0][1], m->inertia[0][5],
+                  m->inertia[0][4], m->inertia[0][5], m->inertia[0][2]};
+    real T[9], Rt[9], Iw[9], Iom[3];
+    matmul3(w->R[0], Il, T);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Rt[3 * i + j] = w->R[0][3 * j + i];
+    matmul3(T, Rt, Iw);
+    matvec3(Iw, s->omg, Iom);
+    for (int k = 0; k < 3; ++k) {
+      w->pA[0][k] += (real)m->ang_damp * Iom[k];
+      w->pA[0][3 + k] += (real)m->lin_damp * (real)m->mass[0] * s->vel[k];
+    }
+  }
+  /* pass 2 */
+  for (int b = nb - 1; b >= 1; --b) {
+    int p = m->parent[b];
+    matvec6(w->IA[b], w->S[b], w->U[b]);
+    w->d[b] = dot6(w->S[b], w->U[b]) + (real)m->jarm[b];
+    real tq = tau[b] - (with_bias ? (real)m->jdamp[b] * s->qd[b] : 0);
+    w->u[b] = tq - dot6(w->S[b], w->pA[b]);
+    real id = 1 / w->d[b];
+    real Ia[36], pa[6], Iac[6];
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) Ia[6 * i + j] = w->IA[b][6 * i + j] - w->U[b][i] * w->U[b][j] * id;
+    matvec6(Ia, w->c[b], Iac);
+    for (int i = 0; i < 6; ++i) pa[i] = w->pA[b][i] + Iac[i] + w->U[b][i] * (w->u[b] * id);
+    for (int i = 0; i < 36; ++i) w->IA[p][i] += Ia[i];
+    for (int i = 0; i < 6; ++i) w->pA[p][i] += pa[i];
+  }
+  spd6_inverse(w->IA[0], w->IA0inv);
+  real a0[6];
+  matvec6(w->IA0inv, w->pA[0], a0);
+  for (int k = 0; k < 6; ++k) w->acc[0][k] = -a0[k];
+  /* pass 3 */
+  for (int b = 1; b < nb; ++b) {
+    int p = m->parent[b];
+    real ap[6];
+    for (int k = 0; k < 6; ++k) ap[k] = w->acc[p][k] + w->c[b][k];
+    w->qdd[b] = (w->u[b] - dot6(w->U[b], ap)) / w->d[b];
+    for (int k = 0; k < 6; ++k) w->acc[b][k] = ap[k] + w->S[b][k] * w->qdd[b];
+  }
+}
+
+/* generalised acceleration response to a generalised force f (6 base + joints by body index at 5+b),
+ * using the articulated quantities cached by the last aba() call: out = M^-1 f. */
+static void minv_apply(const MoccaModel *m, const Work *w, const real *f, real *out) {
+  int nb = m->n_bodies;
+  real p[MB][6], uu[MB], a[MB][6];
+  memset(p, 0, sizeof(p));
+  for (int b = nb - 1; b >= 1; --b) {
+    int pr = m->parent[b];
+    uu[b] = f[5 + b] - dot6(w->S[b], p[b]);
+    real s = uu[b] / w->d[b];
+    for (int k = 0; k < 6; ++k) p[pr][k] += p[b][k] + w->U[b][k] * s;
+  }
+  real rhs[6];
+  for (int k = 0; k < 6; ++k) rhs[k] = f[k] - p[0][k];
+  matvec6(w->IA0inv, rhs, a[0]);
+  for (int k = 0; k < 6; ++k) out[k] = a[0][k];
+  for (int b = 1; b < nb; ++b) {
+    int pr = m->parent[b];
+    real qdd = (uu[b] - dot6(w->U[b], a[pr])) / w->d[b];
+    out[5 + b] = qdd;
+    for (int k = 0; k < 6; ++k) a[b][k] = a[pr][k] + w->S[b][k] * qdd;
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* collision detection                                                 */
+/* ------------------------------------------------------------------ */
+static void plane_space(const real *n, real *t1, real *t2) { /* btPlaneSpace1 */
+  if (fabs(n[2]) > (real)0.7071067811865475244) {
+    real a = n[1] * n[1] + n[2] * n[2], k = 1 / sqrt(a);
+    t1[0] = 0; t1[1] = -n[2] * k; t1[2] = n[1] * k;
+    t2[0] = a * k; t2[1] = -n[0] * t1[2]; t2[2] = n[0] * t1[1];
+  } else {
+    real a = n[0] * n[0] + n[1] * n[1], k = 1 / sqrt(a);
+    t1[0] = -n[1] * k; t1[1] = n[0] * k; t1[2] = 0;
+    t2[0] = -n[2] * t1[1]; t2[1] = n[2] * t1[0]; t2[2] = a * k;
+  }
+}
+
+/* getQuaternionFromEuler (roll,pitch,yaw) -> rotation matrix Rz(yaw) Ry(pitch) Rx(roll) */
+static void euler_to_mat(real roll, real pitch, real yaw, real *R) {
+  real cr = cos(roll), sr = sin(roll), cp = cos(pitch), sp = sin(pitch), cy = cos(yaw), sy = sin(yaw);
+  R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
+  R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
+  R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
+}
+
+/* sphere (world centre C, radius rad) against a box with centre bc, rotation Rb (world<-box), half
+ * extents h.  Returns gap (negative = penetration), normal n (box -> sphere), surface point on sphere. */
+static real sphere_box(const real *C, real rad, const real *bc, const real *Rb, const real *h, real *n) {
+  real d[3] = {C[0] - bc[0], C[1] - bc[1], C[2] - bc[2]}, l[3], q[3];
+  for (int i = 0; i < 3; ++i) l[i] = Rb[i] * d[0] + Rb[3 + i] * d[1] + Rb[6 + i] * d[2]; /* Rb^T d */
+  int inside = 1;
+  for (int i = 0; i < 3; ++i) {
+    q[i] = l[i];
+    if (q[i] > h[i]) { q[i] = h[i]; inside = 0; }
+    if (q[i] < -h[i]) { q[i] = -h[i]; inside = 0; }
+  }
+  real nl[3] = {0, 0, 0}, dist;
+  if (!inside) {
+    real e[3] = {l[0] - q[0], l[1] - q[1], l[2] - q[2]};
+    dist = sqrt(dot3(e, e));
+    for (int i = 0; i < 3; ++i) nl[i] = e[i] / dist;
+  } else {
+    /* centre inside the box: leave through the nearest face */
+    int best = 0;
+    real bd = h[0] - fabs(l[0]);
+    for (int i = 1; i < 3; ++i) {
+      real di = h[i] - fabs(l[i]);
+      if (di < bd) { bd = di; best = i; }
+    }
+    nl[best] = l[best] >= 0 ? 1 : -1;
+    dist = -bd;
+  }
+  matvec3(Rb, nl, n);
+  return dist - rad;
+}
+
+static void geom_point(const MoccaModel *m, const Work *w, int g, int e, real *C) {
+  int b = m->g_body[g];
+  real pl[3], pw[3];
+  for (int k = 0; k < 3; ++k) pl[k] = e ? m->g_p2[g][k] : m->g_p1[g][k];
+  matvec3(w->R[b], pl, pw);
+  for (int k = 0; k < 3; ++k) C[k] = w->r[b][k] + pw[k];
+}
+
+/* closest points between segments p1-q1 and p2-q2 (Ericson, Real-Time Collision Detection 5.1.9) */
+static void seg_seg(const real *p1, const real *q1, const real *p2, const real *q2, real *c1, real *c2) {
+  real d1[3], d2[3], r[3];
+  for (int k = 0; k < 3; ++k) { d1[k] = q1[k] - p1[k]; d2[k] = q2[k] - p2[k]; r[k] = p1[k] - p2[k]; }
+  real a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r), s, t;
+  const real EPS = (real)1e-12;
+  if (a <= EPS && e <= EPS) { s = t = 0; }
+  else if (a <= EPS) { s = 0; t = f / e; t = t < 0 ? 0 : (t > 1 ? 1 : t); }
+  else {
+    real c = dot3(d1, r);
+    if (e <= EPS) { t = 0; s = -c / a; s = s < 0 ? 0 : (s > 1 ? 1 : s); }
+    else {
+      real b = dot3(d1, d2), den = a * e - b * b;
+      if (den > EPS) { s = (b * f - c * e) / den; s = s < 0 ? 0 : (s > 1 ? 1 : s); }
+      else s = 0;
+      t = (b * s + f) / e;
+      if (t < 0) { t = 0; s = -c / a; s = s < 0 ? 0 : (s > 1 ? 1 : s); }
+      else if (t > 1) { t = 1; s = (b - c) / a; s = s < 0 ? 0 : (s > 1 ? 1 : s); }
+    }
+  }
+  for (int k = 0; k < 3; ++k) { c1[k] = p1[k] + d1[k] * s; c2[k] = p2[k] + d2[k] * t; }
+}
+
+static void plank_frame(const Oracle *o, const Terrain *tr, int k, real *bc, real *Rb) {
+  const MoccaModel *m = &o->m;
+  const real *ti = tr->terrain[tr->plank_info[k]];
+  /* set_step_state: quat = Euler(x_tilt, y_tilt, phi), env_locomotion.py:461-465 */
+  euler_to_mat(ti[4], ti[5], ti[3], Rb);
+  /* BaseStep.set_position (bullet_objects.py:77-83) puts the base link's inertial frame at
+   * pos + _pos_offset with _pos_offset = (0,0,plank_com_z) NOT rotated by the plank orientation;
+   * the slab centre sits half a thickness below the plank frame origin (the top face). */
+  real cz = m->plank_com_z;
+  real dn[3] = {0, 0, -(real)m->plank_half[2] - cz}, off[3];
+  matvec3(Rb, dn, off);
+  for (int i = 0; i < 3; ++i) bc[i] = ti[i] + off[i];
+  bc[2] += cz;
+}
+
+static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain *tr, Work *w) {
+  const MoccaModel *m = &o->m;
+  w->nc = 0;
+  for (int k = 0; k < m->n_feet; ++k) w->foot_touch[k] = w->foot_target[k] = 0;
+  real margin = m->contact_margin;
+  /* terrain */
+  for (int g = 0; g < m->n_geoms; ++g) {
+    if (!m->g_terrain[g]) continue;
+    int ne = m->g_type[g] == MOCCA_GEOM_CAPSULE ? 2 : 1;
+    for (int e = 0; e < ne; ++e) {
+      real C[3], Cw[3], n[3] = {0, 0, 1}, gap, rad = m->g_radius[g];
+      real mu, erp = m->erp, cfm = 0;
+      int is_target = 0;
+      geom_point(m, w, g, e, C);
+      for (int k = 0; k < 3; ++k) Cw[k] = C[k] + s->pos[k];
+      if (o->task_id == MOCCA_TASK_WALKER3D_CUSTOM) {
+        gap = Cw[2] - rad;
+        mu = (real)m->ground_friction * (real)m->g_friction[g];
+      } else {
+        gap = 1e30;
+        real h[3] = {m->plank_half[0], m->plank_half[1], m->plank_half[2]};
+        for (int k = 0; k < MOCCA_MAX_PLANKS; ++k) {
+          real bc[3], Rb[9], nn[3];
+          plank_frame(o, tr, k, bc, Rb);
+          real gk = sphere_box(Cw, rad, bc, Rb, h, nn);
+          if (gk < gap) {
+            gap = gk;
+            n[0] = nn[0]; n[1] = nn[1]; n[2] = nn[2];
+            /* cover link = top 1/10 of the slab (plank_large.urdf:40,49): contact with the target
+             * plank's cover is what calc_feet_state tests (env_locomotion.py:634-650) */
+            real d[3] = {Cw[0] - rad * nn[0] - bc[0], Cw[1] - rad * nn[1] - bc[1], Cw[2] - rad * nn[2] - bc[2]};
+            real lz = Rb[2] * d[0] + Rb[5] * d[1] + Rb[8] * d[2];
+            int cover = lz >= (real)m->plank_half[2] * (real)0.8;
+            is_target = cover && (k == tk->next_step_index % MOCCA_MAX_PLANKS);
+          }
+        }
+        mu = (real)m->plank_friction * (real)m->g_friction[g];
+        real kk = m->plank_stiffness, cc = m->plank_damping, dt = m->dt;
+        erp = dt * kk / (dt * kk + cc);
+        cfm = 1 / (dt * kk + cc) / dt;
+      }
+      if (gap < margin) {
+        for (int k = 0; k < m->n_feet; ++k)
+          if (m->g_body[g] == m->foot_body[k]) { w->foot_touch[k] = 1; if (is_target) w->foot_target[k] = 1; }
+        if (w->nc < MAX_CONTACTS) {
+          int i = w->nc++;
+          w->c_a[i] = m->g_body[g]; w->c_b[i] = -1; w->c_slot[i] = m->g_slot[g] + e;
+          for (int k = 0; k < 3; ++k) { w->c_n[i][k] = n[k]; w->c_P[i][k] = C[k] - rad * n[k]; }
+          w->c_depth[i] = -gap; w->c_mu[i] = mu; w->c_erp[i] = erp; w->c_cfm[i] = cfm;
+        }
+      }
+    }
+  }
+  /* self collisions */
+  for (int k = 0; k < m->n_pairs; ++k) {
+    int ga = m->pair_a[k], gb = m->pair_b[k];
+    real a1[3], a2[3], b1[3], b2[3], ca[3], cb[3];
+    geom_point(m, w, ga, 0, a1); geom_point(m, w, ga, 1, a2);
+    geom_point(m, w, gb, 0, b1); geom_point(m, w, gb, 1, b2);
+    seg_seg(a1, a2, b1, b2, ca, cb);
+    real d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
+    real dist = sqrt(dot3(d, d)), ra = m->g_radius[ga], rb = m->g_radius[gb];
+    real gap = dist - ra - rb;
+    if (gap < margin && w->nc < MAX_CONTACTS && dist > (real)1e-9) {
+      int i = w->nc++;
+      w->c_a[i] = m->g_body[ga]; w->c_b[i] = m->g_body[gb]; w->c_slot[i] = -1;
+      for (int j = 0; j < 3; ++j) {
+        w->c_n[i][j] = d[j] / dist;
+        /* midpoint between the two surface points */
+        w->c_P[i][j] = (real)0.5 * ((ca[j] - ra * d[j] / dist) + (cb[j] + rb * d[j] / dist));
+      }
+      w->c_depth[i] = -gap; w->c_mu[i] = (real)m->g_friction[ga] * (real)m->g_friction[gb];
+      w->c_erp[i] = m->erp; w->c_cfm[i] = 0;
+    }
+    /* Walker3DStepperEnv.calc_feet_state counts ANY contact of a foot link (env_locomotion.py:645-647) */
+    if (gap < margin && dist > (real)1e-9 && o->task_id == MOCCA_TASK_WALKER3D_STEPPER)
+      for (int f = 0; f < m->n_feet; ++f)
+        if (m->g_body[ga] == m->foot_body[f] || m->g_body[gb] == m->foot_body[f]) w->foot_touch[f] = 1;
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* constraint rows + PGS                                               */
+/* ------------------------------------------------------------------ */
+static void contact_jacobian(const MoccaModel *m, const Work *w, int ba, int bb, const real *P, const real *dir, real *J) {
+  int nd = 6 + m->n_joints;
+  real F[6], pn[3];
+  cross3(P, dir, pn);
+  for (int k = 0; k < 3; ++k) { F[k] = pn[k]; F[3 + k] = dir[k]; }
+  for (int k = 0; k < nd; ++k) J[k] = 0;
+  for (int k = 0; k < 6; ++k) J[k] = F[k];
+  for (int b = 1; b < m->n_bodies; ++b)
+    if (m->anc_mask[ba] & (1u << b)) J[5 + b] = dot6(w->S[b], F);
+  if (bb >= 0) {
+    for (int k = 0; k < 6; ++k) J[k] -= F[k];
+    for (int b = 1; b < m->n_bodies; ++b)
+      if (m->anc_mask[bb] & (1u << b)) J[5 + b] -= dot6(w->S[b], F);
+  }
+}
+
+/* nu = [omega(3) v(3) qd(by body, at 5+b)] */
+static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
+  int nd = 6 + m->n_joints, nr = 0;
+  real dt = m->dt, idt = 1 / dt;
+  /* --- joint limit rows first (Bullet solves non-contact rows first) --- */
+  for (int b = 1; b < m->n_bodies; ++b) {
+    for (int side = 0; side < 2; ++side) {
+      real sgn = side == 0 ? 1 : -1;
+      real gap = side == 0 ? s->q[b] - (real)m->jlo[b] : (real)m->jhi[b] - s->q[b];
+      real vel = sgn * nu[5 + b];
+      if (gap + dt * vel >= (real)m->limit_slack || nr >= MAX_ROWS) continue;
+      int r = nr++;
+      for (int k = 0; k < nd; ++k) w->J[r][k] = 0;
+      w->J[r][5 + b] = sgn;
+      w->row_kind[r] = 0; w->row_normal[r] = -1; w->row_mu[r] = 0; w->row_slot[r] = -1;
+      w->bias[r] = gap < 0 ? (real)m->erp * (-gap) * idt : -gap * idt;
+      w->cfm[r] = 0; w->lam[r] = 0;
+    }
+  }
+  /* --- contact normals, then friction pairs --- */
+  int first_normal = nr;
+  int nc = w->nc;
+  if (nc > (MAX_ROWS - nr) / 3) nc = (MAX_ROWS - nr) / 3;
+  for (int i = 0; i < nc; ++i) {
+    int r = nr++;
+    contact_jacobian(m, w, w->c_a[i], w->c_b[i], w->c_P[i], w->c_n[i], w->J[r]);
+    w->row_kind[r] = 1; w->row_normal[r] = -1; w->row_mu[r] = 0; w->row_slot[r] = w->c_slot[i];
+    real depth = w->c_depth[i];
+    w->bias[r] = depth > 0 ? w->c_erp[i] * depth * idt : depth * idt;
+    w->cfm[r] = w->c_cfm[i];
+    w->lam[r] = (w->c_slot[i] >= 0) ? (real)m->warmstart * s->warm[w->c_slot[i]] : 0;
+  }
+  for (int i = 0; i < nc; ++i) {
+    real t1[3], t2[3];
+    plane_space(w->c_n[i], t1, t2);
+    for (int dsel = 0; dsel < 2; ++dsel) {
+      int r = nr++;
+      contact_jacobian(m, w, w->c_a[i], w->c_b[i], w->c_P[i], dsel ? t2 : t1, w->J[r]);
+      w->row_kind[r] = 2; w->row_normal[r] = first_normal + i; w->row_mu[r] = w->c_mu[i]; w->row_slot[r] = -1;
+      w->bias[r] = 0; w->cfm[r] = 0; w->lam[r] = 0;
+    }
+  }
+  w->nr = nr;
+  /* --- responses, Delassus matrix, initial velocities --- */
+  for (int r = 0; r < nr; ++r) minv_apply(m, w, w->J[r], w->Mi[r]);
+  for (int r = 0; r < nr; ++r)
+    for (int c = 0; c < nr; ++c) {
+      real a = 0;
+      for (int k = 0; k < nd; ++k) a += w->J[r][k] * w->Mi[c][k];
+      w->A[r][c] = a;
+    }
+  for (int r = 0; r < nr; ++r) {
+    real a = 0;
+    for (int k = 0; k < nd; ++k) a += w->J[r][k] * nu[k];
+    w->w[r] = a;
+  }
+  /* warm-start impulses act before the first iteration */
+  for (int r = 0; r < nr; ++r)
+    if (w->lam[r] != 0)
+      for (int c = 0; c < nr; ++c) w->w[c] += w->A[r][c] * w->lam[r];
+  /* --- projected Gauss-Seidel --- */
+  for (int it = 0; it < m->n_iters; ++it) {
+    for (int r = 0; r < nr; ++r) {
+      real lo = 0, hi = (real)1e30;
+      if (w->row_kind[r] == 2) {
+        real lim = w->row_mu[r] * w->lam[w->row_normal[r]];
+        lo = -lim; hi = lim;
+      }
+      real dl = (w->bias[r] - w->w[r] - w->cfm[r] * w->lam[r]) / (w->A[r][r] + w->cfm[r]);
+      real nl = w->lam[r] + dl;
+      nl = nl < lo ? lo : (nl > hi ? hi : nl);
+      dl = nl - w->lam[r];
+      w->lam[r] = nl;
+      if (dl != 0)
+        for (int c = 0; c < nr; ++c) w->w[c] += w->A[r][c] * dl;
+    }
+  }
+  /* --- apply --- */
+  for (int k = 0; k < nd; ++k) {
+    real a = 0;
+    for (int r = 0; r < nr; ++r) a += w->Mi[r][k] * w->lam[r];
+    nu[k] += a;
+  }
+  for (int k = 0; k < m->n_slots; ++k) s->warm[k] = 0;
+  for (int r = 0; r < nr; ++r)
+    if (w->row_slot[r] >= 0) s->warm[w->row_slot[r]] = w->lam[r];
+}
+
+/* one physics substep: bullet_utils.py:352-353 stepSimulation() does n_substeps of these */
+static void substep(const Oracle *o, Dyn *s, const Task *tk, const Terrain *tr, const real *tau, Work *w) {
+  const MoccaModel *m = &o->m;
+  real dt = m->dt;
+  kinematics(m, s, w);
+  collide(o, s, tk, tr, w);
+  aba(m, s, tau, w, 1);
+  real nu[NDOF_MAX];
+  const real *a0 = w->acc[0];
+  real wxv[3];
+  cross3(s->omg, s->vel, wxv);
+  for (int k = 0; k < 3; ++k) {
+    nu[k] = s->omg[k] + dt * a0[k];
+    nu[3 + k] = s->vel[k] + dt * (a0[3 + k] + wxv[k]); /* spatial -> classical acceleration */
+  }
+  for (int b = 1; b < m->n_bodies; ++b) nu[5 + b] = s->qd[b] + dt * w->qdd[b];
+  solve_constraints(m, s, w, nu);
+  for (int k = 0; k < 3; ++k) { s->omg[k] = nu[k]; s->vel[k] = nu[3 + k]; }
+  for (int b = 1; b < m->n_bodies; ++b) {
+    real v = nu[5 + b], mx = m->max_qd;
+    v = v > mx ? mx : (v < -mx ? -mx : v);
+    s->qd[b] = v;
+    s->q[b] += dt * v;
+  }
+  for (int k = 0; k < 3; ++k) s->pos[k] += dt * s->vel[k];
+  /* quaternion exponential map, world-frame omega */
+  real wn = sqrt(dot3(s->omg, s->omg)), th = wn * dt, dq[4];
+  if (th > (real)1e-8) {
+    real sn = sin((real)0.5 * th) / wn;
+    dq[0] = s->omg[0] * sn; dq[1] = s->omg[1] * sn; dq[2] = s->omg[2] * sn; dq[3] = cos((real)0.5 * th);
+  } else {
+    dq[0] = (real)0.5 * dt * s->omg[0]; dq[1] = (real)0.5 * dt * s->omg[1]; dq[2] = (real)0.5 * dt * s->omg[2]; dq[3] = 1;
+  }
+  real *q = s->quat, nq[4];
+  nq[0] = dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1];
+  nq[1] = dq[3] * q[1] - dq[0] * q[2] + dq[1] * q[3] + dq[2] * q[0];
+  nq[2] = dq[3] * q[2] + dq[0] * q[1] - dq[1] * q[0] + dq[2] * q[3];
+  nq[3] = dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2];
+  real nn = 1 / sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+  for (int k = 0; k < 4; ++k) q[k] = nq[k] * nn;
+}
+
+/* ------------------------------------------------------------------ */
+/* task layer                                                          */
+/* ------------------------------------------------------------------ */
+/* pybullet.getEulerFromQuaternion [UNVERIFIED-BULLET singularity handling], bullet_utils.py:84 */
+static void quat_to_rpy(const real *q, real *rpy) {
+  real x = q[0], y = q[1], z = q[2], w = q[3];
+  real sarg = -2 * (x * z - w * y);
+  if (sarg <= (real)-0.99999) { rpy[1] = (real)-1.5707963267948966; rpy[0] = 0; rpy[2] = 2 * atan2(x, -y); }
+  else if (sarg >= (real)0.99999) { rpy[1] = (real)1.5707963267948966; rpy[0] = 0; rpy[2] = 2 * atan2(-x, y); }
+  else {
+    rpy[0] = atan2(2 * (y * z + w * x), w * w - x * x - y * y + z * z);
+    rpy[1] = asin(sarg);
+    rpy[2] = atan2(2 * (x * y + w * z), w * w + x * x - y * y - z * z);
+  }
+}
+
+/* WalkerBase.calc_state, robots.py:42-95.  Needs kinematics() done on the current state.
+ * Writes 6 + 2 nj + n_feet floats; returns joints_at_limit via *jal; speeds in `spd`. */
+static void calc_robot_state(Oracle *o, const Dyn *s, const Task *tk, float *out, int *jal, float *spd) {
+  const MoccaModel *m = &o->m;
+  Work *w = &o->wk;
+  int nj = m->n_joints, cnt = 0;
+  for (int b = 1; b <= nj; ++b) {
+    float ang = (float)s->q[b], lo = m->jlo[b], wt = m->jhi[b] - m->jlo[b]; /* robots.py:46,125-132 */
+    float nrm = 2 * (ang - lo) / wt - 1;
+    float sp = 0.1f * (float)s->qd[b];
+    out[6 + b - 1] = nrm;
+    out[6 + nj + b - 1] = sp;
+    spd[b - 1] = sp;
+    if (fabsf(nrm) > 0.99f) ++cnt;
+  }
+  *jal = cnt;
+  quat_to_rpy(s->quat, o->body_rpy);
+  real yaw = o->body_rpy[2], cy = cos(-yaw), sy = sin(-yaw);
+  o->body_vel[0] = cy * s->vel[0] - sy * s->vel[1]; /* robots.py:63-70 */
+  o->body_vel[1] = sy * s->vel[0] + cy * s->vel[1];
+  o->body_vel[2] = s->vel[2];
+  real minz = 1e30;
+  for (int k = 0; k < m->n_feet; ++k) {
+    int b = m->foot_body[k];
+    for (int i = 0; i < 3; ++i) o->feet_xyz[k][i] = s->pos[i] + w->comw[b][i]; /* getLinkState[0], bullet_utils.py:106 */
+    if (o->feet_xyz[k][2] < minz) minz = o->feet_xyz[k][2];
+  }
+  out[0] = (float)(s->pos[2] - minz); /* robots.py:88-89 */
+  out[1] = (float)o->body_vel[0]; out[2] = (float)o->body_vel[1]; out[3] = (float)o->body_vel[2];
+  out[4] = (float)o->body_rpy[0]; out[5] = (float)o->body_rpy[1];
+  for (int k = 0; k < m->n_feet; ++k) out[6 + 2 * nj + k] = (float)tk->feet_contact[k];
+  int n = 6 + 2 * nj + m->n_feet;
+  for (int i = 0; i < n; ++i) out[i] = out[i] > 5.f ? 5.f : (out[i] < -5.f ? -5.f : out[i]); /* robots.py:95 */
+}
+
+/* calc_potential, env_locomotion.py:143-158 / :584-596 */
+static void calc_potential(const Oracle *o, const Dyn *s, Task *tk, real *dist_out, real *ang_out) {
+  real dx = tk->walk_target[0] - s->pos[0], dy = tk->walk_target[1] - s->pos[1];
+  real theta = atan2(dy, dx);
+  real ang = theta - o->body_rpy[2];
+  real dist = sqrt(dx * dx + dy * dy);
+  tk->linear_potential = -dist / (real)o->m.control_dt;
+  tk->angular_potential = cos(ang);
+  *dist_out = dist; *ang_out = ang;
+}
+
+static void randomize_target(Oracle *o, int env, Task *tk) { /* env_locomotion.py:67-74 */
+  if (o->eval_mode) { tk->dist = 4; tk->angle = 0; }
+  else {
+    real u0 = draw_uniform(o, env, tk), u1 = draw_uniform(o, env, tk);
+    tk->dist = 3 + 2 * u0;
+    tk->angle = (real)-1.5707963267948966 + (real)3.141592653589793 * u1;
+  }
+  real u2 = draw_uniform(o, env, tk);
+  tk->stop_frames = u2 < (real)0.5 ? 30 : 60;
+}
+
+static void softsign_tail(real dist, real ang, float *o2) { /* env_locomotion.py:102-105,124-127 */
+  real s = dist * sin(ang), c = dist * cos(ang);
+  o2[0] = (float)(s / (1 + fabs(s)));
+  o2[1] = (float)(c / (1 + fabs(c)));
+}
+
+/* ---- stepper terrain, env_locomotion.py:395-441 (device RNG version) ---- */
+static void generate_step_placements(Oracle *o, int env, Task *tk, Terrain *tr) {
+  const real DEG2RAD = (real)(3.14159265358979323846 / 180.0);
+  int N = MOCCA_MAX_TERRAIN_STEPS, cur = tk->curriculum > 9 ? 9 : tk->curriculum;
+  real ratio = (real)cur / 9;
+  real dist_lo = 0.65, dist_hi = (real)0.65 + ((real)1.25 - (real)0.65) * cur / 9; /* np.linspace(0.65,1.25,10)[cur] */
+  real yaw_lo = -20 * ratio * DEG2RAD, yaw_hi = 20 * ratio * DEG2RAD;
+  real pit_lo = -30 * ratio * DEG2RAD + (real)1.5707963267948966, pit_hi = 30 * ratio * DEG2RAD + (real)1.5707963267948966;
+  real tl_lo = -15 * ratio * DEG2RAD, tl_hi = 15 * ratio * DEG2RAD;
+  real dr[MOCCA_MAX_TERRAIN_STEPS], dphi[MOCCA_MAX_TERRAIN_STEPS], dth[MOCCA_MAX_TERRAIN_STEPS];
+  real xt[MOCCA_MAX_TERRAIN_STEPS], yt[MOCCA_MAX_TERRAIN_STEPS];
+  /* draw order = the five np_random.uniform(size=N) calls of env_locomotion.py:408-412 */
+  for (int i = 0; i < N; ++i) dr[i] = dist_lo + (dist_hi - dist_lo) * draw_uniform(o, env, tk);
+  for (int i = 0; i < N; ++i) dphi[i] = yaw_lo + (yaw_hi - yaw_lo) * draw_uniform(o, env, tk);
+  for (int i = 0; i < N; ++i) dth[i] = pit_lo + (pit_hi - pit_lo) * draw_uniform(o, env, tk);
+  for (int i = 0; i < N; ++i) xt[i] = tl_lo + (tl_hi - tl_lo) * draw_uniform(o, env, tk);
+  for (int i = 0; i < N; ++i) yt[i] = tl_lo + (tl_hi - tl_lo) * draw_uniform(o, env, tk);
+  dr[0] = 0; dphi[0] = 0; dth[0] = (real)1.5707963267948966;
+  dr[1] = dr[2] = 0.75; dphi[1] = dphi[2] = 0; dth[1] = dth[2] = (real)1.5707963267948966;
+  xt[0] = xt[1] = xt[2] = 0; yt[0] = yt[1] = yt[2] = 0;
+  real x = 0, y = 0, z = 0, phi = 0;
+  for (int i = 0; i < N; ++i) {
+    phi += dphi[i];
+    real dx = dr[i] * sin(dth[i]) * cos(phi), dy = dr[i] * sin(dth[i]) * sin(phi), dz = dr[i] * cos(dth[i]);
+    if (i >= 2) {
+      real ax = fabs(dx), mx = ax > (real)0.625 ? ax : (real)0.625;
+      real sg = dx > 0 ? 1 : (dx < 0 ? -1 : 0);
+      dx = sg * (mx < (real)1.25 ? mx : (real)1.25);
+    }
+    x += dx; y += dy; z += dz;
+    tr->terrain[i][0] = x; tr->terrain[i][1] = y; tr->terrain[i][2] = z;
+    tr->terrain[i][3] = phi; tr->terrain[i][4] = xt[i]; tr->terrain[i][5] = yt[i];
+  }
+}
+
+/* delta_to_k_targets, env_locomotion.py:712-759 : 3 rows x (x,y,z,x_tilt,y_tilt), sets walk_target */
+static void delta_to_k_targets(const Oracle *o, const Dyn *s, Task *tk, const Terrain *tr, float *out15) {
+  int N = tk->next_step_index, T = MOCCA_MAX_TERRAIN_STEPS, idx[3];
+  if (!tk->stop_on_next_step) {
+    idx[0] = N - 1 >= 0 ? N - 1 : 0;
+    idx[1] = N; idx[2] = N + 1;
+    for (int i = 0; i < 3; ++i) if (idx[i] > T - 1) idx[i] = T - 1; /* repeat last target */
+  } else { idx[0] = N - 1; idx[1] = N; idx[2] = N; }
+  for (int i = 0; i < 3; ++i) tk->walk_target[i] = tr->terrain[idx[2]][i]; /* walk_target_index = -1 */
+  for (int i = 0; i < 3; ++i) {
+    const real *t = tr->terrain[idx[i]];
+    real dx = t[0] - s->pos[0], dy = t[1] - s->pos[1], dz = t[2] - s->pos[2];
+    real ang = atan2(dy, dx) - o->body_rpy[2], dist = sqrt(dx * dx + dy * dy);
+    out15[5 * i + 0] = (float)(sin(ang) * dist);
+    out15[5 * i + 1] = (float)(cos(ang) * dist);
+    out15[5 * i + 2] = (float)dz;
+    out15[5 * i + 3] = (float)t[4];
+    out15[5 * i + 4] = (float)t[5];
+  }
+}
+
+static int obs_dim(const Oracle *o) {
+  int base = 6 + 2 * o->m.n_joints + o->m.n_feet;
+  return o->task_id == MOCCA_TASK_WALKER3D_CUSTOM ? base + 2 : base + 15;
+}
+
+/* reset one env.  The pose randomisation follows robots.py:179-210 with Philox draws. */
+static void reset_env(Oracle *o, int env, float *obs) {
+  const MoccaModel *m = &o->m;
+  Dyn *s = &o->dyn[env];
+  Task *tk = &o->task[env];
+  Terrain *tr = &o->ter[env];
+  int nj = m->n_joints;
+  int keep_cur = tk->curriculum;
+  int ep = tk->episode + 1;
+  memset(tk, 0, sizeof(*tk));
+  tk->episode = ep; tk->curriculum = keep_cur;
+  tk->applied_gain = 1;
+  if (o->task_id == MOCCA_TASK_WALKER3D_CUSTOM) {
+    randomize_target(o, env, tk); /* draws 0..2 */
+    tk->walk_target[0] = tk->dist * cos(tk->angle);
+    tk->walk_target[1] = tk->dist * sin(tk->angle);
+    tk->walk_target[2] = 1;
+  } else {
+    tk->applied_gain = 1 + (real)0.2 * tk->curriculum / 9; /* np.linspace(1.0,1.2,10), :369,489 */
+  }
+  /* robot.reset */
+  real u = draw_uniform(o, env, tk);
+  tk->mirrored = u < (real)0.5;
+  real base[MB];
+  for (int b = 1; b <= nj; ++b) base[b] = m->init_q[b];
+  if (tk->mirrored) { /* robots.py:182-188 */
+    for (int k = 0; k < m->n_mirror_side; ++k) {
+      int r = m->mirror_right[k] + 1, l = m->mirror_left[k] + 1;
+      real t = base[r]; base[r] = base[l]; base[l] = t;
+    }
+    for (int k = 0; k < m->n_mirror_neg; ++k) base[m->mirror_neg[k] + 1] *= -1;
+  }
+  real dsv[MB];
+  for (int b = 1; b <= nj; ++b) {
+    dsv[b] = (real)-0.1 + (real)0.2 * draw_uniform(o, env, tk);
+  }
+  for (int b = 1; b <= nj; ++b) {
+    real ds = o->random_pose ? dsv[b] : 0;
+    real wt = (real)(float)(m->jhi[b] - m->jlo[b]), bs = m->jlo[b];
+    real ps = 2 * (base[b] + ds - bs) / wt - 1;
+    ps = ps < (real)-0.95 ? (real)-0.95 : (ps > (real)0.95 ? (real)0.95 : ps);
+    s->q[b] = wt * (ps + 1) / 2 + bs;
+    s->qd[b] = 0;
+  }
+  for (int k = 0; k < 3; ++k) { s->pos[k] = m->init_pos[k]; s->vel[k] = 0; s->omg[k] = 0; }
+  s->quat[0] = s->quat[1] = s->quat[2] = 0; s->quat[3] = 1;
+  for (int k = 0; k < MOCCA_MAX_SLOTS; ++k) s->warm[k] = 0;
+  kinematics(m, s, &o->wk);
+  int jal; float spd[MB];
+  calc_robot_state(o, s, tk, obs, &jal, spd);
+  int nb = 6 + 2 * nj + m->n_feet;
+  if (o->task_id == MOCCA_TASK_WALKER3D_CUSTOM) {
+    real dist, ang;
+    calc_potential(o, s, tk, &dist, &ang);
+    softsign_tail(dist, ang, obs + nb);
+  } else {
+    /* env_locomotion.py:481-513: calc_feet_state() on the fresh pose finds no contacts (planks
+     * not yet placed relative to a robot at rest above them): feet_contact = 0 */
+    generate_step_placements(o, env, tk, tr);
+    for (int k = 0; k < MOCCA_MAX_PLANKS; ++k) tr->plank_info[k] = k;
+    tk->next_step_index = 1; /* lookbehind */
+    delta_to_k_targets(o, s, tk, tr, obs + nb);
+    real dist, ang;
+    calc_potential(o, s, tk, &dist, &ang);
+  }
+  tk->prev_body_x = s->pos[0];
+}
+
+static void step_env(Oracle *o, int env, const float *act, float *obs, float *rew, uint8_t *done, int32_t *info,
+                     const int32_t *ext_touch, const int32_t *ext_target) {
+  const MoccaModel *m = &o->m;
+  Dyn *s = &o->dyn[env];
+  Task *tk = &o->task[env];
+  Terrain *tr = &o->ter[env];
+  Work *w = &o->wk;
+  int nj = m->n_joints, nb = 6 + 2 * nj + m->n_feet;
+  real tau[MB];
+  tau[0] = 0;
+  for (int b = 1; b <= nj; ++b) { /* robots.py:31-40 */
+    real a = act[b - 1];
+    a = a < -1 ? -1 : (a > 1 ? 1 : a);
+    tau[b] = (real)m->gain[b] * tk->applied_gain * a;
+  }
+  int touch[MOCCA_MAX_FEET] = {0, 0}, target[MOCCA_MAX_FEET] = {0, 0};
+  if (!ext_touch) {
+    for (int k = 0; k < m->n_substeps; ++k) substep(o, s, tk, tr, tau, w);
+    /* contact queries after stepSimulation see the manifolds of the LAST substep's collision pass */
+    for (int k = 0; k < m->n_feet; ++k) { touch[k] = w->foot_touch[k]; target[k] = w->foot_target[k]; }
+  } else {
+    /* task-only step (golden tests): the caller injected the post-physics state and the contacts */
+    for (int k = 0; k < m->n_feet; ++k) { touch[k] = ext_touch[k]; target[k] = ext_target[k]; }
+  }
+  tk->t += 1;
+  kinematics(m, s, w);
+  int jal; float spd[MB];
+  real dist, ang, progress, posture = 0, energy, joints, tall, target_bonus = 0, step_bonus = 0;
+  if (o->task_id == MOCCA_TASK_WALKER3D_CUSTOM) {
+    if (o->eval_mode) { tk->walk_target[0] = tk->prev_body_x + 4; tk->walk_target[1] = 0; tk->walk_target[2] = 1; } /* :115-116 */
+    for (int k = 0; k < m->n_feet; ++k) tk->feet_contact[k] = touch[k]; /* robots.py:74-86 */
+    calc_robot_state(o, s, tk, obs, &jal, spd);
+    int finite = 1;
+    for (int i = 0; i < nb; ++i) if (!isfinite(obs[i])) finite = 0;
+    if (!finite) tk->done = 1; /* :205-207 */
+    real old = tk->linear_potential;
+    calc_potential(o, s, tk, &dist, &ang);
+    progress = tk->linear_potential - old;
+    real pitch = o->body_rpy[1], roll = o->body_rpy[0];
+    if (!((real)-0.2 < pitch && pitch < (real)0.4)) posture = fabs(pitch); /* :178-183 */
+    if (!((real)-0.4 < roll && roll < (real)0.4)) posture += fabs(roll);
+    real e1 = 0, e2 = 0;
+    for (int j = 0; j < nj; ++j) { e1 += fabs((real)act[j] * (real)spd[j]); e2 += (real)act[j] * (real)act[j]; }
+    energy = (real)m->electricity_cost * (e1 / nj) + (real)m->stall_torque_cost * (e2 / nj);
+    joints = (real)m->joints_at_limit_cost * jal;
+    tall = obs[0] > m->termination_height ? 2 : -1;
+    if (tall < 0) tk->done = 1;
+    if (dist < (real)0.15) { tk->close_count += 1; target_bonus = 2; } /* :198-202 */
+    if (tk->close_count >= tk->stop_frames) { /* :214-222 */
+      tk->close_count = 0;
+      randomize_target(o, env, tk);
+      tk->walk_target[0] += tk->dist * cos(tk->angle);
+      tk->walk_target[1] += tk->dist * sin(tk->angle);
+      calc_potential(o, s, tk, &dist, &ang);
+    }
+    *rew = (float)(progress + target_bonus - energy + tall - posture - joints); /* :121-122 */
+    softsign_tail(dist, ang, obs + nb);
+    *info = 0;
+  } else {
+    /* env_locomotion.py:515-568 */
+    tk->set_stop_on_next_step = (tk->next_step_index == 6 || tk->next_step_index == 7 ||
+                                 tk->next_step_index == 13 || tk->next_step_index == 14); /* :522 */
+    calc_robot_state(o, s, tk, obs, &jal, spd); /* previous step's feet_contact, :525 */
+    int finite = 1;
+    for (int i = 0; i < nb; ++i) if (!isfinite(obs[i])) finite = 0;
+    if (!finite) tk->done = 1;
+    int cur_step_index = tk->next_step_index;
+    /* calc_feet_state :632-674 */
+    real fd[MOCCA_MAX_FEET];
+    for (int k = 0; k < m->n_feet; ++k) {
+      real dx = o->feet_xyz[k][0] - tr->terrain[tk->next_step_index][0];
+      real dy = o->feet_xyz[k][1] - tr->terrain[tk->next_step_index][1];
+      fd[k] = sqrt(dx * dx + dy * dy);
+      tk->feet_contact[k] = touch[k];
+    }
+    int target_reached = target[0] || target[1];
+    if (target_reached) {
+      tk->target_reached_count += 1;
+      if (tk->target_reached_count > 120) { tk->stop_on_next_step = 0; tk->set_stop_on_next_step = 0; }
+      if (tk->target_reached_count >= 2) {
+        if (!tk->stop_on_next_step) {
+          tk->next_step_index += 1;
+          tk->target_reached_count = 0;
+          if (tk->next_step_index >= MOCCA_MAX_PLANKS) { /* update_steps :472-479 */
+            int oldest = tk->next_step_index % MOCCA_MAX_PLANKS;
+            int nx = tk->next_step_index < MOCCA_MAX_TERRAIN_STEPS - 1 ? tk->next_step_index : MOCCA_MAX_TERRAIN_STEPS - 1;
+            tr->plank_info[oldest] = nx;
+          }
+        }
+        tk->stop_on_next_step = tk->set_stop_on_next_step;
+      }
+      if (tk->next_step_index >= MOCCA_MAX_TERRAIN_STEPS) tk->next_step_index -= 1;
+    }
+    /* calc_base_reward :598-630 */
+    real old = tk->linear_potential;
+    calc_potential(o, s, tk, &dist, &ang);
+    progress = tk->linear_potential - old;
+    real pitch = o->body_rpy[1], roll = o->body_rpy[0];
+    if (!((real)-0.2 < pitch && pitch < (real)0.4)) posture = fabs(pitch);
+    if (!((real)-0.4 < roll && roll < (real)0.4)) posture += fabs(roll);
+    real e1 = 0, e2 = 0;
+    for (int j = 0; j < nj; ++j) { e1 += fabs((real)act[j] * (real)spd[j]); e2 += (real)act[j] * (real)act[j]; }
+    energy = (real)m->electricity_cost * (e1 / nj) + (real)m->stall_torque_cost * (e2 / nj);
+    joints = (real)m->joints_at_limit_cost * jal;
+    real term_h = (real)0.75 + ((real)0.45 - (real)0.75) * tk->curriculum / 9; /* np.linspace(0.75,0.45,10) :368 */
+    tall = obs[0] > term_h ? 2 : -1;
+    if (tall < 0) tk->done = 1;
+    /* calc_step_reward :676-693 */
+    int last = MOCCA_MAX_TERRAIN_STEPS - 1;
+    if (target_reached && tk->target_reached_count == 1 && tk->next_step_index != last) {
+      real dmin = fd[0] < fd[1] ? fd[0] : fd[1];
+      step_bonus = 50 * pow((real)2.718, -dmin / (real)0.25);
+    }
+    if ((tk->next_step_index == last || tk->stop_on_next_step) && dist < (real)0.15) target_bonus = 2;
+    delta_to_k_targets(o, s, tk, tr, obs + nb);
+    if (cur_step_index != tk->next_step_index) calc_potential(o, s, tk, &dist, &ang);
+    *rew = (float)(progress - energy + step_bonus + target_bonus + tall - posture - joints); /* :528-531 */
+    *info = tk->next_step_index;
+  }
+  tk->prev_body_x = s->pos[0];
+  int timeout = tk->t >= m->max_episode_steps;
+  *done = (uint8_t)((tk->done ? 1 : 0) | (timeout ? 2 : 0));
+  if (o->auto_reset && (*done)) reset_env(o, env, obs);
+}
+
+/* ------------------------------------------------------------------ */
+/* C API (mirrors include/mocca.h on host pointers)                    */
+/* ------------------------------------------------------------------ */
+API int orc_real_bytes(void) { return (int)sizeof(real); }
+API int orc_model_sizeof(void) { return (int)sizeof(MoccaModel); }
+
+API void *orc_create(const void *blob, int nbytes, int task_id, int n_envs) {
+  if (nbytes != (int)sizeof(MoccaModel)) return NULL;
+  Oracle *o = (Oracle *)calloc(1, sizeof(Oracle));
+  memcpy(&o->m, blob, sizeof(MoccaModel));
+  if (o->m.magic != MOCCA_MODEL_MAGIC || o->m.version != MOCCA_MODEL_VERSION) { free(o); return NULL; }
+  o->task_id = task_id; o->n_envs = n_envs; o->random_pose = 1;
+  o->dyn = (Dyn *)calloc(n_envs, sizeof(Dyn));
+  o->task = (Task *)calloc(n_envs, sizeof(Task));
+  o->ter = (Terrain *)calloc(n_envs, sizeof(Terrain));
+  for (int e = 0; e < n_envs; ++e) { o->dyn[e].quat[3] = 1; o->task[e].applied_gain = 1; o->task[e].episode = -1; }
+  return o;
+}
+API void orc_destroy(void *h) {
+  Oracle *o = (Oracle *)h;
+  if (!o) return;
+  free(o->dyn); free(o->task); free(o->ter); free(o);
+}
+API int orc_obs_dim(void *h) { return obs_dim((Oracle *)h); }
+API int orc_state_dim(void *h) { Oracle *o = (Oracle *)h; return MOCCA_STATE_DIM(o->m.n_joints, o->m.n_slots); }
+
+enum { PARAM_AUTO_RESET = 0, PARAM_EVAL_MODE = 1, PARAM_CURRICULUM = 2, PARAM_RANDOM_POSE = 3 };
+API void orc_set_param(void *h, int id, double v) {
+  Oracle *o = (Oracle *)h;
+  if (id == PARAM_AUTO_RESET) o->auto_reset = v != 0;
+  else if (id == PARAM_EVAL_MODE) o->eval_mode = v != 0;
+  else if (id == PARAM_CURRICULUM) for (int e = 0; e < o->n_envs; ++e) o->task[e].curriculum = (int)v;
+  else if (id == PARAM_RANDOM_POSE) o->random_pose = v != 0;
+}
+
+API void orc_reset(void *h, const uint8_t *mask, uint64_t seed, float *obs) {
+  Oracle *o = (Oracle *)h;
+  int od = obs_dim(o);
+  o->seed = seed;
+  for (int e = 0; e < o->n_envs; ++e)
+    if (!mask || mask[e]) reset_env(o, e, obs + (size_t)e * od);
+}
+API void orc_step(void *h, const float *act, float *obs, float *rew, uint8_t *done, int32_t *info) {
+  Oracle *o = (Oracle *)h;
+  int od = obs_dim(o), nj = o->m.n_joints;
+  for (int e = 0; e < o->n_envs; ++e) {
+    int32_t inf = 0;
+    step_env(o, e, act + (size_t)e * nj, obs + (size_t)e * od, rew + e, done + e, &inf, NULL, NULL);
+    if (info) info[e] = inf;
+  }
+}
+/* task logic only: the dynamic state currently stored is taken as the post-stepSimulation state,
+ * touch/target [N][2] are the foot contact query results. */
+API void orc_task_step(void *h, const float *act, const int32_t *touch, const int32_t *target, float *obs, float *rew,
+                       uint8_t *done, int32_t *info) {
+  Oracle *o = (Oracle *)h;
+  int od = obs_dim(o), nj = o->m.n_joints;
+  for (int e = 0; e < o->n_envs; ++e) {
+    int32_t inf = 0;
+    step_env(o, e, act + (size_t)e * nj, obs + (size_t)e * od, rew + e, done + e, &inf, touch + 2 * e, target + 2 * e);
+    if (info) info[e] = inf;
+  }
+}
+API void orc_set_tape(void *h, const double *tape, int n) {
+  Oracle *o = (Oracle *)h;
+  o->tape = tape; o->tape_n = n; o->tape_pos = 0;
+}
+/* dynamic state, layout of include/mocca_model.h (doubles so both builds share the binding) */
+API void orc_get_state(void *h, double *st) {
+  Oracle *o = (Oracle *)h;
+  int nj = o->m.n_joints, ns = o->m.n_slots, S = MOCCA_STATE_DIM(nj, ns);
+  for (int e = 0; e < o->n_envs; ++e) {
+    const Dyn *s = &o->dyn[e];
+    double *p = st + (size_t)e * S;
+    for (int k = 0; k < 3; ++k) { p[k] = s->pos[k]; p[7 + k] = s->vel[k]; p[10 + k] = s->omg[k]; }
+    for (int k = 0; k < 4; ++k) p[3 + k] = s->quat[k];
+    for (int b = 1; b <= nj; ++b) { p[13 + b - 1] = s->q[b]; p[13 + nj + b - 1] = s->qd[b]; }
+    for (int k = 0; k < ns; ++k) p[13 + 2 * nj + k] = s->warm[k];
+  }
+}
+API void orc_set_state(void *h, const double *st) {
+  Oracle *o = (Oracle *)h;
+  int nj = o->m.n_joints, ns = o->m.n_slots, S = MOCCA_STATE_DIM(nj, ns);
+  for (int e = 0; e < o->n_envs; ++e) {
+    Dyn *s = &o->dyn[e];
+    const double *p = st + (size_t)e * S;
+    for (int k = 0; k < 3; ++k) { s->pos[k] = (real)p[k]; s->vel[k] = (real)p[7 + k]; s->omg[k] = (real)p[10 + k]; }
+    for (int k = 0; k < 4; ++k) s->quat[k] = (real)p[3 + k];
+    for (int b = 1; b <= nj; ++b) { s->q[b] = (real)p[13 + b - 1]; s->qd[b] = (real)p[13 + nj + b - 1]; }
+    for (int k = 0; k < ns; ++k) s->warm[k] = (real)p[13 + 2 * nj + k];
+  }
+}
+/* task record: MOCCA_TASK_WORDS doubles per env, same word order as include/mocca_model.h */
+API void orc_get_task(void *h, double *t) {
+  Oracle *o = (Oracle *)h;
+  for (int e = 0; e < o->n_envs; ++e) {
+    const Task *k = &o->task[e];
+    double *p = t + (size_t)e * MOCCA_TASK_WORDS;
+    memset(p, 0, MOCCA_TASK_WORDS * sizeof(double));
+    p[0] = k->walk_target[0]; p[1] = k->walk_target[1]; p[2] = k->walk_target[2];
+    p[3] = k->linear_potential; p[4] = k->angular_potential; p[5] = k->close_count; p[6] = k->stop_frames;
+    p[7] = k->done; p[8] = k->t; p[9] = k->episode; p[10] = k->draw; p[11] = k->mirrored;
+    p[12] = k->feet_contact[0]; p[13] = k->feet_contact[1]; p[14] = k->dist; p[15] = k->angle;
+    p[16] = k->next_step_index; p[17] = k->target_reached_count; p[18] = k->stop_on_next_step;
+    p[19] = k->set_stop_on_next_step; p[20] = k->curriculum; p[21] = k->applied_gain; p[22] = k->prev_body_x;
+  }
+}
+API void orc_set_task(void *h, const double *t) {
+  Oracle *o = (Oracle *)h;
+  for (int e = 0; e < o->n_envs; ++e) {
+    Task *k = &o->task[e];
+    const double *p = t + (size_t)e * MOCCA_TASK_WORDS;
+    k->walk_target[0] = (real)p[0]; k->walk_target[1] = (real)p[1]; k->walk_target[2] = (real)p[2];
+    k->linear_potential = (real)p[3]; k->angular_potential = (real)p[4]; k->close_count = (int)p[5];
+    k->stop_frames = (real)p[6]; k->done = (int)p[7]; k->t = (int)p[8]; k->episode = (int)p[9];
+    k->draw = (int)p[10]; k->mirrored = (int)p[11]; k->feet_contact[0] = (real)p[12]; k->feet_contact[1] = (real)p[13];
+    k->dist = (real)p[14]; k->angle = (real)p[15]; k->next_step_index = (int)p[16];
+    k->target_reached_count = (int)p[17]; k->stop_on_next_step = (int)p[18]; k->set_stop_on_next_step = (int)p[19];
+    k->curriculum = (int)p[20]; k->applied_gain = (real)p[21]; k->prev_body_x = (real)p[22];
+  }
+}
+API void orc_get_terrain(void *h, double *t) { /* [N][20][6] + plank_info appended per env [3] */
+  Oracle *o = (Oracle *)h;
+  for (int e = 0; e < o->n_envs; ++e) {
+    double *p = t + (size_t)e * (MOCCA_MAX_TERRAIN_STEPS * 6 + MOCCA_MAX_PLANKS);
+    for (int i = 0; i < MOCCA_MAX_TERRAIN_STEPS; ++i)
+      for (int k = 0; k < 6; ++k) p[6 * i + k] = o->ter[e].terrain[i][k];
+    for (int k = 0; k < MOCCA_MAX_PLANKS; ++k) p[MOCCA_MAX_TERRAIN_STEPS * 6 + k] = o->ter[e].plank_info[k];
+  }
+}
+API void orc_set_terrain(void *h, const double *t) {
+  Oracle *o = (Oracle *)h;
+  for (int e = 0; e < o->n_envs; ++e) {
+    const double *p = t + (size_t)e * (MOCCA_MAX_TERRAIN_STEPS * 6 + MOCCA_MAX_PLANKS);
+    for (int i = 0; i < MOCCA_MAX_TERRAIN_STEPS; ++i)
+      for (int k = 0; k < 6; ++k) o->ter[e].terrain[i][k] = (real)p[6 * i + k];
+    for (int k = 0; k < MOCCA_MAX_PLANKS; ++k) o->ter[e].plank_info[k] = (int)p[MOCCA_MAX_TERRAIN_STEPS * 6 + k];
+  }
+}
+
+/* ---- physics-only probes for the invariant tests ---- */
+/* advance env `e` by n substeps with torques tau[nj] (no task logic) */
+API void orc_physics_substeps(void *h, int e, const double *tau, int n) {
+  Oracle *o = (Oracle *)h;
+  real t[MB];
+  t[0] = 0;
+  for (int b = 1; b <= o->m.n_joints; ++b) t[b] = (real)tau[b - 1];
+  for (int k = 0; k < n; ++k) substep(o, &o->dyn[e], &o->task[e], &o->ter[e], t, &o->wk);
+}
+/* forward dynamics at the current state: out = [a_base(6, spatial about base origin); qdd(nj)] */
+API void orc_forward_dynamics(void *h, int e, const double *tau, int with_bias, double *out) {
+  Oracle *o = (Oracle *)h;
+  real t[MB];
+  t[0] = 0;
+  for (int b = 1; b <= o->m.n_joints; ++b) t[b] = (real)tau[b - 1];
+  kinematics(&o->m, &o->dyn[e], &o->wk);
+  aba(&o->m, &o->dyn[e], t, &o->wk, with_bias);
+  for (int k = 0; k < 6; ++k) out[k] = o->wk.acc[0][k];
+  for (int b = 1; b <= o->m.n_joints; ++b) out[5 + b] = o->wk.qdd[b];
+}
+/* out = M^-1 f using the articulated quantities of the last forward dynamics call */
+API void orc_minv_apply(void *h, const double *f, double *out) {
+  Oracle *o = (Oracle *)h;
+  int nd = 6 + o->m.n_joints;
+  real ff[NDOF_MAX], oo[NDOF_MAX];
+  for (int k = 0; k < nd; ++k) ff[k] = (real)f[k];
+  minv_apply(&o->m, &o->wk, ff, oo);
+  for (int k = 0; k < nd; ++k) out[k] = oo[k];
+}
+/* link frames of env e: per body R(9), origin world(3), com world(3) */
+API void orc_link_frames(void *h, int e, double *out) {
+  Oracle *o = (Oracle *)h;
+  kinematics(&o->m, &o->dyn[e], &o->wk);
+  for (int b = 0; b < o->m.n_bodies; ++b) {
+    double *p = out + 15 * b;
+    for (int k = 0; k < 9; ++k) p[k] = o->wk.R[b][k];
+    for (int k = 0; k < 3; ++k) { p[9 + k] = o->wk.r[b][k] + o->dyn[e].pos[k]; p[12 + k] = o->wk.comw[b][k] + o->dyn[e].pos[k]; }
+  }
+}
+/* link spatial velocities about the base origin (after kinematics+aba pass 1): [nb][6] */
+API void orc_link_velocities(void *h, int e, double *out) {
+  Oracle *o = (Oracle *)h;
+  real t[MB];
+  memset(t, 0, sizeof(t));
+  kinematics(&o->m, &o->dyn[e], &o->wk);
+  aba(&o->m, &o->dyn[e], t, &o->wk, 1);
+  for (int b = 0; b < o->m.n_bodies; ++b)
+    for (int k = 0; k < 6; ++k) out[6 * b + k] = o->wk.v[b][k];
+}
+API int orc_last_contacts(void *h, double *out) { /* per contact: a, b, slot, P(3) n(3) depth mu */
+  Oracle *o = (Oracle *)h;
+  for (int i = 0; i < o->wk.nc; ++i) {
+    double *p = out + 11 * i;
+    p[0] = o->wk.c_a[i]; p[1] = o->wk.c_b[i]; p[2] = o->wk.c_slot[i];
+    for (int k = 0; k < 3; ++k) { p[3 + k] = o->wk.c_P[i][k]; p[6 + k] = o->wk.c_n[i][k]; }
+    p[9] = o->wk.c_depth[i]; p[10] = o->wk.c_mu[i];
+  }
+  return o->wk.nc;
+}
+API int orc_last_rows(void *h) { return ((Oracle *)h)->wk.nr; }

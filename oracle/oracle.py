@@ -1,0 +1,197 @@
+"""ctypes binding of the CPU oracle (oracle/mocca_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke(); never by the product package ``mocca_envs_amd``.
+Physics parity with PyBullet is *unpinned* (see the header of mocca_oracle.c).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+TASK_WORDS = 24
+TERRAIN_WORDS = 20 * 6 + 3
+
+
+def build(force: bool = False) -> None:
+    """Compile liboracle_f32.so / liboracle_f64.so with gcc (oracle/Makefile)."""
+    libs = [os.path.join(_HERE, f"liboracle_{p}.so") for p in ("f32", "f64")]
+    src = os.path.join(_HERE, "mocca_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "mocca_model.h")
+    stale = force or any(
+        (not os.path.exists(l)) or os.path.getmtime(l) < max(os.path.getmtime(src), os.path.getmtime(hdr))
+        for l in libs
+    )
+    if stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+def _load(precision: str) -> C.CDLL:
+    path = os.path.join(_HERE, f"liboracle_{precision}.so")
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    lib.orc_create.restype = C.c_void_p
+    lib.orc_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.orc_destroy.argtypes = [C.c_void_p]
+    for name in ("orc_obs_dim", "orc_state_dim", "orc_last_rows"):
+        getattr(lib, name).argtypes = [C.c_void_p]
+        getattr(lib, name).restype = C.c_int
+    lib.orc_set_param.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    lib.orc_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.orc_step.argtypes = [C.c_void_p] * 6
+    for name in ("orc_get_state", "orc_set_state", "orc_get_task", "orc_set_task",
+                 "orc_get_terrain", "orc_set_terrain"):
+        getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_task_step.argtypes = [C.c_void_p] * 8
+    lib.orc_set_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.orc_physics_substeps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    lib.orc_forward_dynamics.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    lib.orc_minv_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_link_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.orc_link_velocities.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.orc_last_contacts.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_last_contacts.restype = C.c_int
+    return lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+PARAM_AUTO_RESET, PARAM_EVAL_MODE, PARAM_CURRICULUM, PARAM_RANDOM_POSE = 0, 1, 2, 3
+
+
+class Oracle:
+    """N independent environments stepped serially on the host."""
+
+    def __init__(self, model_blob: bytes, task_id: int, n_envs: int, precision: str = "f32"):
+        self.lib = _load(precision)
+        self.precision = precision
+        self._blob = C.create_string_buffer(model_blob, len(model_blob))
+        self.h = self.lib.orc_create(self._blob, len(model_blob), task_id, n_envs)
+        if not self.h:
+            raise RuntimeError("orc_create rejected the model blob")
+        self.n_envs = n_envs
+        self.obs_dim = self.lib.orc_obs_dim(self.h)
+        self.state_dim = self.lib.orc_state_dim(self.h)
+        nj = (self.state_dim - 13)
+        self.n_joints = None
+
+    def close(self):
+        if self.h:
+            self.lib.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_param(self, pid: int, v: float):
+        self.lib.orc_set_param(self.h, pid, float(v))
+
+    def reset(self, seed: int = 0, mask: Optional[np.ndarray] = None) -> np.ndarray:
+        obs = np.zeros((self.n_envs, self.obs_dim), np.float32)
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, np.uint8)
+        self.lib.orc_reset(self.h, _p(mask) if mask is not None else None, seed, _p(obs))
+        return obs
+
+    def step(self, act: np.ndarray):
+        act = np.ascontiguousarray(act, np.float32)
+        obs = np.zeros((self.n_envs, self.obs_dim), np.float32)
+        rew = np.zeros(self.n_envs, np.float32)
+        done = np.zeros(self.n_envs, np.uint8)
+        info = np.zeros(self.n_envs, np.int32)
+        self.lib.orc_step(self.h, _p(act), _p(obs), _p(rew), _p(done), _p(info))
+        return obs, rew, done, info
+
+    def task_step(self, act: np.ndarray, touch: np.ndarray, target: Optional[np.ndarray] = None):
+        """Task logic only on the injected post-physics state (golden tests)."""
+        act = np.ascontiguousarray(act, np.float32)
+        touch = np.ascontiguousarray(touch, np.int32).reshape(self.n_envs, 2)
+        target = np.zeros_like(touch) if target is None else np.ascontiguousarray(target, np.int32).reshape(self.n_envs, 2)
+        obs = np.zeros((self.n_envs, self.obs_dim), np.float32)
+        rew = np.zeros(self.n_envs, np.float32)
+        done = np.zeros(self.n_envs, np.uint8)
+        info = np.zeros(self.n_envs, np.int32)
+        self.lib.orc_task_step(self.h, _p(act), _p(touch), _p(target), _p(obs), _p(rew), _p(done), _p(info))
+        return obs, rew, done, info
+
+    def set_tape(self, tape: Optional[np.ndarray]):
+        """Feed the next random draws from `tape` (uniforms in [0,1)) instead of Philox."""
+        if tape is None:
+            self._tape = None
+            self.lib.orc_set_tape(self.h, None, 0)
+        else:
+            self._tape = np.ascontiguousarray(tape, np.float64)
+            self.lib.orc_set_tape(self.h, _p(self._tape), len(self._tape))
+
+    def get_state(self) -> np.ndarray:
+        st = np.zeros((self.n_envs, self.state_dim), np.float64)
+        self.lib.orc_get_state(self.h, _p(st))
+        return st
+
+    def set_state(self, st: np.ndarray):
+        st = np.ascontiguousarray(st, np.float64).reshape(self.n_envs, self.state_dim)
+        self.lib.orc_set_state(self.h, _p(st))
+
+    def get_task(self) -> np.ndarray:
+        t = np.zeros((self.n_envs, TASK_WORDS), np.float64)
+        self.lib.orc_get_task(self.h, _p(t))
+        return t
+
+    def set_task(self, t: np.ndarray):
+        t = np.ascontiguousarray(t, np.float64).reshape(self.n_envs, TASK_WORDS)
+        self.lib.orc_set_task(self.h, _p(t))
+
+    def get_terrain(self) -> np.ndarray:
+        t = np.zeros((self.n_envs, TERRAIN_WORDS), np.float64)
+        self.lib.orc_get_terrain(self.h, _p(t))
+        return t
+
+    def set_terrain(self, t: np.ndarray):
+        t = np.ascontiguousarray(t, np.float64).reshape(self.n_envs, TERRAIN_WORDS)
+        self.lib.orc_set_terrain(self.h, _p(t))
+
+    # ---- physics probes -------------------------------------------------
+    def physics_substeps(self, env: int, tau: np.ndarray, n: int):
+        tau = np.ascontiguousarray(tau, np.float64)
+        self.lib.orc_physics_substeps(self.h, env, _p(tau), n)
+
+    def forward_dynamics(self, env: int, tau: np.ndarray, with_bias: bool = True) -> np.ndarray:
+        tau = np.ascontiguousarray(tau, np.float64)
+        out = np.zeros(6 + len(tau), np.float64)
+        self.lib.orc_forward_dynamics(self.h, env, _p(tau), int(with_bias), _p(out))
+        return out
+
+    def minv_apply(self, f: np.ndarray) -> np.ndarray:
+        f = np.ascontiguousarray(f, np.float64)
+        out = np.zeros_like(f)
+        self.lib.orc_minv_apply(self.h, _p(f), _p(out))
+        return out
+
+    def link_frames(self, env: int, n_bodies: int) -> np.ndarray:
+        out = np.zeros((n_bodies, 15), np.float64)
+        self.lib.orc_link_frames(self.h, env, _p(out))
+        return out
+
+    def link_velocities(self, env: int, n_bodies: int) -> np.ndarray:
+        out = np.zeros((n_bodies, 6), np.float64)
+        self.lib.orc_link_velocities(self.h, env, _p(out))
+        return out
+
+    def last_contacts(self) -> np.ndarray:
+        out = np.zeros((14, 11), np.float64)
+        n = self.lib.orc_last_contacts(self.h, _p(out))
+        return out[:n]
+
+    def last_rows(self) -> int:
+        return self.lib.orc_last_rows(self.h)
