@@ -1,0 +1,134 @@
+"""Oracle task logic vs golden vectors captured from the reference's own Python
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from mocca_envs_amd import model as M
+from oracle.oracle import Oracle, PARAM_EVAL_MODE, PARAM_CURRICULUM
+
+NJ = 21
+
+
+def _full_state(orc, st55):
+    full = np.zeros((1, orc.state_dim))
+    full[0, :55] = st55
+    return full
+
+
+def test_model_constants_match_reference(golden):
+    m = M.compile_walker3d()
+    assert list(golden["joint_names"]) == M.WALKER3D_JOINT_NAMES
+    lo, hi = M.joint_limits(m)
+    np.testing.assert_allclose(lo, golden["joint_lo"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(hi, golden["joint_hi"], rtol=0, atol=1e-6)
+    gains = np.array([m.gain[b] for b in range(1, NJ + 1)])
+    np.testing.assert_array_equal(gains, golden["gains"])
+    init_q = np.array([m.init_q[b] for b in range(1, NJ + 1)])
+    np.testing.assert_allclose(init_q, golden["running_start"], atol=1e-7)
+    np.testing.assert_allclose(list(m.init_pos), golden["base_position"], atol=1e-7)
+    assert m.n_substeps == int(golden["physics_numSubSteps"])
+    assert m.n_iters == int(golden["physics_numSolverIterations"])
+    assert abs(m.dt * m.n_substeps - float(golden["physics_fixedTimeStep"])) < 1e-9
+    assert abs(m.erp - float(golden["physics_erp"])) < 1e-7
+    assert abs(m.gravity + golden["physics_gravity"][2]) < 1e-6
+    assert abs(m.control_dt - float(golden["scene_dt"])) < 1e-9
+    ms = M.compile_walker3d(M.TASK_WALKER3D_STEPPER)
+    np.testing.assert_allclose(list(ms.init_pos), golden["stepper_init_position"], atol=1e-7)
+    assert abs(ms.plank_com_z - golden["plank_pos_offset"][2]) < 1e-7
+
+
+def test_torque_map(golden):
+    """robots.py:31-40: tau = gains * applied_gain * clip(a, -1, 1)."""
+    m = M.compile_walker3d()
+    gains = np.array([m.gain[b] for b in range(1, NJ + 1)], np.float64)
+    for gi, g in enumerate((1.0, 1.2)):
+        want = golden["torque_out"][gi]
+        got = gains * g * np.clip(golden["torque_act"], -1, 1)
+        np.testing.assert_allclose(got, want, rtol=1e-12)
+
+
+@pytest.mark.parametrize("prec,tol", [("f64", 2e-6), ("f32", 2e-5)])
+def test_custom_env_episodes(golden, prec, tol):
+    m = M.compile_walker3d()
+    for ep in range(int(golden["custom_n_episodes"])):
+        g = lambda k: golden[f"custom_ep{ep}_{k}"]
+        orc = Oracle(m.to_bytes(), M.TASK_WALKER3D_CUSTOM, 1, prec)
+        orc.set_param(PARAM_EVAL_MODE, int(g("eval_mode")))
+        orc.set_tape(g("tape"))
+        obs0 = orc.reset(seed=0)
+        st = orc.get_state()[0]
+        np.testing.assert_allclose(st[13:13 + NJ], g("reset_q"), atol=tol, err_msg=f"ep{ep} reset pose")
+        tk = orc.get_task()[0]
+        assert int(tk[11]) == int(g("reset_mirrored"))
+        np.testing.assert_allclose(tk[0:3], g("reset_walk_target"), atol=tol)
+        assert tk[6] == float(g("reset_stop_frames"))
+        # reset obs: the fake client reports zero foot positions at reset, the oracle uses real FK,
+        # so only the entries that do not involve the feet are comparable
+        np.testing.assert_allclose(obs0[0, 1:], g("reset_obs")[1:], atol=10 * tol, err_msg=f"ep{ep} reset obs")
+        states, touch, actions = g("states"), g("touch"), g("actions")
+        for t in range(len(states)):
+            orc.set_state(_full_state(orc, states[t]))
+            o, r, d, _ = orc.task_step(actions[t][None], touch[t][None])
+            want_o = g("obs")[t]
+            fin = np.isfinite(want_o)
+            np.testing.assert_allclose(o[0][fin], want_o[fin], atol=20 * tol, err_msg=f"ep{ep} t{t} obs")
+            assert (d[0] & 1) == int(g("done")[t]), f"ep{ep} t{t} done"
+            if np.isfinite(g("rew")[t]):
+                # progress = d(potential) is a difference of O(300) numbers in fp32
+                np.testing.assert_allclose(r[0], g("rew")[t], atol=2e3 * tol, err_msg=f"ep{ep} t{t} reward")
+            tk = orc.get_task()[0]
+            np.testing.assert_allclose(tk[0:3], g("walk_target")[t], atol=10 * tol, err_msg=f"ep{ep} t{t} target")
+            assert int(tk[5]) == int(g("close_count")[t]), f"ep{ep} t{t} close_count"
+
+
+def test_terrain_generator(golden):
+    """generate_step_placements, env_locomotion.py:395-441, same uniforms in -> same table out."""
+    m = M.compile_walker3d(M.TASK_WALKER3D_STEPPER)
+    for cur in (0, 5, 9):
+        orc = Oracle(m.to_bytes(), M.TASK_WALKER3D_STEPPER, 1, "f64")
+        orc.set_param(PARAM_CURRICULUM, cur)
+        tape = np.concatenate([np.full(22, 0.5), golden[f"terrain_c{cur}_tape"]])  # 22 draws of robot.reset first
+        orc.set_tape(tape)
+        orc.reset(seed=0)
+        table = orc.get_terrain()[0][:120].reshape(20, 6)
+        np.testing.assert_allclose(table, golden[f"terrain_c{cur}_table"], atol=1e-6)
+
+
+@pytest.mark.parametrize("prec,tol", [("f64", 2e-6), ("f32", 3e-5)])
+def test_stepper_env_episodes(golden, prec, tol):
+    m = M.compile_walker3d(M.TASK_WALKER3D_STEPPER)
+    for ep in range(int(golden["stepper_n_episodes"])):
+        g = lambda k: golden[f"stepper_ep{ep}_{k}"]
+        orc = Oracle(m.to_bytes(), M.TASK_WALKER3D_STEPPER, 1, prec)
+        orc.set_param(PARAM_CURRICULUM, int(g("curriculum")))
+        orc.set_tape(g("tape"))
+        obs0 = orc.reset(seed=0)
+        st = orc.get_state()[0]
+        np.testing.assert_allclose(st[13:13 + NJ], g("reset_q"), atol=tol)
+        np.testing.assert_allclose(st[0:3], g("reset_base"), atol=tol)
+        table = orc.get_terrain()[0][:120].reshape(20, 6)
+        np.testing.assert_allclose(table, g("terrain"), atol=10 * tol)
+        tk = orc.get_task()[0]
+        assert abs(tk[21] - float(g("applied_gain"))) < 1e-6
+        np.testing.assert_allclose(obs0[0, 1:], g("reset_obs")[1:], atol=20 * tol)
+        states, touch, target, actions = g("states"), g("touch"), g("target"), g("actions")
+        for t in range(len(states)):
+            orc.set_state(_full_state(orc, states[t]))
+            o, r, d, info = orc.task_step(actions[t][None], touch[t][None], target[t][None])
+            np.testing.assert_allclose(o[0], g("obs")[t], atol=20 * tol, err_msg=f"ep{ep} t{t} obs")
+            assert (d[0] & 1) == int(g("done")[t]), f"ep{ep} t{t} done"
+            np.testing.assert_allclose(r[0], g("rew")[t], atol=2e3 * tol, err_msg=f"ep{ep} t{t} reward")
+            assert int(info[0]) == int(g("next_step_index")[t]), f"ep{ep} t{t} next_step_index"
+            # plank recycling: where the three live planks sit (bullet_objects.py:77-83 offset included)
+            ter = orc.get_terrain()[0]
+            pinfo = ter[120:123].astype(int)
+            want = g("plank_pos")[t] - np.array([0, 0, m.plank_com_z])
+            np.testing.assert_allclose(table[pinfo, 0:3], want, atol=10 * tol, err_msg=f"ep{ep} t{t} planks")
+
+
+def test_mirror_indices(golden):
+    from mocca_envs_amd import envs
+    for name, cls in (("custom", envs.Walker3DCustomEnv), ("stepper", envs.Walker3DStepperEnv)):
+        got = cls.mirror_indices()
+        for k, v in zip(["neg_obs", "right_obs", "left_obs", "neg_act", "right_act", "left_act"], got):
+            np.testing.assert_array_equal(np.asarray(v), golden[f"mirror_{name}_{k}"])
