@@ -1,0 +1,105 @@
+/*
+ * mocca.h -- C ABI of libmocca_hip.so, the MI355X-native replacement for the
+ * pybullet client the reference env owns (`EnvBase._p`,
+ * /root/reference/mocca_envs/env_base.py:55) and for everything the reference
+ * does through it on the env.step()/reset() path.
+ *
+ * There is no FFI seam in the reference (it is pure Python over the pybullet
+ * CPython extension); the seam is introduced here, at the `_p` object.  Each
+ * entry point cites the reference calls it stands in for.
+ *
+ * Conventions
+ *   - every pointer named *_dev is device memory of the GPU the handle was
+ *     created on (e.g. torch tensor .data_ptr()); tensors are caller-owned,
+ *     contiguous, row-major [n_envs][dim].
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued
+ *     asynchronously, no call synchronises the device except the *_host
+ *     helpers and mocca_create/mocca_destroy.
+ *   - return 0 on success, negative MOCCA_E_* otherwise; the message is
+ *     available from mocca_last_error().  Nothing throws across the ABI.
+ *   - a non-finite state is NOT an error: it sets done, as the reference does
+ *     (env_locomotion.py:205-207).
+ *   - a handle is not thread-safe; use one handle per (process, device).
+ */
+#ifndef MOCCA_H
+#define MOCCA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mocca_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOCCA_ABI_VERSION 1
+
+typedef struct mocca_ctx *mocca_handle;
+
+enum {
+  MOCCA_OK = 0,
+  MOCCA_E_ARG = -1,      /* bad argument / blob */
+  MOCCA_E_HIP = -2,      /* HIP runtime error */
+  MOCCA_E_TOPOLOGY = -3, /* blob topology differs from the compiled kernel's */
+  MOCCA_E_NODEVICE = -4,
+};
+
+/* mocca_set_param ids */
+enum {
+  MOCCA_PARAM_AUTO_RESET = 0,  /* vec-env semantics: a done env is reset inside step() and returns the reset obs */
+  MOCCA_PARAM_EVAL_MODE = 1,   /* Walker3DCustomEnv.evaluation_mode(), env_locomotion.py:76-77 */
+  MOCCA_PARAM_CURRICULUM = 2,  /* set_env_params({"curriculum": k}), env_base.py:103-106 (takes effect at reset) */
+  MOCCA_PARAM_RANDOM_POSE = 3, /* robot_random_start, env_locomotion.py:45 */
+};
+
+int mocca_abi_version(void);
+size_t mocca_model_sizeof(void);
+
+/* EnvBase.initialize_scene_and_robot (env_base.py:49-101): BulletClient(DIRECT), scene + physics
+ * parameters, loadMJCF / loadSDF / loadURDF.  `model_blob` is a MoccaModel; `task_id` a MOCCA_TASK_*. */
+int mocca_create(const void *model_blob, size_t nbytes, int task_id, int n_envs, int device, mocca_handle *out);
+/* EnvBase.close (env_base.py:44-47): disconnect. */
+int mocca_destroy(mocca_handle h);
+
+int mocca_n_envs(mocca_handle h);
+int mocca_obs_dim(mocca_handle h);   /* 52 (Custom, env_locomotion.py:58) / 65 (Stepper, :386-393) */
+int mocca_act_dim(mocca_handle h);   /* 21, robots.py:21-23 */
+int mocca_state_dim(mocca_handle h); /* MOCCA_STATE_DIM */
+
+/* env.reset() (env_locomotion.py:79-109 / :481-513) for every env whose mask byte is non-zero
+ * (NULL = all).  Draws come from Philox keyed by (seed, env, episode).  obs_dev: [N][obs_dim] f32;
+ * rows of unmasked envs are left untouched. */
+int mocca_reset(mocca_handle h, const uint8_t *mask_dev, uint64_t seed, float *obs_dev, void *stream);
+
+/* env.step(a) (env_locomotion.py:111-141 / :515-568): apply_action (robots.py:31-40) ->
+ * stepSimulation (bullet_utils.py:352-353) -> calc_state (robots.py:42-95) -> reward/termination.
+ *   act_dev  [N][act_dim] f32 (clipped to [-1,1] inside, robots.py:33)
+ *   obs_dev  [N][obs_dim] f32, rew_dev [N] f32
+ *   done_dev [N] u8: bit0 = terminated (self.done), bit1 = TimeLimit (max_episode_steps, __init__.py:55)
+ *   info_dev [N] i32 or NULL: Stepper "steps_reached" (env_locomotion.py:562-566), 0 for Custom */
+int mocca_step(mocca_handle h, const float *act_dev, float *obs_dev, float *rew_dev, uint8_t *done_dev,
+               int32_t *info_dev, void *stream);
+
+/* In-memory snapshot of the simulation (the role of saveState/restoreState, env_base.py:101): dynamic
+ * state [N][state_dim] f32, task record [N][MOCCA_TASK_WORDS] 32-bit words, terrain [N][128] f32
+ * (Stepper: 20 rows x 6 then the 3 live plank rows as floats). Device pointers. */
+int mocca_get_state(mocca_handle h, float *state_dev, void *stream);
+int mocca_set_state(mocca_handle h, const float *state_dev, void *stream);
+int mocca_get_task(mocca_handle h, uint32_t *task_dev, void *stream);
+int mocca_set_task(mocca_handle h, const uint32_t *task_dev, void *stream);
+int mocca_get_terrain(mocca_handle h, float *terrain_dev, void *stream);
+int mocca_set_terrain(mocca_handle h, const float *terrain_dev, void *stream);
+
+/* set_env_params / evaluation_mode / auto-reset switch (see MOCCA_PARAM_*) */
+int mocca_set_param(mocca_handle h, int param_id, double value);
+
+/* name, registers, LDS and scratch of the step kernel as built (for DESIGN.md / bench) */
+int mocca_kernel_info(mocca_handle h, int *vgprs, int *sgprs, int *lds_bytes, int *scratch_bytes, int *max_blocks_per_cu);
+
+const char *mocca_last_error(mocca_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOCCA_H */

@@ -127,7 +127,8 @@ typedef struct MoccaModel {
   int32_t mirror_neg[2];          /* robots.py:288 */
   int32_t n_mirror_side;
   int32_t n_mirror_neg;
-  int32_t pad_[2];
+  int32_t max_contacts;           /* contacts kept per substep (priority: terrain slots, then self pairs) */
+  int32_t max_rows;               /* constraint rows per substep: limits, then 3 per contact */
 } MoccaModel;
 
 /* ------------------------------------------------------------------------

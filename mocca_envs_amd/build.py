@@ -1,0 +1,41 @@
+"""Build libmocca_hip.so (hand-written HIP for gfx950) in-tree with hipcc."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(HERE, "libmocca_hip.so")
+SOURCES = ["mocca_api.hip"]
+DEPS = ["mocca_api.hip", "mocca_device.h", "topo_walker3d.h"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, d) for d in DEPS] + [os.path.join(INCLUDE, h) for h in ("mocca.h", "mocca_model.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    """hipcc --offload-arch=gfx950 -O3 -shared -fPIC; cross-compiles without a GPU."""
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
+           "-o", LIB] + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_lib(force=True, verbose="-v" in sys.argv)
+    print(LIB)

@@ -1,0 +1,1189 @@
+// mocca_device.h -- device code of the MI355X (gfx950) locomotion stepper.
+//
+// One 64-lane wavefront advances one environment through a whole env.step():
+// 4 physics substeps (articulated-body forward dynamics, collision detection,
+// contact / friction / joint-limit rows, projected Gauss-Seidel, integration)
+// plus observation, reward and termination -- what the reference does through
+//   robots.py:31-40   apply_action            (TORQUE_CONTROL)
+//   bullet_utils.py:352-353 stepSimulation()  (inside the pybullet wheel)
+//   robots.py:42-95   calc_state
+//   env_locomotion.py:111-222 / :515-759      reward, termination, targets
+// The dynamic state is read from HBM once, lives in LDS / VGPRs for the four
+// substeps and is written back once.  No MFMA: the work is a tree recursion over
+// 6-vectors and 6x6 blocks plus a sequential row solver; lanes map to bodies,
+// geoms, contact candidates and constraint rows.
+//
+// Lane roles per phase (see DESIGN.md "Kernel anatomy"):
+//   kinematics walk  lane = body       root->body walk, no cross-lane traffic
+//   ABA inward pass  lane = body of the current tree level (<= 4 busy lanes)
+//   ABA outward pass lane = body       root->body walk
+//   collision        lane = terrain contact slot / self-collision pair (strided)
+//   rows             lane = constraint row: unit-impulse response (O(n) sweep),
+//                    Delassus column in registers, PGS with one readlane per row
+//   integration/obs  lane = joint / obs entry
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mocca_model.h"
+#include "topo_walker3d.h"
+
+#define DI __device__ __forceinline__
+
+namespace mocca {
+
+constexpr int MAXR = 48;  // rows held by one wave (MoccaModel.max_rows must be <= MAXR)
+constexpr int MAXC = 12;  // contacts            (MoccaModel.max_contacts <= MAXC)
+constexpr int DYN_STRIDE = 96;      // floats per env in the dynamic-state buffer
+constexpr int TERRAIN_STRIDE = 128; // floats per env in the terrain buffer
+
+// ---- LDS layout, float offsets (one wave = one env) ----
+enum : int {
+  L_Q = 0,        // [24] q, index = body
+  L_QD = 24,      // [24]
+  L_TAU = 48,     // [24]
+  L_SQ = 72,      // [24] sin q
+  L_CQ = 96,      // [24] cos q
+  L_NU = 120,     // [28] omega(3) v(3) qd(at 5+body)
+  L_BASE = 148,   // [16] pos3 quat4 vel3 omg3
+  L_S = 164,      // [NB][6] joint motion vectors about the base origin, world axes
+  L_U = 296,      // [NB][6] IA S
+  L_INVD = 428,   // [24] 1 / (S.U + armature)
+  L_UU = 452,     // [24] u = tau - S.pA
+  L_A0 = 476,     // [24] IA0^-1 (sym 21) ; [8] base spatial acceleration
+  L_GP = 508,     // [NG][2][3] geom end points rel. base origin (136)
+  L_CT = 644,     // [MAXC][16] contact records (192)
+  L_WARM = 836,   // [40] warm-start impulses per terrain slot
+  L_ROWD = 876,   // [48] compacted limit-row candidates (int)
+  L_FEET = 924,   // [8] feet COM xyz (2x3), pad
+  L_MISC = 932,   // [12] scratch scalars
+  L_T = 944,      // transient region
+  // ABA view of the transient region
+  L_R = L_T,            // [NB][9]
+  L_RR = L_T + 200,     // [NB][3]
+  L_C = L_T + 268,      // [NB][6]
+  L_M = L_T + 400,      // [NB][21] link / articulated inertias (sym)
+  L_P = L_T + 864,      // [NB][6]  bias forces
+  // constraint view
+  L_J = L_T,            // [MAXR][28] Jacobian rows, later M^-1 J^T lambda
+  L_TOTAL = L_T + MAXR * 28,
+};
+static_assert(L_P + 22 * 6 <= L_TOTAL, "ABA view must fit the transient region");
+
+// contact record fields
+enum : int { C_BA = 0, C_BB = 1, C_SLOT = 2, C_P = 3, C_N = 6, C_DEPTH = 9, C_MU = 10, C_ERP = 11, C_CFM = 12 };
+
+// task record words (include/mocca_model.h)
+enum : int { T_WTX = 0, T_WTY, T_WTZ, T_LINPOT, T_ANGPOT, T_CLOSE, T_STOPF, T_DONE, T_T, T_EPISODE, T_DRAW, T_MIRROR,
+             T_FC0, T_FC1, T_DIST, T_ANGLE, T_NSI, T_TRC, T_STOP, T_SETSTOP, T_CUR, T_GAIN, T_PREVX };
+
+struct StepArgs {
+  const MoccaModel* model;
+  float* dyn;        // [N][DYN_STRIDE]
+  uint32_t* task;    // [N][MOCCA_TASK_WORDS]
+  float* terrain;    // [N][TERRAIN_STRIDE] (stepper)
+  const float* act;  // [N][NJ]
+  float* obs;        // [N][obs_dim]
+  float* rew;        // [N]
+  uint8_t* done;     // [N]
+  int32_t* info;     // [N] or null
+  const uint8_t* mask;  // reset only
+  int n_envs;
+  int obs_dim;
+  int auto_reset;
+  int eval_mode;
+  int random_pose;
+  int curriculum;    // applied at reset (stepper)
+  uint32_t seed_lo, seed_hi;
+};
+
+// ------------------------------------------------------------------ helpers
+DI void wsync() {
+  // one wave per env: LDS traffic of a wave is processed in issue order, so a compiler-level
+  // fence is all that is needed between a phase that writes LDS and one that reads other lanes' data
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+DI float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+DI void cross3(const float* a, const float* b, float* o) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+DI float dot6(const float* a, const float* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+DI void matvec3(const float* R, const float* x, float* o) {
+  float a = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
+  float b = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
+  float c = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
+  o[0] = a; o[1] = b; o[2] = c;
+}
+DI void matmul3(const float* A, const float* B, float* C) {
+  float T[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) T[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) C[i] = T[i];
+}
+DI void quat_to_mat(const float* q, float* R) {
+  float x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+DI void crm(const float* v, const float* m, float* o) {  // spatial motion cross product
+  float a[3], b[3], c[3];
+  cross3(v, m, a); cross3(v, m + 3, b); cross3(v + 3, m, c);
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2];
+  o[3] = b[0] + c[0]; o[4] = b[1] + c[1]; o[5] = b[2] + c[2];
+}
+DI void crf(const float* v, const float* f, float* o) {  // spatial force cross product
+  float a[3], b[3], c[3];
+  cross3(v, f, a); cross3(v + 3, f + 3, b); cross3(v, f + 3, c);
+  o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2];
+  o[3] = c[0]; o[4] = c[1]; o[5] = c[2];
+}
+// symmetric 6x6 stored as 21 floats, row-major upper triangle
+DI constexpr int sym(int i, int j) { return i <= j ? i * 6 - i * (i - 1) / 2 + (j - i) : j * 6 - j * (j - 1) / 2 + (i - j); }
+DI void symmv6(const float* A, const float* x, float* o) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float s = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) s += A[sym(i, j)] * x[j];
+    o[i] = s;
+  }
+}
+DI float readlane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+DI int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+DI int lane_rank(unsigned long long mask) {  // number of set bits below this lane
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+DI float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Philox4x32-10; identical to oracle/mocca_oracle.c so device resets are reproducible on the host
+DI void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+DI float rng_uniform(uint32_t slo, uint32_t shi, uint32_t env, uint32_t episode, uint32_t d) {
+  uint32_t o[4];
+  philox4x32(d >> 2, episode, env, 0u, slo, shi, o);
+  uint32_t w = (d & 3) == 0 ? o[0] : (d & 3) == 1 ? o[1] : (d & 3) == 2 ? o[2] : o[3];
+  return (float)(w >> 8) * (1.0f / 16777216.0f);
+}
+
+// ------------------------------------------------------------------ kinematics
+// lane = body.  Walks root -> body composing joint transforms; with FULL also joint motion vectors,
+// spatial velocities, velocity-product accelerations, link inertia and bias force (ABA pass 1).
+template <class T, bool FULL>
+DI void walk_kinematics(const MoccaModel* __restrict__ M, float* L, int lane) {
+  const int b = lane < T::NB ? lane : 0;
+  float R[9], r[3] = {0, 0, 0}, v[6], S[6] = {0, 0, 0, 0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
+  {
+    float q[4] = {L[L_BASE + 3], L[L_BASE + 4], L[L_BASE + 5], L[L_BASE + 6]};
+    quat_to_mat(q, R);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { v[k] = L[L_BASE + 10 + k]; v[3 + k] = L[L_BASE + 7 + k]; }
+  }
+#pragma unroll
+  for (int k = 0; k < T::MAXD; ++k) {
+    const int j = kPathWalker3D[b][k];
+    if (j >= 0) {
+      float jp[3], ax[3], Tm[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { jp[i] = M->jpos[j][i]; ax[i] = M->jaxis[j][i]; }
+      // most hinges carry an identity rest rotation; only test the diagonal, the compiler keeps one branch
+      const float j0 = M->jrot[j][0], j4 = M->jrot[j][4], j8 = M->jrot[j][8];
+      if (j0 == 1.0f && j4 == 1.0f && j8 == 1.0f) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Tm[i] = R[i];
+      } else {
+        float jr[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) jr[i] = M->jrot[j][i];
+        matmul3(R, jr, Tm);
+      }
+      float a[3], off[3], Rq[9];
+      matvec3(Tm, ax, a);
+      const float s = L[L_SQ + j], cq = L[L_CQ + j], t = 1.0f - cq;
+      Rq[0] = cq + t * ax[0] * ax[0];          Rq[1] = t * ax[0] * ax[1] - s * ax[2];   Rq[2] = t * ax[0] * ax[2] + s * ax[1];
+      Rq[3] = t * ax[0] * ax[1] + s * ax[2];   Rq[4] = cq + t * ax[1] * ax[1];          Rq[5] = t * ax[1] * ax[2] - s * ax[0];
+      Rq[6] = t * ax[0] * ax[2] - s * ax[1];   Rq[7] = t * ax[1] * ax[2] + s * ax[0];   Rq[8] = cq + t * ax[2] * ax[2];
+      matvec3(R, jp, off);
+      matmul3(Tm, Rq, R);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) r[i] += off[i];
+      if (FULL) {
+        float ra[3], vJ[6];
+        cross3(r, a, ra);
+        const float qd = L[L_QD + j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { S[i] = a[i]; S[3 + i] = ra[i]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) vJ[i] = S[i] * qd;
+        crm(v, vJ, c);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] += vJ[i];
+      }
+    }
+  }
+  if (lane < T::NB) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) L[L_R + 9 * b + i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) L[L_RR + 3 * b + i] = r[i];
+    float cl[3] = {M->com[b][0], M->com[b][1], M->com[b][2]}, cw[3];
+    matvec3(R, cl, cw);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cw[i] += r[i];
+    // feet COM (getLinkState[0], bullet_utils.py:106) for the observation
+#pragma unroll
+    for (int f = 0; f < MOCCA_MAX_FEET; ++f)
+      if (b == M->foot_body[f]) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) L[L_FEET + 3 * f + i] = cw[i] + L[L_BASE + i];
+      }
+    if (FULL) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { L[L_S + 6 * b + i] = S[i]; L[L_C + 6 * b + i] = c[i]; }
+      // spatial inertia about the base origin, world axes
+      const float ixx = M->inertia[b][0], iyy = M->inertia[b][1], izz = M->inertia[b][2];
+      const float ixy = M->inertia[b][3], ixz = M->inertia[b][4], iyz = M->inertia[b][5];
+      float Il[9] = {ixx, ixy, ixz, ixy, iyy, iyz, ixz, iyz, izz}, Tm[9], Iw[9];
+      matmul3(R, Il, Tm);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int jx = i; jx < 3; ++jx)
+          Iw[3 * i + jx] = Tm[3 * i] * R[3 * jx] + Tm[3 * i + 1] * R[3 * jx + 1] + Tm[3 * i + 2] * R[3 * jx + 2];
+      const float ms = M->mass[b], cc = dot3(cw, cw);
+      float I[21];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int jx = i; jx < 3; ++jx) I[sym(i, jx)] = Iw[3 * i + jx] + ms * ((i == jx ? cc : 0.0f) - cw[i] * cw[jx]);
+      // upper-right block m [c]x
+      I[sym(0, 3)] = 0;           I[sym(0, 4)] = -ms * cw[2]; I[sym(0, 5)] = ms * cw[1];
+      I[sym(1, 3)] = ms * cw[2];  I[sym(1, 4)] = 0;           I[sym(1, 5)] = -ms * cw[0];
+      I[sym(2, 3)] = -ms * cw[1]; I[sym(2, 4)] = ms * cw[0];  I[sym(2, 5)] = 0;
+      I[sym(3, 3)] = ms; I[sym(3, 4)] = 0; I[sym(3, 5)] = 0; I[sym(4, 4)] = ms; I[sym(4, 5)] = 0; I[sym(5, 5)] = ms;
+      float Iv[6], p[6];
+      symmv6(I, v, Iv);
+      crf(v, Iv, p);
+      // gravity through the COM
+      const float fz = -M->gravity * ms;
+      p[0] -= cw[1] * fz; p[1] -= -cw[0] * fz; p[5] -= fz;
+      if (b == 0) {  // base damping [UNVERIFIED-BULLET], see oracle aba()
+        float om[3] = {v[0], v[1], v[2]}, Iom[3];
+        float Iwf[9] = {Iw[0], Iw[1], Iw[2], Iw[1], Iw[4], Iw[5], Iw[2], Iw[5], Iw[8]};
+        matvec3(Iwf, om, Iom);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { p[i] += M->ang_damp * Iom[i]; p[3 + i] += M->lin_damp * ms * v[3 + i]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 21; ++i) L[L_M + 21 * b + i] = I[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) L[L_P + 6 * b + i] = p[i];
+    }
+  }
+}
+
+// 6x6 SPD inverse via Cholesky on symmetric storage; all indices static
+DI void spd6_inverse_sym(const float* A, float* Ainv) {
+  float Lm[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float s = A[sym(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= Lm[j][k] * Lm[j][k];
+    const float d = sqrtf(s), id = 1.0f / d;
+    Lm[j][j] = d;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      float t = A[sym(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= Lm[i][k] * Lm[j][k];
+      Lm[i][j] = t * id;
+    }
+  }
+  float Li[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    Li[j][j] = 1.0f / Lm[j][j];
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      float t = 0;
+#pragma unroll
+      for (int k = j; k < i; ++k) t -= Lm[i][k] * Li[k][j];
+      Li[i][j] = t / Lm[i][i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j) {
+      float t = 0;
+#pragma unroll
+      for (int k = j; k < 6; ++k) t += Li[k][i] * Li[k][j];
+      Ainv[sym(i, j)] = t;
+    }
+}
+
+// ABA inward pass (lane = body of the current level) + base solve + outward pass (lane = body).
+// Leaves S, U, 1/D, u, IA0^-1 in LDS for the row sweeps and the new generalised velocity in L_NU.
+template <class T>
+DI void aba_passes(const MoccaModel* __restrict__ M, float* L, int lane) {
+#pragma unroll 1
+  for (int d = T::MAXD; d >= 1; --d) {
+    const int b = lane < T::MAXW ? (int)kLevelWalker3D[d][lane] : -1;
+    if (b >= 0) {
+      float IA[21], pA[6], S[6], c[6];
+#pragma unroll
+      for (int i = 0; i < 21; ++i) IA[i] = L[L_M + 21 * b + i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { pA[i] = L[L_P + 6 * b + i]; S[i] = L[L_S + 6 * b + i]; c[i] = L[L_C + 6 * b + i]; }
+#pragma unroll
+      for (int k = 0; k < T::MAXCH; ++k) {
+        const int ch = kChildWalker3D[b][k];
+        if (ch >= 0) {
+#pragma unroll
+          for (int i = 0; i < 21; ++i) IA[i] += L[L_M + 21 * ch + i];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) pA[i] += L[L_P + 6 * ch + i];
+        }
+      }
+      float U[6];
+      symmv6(IA, S, U);
+      const float dd = dot6(S, U) + M->jarm[b], id = 1.0f / dd;
+      const float u = L[L_TAU + b] - M->jdamp[b] * L[L_QD + b] - dot6(S, pA);
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) IA[sym(i, j)] -= U[i] * U[j] * id;
+      float Iac[6];
+      symmv6(IA, c, Iac);
+      const float ud = u * id;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pA[i] += Iac[i] + U[i] * ud;
+#pragma unroll
+      for (int i = 0; i < 21; ++i) L[L_M + 21 * b + i] = IA[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { L[L_P + 6 * b + i] = pA[i]; L[L_U + 6 * b + i] = U[i]; }
+      L[L_INVD + b] = id;
+      L[L_UU + b] = u;
+    }
+    wsync();
+  }
+  // base: every lane computes the same 6x6 solve (uniform data, broadcast LDS reads)
+  {
+    float IA[21], pA[6];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) IA[i] = L[L_M + i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pA[i] = L[L_P + i];
+#pragma unroll
+    for (int k = 0; k < T::MAXCH; ++k) {
+      const int ch = kChildWalker3D[0][k];
+      if (ch >= 0) {
+#pragma unroll
+        for (int i = 0; i < 21; ++i) IA[i] += L[L_M + 21 * ch + i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pA[i] += L[L_P + 6 * ch + i];
+      }
+    }
+    float Ai[21], a0[6];
+    spd6_inverse_sym(IA, Ai);
+    symmv6(Ai, pA, a0);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 21; ++i) L[L_A0 + i] = Ai[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) L[L_A0 + 24 + i] = -a0[i];
+    }
+    wsync();
+  }
+  // outward pass: lane = body, walk from the root accumulating the spatial acceleration
+  {
+    const int b = lane < T::NB ? lane : 0;
+    float a[6], qdd = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a[i] = L[L_A0 + 24 + i];
+#pragma unroll
+    for (int k = 0; k < T::MAXD; ++k) {
+      const int j = kPathWalker3D[b][k];
+      if (j >= 0) {
+        float U[6], S[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { a[i] += L[L_C + 6 * j + i]; U[i] = L[L_U + 6 * j + i]; S[i] = L[L_S + 6 * j + i]; }
+        qdd = (L[L_UU + j] - dot6(U, a)) * L[L_INVD + j];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a[i] += S[i] * qdd;
+      }
+    }
+    const float dt = M->dt;
+    if (lane >= 1 && lane < T::NB) L[L_NU + 5 + b] = L[L_QD + b] + dt * qdd;
+    if (lane == 0) {
+      float om[3] = {L[L_BASE + 10], L[L_BASE + 11], L[L_BASE + 12]}, vl[3] = {L[L_BASE + 7], L[L_BASE + 8], L[L_BASE + 9]}, wxv[3];
+      cross3(om, vl, wxv);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        L[L_NU + i] = om[i] + dt * a[i];
+        L[L_NU + 3 + i] = vl[i] + dt * (a[3 + i] + wxv[i]);  // spatial -> classical acceleration of the base origin
+      }
+    }
+    wsync();
+  }
+}
+
+// ------------------------------------------------------------------ collision
+DI void plane_space(const float* n, float* t1, float* t2) {  // btPlaneSpace1
+  if (fabsf(n[2]) > 0.70710678f) {
+    const float a = n[1] * n[1] + n[2] * n[2], k = 1.0f / sqrtf(a);
+    t1[0] = 0; t1[1] = -n[2] * k; t1[2] = n[1] * k;
+    t2[0] = a * k; t2[1] = -n[0] * t1[2]; t2[2] = n[0] * t1[1];
+  } else {
+    const float a = n[0] * n[0] + n[1] * n[1], k = 1.0f / sqrtf(a);
+    t1[0] = -n[1] * k; t1[1] = n[0] * k; t1[2] = 0;
+    t2[0] = -n[2] * t1[1]; t2[1] = n[2] * t1[0]; t2[2] = a * k;
+  }
+}
+DI void euler_to_mat(float roll, float pitch, float yaw, float* R) {
+  const float cr = cosf(roll), sr = sinf(roll), cp = cosf(pitch), sp = sinf(pitch), cy = cosf(yaw), sy = sinf(yaw);
+  R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
+  R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
+  R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
+}
+DI float sphere_box(const float* C, float rad, const float* bc, const float* Rb, const float* h, float* n) {
+  float d[3] = {C[0] - bc[0], C[1] - bc[1], C[2] - bc[2]}, l[3], q[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) l[i] = Rb[i] * d[0] + Rb[3 + i] * d[1] + Rb[6 + i] * d[2];
+  bool inside = true;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    q[i] = l[i];
+    if (q[i] > h[i]) { q[i] = h[i]; inside = false; }
+    if (q[i] < -h[i]) { q[i] = -h[i]; inside = false; }
+  }
+  float nl[3] = {0, 0, 0}, dist;
+  if (!inside) {
+    float e[3] = {l[0] - q[0], l[1] - q[1], l[2] - q[2]};
+    dist = sqrtf(dot3(e, e));
+    const float id = 1.0f / dist;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) nl[i] = e[i] * id;
+  } else {
+    float d0 = h[0] - fabsf(l[0]), d1 = h[1] - fabsf(l[1]), d2 = h[2] - fabsf(l[2]);
+    int best = 0;
+    float bd = d0;
+    if (d1 < bd) { bd = d1; best = 1; }
+    if (d2 < bd) { bd = d2; best = 2; }
+    const float sg = (best == 0 ? l[0] : best == 1 ? l[1] : l[2]) >= 0 ? 1.0f : -1.0f;
+    nl[0] = best == 0 ? sg : 0; nl[1] = best == 1 ? sg : 0; nl[2] = best == 2 ? sg : 0;
+    dist = -bd;
+  }
+  matvec3(Rb, nl, n);
+  return dist - rad;
+}
+DI float clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
+DI void seg_seg(const float* p1, const float* q1, const float* p2, const float* q2, float* c1, float* c2) {
+  float d1[3], d2[3], r[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { d1[k] = q1[k] - p1[k]; d2[k] = q2[k] - p2[k]; r[k] = p1[k] - p2[k]; }
+  const float a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r), EPS = 1e-12f;
+  float s, t;
+  if (a <= EPS && e <= EPS) { s = t = 0; }
+  else if (a <= EPS) { s = 0; t = clamp01(f / e); }
+  else {
+    const float c = dot3(d1, r);
+    if (e <= EPS) { t = 0; s = clamp01(-c / a); }
+    else {
+      const float b = dot3(d1, d2), den = a * e - b * b;
+      s = den > EPS ? clamp01((b * f - c * e) / den) : 0.0f;
+      t = (b * s + f) / e;
+      if (t < 0) { t = 0; s = clamp01(-c / a); }
+      else if (t > 1) { t = 1; s = clamp01((b - c) / a); }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { c1[k] = p1[k] + d1[k] * s; c2[k] = p2[k] + d2[k] * t; }
+}
+
+// world (base-origin relative) end points of every geom: lane = geom end
+template <class T>
+DI void geom_points(const MoccaModel* __restrict__ M, float* L, int lane) {
+  if (lane < 2 * T::NG) {
+    const int g = lane >> 1, e = lane & 1, b = M->g_body[g];
+    float pl[3], R[9], pw[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pl[i] = e ? M->g_p2[g][i] : M->g_p1[g][i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = L[L_R + 9 * b + i];
+    matvec3(R, pl, pw);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) L[L_GP + 3 * lane + i] = pw[i] + L[L_RR + 3 * b + i];
+  }
+}
+
+struct ContactFlags { int touch0, touch1, target0, target1; };
+
+// lane = terrain contact slot, then self-collision pairs strided over the wave.
+// Contacts are compacted in slot order, then pair order (the oracle's priority), up to max_contacts.
+template <class T, int TASK>
+DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, const float* ter, int next_step_index,
+                        int* nc_out) {
+  const float margin = M->contact_margin;
+  ContactFlags fl = {0, 0, 0, 0};
+  const int maxc = M->max_contacts;
+  // ---- terrain: lane -> (geom, end)
+  bool active = false;
+  float n[3] = {0, 0, 1}, P[3] = {0, 0, 0}, gap = 1e30f, mu = 0, erp = M->erp, cfm = 0;
+  int body = -1, slot = lane, is_target = 0;
+  if (lane < T::NSLOT) {
+    // slot -> geom: geoms are few, scan the prefix table
+    int g = 0;
+#pragma unroll 1
+    for (int k = 0; k < T::NG; ++k) if (M->g_slot[k] <= lane) g = k;
+    const int e = lane - M->g_slot[g];
+    if (M->g_terrain[g]) {
+      float C[3], Cw[3];
+      const float rad = M->g_radius[g];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { C[i] = L[L_GP + 3 * (2 * g + e) + i]; Cw[i] = C[i] + L[L_BASE + i]; }
+      body = M->g_body[g];
+      if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
+        gap = Cw[2] - rad;
+        mu = M->ground_friction * M->g_friction[g];
+      } else {
+        const float h[3] = {M->plank_half[0], M->plank_half[1], M->plank_half[2]};
+        const float cz = M->plank_com_z;
+#pragma unroll 1
+        for (int k = 0; k < MOCCA_MAX_PLANKS; ++k) {
+          const int row = (int)ter[120 + k];
+          const float* ti = ter + 6 * row;
+          float Rb[9], bc[3], nn[3];
+          euler_to_mat(ti[4], ti[5], ti[3], Rb);
+          const float dz = -h[2] - cz;
+          bc[0] = ti[0] + Rb[2] * dz; bc[1] = ti[1] + Rb[5] * dz; bc[2] = ti[2] + Rb[8] * dz + cz;
+          const float gk = sphere_box(Cw, rad, bc, Rb, h, nn);
+          if (gk < gap) {
+            gap = gk;
+            n[0] = nn[0]; n[1] = nn[1]; n[2] = nn[2];
+            float d[3] = {Cw[0] - rad * nn[0] - bc[0], Cw[1] - rad * nn[1] - bc[1], Cw[2] - rad * nn[2] - bc[2]};
+            const float lz = Rb[2] * d[0] + Rb[5] * d[1] + Rb[8] * d[2];
+            is_target = (lz >= h[2] * 0.8f) && (k == next_step_index % MOCCA_MAX_PLANKS);
+          }
+        }
+        mu = M->plank_friction * M->g_friction[g];
+        const float kk = M->plank_stiffness, cc = M->plank_damping, dt = M->dt;
+        erp = dt * kk / (dt * kk + cc);
+        cfm = 1.0f / (dt * kk + cc) / dt;
+      }
+      active = gap < margin;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) P[i] = C[i] - rad * n[i];
+    }
+  }
+  unsigned long long am = __ballot(active);
+  {
+    const int f0 = M->foot_body[0], f1 = M->foot_body[1];
+    fl.touch0 = __ballot(active && body == f0) != 0ull;
+    fl.touch1 = __ballot(active && body == f1) != 0ull;
+    fl.target0 = __ballot(active && body == f0 && is_target) != 0ull;
+    fl.target1 = __ballot(active && body == f1 && is_target) != 0ull;
+  }
+  int nc = __popcll(am);
+  {
+    const int idx = lane_rank(am);
+    if (active && idx < maxc) {
+      float* ct = L + L_CT + 16 * idx;
+      ct[C_BA] = __int_as_float(body); ct[C_BB] = __int_as_float(-1); ct[C_SLOT] = __int_as_float(slot);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { ct[C_P + i] = P[i]; ct[C_N + i] = n[i]; }
+      ct[C_DEPTH] = -gap; ct[C_MU] = mu; ct[C_ERP] = erp; ct[C_CFM] = cfm;
+    }
+  }
+  if (nc > maxc) nc = maxc;
+  // ---- self collisions
+  const int npairs = M->n_pairs;
+#pragma unroll 1
+  for (int base = 0; base < npairs; base += 64) {
+    const int k = base + lane;
+    bool hit = false;
+    float nn[3] = {0, 0, 0}, PP[3] = {0, 0, 0}, g2 = 0, mu2 = 0;
+    int ba = -1, bb = -1;
+    if (k < npairs) {
+      const int ga = M->pair_a[k], gb = M->pair_b[k];
+      float a1[3], a2[3], b1[3], b2[3], ca[3], cb[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        a1[i] = L[L_GP + 6 * ga + i]; a2[i] = L[L_GP + 6 * ga + 3 + i];
+        b1[i] = L[L_GP + 6 * gb + i]; b2[i] = L[L_GP + 6 * gb + 3 + i];
+      }
+      seg_seg(a1, a2, b1, b2, ca, cb);
+      float d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
+      const float dist = sqrtf(dot3(d, d)), ra = M->g_radius[ga], rb = M->g_radius[gb];
+      g2 = dist - ra - rb;
+      hit = g2 < margin && dist > 1e-9f;
+      if (hit) {
+        const float id = 1.0f / dist;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          nn[i] = d[i] * id;
+          PP[i] = 0.5f * ((ca[i] - ra * d[i] * id) + (cb[i] + rb * d[i] * id));
+        }
+        ba = M->g_body[ga]; bb = M->g_body[gb];
+        mu2 = M->g_friction[ga] * M->g_friction[gb];
+      }
+    }
+    const unsigned long long hm = __ballot(hit);
+    if (TASK == MOCCA_TASK_WALKER3D_STEPPER) {  // calc_feet_state counts any contact of a foot link
+      const int f0 = M->foot_body[0], f1 = M->foot_body[1];
+      if (__ballot(hit && (ba == f0 || bb == f0)) != 0ull) fl.touch0 = 1;
+      if (__ballot(hit && (ba == f1 || bb == f1)) != 0ull) fl.touch1 = 1;
+    }
+    const int idx = nc + lane_rank(hm);
+    if (hit && idx < maxc) {
+      float* ct = L + L_CT + 16 * idx;
+      ct[C_BA] = __int_as_float(ba); ct[C_BB] = __int_as_float(bb); ct[C_SLOT] = __int_as_float(-1);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { ct[C_P + i] = PP[i]; ct[C_N + i] = nn[i]; }
+      ct[C_DEPTH] = -g2; ct[C_MU] = mu2; ct[C_ERP] = M->erp; ct[C_CFM] = 0.0f;
+    }
+    nc += __popcll(hm);
+    if (nc > maxc) nc = maxc;
+  }
+  *nc_out = nc;
+  return fl;
+}
+
+// ------------------------------------------------------------------ constraint rows + PGS
+// lane = row.  See oracle solve_constraints() for the reference formulation.
+template <class T>
+DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, int nc_found) {
+  const float dt = M->dt, idt = 1.0f / dt;
+  const int maxr = M->max_rows;
+  // ---- joint-limit candidates: lane c -> (body, side)
+  int nl;
+  {
+    bool act = false;
+    if (lane < 2 * T::NJ) {
+      const int b = 1 + (lane >> 1), side = lane & 1;
+      const float q = L[L_Q + b];
+      const float gap = side == 0 ? q - M->jlo[b] : M->jhi[b] - q;
+      const float vel = (side == 0 ? 1.0f : -1.0f) * L[L_NU + 5 + b];
+      act = gap + dt * vel < M->limit_slack;
+    }
+    const unsigned long long lm = __ballot(act);
+    const int rk = lane_rank(lm);
+    if (act && rk < maxr) reinterpret_cast<int*>(L)[L_ROWD + rk] = lane;
+    nl = __popcll(lm);
+    if (nl > maxr) nl = maxr;
+  }
+  int nc = nc_found;
+  if (nc > (maxr - nl) / 3) nc = (maxr - nl) / 3;
+  const int nr = nl + 3 * nc;
+  wsync();
+  // ---- my row
+  const int r = lane;
+  int kind = -1, ba = 0, bb = -1, jl = -1, nrm = -1, slot = -1;
+  float F[6] = {0, 0, 0, 0, 0, 0}, sgn = 0, bias = 0, cfm = 0, lam = 0, mu = 0;
+  if (r < nl) {
+    const int c = reinterpret_cast<int*>(L)[L_ROWD + r];
+    const int b = 1 + (c >> 1), side = c & 1;
+    const float q = L[L_Q + b];
+    const float gap = side == 0 ? q - M->jlo[b] : M->jhi[b] - q;
+    kind = 0; jl = b; ba = b; sgn = side == 0 ? 1.0f : -1.0f;
+    bias = gap < 0 ? M->erp * (-gap) * idt : -gap * idt;
+  } else if (r < nr) {
+    const int k = r - nl;
+    const int i = k < nc ? k : (k - nc) >> 1;
+    const float* ct = L + L_CT + 16 * i;
+    float n[3] = {ct[C_N], ct[C_N + 1], ct[C_N + 2]}, P[3] = {ct[C_P], ct[C_P + 1], ct[C_P + 2]}, dir[3];
+    ba = __float_as_int(ct[C_BA]); bb = __float_as_int(ct[C_BB]);
+    if (k < nc) {
+      kind = 1;
+      dir[0] = n[0]; dir[1] = n[1]; dir[2] = n[2];
+      const float depth = ct[C_DEPTH];
+      bias = depth > 0 ? ct[C_ERP] * depth * idt : depth * idt;
+      cfm = ct[C_CFM];
+      slot = __float_as_int(ct[C_SLOT]);
+      lam = slot >= 0 ? M->warmstart * L[L_WARM + slot] : 0.0f;
+    } else {
+      kind = 2;
+      float t1[3], t2[3];
+      plane_space(n, t1, t2);
+      const bool second = ((k - nc) & 1) != 0;
+#pragma unroll
+      for (int x = 0; x < 3; ++x) dir[x] = second ? t2[x] : t1[x];
+      nrm = nl + i;
+      mu = ct[C_MU];
+    }
+    float pn[3];
+    cross3(P, dir, pn);
+#pragma unroll
+    for (int x = 0; x < 3; ++x) { F[x] = pn[x]; F[3 + x] = dir[x]; }
+  }
+  const unsigned ma = (kind >= 0) ? M->anc_mask[ba] : 0u;
+  const unsigned mb = (kind >= 1 && bb >= 0) ? M->anc_mask[bb] : 0u;
+  const float basesign = (kind >= 1 && bb < 0) ? 1.0f : 0.0f;  // base part of J cancels for self contacts
+
+  // ---- unit response M^-1 J^T (inward sweep along the row's path(s), outward sweep over the tree)
+  float J[T::ND], X[T::ND];  // X: u_b during the inward sweep, then the response
+  float pa[6] = {0, 0, 0, 0, 0, 0}, pb[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int b = T::NB - 1; b >= 1; --b) {
+    const bool ina = (ma >> b) & 1u, inb = (mb >> b) & 1u;
+    float S[6], U[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { S[i] = L[L_S + 6 * b + i]; U[i] = L[L_U + 6 * b + i]; }
+    const float sf = dot6(S, F);
+    float jb = sf * ((ina ? 1.0f : 0.0f) - (inb ? 1.0f : 0.0f));
+    if (b == jl) jb = sgn;
+    float pc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pc[i] = (ina ? pa[i] : 0.0f) + (inb ? pb[i] : 0.0f);
+    const float uu = jb - dot6(S, pc);
+    const float s = uu * L[L_INVD + b];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const float pn = pc[i] + U[i] * s;
+      if (ina) { pa[i] = pn; if (inb) pb[i] = 0.0f; }
+      else if (inb) pb[i] = pn;
+    }
+    J[5 + b] = jb;
+    X[5 + b] = uu;
+  }
+  float a0[6];
+  {
+    float rhs[6], Ai[21];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { J[i] = F[i] * basesign; rhs[i] = J[i] - (pa[i] + pb[i]); }
+#pragma unroll
+    for (int i = 0; i < 21; ++i) Ai[i] = L[L_A0 + i];
+    symmv6(Ai, rhs, a0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) X[i] = a0[i];
+  }
+  {
+    float acc[T::NB][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[0][i] = a0[i];
+#pragma unroll
+    for (int b = 1; b < T::NB; ++b) {
+      constexpr int dummy = 0; (void)dummy;
+      const int p = T::parent(b);
+      float S[6], U[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { S[i] = L[L_S + 6 * b + i]; U[i] = L[L_U + 6 * b + i]; }
+      const float qdd = (X[5 + b] - dot6(U, acc[p])) * L[L_INVD + b];
+      X[5 + b] = qdd;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) acc[b][i] = acc[p][i] + S[i] * qdd;
+    }
+  }
+  // ---- initial row velocity w = J nu
+  float w = 0;
+#pragma unroll
+  for (int d = 0; d < T::ND; ++d) w += J[d] * L[L_NU + d];
+  wsync();  // everyone is done with the ABA view before J overwrites it
+  if (r < nr) {
+#pragma unroll
+    for (int d = 0; d < T::ND; ++d) L[L_J + 28 * r + d] = J[d];
+  }
+  wsync();
+  // ---- Delassus column: A[r'] = J_r' . X (this lane's response), r' uniform
+  float A[MAXR];
+  float diag = 1.0f;
+#pragma unroll
+  for (int rr = 0; rr < MAXR; ++rr) {
+    A[rr] = 0.0f;
+    if (rr < nr) {
+      float s = 0;
+#pragma unroll
+      for (int d = 0; d < T::ND; ++d) s += L[L_J + 28 * rr + d] * X[d];
+      A[rr] = s;
+      if (rr == r) diag = s;
+    }
+  }
+  const float invdiag = 1.0f / (diag + cfm);
+  // warm-start impulses act before the first iteration
+  float lim = 0.0f;  // friction bound mu * lambda_normal, maintained incrementally
+#pragma unroll
+  for (int rr = 0; rr < MAXR; ++rr) {
+    if (rr < nr) {
+      const float l0 = readlane(lam, rr);
+      if (l0 != 0.0f) {
+        w += A[rr] * l0;
+        if (nrm == rr) lim = mu * l0;
+      }
+    }
+  }
+  // ---- projected Gauss-Seidel, rows in lane order (limits, normals, frictions)
+  const int iters = M->n_iters;
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int rr = 0; rr < MAXR; ++rr) {
+      if (rr < nr) {
+        const float lo = kind == 2 ? -lim : 0.0f, hi = kind == 2 ? lim : 1e30f;
+        float nl_ = lam + (bias - w - cfm * lam) * invdiag;
+        nl_ = nl_ < lo ? lo : (nl_ > hi ? hi : nl_);
+        const float dl = readlane(nl_ - lam, rr);
+        const float newl = readlane(nl_, rr);
+        if (r == rr) lam = nl_;
+        if (nrm == rr) lim = mu * newl;
+        w += A[rr] * dl;
+      }
+    }
+  }
+  // ---- apply: nu += sum_r X_r lambda_r, summed in row order through LDS
+  wsync();
+  if (r < nr) {
+#pragma unroll
+    for (int d = 0; d < T::ND; ++d) L[L_J + 28 * r + d] = X[d] * lam;
+  }
+  if (lane < T::NSLOT) L[L_WARM + lane] = 0.0f;
+  wsync();
+  if (kind == 1 && slot >= 0 && r < nr) L[L_WARM + slot] = lam;
+  if (lane < T::ND) {
+    float s = 0;
+#pragma unroll 1
+    for (int rr = 0; rr < nr; ++rr) s += L[L_J + 28 * rr + lane];
+    // body index of generalised coordinate `lane`: nu layout is omega, v, then qd at 5 + body
+    L[L_NU + lane] += s;
+  }
+  wsync();
+}
+
+// ------------------------------------------------------------------ integration
+template <class T>
+DI void integrate(const MoccaModel* __restrict__ M, float* L, int lane) {
+  const float dt = M->dt;
+  if (lane >= 1 && lane < T::NB) {
+    float v = L[L_NU + 5 + lane];
+    const float mx = M->max_qd;
+    v = v > mx ? mx : (v < -mx ? -mx : v);
+    L[L_QD + lane] = v;
+    L[L_Q + lane] += dt * v;
+  }
+  if (lane == 0) {
+    float om[3] = {L[L_NU], L[L_NU + 1], L[L_NU + 2]}, vl[3] = {L[L_NU + 3], L[L_NU + 4], L[L_NU + 5]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { L[L_BASE + 10 + i] = om[i]; L[L_BASE + 7 + i] = vl[i]; L[L_BASE + i] += dt * vl[i]; }
+    const float wn = sqrtf(dot3(om, om)), th = wn * dt;
+    float dq[4];
+    if (th > 1e-8f) {
+      const float sn = sinf(0.5f * th) / wn;
+      dq[0] = om[0] * sn; dq[1] = om[1] * sn; dq[2] = om[2] * sn; dq[3] = cosf(0.5f * th);
+    } else {
+      dq[0] = 0.5f * dt * om[0]; dq[1] = 0.5f * dt * om[1]; dq[2] = 0.5f * dt * om[2]; dq[3] = 1.0f;
+    }
+    const float q0 = L[L_BASE + 3], q1 = L[L_BASE + 4], q2 = L[L_BASE + 5], q3 = L[L_BASE + 6];
+    float nq[4];
+    nq[0] = dq[3] * q0 + dq[0] * q3 + dq[1] * q2 - dq[2] * q1;
+    nq[1] = dq[3] * q1 - dq[0] * q2 + dq[1] * q3 + dq[2] * q0;
+    nq[2] = dq[3] * q2 + dq[0] * q1 - dq[1] * q0 + dq[2] * q3;
+    nq[3] = dq[3] * q3 - dq[0] * q0 - dq[1] * q1 - dq[2] * q2;
+    const float nn = 1.0f / sqrtf(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) L[L_BASE + 3 + i] = nq[i] * nn;
+  }
+  wsync();
+}
+
+DI void sincos_joints(float* L, int lane, int nb) {
+  if (lane >= 1 && lane < nb) {
+    float s, c;
+    sincosf(L[L_Q + lane], &s, &c);
+    L[L_SQ + lane] = s;
+    L[L_CQ + lane] = c;
+  }
+  wsync();
+}
+
+// one physics substep (what stepSimulation does numSubSteps times, bullet_utils.py:346-353)
+template <class T, int TASK>
+DI ContactFlags substep(const MoccaModel* __restrict__ M, float* L, int lane, const float* ter, int next_step_index) {
+  sincos_joints(L, lane, T::NB);
+  walk_kinematics<T, true>(M, L, lane);
+  wsync();
+  geom_points<T>(M, L, lane);
+  wsync();
+  int nc = 0;
+  ContactFlags fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc);
+  aba_passes<T>(M, L, lane);
+  solve_constraints<T>(M, L, lane, nc);
+  integrate<T>(M, L, lane);
+  return fl;
+}
+
+// ------------------------------------------------------------------ task layer
+DI void quat_to_rpy(const float* q, float* rpy) {  // pybullet.getEulerFromQuaternion, bullet_utils.py:84
+  const float x = q[0], y = q[1], z = q[2], w = q[3];
+  const float sarg = -2 * (x * z - w * y);
+  if (sarg <= -0.99999f) { rpy[1] = -1.5707963267948966f; rpy[0] = 0; rpy[2] = 2 * atan2f(x, -y); }
+  else if (sarg >= 0.99999f) { rpy[1] = 1.5707963267948966f; rpy[0] = 0; rpy[2] = 2 * atan2f(-x, y); }
+  else {
+    rpy[0] = atan2f(2 * (y * z + w * x), w * w - x * x - y * y + z * z);
+    rpy[1] = asinf(sarg);
+    rpy[2] = atan2f(2 * (x * y + w * z), w * w + x * x - y * y - z * z);
+  }
+}
+
+struct RobotObs { float rpy[3]; int jal; float spd; float height; bool finite; };
+
+// WalkerBase.calc_state (robots.py:42-95): writes obs[0 .. 6+2NJ+2) ; needs kinematics done (L_FEET).
+// lane j < NJ keeps its scaled joint speed in the return value for the energy term.
+template <class T>
+DI RobotObs robot_obs(const MoccaModel* __restrict__ M, float* L, int lane, float fc0, float fc1, float* obs) {
+  RobotObs ro;
+  float q[4] = {L[L_BASE + 3], L[L_BASE + 4], L[L_BASE + 5], L[L_BASE + 6]};
+  quat_to_rpy(q, ro.rpy);
+  const float yaw = ro.rpy[2], cy = cosf(-yaw), sy = sinf(-yaw);
+  const float vx = cy * L[L_BASE + 7] - sy * L[L_BASE + 8], vy = sy * L[L_BASE + 7] + cy * L[L_BASE + 8], vz = L[L_BASE + 9];
+  const float minz = fminf(L[L_FEET + 2], L[L_FEET + 5]);
+  const float height = L[L_BASE + 2] - minz;
+  auto clip5 = [](float x) { return x > 5.f ? 5.f : (x < -5.f ? -5.f : x); };
+  float nrm = 0, sp = 0;
+  bool fin = true;
+  if (lane < T::NJ) {
+    const int b = lane + 1;
+    const float ang = L[L_Q + b], lo = M->jlo[b], wt = M->jhi[b] - lo;
+    nrm = 2 * (ang - lo) / wt - 1;
+    sp = 0.1f * L[L_QD + b];
+    obs[6 + lane] = clip5(nrm);
+    obs[6 + T::NJ + lane] = clip5(sp);
+    fin = isfinite(nrm) && isfinite(sp);
+  }
+  const float head[6] = {height, vx, vy, vz, ro.rpy[0], ro.rpy[1]};
+  bool hfin = true;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) hfin = hfin && isfinite(head[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) obs[i] = clip5(head[i]);
+    obs[6 + 2 * T::NJ] = fc0;
+    obs[6 + 2 * T::NJ + 1] = fc1;
+  }
+  ro.jal = __popcll(__ballot(lane < T::NJ && fabsf(nrm) > 0.99f));
+  ro.spd = sp;
+  ro.height = clip5(height);
+  ro.finite = (__ballot(!fin) == 0ull) && hfin;
+  return ro;
+}
+
+struct TaskRegs {  // uniform across the wave
+  float wt[3], linpot, angpot, stopf, fc0, fc1, dist, angle, gain, prevx;
+  int close, done, t, episode, draw, mirrored, nsi, trc, stop, setstop, cur;
+};
+DI void load_task(const uint32_t* tk, TaskRegs& t) {
+  auto f = [&](int i) { return __uint_as_float(tk[i]); };
+  t.wt[0] = f(T_WTX); t.wt[1] = f(T_WTY); t.wt[2] = f(T_WTZ); t.linpot = f(T_LINPOT); t.angpot = f(T_ANGPOT);
+  t.close = (int)tk[T_CLOSE]; t.stopf = f(T_STOPF); t.done = (int)tk[T_DONE]; t.t = (int)tk[T_T];
+  t.episode = (int)tk[T_EPISODE]; t.draw = (int)tk[T_DRAW]; t.mirrored = (int)tk[T_MIRROR];
+  t.fc0 = f(T_FC0); t.fc1 = f(T_FC1); t.dist = f(T_DIST); t.angle = f(T_ANGLE);
+  t.nsi = (int)tk[T_NSI]; t.trc = (int)tk[T_TRC]; t.stop = (int)tk[T_STOP]; t.setstop = (int)tk[T_SETSTOP];
+  t.cur = (int)tk[T_CUR]; t.gain = f(T_GAIN); t.prevx = f(T_PREVX);
+}
+DI void store_task(uint32_t* tk, const TaskRegs& t) {
+  auto u = [](float x) { return __float_as_uint(x); };
+  tk[T_WTX] = u(t.wt[0]); tk[T_WTY] = u(t.wt[1]); tk[T_WTZ] = u(t.wt[2]); tk[T_LINPOT] = u(t.linpot); tk[T_ANGPOT] = u(t.angpot);
+  tk[T_CLOSE] = (uint32_t)t.close; tk[T_STOPF] = u(t.stopf); tk[T_DONE] = (uint32_t)t.done; tk[T_T] = (uint32_t)t.t;
+  tk[T_EPISODE] = (uint32_t)t.episode; tk[T_DRAW] = (uint32_t)t.draw; tk[T_MIRROR] = (uint32_t)t.mirrored;
+  tk[T_FC0] = u(t.fc0); tk[T_FC1] = u(t.fc1); tk[T_DIST] = u(t.dist); tk[T_ANGLE] = u(t.angle);
+  tk[T_NSI] = (uint32_t)t.nsi; tk[T_TRC] = (uint32_t)t.trc; tk[T_STOP] = (uint32_t)t.stop; tk[T_SETSTOP] = (uint32_t)t.setstop;
+  tk[T_CUR] = (uint32_t)t.cur; tk[T_GAIN] = u(t.gain); tk[T_PREVX] = u(t.prevx);
+}
+
+// calc_potential, env_locomotion.py:143-158
+DI void calc_potential(const MoccaModel* __restrict__ M, const float* L, TaskRegs& t, float yaw, float* dist, float* ang) {
+  const float dx = t.wt[0] - L[L_BASE], dy = t.wt[1] - L[L_BASE + 1];
+  *ang = atan2f(dy, dx) - yaw;
+  *dist = sqrtf(dx * dx + dy * dy);
+  t.linpot = -(*dist) / M->control_dt;
+  t.angpot = cosf(*ang);
+}
+DI void randomize_target(const StepArgs& a, int env, TaskRegs& t) {  // env_locomotion.py:67-74
+  if (a.eval_mode) { t.dist = 4; t.angle = 0; }
+  else {
+    const float u0 = rng_uniform(a.seed_lo, a.seed_hi, env, t.episode, t.draw);
+    const float u1 = rng_uniform(a.seed_lo, a.seed_hi, env, t.episode, t.draw + 1);
+    t.draw += 2;
+    t.dist = 3 + 2 * u0;
+    t.angle = -1.5707963267948966f + 3.141592653589793f * u1;
+  }
+  const float u2 = rng_uniform(a.seed_lo, a.seed_hi, env, t.episode, t.draw);
+  t.draw += 1;
+  t.stopf = u2 < 0.5f ? 30.0f : 60.0f;
+}
+DI void softsign_tail(float dist, float ang, float* o2) {
+  const float s = dist * sinf(ang), c = dist * cosf(ang);
+  o2[0] = s / (1 + fabsf(s));
+  o2[1] = c / (1 + fabsf(c));
+}
+
+// delta_to_k_targets, env_locomotion.py:712-759 (lane 0 writes the 15 floats; sets walk_target)
+DI void delta_to_k_targets(const float* L, const float* ter, TaskRegs& t, float yaw, int lane, float* out15) {
+  const int N = t.nsi, TT = MOCCA_MAX_TERRAIN_STEPS;
+  int idx[3];
+  if (!t.stop) {
+    idx[0] = N - 1 >= 0 ? N - 1 : 0; idx[1] = N; idx[2] = N + 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) if (idx[i] > TT - 1) idx[i] = TT - 1;
+  } else { idx[0] = N - 1; idx[1] = N; idx[2] = N; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t.wt[i] = ter[6 * idx[2] + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float* tt = ter + 6 * idx[i];
+    const float dx = tt[0] - L[L_BASE], dy = tt[1] - L[L_BASE + 1], dz = tt[2] - L[L_BASE + 2];
+    const float ang = atan2f(dy, dx) - yaw, dist = sqrtf(dx * dx + dy * dy);
+    if (lane == 0) {
+      out15[5 * i + 0] = sinf(ang) * dist;
+      out15[5 * i + 1] = cosf(ang) * dist;
+      out15[5 * i + 2] = dz;
+      out15[5 * i + 3] = tt[4];
+      out15[5 * i + 4] = tt[5];
+    }
+  }
+}
+
+// generate_step_placements, env_locomotion.py:395-441: 100 uniforms (5 x 20) -> 20 x 6 table in `ter`.
+// Lanes draw in parallel (counter-based RNG), lane 0 runs the cumulative sums.
+DI void generate_terrain(const StepArgs& a, int env, TaskRegs& t, float* L, float* ter, int lane) {
+  const float DEG = 3.14159265358979323846f / 180.0f, HP = 1.5707963267948966f;
+  const int N = MOCCA_MAX_TERRAIN_STEPS;
+  const int cur = t.cur > 9 ? 9 : t.cur;
+  const float ratio = (float)cur / 9.0f;
+  float* u = L + L_J;  // scratch
+  for (int k = lane; k < 5 * N; k += 64) u[k] = rng_uniform(a.seed_lo, a.seed_hi, env, t.episode, t.draw + k);
+  t.draw += 5 * N;
+  wsync();
+  if (lane == 0) {
+    const float dist_lo = 0.65f, dist_hi = 0.65f + (1.25f - 0.65f) * cur / 9;
+    const float yaw_lo = -20 * ratio * DEG, yaw_hi = 20 * ratio * DEG;
+    const float pit_lo = -30 * ratio * DEG + HP, pit_hi = 30 * ratio * DEG + HP;
+    const float tl_lo = -15 * ratio * DEG, tl_hi = 15 * ratio * DEG;
+    float x = 0, y = 0, z = 0, phi = 0;
+#pragma unroll 1
+    for (int i = 0; i < N; ++i) {
+      float dr = dist_lo + (dist_hi - dist_lo) * u[i];
+      float dphi = yaw_lo + (yaw_hi - yaw_lo) * u[N + i];
+      float dth = pit_lo + (pit_hi - pit_lo) * u[2 * N + i];
+      float xt = tl_lo + (tl_hi - tl_lo) * u[3 * N + i];
+      float yt = tl_lo + (tl_hi - tl_lo) * u[4 * N + i];
+      if (i == 0) { dr = 0; dphi = 0; dth = HP; }
+      if (i == 1 || i == 2) { dr = 0.75f; dphi = 0; dth = HP; }
+      if (i < 3) { xt = 0; yt = 0; }
+      phi += dphi;
+      float dx = dr * sinf(dth) * cosf(phi);
+      const float dy = dr * sinf(dth) * sinf(phi), dz = dr * cosf(dth);
+      if (i >= 2) {
+        const float ax = fabsf(dx), mx = ax > 0.625f ? ax : 0.625f;
+        const float sg = dx > 0 ? 1.0f : (dx < 0 ? -1.0f : 0.0f);
+        dx = sg * (mx < 1.25f ? mx : 1.25f);
+      }
+      x += dx; y += dy; z += dz;
+      ter[6 * i] = x; ter[6 * i + 1] = y; ter[6 * i + 2] = z; ter[6 * i + 3] = phi; ter[6 * i + 4] = xt; ter[6 * i + 5] = yt;
+    }
+    ter[120] = 0.0f; ter[121] = 1.0f; ter[122] = 2.0f;
+  }
+  wsync();
+}
+
+// env.reset() for one env (lane-parallel); leaves the new state in LDS and writes obs.
+template <class T, int TASK>
+DI void reset_env(const StepArgs& a, const MoccaModel* __restrict__ M, float* L, float* ter, int env, int lane, TaskRegs& t,
+                  float* obs) {
+  const int ep = t.episode + 1, cur = t.cur;
+  t = TaskRegs{};
+  t.episode = ep;
+  t.cur = TASK == MOCCA_TASK_WALKER3D_STEPPER ? a.curriculum : cur;
+  t.gain = 1.0f;
+  if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
+    randomize_target(a, env, t);
+    t.wt[0] = t.dist * cosf(t.angle);
+    t.wt[1] = t.dist * sinf(t.angle);
+    t.wt[2] = 1.0f;
+  } else {
+    t.gain = 1.0f + 0.2f * t.cur / 9;
+  }
+  t.mirrored = rng_uniform(a.seed_lo, a.seed_hi, env, t.episode, t.draw) < 0.5f;
+  t.draw += 1;
+  if (lane >= 1 && lane < T::NB) {
+    const int b = lane;
+    int src = b;  // robots.py:182-188 mirror: swap right/left, negate abdomen z/x
+    float sgn = 1.0f;
+    if (t.mirrored) {
+      const int j = b - 1;
+#pragma unroll 1
+      for (int k = 0; k < M->n_mirror_side; ++k) {
+        if (M->mirror_right[k] == j) src = M->mirror_left[k] + 1;
+        if (M->mirror_left[k] == j) src = M->mirror_right[k] + 1;
+      }
+#pragma unroll 1
+      for (int k = 0; k < M->n_mirror_neg; ++k) if (M->mirror_neg[k] == j) sgn = -1.0f;
+    }
+    const float base = sgn * M->init_q[src];
+    float ds = -0.1f + 0.2f * rng_uniform(a.seed_lo, a.seed_hi, env, t.episode, t.draw + (b - 1));
+    if (!a.random_pose) ds = 0.0f;
+    const float wt = M->jhi[b] - M->jlo[b], bs = M->jlo[b];
+    float ps = 2 * (base + ds - bs) / wt - 1;
+    ps = ps < -0.95f ? -0.95f : (ps > 0.95f ? 0.95f : ps);
+    L[L_Q + b] = wt * (ps + 1) / 2 + bs;
+    L[L_QD + b] = 0.0f;
+  }
+  t.draw += T::NJ;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { L[L_BASE + i] = M->init_pos[i]; L[L_BASE + 7 + i] = 0; L[L_BASE + 10 + i] = 0; }
+    L[L_BASE + 3] = 0; L[L_BASE + 4] = 0; L[L_BASE + 5] = 0; L[L_BASE + 6] = 1.0f;
+  }
+  if (lane < MOCCA_MAX_SLOTS) L[L_WARM + lane] = 0.0f;
+  wsync();
+  sincos_joints(L, lane, T::NB);
+  walk_kinematics<T, false>(M, L, lane);
+  wsync();
+  const int nbo = 6 + 2 * T::NJ + 2;
+  RobotObs ro = robot_obs<T>(M, L, lane, 0.0f, 0.0f, obs);
+  float dist, ang;
+  if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
+    calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+    if (lane == 0) softsign_tail(dist, ang, obs + nbo);
+  } else {
+    generate_terrain(a, env, t, L, ter, lane);
+    t.nsi = 1;
+    delta_to_k_targets(L, ter, t, ro.rpy[2], lane, obs + nbo);
+    calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+  }
+  t.prevx = L[L_BASE];
+}
+
+DI void load_dyn(const float* st, float* L, int lane, int nj, int nslots) {
+  if (lane < 13) L[L_BASE + lane] = st[lane];
+  if (lane < nj) { L[L_Q + 1 + lane] = st[13 + lane]; L[L_QD + 1 + lane] = st[13 + nj + lane]; }
+  if (lane < nslots) L[L_WARM + lane] = st[13 + 2 * nj + lane];
+}
+DI void store_dyn(float* st, const float* L, int lane, int nj, int nslots) {
+  if (lane < 13) st[lane] = L[L_BASE + lane];
+  if (lane < nj) { st[13 + lane] = L[L_Q + 1 + lane]; st[13 + nj + lane] = L[L_QD + 1 + lane]; }
+  if (lane < nslots) st[13 + 2 * nj + lane] = L[L_WARM + lane];
+}
+
+}  // namespace mocca

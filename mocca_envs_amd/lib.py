@@ -1,0 +1,70 @@
+"""ctypes binding of libmocca_hip.so (include/mocca.h).
+
+There is no CPU fallback: if the HIP library is missing or does not load, every
+entry point raises -- the product path is the hand-written gfx950 kernels only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmocca_hip.so")
+
+ABI_VERSION = 1
+PARAM_AUTO_RESET, PARAM_EVAL_MODE, PARAM_CURRICULUM, PARAM_RANDOM_POSE = 0, 1, 2, 3
+
+# every symbol include/mocca.h declares: (name, restype, argtypes)
+_vp, _i, _u64, _sz, _d = C.c_void_p, C.c_int, C.c_uint64, C.c_size_t, C.c_double
+SYMBOLS = {
+    "mocca_abi_version": (_i, []),
+    "mocca_model_sizeof": (_sz, []),
+    "mocca_create": (_i, [_vp, _sz, _i, _i, _i, C.POINTER(_vp)]),
+    "mocca_destroy": (_i, [_vp]),
+    "mocca_n_envs": (_i, [_vp]),
+    "mocca_obs_dim": (_i, [_vp]),
+    "mocca_act_dim": (_i, [_vp]),
+    "mocca_state_dim": (_i, [_vp]),
+    "mocca_reset": (_i, [_vp, _vp, _u64, _vp, _vp]),
+    "mocca_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocca_get_state": (_i, [_vp, _vp, _vp]),
+    "mocca_set_state": (_i, [_vp, _vp, _vp]),
+    "mocca_get_task": (_i, [_vp, _vp, _vp]),
+    "mocca_set_task": (_i, [_vp, _vp, _vp]),
+    "mocca_get_terrain": (_i, [_vp, _vp, _vp]),
+    "mocca_set_terrain": (_i, [_vp, _vp, _vp]),
+    "mocca_set_param": (_i, [_vp, _i, _d]),
+    "mocca_kernel_info": (_i, [_vp] + [C.POINTER(_i)] * 5),
+    "mocca_last_error": (C.c_char_p, [_vp]),
+}
+
+_lib = None
+
+
+class MoccaError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raises (never falls back) when it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MoccaError(
+            f"{LIB_PATH} not found: build it with `python -m mocca_envs_amd.build` "
+            "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.mocca_abi_version() != ABI_VERSION:
+        raise MoccaError("libmocca_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, handle=None) -> None:
+    if rc != 0:
+        msg = load().mocca_last_error(handle)
+        raise MoccaError(f"libmocca_hip error {rc}: {msg.decode() if msg else ''}")

@@ -105,7 +105,8 @@ class MoccaModel(C.Structure):
         ("mirror_neg", C.c_int32 * 2),
         ("n_mirror_side", C.c_int32),
         ("n_mirror_neg", C.c_int32),
-        ("pad_", C.c_int32 * 2),
+        ("max_contacts", C.c_int32),
+        ("max_rows", C.c_int32),
     ]
 
     def to_bytes(self) -> bytes:
@@ -512,6 +513,8 @@ def compile_model(
     # plank_large.urdf boxes 1 x 20 x (0.45 + 0.05) scaled by 2*step_radius = 0.5
     m.plank_half[0], m.plank_half[1], m.plank_half[2] = 0.25, 5.0, 0.125
     m.limit_slack = 0.05
+    m.max_contacts = 12
+    m.max_rows = 48
     m.plank_com_z = -0.275 * 0.5    # plank_large.urdf:8 scaled by 2*step_radius (bullet_objects.py:62,98-103)
 
     for k in range(3):
@@ -579,3 +582,77 @@ def joint_limits(m: MoccaModel) -> Tuple[np.ndarray, np.ndarray]:
     lo = np.array([m.jlo[b] for b in range(1, nj + 1)], dtype=np.float32)
     hi = np.array([m.jhi[b] for b in range(1, nj + 1)], dtype=np.float32)
     return lo, hi
+
+
+# --------------------------------------------------------------------------
+# compile-time topology for the HIP kernels
+# --------------------------------------------------------------------------
+def topology_header(m: MoccaModel, name: str = "Walker3D") -> str:
+    """C++ header with the tree as constexpr tables (mocca_envs_amd/csrc/topo_*.h).
+
+    The step kernel unrolls its sweeps over bodies, so parent/ancestor indices must be
+    compile-time constants (runtime-indexed register arrays would go to scratch).  Every
+    numeric model parameter stays in the runtime blob.
+    """
+    nb = m.n_bodies
+    parent = [m.parent[b] for b in range(nb)]
+    depth = [m.depth[b] for b in range(nb)]
+    maxd = max(depth)
+    children = [[c for c in range(nb) if parent[c] == b] for b in range(nb)]
+    maxc = max(len(c) for c in children)
+    levels = [[b for b in range(nb) if depth[b] == d] for d in range(maxd + 1)]
+    maxw = max(len(l) for l in levels[1:])
+    path = []
+    for b in range(nb):
+        p, cur = [], b
+        while cur > 0:
+            p.append(cur)
+            cur = parent[cur]
+        p = p[::-1]
+        path.append(p + [-1] * (maxd - len(p)))
+
+    def arr(vals):
+        return "{" + ", ".join(str(v) for v in vals) + "}"
+
+    lines = [
+        "// GENERATED by mocca_envs_amd.model.topology_header() -- do not edit.",
+        "// Kinematic tree of %s as compile-time tables (numbers live in the MoccaModel blob)." % name,
+        "#pragma once",
+        "struct Topo%s {" % name,
+        "  static constexpr int NB = %d;        // bodies incl. floating base" % nb,
+        "  static constexpr int NJ = %d;        // hinges" % (nb - 1),
+        "  static constexpr int ND = %d;        // generalised velocities" % (nb + 5),
+        "  static constexpr int MAXD = %d;      // tree depth" % maxd,
+        "  static constexpr int MAXCH = %d;     // children per body" % maxc,
+        "  static constexpr int MAXW = %d;      // bodies per level" % maxw,
+        "  static constexpr int NG = %d;        // geoms" % m.n_geoms,
+        "  static constexpr int NSLOT = %d;     // terrain contact slots" % m.n_slots,
+        "  static constexpr int NPAIR = %d;     // self-collision candidate pairs" % m.n_pairs,
+        "  // constexpr functions (implicitly __host__ __device__ under hipcc) fold after unrolling",
+        "  static constexpr int parent(int b) { constexpr int t[%d] = %s; return t[b]; }" % (nb, arr(parent)),
+        "  static constexpr int depth(int b) { constexpr int t[%d] = %s; return t[b]; }" % (nb, arr(depth)),
+        "  static constexpr unsigned anc_mask(int b) { constexpr unsigned t[%d] = %s; return t[b]; }"
+        % (nb, arr(["0x%xu" % m.anc_mask[b] for b in range(nb)])),
+        "};",
+        "// runtime-indexed copies (per-lane lookups)",
+        "__device__ static const signed char kPath%s[%d][%d] = {" % (name, nb, maxd),
+    ]
+    lines += ["  %s," % arr(p) for p in path]
+    lines += ["};", "__device__ static const signed char kChild%s[%d][%d] = {" % (name, nb, maxc)]
+    # children in DESCENDING order: the oracle accumulates b = nb-1 .. 1 into parent[b]
+    lines += ["  %s," % arr(sorted(c, reverse=True) + [-1] * (maxc - len(c))) for c in children]
+    lines += ["};", "__device__ static const signed char kLevel%s[%d][%d] = {" % (name, maxd + 1, maxw)]
+    lines += ["  %s," % arr((l if d > 0 else []) + [-1] * (maxw - (len(l) if d > 0 else 0))) for d, l in enumerate(levels)]
+    lines += ["};", ""]
+    return "\n".join(lines)
+
+
+def write_topology_headers(outdir: Optional[str] = None) -> None:
+    import os
+    outdir = outdir or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    with open(os.path.join(outdir, "topo_walker3d.h"), "w") as f:
+        f.write(topology_header(compile_walker3d(), "Walker3D"))
+
+
+if __name__ == "__main__":
+    write_topology_headers()

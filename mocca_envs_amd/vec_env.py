@@ -1,0 +1,164 @@
+"""Batched environments on one MI355X: the trainer-facing surface over libmocca_hip.so.
+
+`VecEnv` keeps observations / rewards / done flags in PyTorch-ROCm tensors (device memory
+and the current HIP stream are the only things torch is used for) and advances all N
+environments with one kernel launch per `step()`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from . import model as M
+
+TASKS = {
+    "Walker3DCustomEnv-v0": M.TASK_WALKER3D_CUSTOM,
+    "Walker3DStepperEnv-v0": M.TASK_WALKER3D_STEPPER,
+}
+
+
+class VecEnv:
+    """N independent copies of a registered env id, stepped together.
+
+    step(actions[N, 21]) -> (obs[N, obs_dim], reward[N], done[N] uint8, info[N] int32), all on
+    `device`.  done bit0 = terminated (reference `self.done`), bit1 = TimeLimit (1000 steps,
+    /root/reference/mocca_envs/__init__.py:55).  With auto_reset=True a finished env is reset
+    inside the same launch and `obs` is the first observation of its next episode.
+    """
+
+    def __init__(self, env_id: str = "Walker3DCustomEnv-v0", n_envs: int = 1, device: Optional[int] = None,
+                 auto_reset: bool = True, seed: int = 0, model_blob: Optional[bytes] = None, **model_kw):
+        if env_id not in TASKS:
+            raise KeyError(f"{env_id!r} has no GPU stepper yet; available: {sorted(TASKS)}")
+        if not torch.cuda.is_available():
+            raise _lib.MoccaError("no HIP device visible: the stepper only runs on the GPU (no CPU fallback)")
+        self.lib = _lib.load()
+        self.env_id, self.task_id, self.n_envs = env_id, TASKS[env_id], int(n_envs)
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        if model_blob is None:
+            self.model = M.compile_walker3d(self.task_id, **model_kw)
+            model_blob = self.model.to_bytes()
+        else:
+            self.model = M.MoccaModel.from_bytes(model_blob)
+        if self.lib.mocca_model_sizeof() != len(model_blob):
+            raise _lib.MoccaError("MoccaModel layout mismatch between model.py and libmocca_hip.so")
+        self._blob = C.create_string_buffer(model_blob, len(model_blob))
+        h = C.c_void_p()
+        _lib.check(self.lib.mocca_create(self._blob, len(model_blob), self.task_id, self.n_envs, self.device_index, C.byref(h)))
+        self.h = h
+        self.obs_dim = self.lib.mocca_obs_dim(h)
+        self.act_dim = self.lib.mocca_act_dim(h)
+        self.state_dim = self.lib.mocca_state_dim(h)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.obs = torch.zeros(self.n_envs, self.obs_dim, **f32)
+        self.rew = torch.zeros(self.n_envs, **f32)
+        self.done = torch.zeros(self.n_envs, dtype=torch.uint8, device=self.device)
+        self.info = torch.zeros(self.n_envs, dtype=torch.int32, device=self.device)
+        self.seed_value = int(seed)
+        self.set_param(_lib.PARAM_AUTO_RESET, 1 if auto_reset else 0)
+
+    # ------------------------------------------------------------------
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.mocca_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_param(self, pid: int, value: float):
+        _lib.check(self.lib.mocca_set_param(self.h, pid, float(value)), self.h)
+
+    def seed(self, seed: int):
+        self.seed_value = int(seed)
+        return [seed]
+
+    def reset(self, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        mp = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            mp = C.c_void_p(mask.data_ptr())
+        _lib.check(self.lib.mocca_reset(self.h, mp, self.seed_value, C.c_void_p(self.obs.data_ptr()), self._stream()), self.h)
+        return self.obs
+
+    def step(self, actions: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        if actions.device != self.device or actions.dtype != torch.float32 or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        if actions.shape != (self.n_envs, self.act_dim):
+            raise ValueError(f"actions must be [{self.n_envs}, {self.act_dim}]")
+        _lib.check(self.lib.mocca_step(self.h, C.c_void_p(actions.data_ptr()), C.c_void_p(self.obs.data_ptr()),
+                                       C.c_void_p(self.rew.data_ptr()), C.c_void_p(self.done.data_ptr()),
+                                       C.c_void_p(self.info.data_ptr()), self._stream()), self.h)
+        return self.obs, self.rew, self.done, self.info
+
+    # ---- snapshots (saveState/restoreState role; used by the parity tests) ----
+    def get_state(self) -> torch.Tensor:
+        st = torch.empty(self.n_envs, self.state_dim, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mocca_get_state(self.h, C.c_void_p(st.data_ptr()), self._stream()), self.h)
+        return st
+
+    def set_state(self, st) -> None:
+        st = torch.as_tensor(st, dtype=torch.float32).to(self.device).contiguous().reshape(self.n_envs, self.state_dim)
+        _lib.check(self.lib.mocca_set_state(self.h, C.c_void_p(st.data_ptr()), self._stream()), self.h)
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def get_task(self) -> torch.Tensor:
+        t = torch.empty(self.n_envs, M.TASK_WORDS, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.mocca_get_task(self.h, C.c_void_p(t.data_ptr()), self._stream()), self.h)
+        return t
+
+    def set_task(self, t: torch.Tensor) -> None:
+        t = t.to(device=self.device, dtype=torch.int32).contiguous().reshape(self.n_envs, M.TASK_WORDS)
+        _lib.check(self.lib.mocca_set_task(self.h, C.c_void_p(t.data_ptr()), self._stream()), self.h)
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def get_terrain(self) -> torch.Tensor:
+        t = torch.empty(self.n_envs, 128, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mocca_get_terrain(self.h, C.c_void_p(t.data_ptr()), self._stream()), self.h)
+        return t
+
+    def set_terrain(self, t) -> None:
+        t = torch.as_tensor(t, dtype=torch.float32).to(self.device).contiguous().reshape(self.n_envs, 128)
+        _lib.check(self.lib.mocca_set_terrain(self.h, C.c_void_p(t.data_ptr()), self._stream()), self.h)
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def kernel_info(self) -> dict:
+        v = [C.c_int() for _ in range(5)]
+        _lib.check(self.lib.mocca_kernel_info(self.h, *[C.byref(x) for x in v]), self.h)
+        return dict(vgprs=v[0].value, sgprs=v[1].value, lds_bytes=v[2].value, scratch_bytes=v[3].value,
+                    max_blocks_per_cu=v[4].value)
+
+
+# task-record helpers: the device record is 24 x 32-bit words, floats and ints mixed (mocca_model.h)
+TASK_FLOAT_WORDS = (0, 1, 2, 3, 4, 6, 12, 13, 14, 15, 21, 22)
+
+
+def task_to_float64(t: torch.Tensor) -> np.ndarray:
+    """int32 view of the device task record -> float64 array in the oracle's get_task() layout."""
+    a = t.cpu().numpy().astype(np.int32)
+    out = a.astype(np.float64)
+    fl = a.view(np.float32)
+    for w in TASK_FLOAT_WORDS:
+        out[:, w] = fl[:, w]
+    return out
+
+
+def task_from_float64(a: np.ndarray) -> torch.Tensor:
+    a = np.asarray(a, np.float64)
+    out = a.astype(np.int32)
+    fl = out.view(np.float32)
+    for w in TASK_FLOAT_WORDS:
+        fl[:, w] = a[:, w].astype(np.float32)
+    return torch.from_numpy(out)

@@ -39,7 +39,7 @@ typedef REAL real;
 
 #define MB MOCCA_MAX_BODIES
 #define NDOF_MAX (6 + MB)
-#define MAX_CONTACTS 14
+#define MAX_CONTACTS 16 /* storage; the live caps are MoccaModel.max_contacts / max_rows */
 #define MAX_ROWS 64
 
 #if defined(__GNUC__)
@@ -541,7 +541,7 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
       if (gap < margin) {
         for (int k = 0; k < m->n_feet; ++k)
           if (m->g_body[g] == m->foot_body[k]) { w->foot_touch[k] = 1; if (is_target) w->foot_target[k] = 1; }
-        if (w->nc < MAX_CONTACTS) {
+        if (w->nc < m->max_contacts) {
           int i = w->nc++;
           w->c_a[i] = m->g_body[g]; w->c_b[i] = -1; w->c_slot[i] = m->g_slot[g] + e;
           for (int k = 0; k < 3; ++k) { w->c_n[i][k] = n[k]; w->c_P[i][k] = C[k] - rad * n[k]; }
@@ -560,7 +560,7 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
     real d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
     real dist = sqrt(dot3(d, d)), ra = m->g_radius[ga], rb = m->g_radius[gb];
     real gap = dist - ra - rb;
-    if (gap < margin && w->nc < MAX_CONTACTS && dist > (real)1e-9) {
+    if (gap < margin && w->nc < m->max_contacts && dist > (real)1e-9) {
       int i = w->nc++;
       w->c_a[i] = m->g_body[ga]; w->c_b[i] = m->g_body[gb]; w->c_slot[i] = -1;
       for (int j = 0; j < 3; ++j) {
@@ -607,7 +607,7 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
       real sgn = side == 0 ? 1 : -1;
       real gap = side == 0 ? s->q[b] - (real)m->jlo[b] : (real)m->jhi[b] - s->q[b];
       real vel = sgn * nu[5 + b];
-      if (gap + dt * vel >= (real)m->limit_slack || nr >= MAX_ROWS) continue;
+      if (gap + dt * vel >= (real)m->limit_slack || nr >= m->max_rows) continue;
       int r = nr++;
       for (int k = 0; k < nd; ++k) w->J[r][k] = 0;
       w->J[r][5 + b] = sgn;
@@ -619,7 +619,7 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
   /* --- contact normals, then friction pairs --- */
   int first_normal = nr;
   int nc = w->nc;
-  if (nc > (MAX_ROWS - nr) / 3) nc = (MAX_ROWS - nr) / 3;
+  if (nc > (m->max_rows - nr) / 3) nc = (m->max_rows - nr) / 3;
   for (int i = 0; i < nc; ++i) {
     int r = nr++;
     contact_jacobian(m, w, w->c_a[i], w->c_b[i], w->c_P[i], w->c_n[i], w->J[r]);
@@ -1070,7 +1070,8 @@ API void *orc_create(const void *blob, int nbytes, int task_id, int n_envs) {
   if (nbytes != (int)sizeof(MoccaModel)) return NULL;
   Oracle *o = (Oracle *)calloc(1, sizeof(Oracle));
   memcpy(&o->m, blob, sizeof(MoccaModel));
-  if (o->m.magic != MOCCA_MODEL_MAGIC || o->m.version != MOCCA_MODEL_VERSION) { free(o); return NULL; }
+  if (o->m.magic != MOCCA_MODEL_MAGIC || o->m.version != MOCCA_MODEL_VERSION || o->m.max_contacts > MAX_CONTACTS ||
+      o->m.max_rows > MAX_ROWS) { free(o); return NULL; }
   o->task_id = task_id; o->n_envs = n_envs; o->random_pose = 1;
   o->dyn = (Dyn *)calloc(n_envs, sizeof(Dyn));
   o->task = (Task *)calloc(n_envs, sizeof(Task));
