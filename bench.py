@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of Walker3DCustomEnv-v0 at 4096 envs per MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches one process per GPU with torch.distributed.run; env batches are
+independent shards (no data-path collective; RCCL is only used for the barrier and the MAX of times).
+
+One "step" = one env.step() of all envs of a rank = one launch of the step kernel (4 physics substeps,
+observation, reward, termination, in-kernel auto-reset), inputs resident in HBM.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+ENV_ID = "Walker3DCustomEnv-v0"
+# algorithmic HBM bytes of one env-step (state + task + action in, state + task +
+# obs + reward + done out) for Walker3DCustomEnv, contact warm-start impulses persisted (34 slots)
+ALGO_BYTES_PER_ENV_STEP = 836 + 2 * 34 * 4
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(seconds_target: float = 12.0):
+    """The CPU oracle (a scalar C port of the same algorithm; PyBullet is not installable here) on one host core."""
+    import numpy as np
+    from oracle.oracle import Oracle, PARAM_AUTO_RESET
+    from mocca_envs_amd import model as M
+    m = M.compile_walker3d()
+    n = 16
+    orc = Oracle(m.to_bytes(), M.TASK_WALKER3D_CUSTOM, n, "f32")
+    orc.set_param(PARAM_AUTO_RESET, 1)
+    orc.reset(seed=0)
+    rng = np.random.default_rng(0)
+    tape = rng.uniform(-1, 1, (64, n, 21)).astype(np.float32)
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < seconds_target:
+        for k in range(64):
+            orc.step(tape[k])
+        steps += 64
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} envs x {steps} steps, auto-reset, U(-1,1) actions, f32 C oracle (oracle/mocca_oracle.c)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--env-id", default=ENV_ID)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from mocca_envs_amd.vec_env import VecEnv
+    env = VecEnv(args.env_id, args.envs, device=local_rank, auto_reset=True, seed=1000 + rank)
+    env.reset()
+    g = torch.Generator(device=dev)
+    g.manual_seed(1 + rank)
+    tape = torch.rand(64, args.envs, env.act_dim, device=dev, generator=g) * 2 - 1  # U(-1,1) action tape, looped
+
+    for i in range(args.warmup):
+        env.step(tape[i % 64])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    n_done = torch.zeros((), device=dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev0[i].record()  # same stream the kernel is launched on (torch's current stream)
+        _, _, done, _ = env.step(tape[i % 64])
+        ev1[i].record()
+        n_done += (done != 0).sum()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+
+    if rank == 0:
+        total_envs = args.envs * world
+        value = total_envs * args.steps / elapsed
+        achieved = ALGO_BYTES_PER_ENV_STEP * args.envs / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec, Walker3DCustomEnv-v0 @ 4096 envs, 1/2/4/8 MI355X",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.env_id}, {args.envs} envs/GPU, flat ground, U(-1,1) action tape, auto-reset",
+                       "envs_per_gpu": args.envs, "parallelism": f"independent env shards x{world}, no collective",
+                       "reset_fraction_per_step": float(n_done.item()) / (args.envs * args.steps)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "mocca_step_kernel<0>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * args.envs,
+                         "note": "path is latency/VALU-bound by construction (SURVEY.md 8d); HBM fraction reported per contract"},
+            "kernel_info": env.kernel_info(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
