@@ -80,21 +80,22 @@ def main():
     g.manual_seed(1 + rank)
     tape = torch.rand(64, args.envs, env.act_dim, device=dev, generator=g) * 2 - 1  # U(-1,1) action tape, looped
 
+    n_done = torch.zeros((), device=dev)
     for i in range(args.warmup):
-        env.step(tape[i % 64])
+        _, _, done, _ = env.step(tape[i % 64])
+        n_done += (done != 0).sum()  # reset fraction is sampled during warm-up, outside the timed region
+    reset_frac = float(n_done.item()) / max(1, args.envs * args.warmup)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    n_done = torch.zeros((), device=dev)
+    # HIP events on the stream the kernel is launched on (torch's current stream is the one handed to mocca_step)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for i in range(args.steps):
-        ev0[i].record()  # same stream the kernel is launched on (torch's current stream)
-        _, _, done, _ = env.step(tape[i % 64])
-        ev1[i].record()
-        n_done += (done != 0).sum()
+        env.step(tape[i % 64])
+    ev1.record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -104,7 +105,7 @@ def main():
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+    kern_ms = ev0.elapsed_time(ev1) / args.steps  # back-to-back launches: average launch duration incl. launch gaps
 
     if rank == 0:
         total_envs = args.envs * world
@@ -117,7 +118,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.env_id}, {args.envs} envs/GPU, flat ground, U(-1,1) action tape, auto-reset",
                        "envs_per_gpu": args.envs, "parallelism": f"independent env shards x{world}, no collective",
-                       "reset_fraction_per_step": float(n_done.item()) / (args.envs * args.steps)},
+                       "reset_fraction_per_step": reset_frac},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "mocca_step_kernel<0>", "kernel_ms": kern_ms,

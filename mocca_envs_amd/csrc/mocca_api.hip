@@ -13,7 +13,7 @@
 using namespace mocca;
 
 #ifndef MOCCA_WAVES_PER_EU
-#define MOCCA_WAVES_PER_EU 1
+#define MOCCA_WAVES_PER_EU 4
 #endif
 
 // --------------------------------------------------------------------------------------------

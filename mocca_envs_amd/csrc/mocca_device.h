@@ -39,37 +39,47 @@ constexpr int DYN_STRIDE = 96;      // floats per env in the dynamic-state buffe
 constexpr int TERRAIN_STRIDE = 128; // floats per env in the terrain buffer
 
 // ---- LDS layout, float offsets (one wave = one env) ----
+// [0, L_V)      survives the whole substep (state, torques, new velocity, warm-start impulses)
+// [L_V, end)    one region with two views: the ABA view (joint vectors, articulated inertias, geom points,
+//               contacts) and the solver view (Delassus matrix A[48][48]; Jacobian rows parked in its tail,
+//               row k of J is consumed before row k of A reaches it: 48 k + 47 < 960 + 28 (k + 1) for k <= 47)
 enum : int {
   L_Q = 0,        // [24] q, index = body
   L_QD = 24,      // [24]
   L_TAU = 48,     // [24]
-  L_SQ = 72,      // [24] sin q
-  L_CQ = 96,      // [24] cos q
-  L_NU = 120,     // [28] omega(3) v(3) qd(at 5+body)
-  L_BASE = 148,   // [16] pos3 quat4 vel3 omg3
-  L_S = 164,      // [NB][6] joint motion vectors about the base origin, world axes
-  L_U = 296,      // [NB][6] IA S
-  L_INVD = 428,   // [24] 1 / (S.U + armature)
-  L_UU = 452,     // [24] u = tau - S.pA
-  L_A0 = 476,     // [24] IA0^-1 (sym 21) ; [8] base spatial acceleration
-  L_GP = 508,     // [NG][2][3] geom end points rel. base origin (136)
-  L_CT = 644,     // [MAXC][16] contact records (192)
-  L_WARM = 836,   // [40] warm-start impulses per terrain slot
-  L_ROWD = 876,   // [48] compacted limit-row candidates (int)
-  L_FEET = 924,   // [8] feet COM xyz (2x3), pad
-  L_MISC = 932,   // [12] scratch scalars
-  L_T = 944,      // transient region
-  // ABA view of the transient region
-  L_R = L_T,            // [NB][9]
-  L_RR = L_T + 200,     // [NB][3]
-  L_C = L_T + 268,      // [NB][6]
-  L_M = L_T + 400,      // [NB][21] link / articulated inertias (sym)
-  L_P = L_T + 864,      // [NB][6]  bias forces
-  // constraint view
-  L_J = L_T,            // [MAXR][28] Jacobian rows, later M^-1 J^T lambda
-  L_TOTAL = L_T + MAXR * 28,
+  L_NU = 72,      // [28] omega(3) v(3) qd(at 5+body)
+  L_BASE = 100,   // [16] pos3 quat4 vel3 omg3
+  L_WARM = 116,   // [40] warm-start impulses per terrain slot
+  L_FEET = 156,   // [8] feet COM xyz (2x3)
+  L_MISC = 164,   // [12]
+  L_V = 176,
+  // ---- ABA view
+  L_SQ = L_V + 0,       // [24] sin q
+  L_CQ = L_V + 24,      // [24] cos q
+  L_S = L_V + 48,       // [NB][6] joint motion vectors about the base origin, world axes
+  L_U = L_V + 180,      // [NB][6] IA S
+  L_INVD = L_V + 312,   // [24] 1 / (S.U + armature)
+  L_UU = L_V + 336,     // [24] u = tau - S.pA
+  L_A0 = L_V + 360,     // [24] IA0^-1 (sym 21) ; [8] base spatial acceleration
+  L_GP = L_V + 392,     // [NG][2][3] geom end points rel. base origin (136)
+  L_CT = L_V + 528,     // [MAXC][16] contact records (192)
+  L_ROWD = L_V + 720,   // [48] compacted limit-row candidates (int)
+  L_R = L_V + 768,      // [NB][9]
+  L_RR = L_V + 968,     // [NB][3]
+  L_C = L_V + 1036,     // [NB][6]
+  L_M = L_V + 1168,     // [NB][21] link / articulated inertias (sym)
+  L_P = L_V + 1632,     // [NB][6]  bias forces
+  L_ABA_END = L_V + 1764,
+  // ---- solver view
+  L_A = L_V,            // [MAXR][MAXR] Delassus matrix, row = updated row, column = lane
+  L_J = L_V + 960,      // [MAXR][28] Jacobian rows (tail of the A region)
+  L_XL = L_V,           // [MAXR][28] M^-1 J^T lambda, after the iterations
+  L_TOTAL = L_V + MAXR * MAXR + 28,  // + one dummy J row for lanes that own no row
 };
-static_assert(L_P + 22 * 6 <= L_TOTAL, "ABA view must fit the transient region");
+static_assert(L_ABA_END <= L_TOTAL, "ABA view must fit");
+static_assert(L_J + (MAXR + 1) * 28 <= L_TOTAL, "Jacobian rows (+ dummy) must fit the tail of the A region");
+static_assert(L_J % 4 == 0 && L_V % 4 == 0, "16-byte alignment of broadcast rows");
+static_assert(L_J >= L_R, "J rows may be written while S, U, 1/D, IA0^-1 and the contacts are still being read");
 
 // contact record fields
 enum : int { C_BA = 0, C_BB = 1, C_SLOT = 2, C_P = 3, C_N = 6, C_DEPTH = 9, C_MU = 10, C_ERP = 11, C_CFM = 12 };
@@ -158,6 +168,13 @@ DI void symmv6(const float* A, const float* x, float* o) {
     o[i] = s;
   }
 }
+DI float rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32, 1 ulp
+DI float rsq(float x) { return __builtin_amdgcn_rsqf(x); }      // v_rsq_f32
+// Pin values at a program point.  SelectionDAG linearises un-chained ALU nodes freely inside a basic block, so
+// in the fully unrolled sweeps it postpones each body's arithmetic until every body's LDS loads were issued
+// (all 21 bodies' S/U live: ~270 VGPRs).  An empty volatile asm is chained, which keeps bodies in order.
+DI void pin6(float* v) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5])); }
+DI void pin1(float& v) { asm volatile("" : "+v"(v)); }
 DI float readlane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 DI int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 DI int lane_rank(unsigned long long mask) {  // number of set bits below this lane
@@ -370,7 +387,7 @@ DI void aba_passes(const MoccaModel* __restrict__ M, float* L, int lane) {
       }
       float U[6];
       symmv6(IA, S, U);
-      const float dd = dot6(S, U) + M->jarm[b], id = 1.0f / dd;
+      const float dd = dot6(S, U) + M->jarm[b], id = rcp(dd);
       const float u = L[L_TAU + b] - M->jdamp[b] * L[L_QD + b] - dot6(S, pA);
 #pragma unroll
       for (int i = 0; i < 6; ++i)
@@ -674,11 +691,18 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
 
 // ------------------------------------------------------------------ constraint rows + PGS
 // lane = row.  See oracle solve_constraints() for the reference formulation.
+//   1. limit-row candidates are compacted with a ballot; contacts come from collide()
+//   2. every lane builds its row (force direction, bias, bounds) in registers
+//   3. unit-impulse response X = M^-1 J^T by an inward sweep along the row's path(s) and an outward
+//      sweep over the tree, re-using S, U, 1/D and IA0^-1 of the ABA (unrolled over bodies so the
+//      per-lane arrays stay in VGPRs)
+//   4. Delassus matrix A[r][c] = J_r . X_c: rows of J are broadcast from LDS, lane c keeps X_c
+//   5. projected Gauss-Seidel in row order; per row update one LDS read, one readlane pair
+//   6. nu += sum_r X_r lambda_r, summed in row order through LDS
 template <class T>
 DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, int nc_found) {
-  const float dt = M->dt, idt = 1.0f / dt;
+  const float dt = M->dt, idt = rcp(dt);
   const int maxr = M->max_rows;
-  // ---- joint-limit candidates: lane c -> (body, side)
   int nl;
   {
     bool act = false;
@@ -699,6 +723,11 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
   if (nc > (maxr - nl) / 3) nc = (maxr - nl) / 3;
   const int nr = nl + 3 * nc;
   wsync();
+  if (nr == 0) {  // nothing touches, no limit near: nothing to solve (uniform branch)
+    if (lane < T::NSLOT) L[L_WARM + lane] = 0.0f;
+    wsync();
+    return;
+  }
   // ---- my row
   const int r = lane;
   int kind = -1, ba = 0, bb = -1, jl = -1, nrm = -1, slot = -1;
@@ -743,8 +772,14 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
   const unsigned mb = (kind >= 1 && bb >= 0) ? M->anc_mask[bb] : 0u;
   const float basesign = (kind >= 1 && bb < 0) ? 1.0f : 0.0f;  // base part of J cancels for self contacts
 
-  // ---- unit response M^-1 J^T (inward sweep along the row's path(s), outward sweep over the tree)
-  float J[T::ND], X[T::ND];  // X: u_b during the inward sweep, then the response
+  // ---- unit response X = M^-1 J^T
+  // Jacobian entries go straight to LDS (the J rows sit in the part of the region the ABA no longer
+  // needs: link frames / inertias, not S, U, 1/D, IA0^-1, contacts); w = J nu is accumulated on the fly.
+  float X[T::ND];  // X holds u_b during the inward sweep, then the response
+  float w = 0;
+  // stores are unconditional (idle lanes write unused rows / the dummy row): a branch per body makes the
+  // compiler sink the whole force recursion below the stores and keep all 21 bodies' S/U live (~270 VGPRs)
+  float* Jrow = L + L_J + 28 * (r < MAXR ? r : MAXR);
   float pa[6] = {0, 0, 0, 0, 0, 0}, pb[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int b = T::NB - 1; b >= 1; --b) {
@@ -759,23 +794,34 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
 #pragma unroll
     for (int i = 0; i < 6; ++i) pc[i] = (ina ? pa[i] : 0.0f) + (inb ? pb[i] : 0.0f);
     const float uu = jb - dot6(S, pc);
-    const float s = uu * L[L_INVD + b];
+    const float sc = uu * L[L_INVD + b];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const float pn = pc[i] + U[i] * s;
-      if (ina) { pa[i] = pn; if (inb) pb[i] = 0.0f; }
-      else if (inb) pb[i] = pn;
+      const float pn = pc[i] + U[i] * sc;
+      pa[i] = ina ? pn : pa[i];
+      pb[i] = ina ? (inb ? 0.0f : pb[i]) : (inb ? pn : pb[i]);
     }
-    J[5 + b] = jb;
+    Jrow[5 + b] = jb;
+    w += jb * L[L_NU + 5 + b];
     X[5 + b] = uu;
+    pin6(pa); pin6(pb); pin1(X[5 + b]); pin1(w);
   }
+  // Launder the LDS pointer: otherwise the compiler keeps all 21 bodies' S/U loads of the inward sweep live
+  // for the outward sweep (273 VGPRs); re-reading 13 broadcast floats per body costs far less than the occupancy.
+  const float* L2 = L;
+  asm volatile("" : "+v"(L2));
   float a0[6];
   {
     float rhs[6], Ai[21];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { J[i] = F[i] * basesign; rhs[i] = J[i] - (pa[i] + pb[i]); }
+    for (int i = 0; i < 6; ++i) {
+      const float jb = F[i] * basesign;
+      Jrow[i] = jb;
+      w += jb * L[L_NU + i];
+      rhs[i] = jb - (pa[i] + pb[i]);
+    }
 #pragma unroll
-    for (int i = 0; i < 21; ++i) Ai[i] = L[L_A0 + i];
+    for (int i = 0; i < 21; ++i) Ai[i] = L2[L_A0 + i];
     symmv6(Ai, rhs, a0);
 #pragma unroll
     for (int i = 0; i < 6; ++i) X[i] = a0[i];
@@ -786,77 +832,63 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
     for (int i = 0; i < 6; ++i) acc[0][i] = a0[i];
 #pragma unroll
     for (int b = 1; b < T::NB; ++b) {
-      constexpr int dummy = 0; (void)dummy;
       const int p = T::parent(b);
       float S[6], U[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) { S[i] = L[L_S + 6 * b + i]; U[i] = L[L_U + 6 * b + i]; }
-      const float qdd = (X[5 + b] - dot6(U, acc[p])) * L[L_INVD + b];
+      for (int i = 0; i < 6; ++i) { S[i] = L2[L_S + 6 * b + i]; U[i] = L2[L_U + 6 * b + i]; }
+      const float qdd = (X[5 + b] - dot6(U, acc[p])) * L2[L_INVD + b];
       X[5 + b] = qdd;
 #pragma unroll
       for (int i = 0; i < 6; ++i) acc[b][i] = acc[p][i] + S[i] * qdd;
+      pin6(acc[b]); pin1(X[5 + b]);
     }
   }
-  // ---- initial row velocity w = J nu
-  float w = 0;
-#pragma unroll
-  for (int d = 0; d < T::ND; ++d) w += J[d] * L[L_NU + d];
-  wsync();  // everyone is done with the ABA view before J overwrites it
-  if (r < nr) {
-#pragma unroll
-    for (int d = 0; d < T::ND; ++d) L[L_J + 28 * r + d] = J[d];
-  }
-  wsync();
-  // ---- Delassus column: A[r'] = J_r' . X (this lane's response), r' uniform
-  float A[MAXR];
+  wsync();  // all lanes are done with the ABA view: the A matrix may overwrite it
+  // ---- Delassus matrix: A[rr][lane] = J_rr . X_lane (rows of J broadcast from LDS)
   float diag = 1.0f;
+#pragma unroll 1
+  for (int rr = 0; rr < nr; ++rr) {
+    float s = 0;
 #pragma unroll
-  for (int rr = 0; rr < MAXR; ++rr) {
-    A[rr] = 0.0f;
-    if (rr < nr) {
-      float s = 0;
-#pragma unroll
-      for (int d = 0; d < T::ND; ++d) s += L[L_J + 28 * rr + d] * X[d];
-      A[rr] = s;
-      if (rr == r) diag = s;
-    }
+    for (int d = 0; d < T::ND; ++d) s += L[L_J + 28 * rr + d] * X[d];
+    if (lane < MAXR) L[L_A + MAXR * rr + lane] = s;
+    if (rr == r) diag = s;
   }
-  const float invdiag = 1.0f / (diag + cfm);
-  // warm-start impulses act before the first iteration
+  const float invdiag = rcp(diag + cfm);
+  wsync();
+  // warm-start impulses act before the first iteration (normal rows only)
   float lim = 0.0f;  // friction bound mu * lambda_normal, maintained incrementally
-#pragma unroll
-  for (int rr = 0; rr < MAXR; ++rr) {
-    if (rr < nr) {
-      const float l0 = readlane(lam, rr);
-      if (l0 != 0.0f) {
-        w += A[rr] * l0;
-        if (nrm == rr) lim = mu * l0;
-      }
+#pragma unroll 1
+  for (int rr = nl; rr < nl + nc; ++rr) {
+    const float l0 = readlane(lam, rr);
+    if (l0 != 0.0f) {
+      const float a = lane < MAXR ? L[L_A + MAXR * rr + lane] : 0.0f;
+      w += a * l0;
+      if (nrm == rr) lim = mu * l0;
     }
   }
   // ---- projected Gauss-Seidel, rows in lane order (limits, normals, frictions)
   const int iters = M->n_iters;
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int rr = 0; rr < MAXR; ++rr) {
-      if (rr < nr) {
-        const float lo = kind == 2 ? -lim : 0.0f, hi = kind == 2 ? lim : 1e30f;
-        float nl_ = lam + (bias - w - cfm * lam) * invdiag;
-        nl_ = nl_ < lo ? lo : (nl_ > hi ? hi : nl_);
-        const float dl = readlane(nl_ - lam, rr);
-        const float newl = readlane(nl_, rr);
-        if (r == rr) lam = nl_;
-        if (nrm == rr) lim = mu * newl;
-        w += A[rr] * dl;
-      }
+#pragma unroll 1
+    for (int rr = 0; rr < nr; ++rr) {
+      const float a = lane < MAXR ? L[L_A + MAXR * rr + lane] : 0.0f;
+      const float lo = kind == 2 ? -lim : 0.0f, hi = kind == 2 ? lim : 1e30f;
+      float nl_ = lam + (bias - w - cfm * lam) * invdiag;
+      nl_ = nl_ < lo ? lo : (nl_ > hi ? hi : nl_);
+      const float dl = readlane(nl_ - lam, rr);
+      const float newl = readlane(nl_, rr);
+      if (r == rr) lam = nl_;
+      if (nrm == rr) lim = mu * newl;
+      w += a * dl;
     }
   }
   // ---- apply: nu += sum_r X_r lambda_r, summed in row order through LDS
   wsync();
   if (r < nr) {
 #pragma unroll
-    for (int d = 0; d < T::ND; ++d) L[L_J + 28 * r + d] = X[d] * lam;
+    for (int d = 0; d < T::ND; ++d) L[L_XL + 28 * r + d] = X[d] * lam;
   }
   if (lane < T::NSLOT) L[L_WARM + lane] = 0.0f;
   wsync();
@@ -864,8 +896,7 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
   if (lane < T::ND) {
     float s = 0;
 #pragma unroll 1
-    for (int rr = 0; rr < nr; ++rr) s += L[L_J + 28 * rr + lane];
-    // body index of generalised coordinate `lane`: nu layout is omega, v, then qd at 5 + body
+    for (int rr = 0; rr < nr; ++rr) s += L[L_XL + 28 * rr + lane];
     L[L_NU + lane] += s;
   }
   wsync();
@@ -1071,7 +1102,7 @@ DI void generate_terrain(const StepArgs& a, int env, TaskRegs& t, float* L, floa
   const int N = MOCCA_MAX_TERRAIN_STEPS;
   const int cur = t.cur > 9 ? 9 : t.cur;
   const float ratio = (float)cur / 9.0f;
-  float* u = L + L_J;  // scratch
+  float* u = L + L_J;  // scratch (solver view is idle during a reset)
   for (int k = lane; k < 5 * N; k += 64) u[k] = rng_uniform(a.seed_lo, a.seed_hi, env, t.episode, t.draw + k);
   t.draw += 5 * N;
   wsync();
