@@ -74,7 +74,10 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from mocca_envs_amd.vec_env import VecEnv
-    env = VecEnv(args.env_id, args.envs, device=local_rank, auto_reset=True, seed=1000 + rank)
+    from mocca_envs_amd import sharding
+    lo, hi = sharding.env_range(rank, world, args.envs)
+    # same seed on every rank, draws keyed by the GLOBAL env id: the job's result does not depend on how many GPUs share it
+    env = VecEnv(args.env_id, args.envs, device=local_rank, auto_reset=True, seed=1000, env_offset=lo)
     env.reset()
     g = torch.Generator(device=dev)
     g.manual_seed(1 + rank)
@@ -101,15 +104,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed, dist, dev)
     kern_ms = ev0.elapsed_time(ev1) / args.steps  # back-to-back launches: average launch duration incl. launch gaps
 
     if rank == 0:
         total_envs = args.envs * world
-        value = total_envs * args.steps / elapsed
+        value = sharding.aggregate_throughput(args.envs, world, args.steps, elapsed)
         achieved = ALGO_BYTES_PER_ENV_STEP * args.envs / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "env-steps/sec, Walker3DCustomEnv-v0 @ 4096 envs, 1/2/4/8 MI355X",

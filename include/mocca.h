@@ -51,6 +51,11 @@ enum {
   MOCCA_PARAM_EVAL_MODE = 1,   /* Walker3DCustomEnv.evaluation_mode(), env_locomotion.py:76-77 */
   MOCCA_PARAM_CURRICULUM = 2,  /* set_env_params({"curriculum": k}), env_base.py:103-106 (takes effect at reset) */
   MOCCA_PARAM_RANDOM_POSE = 3, /* robot_random_start, env_locomotion.py:45 */
+  MOCCA_PARAM_HOST_RETARGET = 4, /* Custom env: leave close_count >= stop_frames for the host to re-randomise the
+                                    target (env_locomotion.py:214-222) with ITS RandomState, as the facade does */
+  MOCCA_PARAM_SEED = 5,        /* Philox key used by step() for in-kernel draws (also set by mocca_reset) */
+  MOCCA_PARAM_ENV_OFFSET = 6,  /* global index of this handle's env 0: draws are keyed by (seed, offset + env, episode),
+                                  so a shard of a larger batch reproduces exactly the envs it owns */
 };
 
 int mocca_abi_version(void);
@@ -80,6 +85,12 @@ int mocca_reset(mocca_handle h, const uint8_t *mask_dev, uint64_t seed, float *o
  *   info_dev [N] i32 or NULL: Stepper "steps_reached" (env_locomotion.py:562-566), 0 for Custom */
 int mocca_step(mocca_handle h, const float *act_dev, float *obs_dev, float *rew_dev, uint8_t *done_dev,
                int32_t *info_dev, void *stream);
+
+/* robot.calc_state() + the task's observation tail on the CURRENT state, without stepping
+ * (robots.py:42-95 with env_locomotion.py:102-109 / :712-759).  Used after set_state/set_task, e.g. by the
+ * single-env facade whose reset draws come from a host numpy RandomState like the reference's.
+ * Updates the task record's potentials (calc_potential) and, for the Stepper, walk_target. */
+int mocca_observe(mocca_handle h, float *obs_dev, void *stream);
 
 /* In-memory snapshot of the simulation (the role of saveState/restoreState, env_base.py:101): dynamic
  * state [N][state_dim] f32, task record [N][MOCCA_TASK_WORDS] 32-bit words, terrain [N][128] f32

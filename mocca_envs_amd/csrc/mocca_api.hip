@@ -78,9 +78,9 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     if (tall < 0) t.done = 1;
     float bonus = 0.0f;
     if (dist < 0.15f) { t.close += 1; bonus = 2.0f; }                                  // :198-202
-    if ((float)t.close >= t.stopf) {                                                   // :214-222
+    if ((float)t.close >= t.stopf && !a.host_retarget) {                               // :214-222
       t.close = 0;
-      randomize_target(a, env, t);
+      randomize_target(a, env + a.env_offset, t);
       t.wt[0] += t.dist * cosf(t.angle);
       t.wt[1] += t.dist * sinf(t.angle);
       calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   }
   if (a.auto_reset && dflag) {
     wsync();
-    reset_env<T, TASK>(a, M, L, ter, env, lane, t, obs);
+    reset_env<T, TASK>(a, M, L, ter, env + a.env_offset, lane, t, obs);
   }
   wsync();
   store_dyn(st, L, lane, T::NJ, T::NSLOT);
@@ -177,9 +177,43 @@ __global__ __launch_bounds__(64) void mocca_reset_kernel(StepArgs a) {
   TaskRegs t;
   load_task(tk, t);
   if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
-  reset_env<T, TASK>(a, M, L, ter, env, lane, t, a.obs + (size_t)env * a.obs_dim);
+  reset_env<T, TASK>(a, M, L, ter, env + a.env_offset, lane, t, a.obs + (size_t)env * a.obs_dim);
   wsync();
   store_dyn(st, L, lane, T::NJ, T::NSLOT);
+  if (lane == 0) store_task(tk, t);
+}
+
+// calc_state + observation tail on the stored state (no physics, no randomness)
+template <int TASK>
+__global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
+  using T = TopoWalker3D;
+  __shared__ float L[L_TOTAL];
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= a.n_envs) return;
+  const MoccaModel* __restrict__ M = a.model;
+  const float* st = a.dyn + (size_t)env * DYN_STRIDE;
+  uint32_t* tk = a.task + (size_t)env * MOCCA_TASK_WORDS;
+  const float* ter = TASK == MOCCA_TASK_WALKER3D_STEPPER ? a.terrain + (size_t)env * TERRAIN_STRIDE : nullptr;
+  float* obs = a.obs + (size_t)env * a.obs_dim;
+  load_dyn(st, L, lane, T::NJ, T::NSLOT);
+  TaskRegs t;
+  load_task(tk, t);
+  if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
+  wsync();
+  sincos_joints(L, lane, T::NB);
+  walk_kinematics<T, false>(M, L, lane);
+  wsync();
+  constexpr int NBO = 6 + 2 * T::NJ + 2;
+  RobotObs ro = robot_obs<T>(M, L, lane, t.fc0, t.fc1, obs);
+  float dist, ang;
+  if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
+    calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+    if (lane == 0) softsign_tail(dist, ang, obs + NBO);
+  } else {
+    delta_to_k_targets(L, ter, t, ro.rpy[2], lane, obs + NBO);
+    calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+  }
+  t.prevx = L[L_BASE];
   if (lane == 0) store_task(tk, t);
 }
 
@@ -193,7 +227,7 @@ struct mocca_ctx {
   float* d_dyn = nullptr;
   uint32_t* d_task = nullptr;
   float* d_terrain = nullptr;
-  int auto_reset = 0, eval_mode = 0, random_pose = 1, curriculum = 0;
+  int auto_reset = 0, eval_mode = 0, random_pose = 1, curriculum = 0, host_retarget = 0, env_offset = 0;
   uint64_t seed = 0;
   std::string err;
 };
@@ -315,6 +349,7 @@ static StepArgs make_args(mocca_handle h) {
   a.model = h->d_model; a.dyn = h->d_dyn; a.task = h->d_task; a.terrain = h->d_terrain;
   a.n_envs = h->n_envs; a.obs_dim = h->obs_dim;
   a.auto_reset = h->auto_reset; a.eval_mode = h->eval_mode; a.random_pose = h->random_pose; a.curriculum = h->curriculum;
+  a.host_retarget = h->host_retarget; a.env_offset = h->env_offset;
   a.seed_lo = (uint32_t)h->seed; a.seed_hi = (uint32_t)(h->seed >> 32);
   return a;
 }
@@ -343,6 +378,19 @@ int mocca_step(mocca_handle h, const float* act_dev, float* obs_dev, float* rew_
     hipLaunchKernelGGL(mocca_step_kernel<MOCCA_TASK_WALKER3D_CUSTOM>, dim3(h->n_envs), dim3(64), 0, s, a);
   else
     hipLaunchKernelGGL(mocca_step_kernel<MOCCA_TASK_WALKER3D_STEPPER>, dim3(h->n_envs), dim3(64), 0, s, a);
+  HIP_TRY(h, hipGetLastError());
+  return MOCCA_OK;
+}
+
+int mocca_observe(mocca_handle h, float* obs_dev, void* stream) {
+  if (!h || !obs_dev) return MOCCA_E_ARG;
+  StepArgs a = make_args(h);
+  a.obs = obs_dev;
+  hipStream_t s = (hipStream_t)stream;
+  if (h->task_id == MOCCA_TASK_WALKER3D_CUSTOM)
+    hipLaunchKernelGGL(mocca_observe_kernel<MOCCA_TASK_WALKER3D_CUSTOM>, dim3(h->n_envs), dim3(64), 0, s, a);
+  else
+    hipLaunchKernelGGL(mocca_observe_kernel<MOCCA_TASK_WALKER3D_STEPPER>, dim3(h->n_envs), dim3(64), 0, s, a);
   HIP_TRY(h, hipGetLastError());
   return MOCCA_OK;
 }
@@ -389,6 +437,9 @@ int mocca_set_param(mocca_handle h, int param_id, double value) {
     case MOCCA_PARAM_EVAL_MODE: h->eval_mode = value != 0; break;
     case MOCCA_PARAM_CURRICULUM: h->curriculum = (int)value < 0 ? 0 : ((int)value > 9 ? 9 : (int)value); break;
     case MOCCA_PARAM_RANDOM_POSE: h->random_pose = value != 0; break;
+    case MOCCA_PARAM_HOST_RETARGET: h->host_retarget = value != 0; break;
+    case MOCCA_PARAM_SEED: h->seed = (uint64_t)value; break;
+    case MOCCA_PARAM_ENV_OFFSET: h->env_offset = (int)value; break;
     default: h->err = "unknown parameter id"; return MOCCA_E_ARG;
   }
   return MOCCA_OK;

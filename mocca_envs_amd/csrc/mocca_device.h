@@ -67,9 +67,9 @@ enum : int {
   L_R = L_V + 768,      // [NB][9]
   L_RR = L_V + 968,     // [NB][3]
   L_C = L_V + 1036,     // [NB][6]
-  L_M = L_V + 1168,     // [NB][21] link / articulated inertias (sym)
-  L_P = L_V + 1632,     // [NB][6]  bias forces
-  L_ABA_END = L_V + 1764,
+  L_M = L_V + 1168,     // [NB][36] link / articulated inertias, full 6x6 rows (lane = row in the inward pass)
+  L_P = L_V + 1960,     // [NB][6]  bias forces
+  L_ABA_END = L_V + 2092,
   // ---- solver view
   L_A = L_V,            // [MAXR][MAXR] Delassus matrix, row = updated row, column = lane
   L_J = L_V + 960,      // [MAXR][28] Jacobian rows (tail of the A region)
@@ -105,6 +105,8 @@ struct StepArgs {
   int eval_mode;
   int random_pose;
   int curriculum;    // applied at reset (stepper)
+  int host_retarget; // Custom: the host re-randomises the walk target
+  int env_offset;    // global id of env 0 (RNG key)
   uint32_t seed_lo, seed_hi;
 };
 
@@ -175,6 +177,17 @@ DI float rsq(float x) { return __builtin_amdgcn_rsqf(x); }      // v_rsq_f32
 // (all 21 bodies' S/U live: ~270 VGPRs).  An empty volatile asm is chained, which keeps bodies in order.
 DI void pin6(float* v) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5])); }
 DI void pin1(float& v) { asm volatile("" : "+v"(v)); }
+template <int CTRL>
+DI float dpp_mov(float v) {  // bound_ctrl: lanes without a source read 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over each aligned group of 8 lanes, result in all 8: quad butterfly (quad_perm) then half-row mirror
+DI float group8_sum(float t) {
+  t += dpp_mov<0xB1>(t);   // quad_perm [1,0,3,2]
+  t += dpp_mov<0x4E>(t);   // quad_perm [2,3,0,1]
+  t += dpp_mov<0x141>(t);  // row_half_mirror
+  return t;
+}
 DI float readlane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 DI int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 DI int lane_rank(unsigned long long mask) {  // number of set bits below this lane
@@ -314,23 +327,26 @@ DI void walk_kinematics(const MoccaModel* __restrict__ M, float* L, int lane) {
         for (int i = 0; i < 3; ++i) { p[i] += M->ang_damp * Iom[i]; p[3 + i] += M->lin_damp * ms * v[3 + i]; }
       }
 #pragma unroll
-      for (int i = 0; i < 21; ++i) L[L_M + 21 * b + i] = I[i];
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int jx = 0; jx < 6; ++jx) L[L_M + 36 * b + 6 * i + jx] = I[sym(i, jx)];
 #pragma unroll
       for (int i = 0; i < 6; ++i) L[L_P + 6 * b + i] = p[i];
     }
   }
 }
 
-// 6x6 SPD inverse via Cholesky on symmetric storage; all indices static
+// 6x6 SPD inverse via Cholesky on symmetric storage; all indices static.  v_rsq/v_rcp (1 ulp) instead of
+// IEEE sqrt/div: the 18 divisions would otherwise be a third of the instructions of the whole ABA base solve.
 DI void spd6_inverse_sym(const float* A, float* Ainv) {
-  float Lm[6][6];
+  float Lm[6][6], idg[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     float s = A[sym(j, j)];
 #pragma unroll
     for (int k = 0; k < j; ++k) s -= Lm[j][k] * Lm[j][k];
-    const float d = sqrtf(s), id = 1.0f / d;
-    Lm[j][j] = d;
+    const float id = rsq(s);
+    idg[j] = id;
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       float t = A[sym(i, j)];
@@ -342,13 +358,13 @@ DI void spd6_inverse_sym(const float* A, float* Ainv) {
   float Li[6][6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    Li[j][j] = 1.0f / Lm[j][j];
+    Li[j][j] = idg[j];
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       float t = 0;
 #pragma unroll
       for (int k = j; k < i; ++k) t -= Lm[i][k] * Li[k][j];
-      Li[i][j] = t / Lm[i][i];
+      Li[i][j] = t * idg[i];
     }
   }
 #pragma unroll
@@ -366,44 +382,49 @@ DI void spd6_inverse_sym(const float* A, float* Ainv) {
 // Leaves S, U, 1/D, u, IA0^-1 in LDS for the row sweeps and the new generalised velocity in L_NU.
 template <class T>
 DI void aba_passes(const MoccaModel* __restrict__ M, float* L, int lane) {
+  // ---- inward pass, one tree level at a time.  8 lanes per body (lane i < 6 owns row i of the 6x6
+  // articulated inertia), up to MAXW = 4 bodies per level: ~45 VALU per level instead of ~260 with one
+  // lane per body.  Children are pulled (summed in descending index order, as the oracle does).
+  static_assert(T::MAXW * 8 <= 64, "level does not fit a wave");
 #pragma unroll 1
   for (int d = T::MAXD; d >= 1; --d) {
-    const int b = lane < T::MAXW ? (int)kLevelWalker3D[d][lane] : -1;
-    if (b >= 0) {
-      float IA[21], pA[6], S[6], c[6];
+    const int s = lane >> 3, i = lane & 7;
+    const int b = (s < T::MAXW) ? (int)kLevelWalker3D[d][s] : -1;
+    const bool valid = b >= 0 && i < 6;
+    const int bb = b >= 0 ? b : 0, ii = i < 6 ? i : 0;
+    float row[6], S[6], c[6], pAi;
 #pragma unroll
-      for (int i = 0; i < 21; ++i) IA[i] = L[L_M + 21 * b + i];
+    for (int j = 0; j < 6; ++j) { row[j] = L[L_M + 36 * bb + 6 * ii + j]; S[j] = L[L_S + 6 * bb + j]; c[j] = L[L_C + 6 * bb + j]; }
+    pAi = L[L_P + 6 * bb + ii];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) { pA[i] = L[L_P + 6 * b + i]; S[i] = L[L_S + 6 * b + i]; c[i] = L[L_C + 6 * b + i]; }
+    for (int k = 0; k < T::MAXCH; ++k) {
+      const int ch = kChildWalker3D[bb][k];
+      if (ch >= 0) {
 #pragma unroll
-      for (int k = 0; k < T::MAXCH; ++k) {
-        const int ch = kChildWalker3D[b][k];
-        if (ch >= 0) {
-#pragma unroll
-          for (int i = 0; i < 21; ++i) IA[i] += L[L_M + 21 * ch + i];
-#pragma unroll
-          for (int i = 0; i < 6; ++i) pA[i] += L[L_P + 6 * ch + i];
-        }
+        for (int j = 0; j < 6; ++j) row[j] += L[L_M + 36 * ch + 6 * ii + j];
+        pAi += L[L_P + 6 * ch + ii];
       }
-      float U[6];
-      symmv6(IA, S, U);
-      const float dd = dot6(S, U) + M->jarm[b], id = rcp(dd);
-      const float u = L[L_TAU + b] - M->jdamp[b] * L[L_QD + b] - dot6(S, pA);
+    }
+    const float Si = i == 0 ? S[0] : i == 1 ? S[1] : i == 2 ? S[2] : i == 3 ? S[3] : i == 4 ? S[4] : S[5];
+    const float Ui = dot6(row, S);
+    const float dsum = group8_sum(valid ? Si * Ui : 0.0f);
+    const float psum = group8_sum(valid ? Si * pAi : 0.0f);
+    const float id = rcp(dsum + M->jarm[bb]);
+    const float u = L[L_TAU + bb] - M->jdamp[bb] * L[L_QD + bb] - psum;
+    if (valid) L[L_U + 6 * bb + ii] = Ui;
+    wsync();
+    float U[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) U[j] = L[L_U + 6 * bb + j];
+    const float uid = Ui * id;
+    float Iac = 0.0f;
 #pragma unroll
-        for (int j = i; j < 6; ++j) IA[sym(i, j)] -= U[i] * U[j] * id;
-      float Iac[6];
-      symmv6(IA, c, Iac);
-      const float ud = u * id;
+    for (int j = 0; j < 6; ++j) { row[j] -= uid * U[j]; Iac += row[j] * c[j]; }
+    if (valid) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) pA[i] += Iac[i] + U[i] * ud;
-#pragma unroll
-      for (int i = 0; i < 21; ++i) L[L_M + 21 * b + i] = IA[i];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { L[L_P + 6 * b + i] = pA[i]; L[L_U + 6 * b + i] = U[i]; }
-      L[L_INVD + b] = id;
-      L[L_UU + b] = u;
+      for (int j = 0; j < 6; ++j) L[L_M + 36 * bb + 6 * ii + j] = row[j];
+      L[L_P + 6 * bb + ii] = pAi + Iac + uid * u;
+      if (i == 0) { L[L_INVD + bb] = id; L[L_UU + bb] = u; }
     }
     wsync();
   }
@@ -411,7 +432,9 @@ DI void aba_passes(const MoccaModel* __restrict__ M, float* L, int lane) {
   {
     float IA[21], pA[6];
 #pragma unroll
-    for (int i = 0; i < 21; ++i) IA[i] = L[L_M + i];
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) IA[sym(i, j)] = L[L_M + 6 * i + j];
 #pragma unroll
     for (int i = 0; i < 6; ++i) pA[i] = L[L_P + i];
 #pragma unroll
@@ -419,7 +442,9 @@ DI void aba_passes(const MoccaModel* __restrict__ M, float* L, int lane) {
       const int ch = kChildWalker3D[0][k];
       if (ch >= 0) {
 #pragma unroll
-        for (int i = 0; i < 21; ++i) IA[i] += L[L_M + 21 * ch + i];
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = i; j < 6; ++j) IA[sym(i, j)] += L[L_M + 36 * ch + 6 * i + j];
 #pragma unroll
         for (int i = 0; i < 6; ++i) pA[i] += L[L_P + 6 * ch + i];
       }
@@ -644,14 +669,26 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
     bool hit = false;
     float nn[3] = {0, 0, 0}, PP[3] = {0, 0, 0}, g2 = 0, mu2 = 0;
     int ba = -1, bb = -1;
+    int ga = 0, gb = 0;
+    float a1[3], a2[3], b1[3], b2[3];
+    bool near = false;
     if (k < npairs) {
-      const int ga = M->pair_a[k], gb = M->pair_b[k];
-      float a1[3], a2[3], b1[3], b2[3], ca[3], cb[3];
+      ga = M->pair_a[k]; gb = M->pair_b[k];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         a1[i] = L[L_GP + 6 * ga + i]; a2[i] = L[L_GP + 6 * ga + 3 + i];
         b1[i] = L[L_GP + 6 * gb + i]; b2[i] = L[L_GP + 6 * gb + 3 + i];
       }
+      // broad phase (conservative): bounding spheres around the segment midpoints
+      float dm[3], ha[3], hb[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { dm[i] = 0.5f * ((a1[i] + a2[i]) - (b1[i] + b2[i])); ha[i] = 0.5f * (a2[i] - a1[i]); hb[i] = 0.5f * (b2[i] - b1[i]); }
+      const float reach = sqrtf(dot3(ha, ha)) + sqrtf(dot3(hb, hb)) + M->g_radius[ga] + M->g_radius[gb] + margin;
+      near = dot3(dm, dm) < reach * reach;
+    }
+    if (__ballot(near) == 0ull) continue;  // wave-uniform: nothing close in this batch of 64 pairs
+    if (near) {
+      float ca[3], cb[3];
       seg_seg(a1, a2, b1, b2, ca, cb);
       float d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
       const float dist = sqrtf(dot3(d, d)), ra = M->g_radius[ga], rb = M->g_radius[gb];
@@ -781,8 +818,18 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
   // compiler sink the whole force recursion below the stores and keep all 21 bodies' S/U live (~270 VGPRs)
   float* Jrow = L + L_J + 28 * (r < MAXR ? r : MAXR);
   float pa[6] = {0, 0, 0, 0, 0, 0}, pb[6] = {0, 0, 0, 0, 0, 0};
+  // bodies on no row's path (typically the arms) have zero Jacobian entries and carry no force: skip them
+  unsigned anymask = ma | mb;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) anymask |= (unsigned)__shfl_xor((int)anymask, o, 64);
+  anymask = (unsigned)__builtin_amdgcn_readfirstlane((int)anymask);
 #pragma unroll
   for (int b = T::NB - 1; b >= 1; --b) {
+    if (!((anymask >> b) & 1u)) {  // wave-uniform
+      Jrow[5 + b] = 0.0f;
+      X[5 + b] = 0.0f;
+      continue;
+    }
     const bool ina = (ma >> b) & 1u, inb = (mb >> b) & 1u;
     float S[6], U[6];
 #pragma unroll
@@ -957,9 +1004,17 @@ DI ContactFlags substep(const MoccaModel* __restrict__ M, float* L, int lane, co
   geom_points<T>(M, L, lane);
   wsync();
   int nc = 0;
+#ifdef MOCCA_SKIP_COLLIDE  // profiling builds only (tools/ablate.sh): results are wrong by construction
+  ContactFlags fl = {0, 0, 0, 0};
+#else
   ContactFlags fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc);
+#endif
+#ifndef MOCCA_SKIP_ABA
   aba_passes<T>(M, L, lane);
+#endif
+#ifndef MOCCA_SKIP_SOLVE
   solve_constraints<T>(M, L, lane, nc);
+#endif
   integrate<T>(M, L, lane);
   return fl;
 }

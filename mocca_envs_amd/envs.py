@@ -1,0 +1,257 @@
+"""Single-environment gym classes with the reference's surface, backed by the HIP stepper.
+
+Drop-in for /root/reference/mocca_envs/env_locomotion.py `Walker3DCustomEnv` / `Walker3DStepperEnv`
+(and `EnvBase`, env_base.py:11-201): same ids, spaces, `reset() -> obs`, `step(a) -> (obs, reward, done,
+info)` (4-tuple, no auto-reset), `seed`, `close`, `get_mirror_indices`, `evaluation_mode`, `set_env_params`,
+`get_env_param`, attributes `robot.mirrored`, `robot.applied_gain`, `curriculum`, `max_curriculum`.
+What is replaced is `EnvBase._p` (the pybullet client) and everything the reference did through it.
+
+A facade env is a batch of one on the GPU; trainers that want throughput use `VecEnv` directly.
+Rendering (`render=True`, egl, ffmpeg) is out of scope and raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+try:  # pragma: no cover - depends on the machine
+    import gym  # type: ignore
+except Exception:  # this image has no gym: use the shim with the same surface
+    from . import gym_shim as _shim
+    gym = _shim.as_module()
+
+from . import host_logic as H
+from . import model as M
+
+
+class _Robot:
+    """The attributes of robots.Walker3D that trainers touch (robots.py:13-29,230-290)."""
+
+    foot_names = ["right_foot", "left_foot"]
+
+    def __init__(self, mdl: M.MoccaModel):
+        self._mdl = mdl
+        self.mirrored = False
+        self.applied_gain = 1.0
+        self.action_dim = mdl.n_joints
+        high = np.ones(self.action_dim)
+        self.action_space = gym.spaces.Box(-high, high, dtype=np.float32)
+        self.state_dim = 6 + self.action_dim * 2 + len(self.foot_names)
+        high = np.inf * np.ones(self.state_dim)
+        self.observation_space = gym.spaces.Box(-high, high, dtype=np.float32)
+        self._right_joint_indices = np.array(list(mdl.mirror_right)[: mdl.n_mirror_side], dtype=np.int64)
+        self._left_joint_indices = np.array(list(mdl.mirror_left)[: mdl.n_mirror_side], dtype=np.int64)
+        self._negation_joint_indices = np.array(list(mdl.mirror_neg)[: mdl.n_mirror_neg], dtype=np.int64)
+        self.body_xyz = np.zeros(3)
+        self.joint_angles = np.zeros(self.action_dim)
+        self.joint_speeds = np.zeros(self.action_dim)
+        self.feet_contact = np.zeros(2, dtype=np.float32)
+
+
+class EnvBase(gym.Env):
+    """env_base.py:11-201 without the Bullet client: the GPU batch-of-one plays `_p`."""
+
+    metadata = {"render.modes": ["human", "rgb_array"]}
+    control_step = 1 / 60
+    llc_frame_skip = 1
+    sim_frame_skip = 4
+    env_id = None
+    task_id = None
+
+    def __init__(self, render=False, remove_ground=False, use_egl=False, use_ffmpeg=False, device=None, **kwargs):
+        if render or use_egl or use_ffmpeg:
+            raise NotImplementedError("rendering is outside the GPU stepper's scope (SURVEY.md section 2.1 #6)")
+        if kwargs:
+            raise TypeError(f"unexpected arguments {sorted(kwargs)}")
+        self.is_rendered = False
+        self.metadata = dict(self.metadata)
+        self.metadata["video.frames_per_second"] = int(1 / self.control_step)
+        from .vec_env import VecEnv  # imports torch; needs the HIP library and a GPU (no CPU fallback)
+        self._vec = VecEnv(self.env_id, 1, device=device, auto_reset=False)
+        self.model = self._vec.model
+        self.robot = _Robot(self.model)
+        self.seed()
+
+    # ---- gym surface --------------------------------------------------------------------------
+    def seed(self, seed=None):
+        self.np_random, seed = gym.utils.seeding.np_random(seed)  # env_base.py:164-166
+        self.robot.np_random = self.np_random
+        return [seed]
+
+    def close(self):
+        if getattr(self, "_vec", None) is not None:
+            self._vec.close()
+            self._vec = None
+
+    def render(self, mode="human"):
+        raise NotImplementedError("rendering is outside the GPU stepper's scope")
+
+    def set_env_params(self, params_dict):  # env_base.py:103-106
+        for k, v in params_dict.items():
+            if hasattr(self, k):
+                setattr(self, k, v)
+
+    def get_env_param(self, param_name, default):  # env_base.py:117-118
+        return getattr(self, param_name, default)
+
+    def set_robot_params(self, params_dict):  # env_base.py:108-115 (its calc_torque_limits does not exist)
+        for k, v in params_dict.items():
+            if hasattr(self.robot, k):
+                setattr(self.robot, k, v)
+
+    # ---- helpers --------------------------------------------------------------------------------
+    def _push(self, state, task, terrain=None):
+        import torch
+        from .vec_env import task_from_float64
+        self._vec.set_state(torch.from_numpy(np.asarray(state, np.float32)[None]))
+        self._vec.set_task(task_from_float64(np.asarray(task, np.float64)[None]))
+        if terrain is not None:
+            self._vec.set_terrain(torch.from_numpy(np.asarray(terrain, np.float32)[None]))
+
+    def _pull_robot(self):
+        st = self._vec.get_state()[0].cpu().numpy()
+        nj = self.model.n_joints
+        self.robot.body_xyz = st[0:3].astype(np.float64)
+        self.robot.joint_angles = st[13:13 + nj].copy()
+        self.robot.joint_speeds = 0.1 * st[13 + nj:13 + 2 * nj]
+
+    def _step_device(self, action):
+        import torch
+        action = np.asarray(action, dtype=np.float64)
+        assert np.isfinite(action).all()  # robots.py:32
+        a = torch.from_numpy(action.astype(np.float32)[None])
+        obs, rew, done, info = self._vec.step(a)
+        return (obs[0].cpu().numpy().astype(np.float64), float(rew[0].item()), bool(int(done[0].item()) & 1),
+                int(info[0].item()))
+
+
+class Walker3DCustomEnv(EnvBase):
+    """env_locomotion.py:37-282.  Every random draw (reset AND mid-episode re-targeting) comes from
+    `self.np_random` with the reference's calls in the reference's order."""
+
+    env_id = "Walker3DCustomEnv-v0"
+    task_id = M.TASK_WALKER3D_CUSTOM
+    termination_height = 0.7
+    robot_random_start = True
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        from . import lib as _lib
+        self._vec.set_param(_lib.PARAM_HOST_RETARGET, 1)
+        self.eval_mode = False
+        self.electricity_cost, self.stall_torque_cost, self.joints_at_limit_cost = 4.5, 0.225, 0.1
+        high = np.inf * np.ones(self.robot.observation_space.shape[0] + 2)
+        self.observation_space = gym.spaces.Box(-high, high, dtype=np.float32)
+        self.action_space = self.robot.action_space
+
+    def evaluation_mode(self):  # env_locomotion.py:76-77
+        self.eval_mode = True
+
+    def reset(self):
+        from . import lib as _lib
+        self._vec.set_param(_lib.PARAM_EVAL_MODE, int(self.eval_mode))
+        self.done = False
+        self.dist, self.angle, self.stop_frames = H.randomize_target(self.np_random, self.eval_mode)
+        self.walk_target = np.array([self.dist * np.cos(self.angle), self.dist * np.sin(self.angle), 1.0])
+        self.close_count = 0
+        q, self.robot.mirrored = H.reset_pose(self.robot.np_random, self.model, self.robot_random_start)
+        self._episode = getattr(self, "_episode", -1) + 1
+        task = H.task_record(walk_target=self.walk_target, stop_frames=self.stop_frames, dist=self.dist, angle=self.angle,
+                             mirrored=int(self.robot.mirrored), episode=self._episode)
+        self._push(H.initial_state(self.model, q), task)
+        obs = self._vec.observe()[0].cpu().numpy().astype(np.float64)
+        self._pull_robot()
+        return obs
+
+    def step(self, action):
+        from .vec_env import task_to_float64, task_from_float64
+        obs, rew, done, _ = self._step_device(action)
+        self._pull_robot()
+        tk = task_to_float64(self._vec.get_task())[0]
+        self.walk_target, self.close_count = tk[0:3].copy(), int(tk[5])
+        if self.close_count >= self.stop_frames:  # env_locomotion.py:214-222, host RandomState like the reference
+            self.close_count = 0
+            self.dist, self.angle, self.stop_frames = H.randomize_target(self.np_random, self.eval_mode)
+            self.walk_target = self.walk_target + self.dist * np.array([np.cos(self.angle), np.sin(self.angle), 0.0])
+            st = self._vec.get_state()[0].cpu().numpy().astype(np.float64)
+            x, y, z, w = st[3:7]
+            yaw = np.arctan2(2 * (x * y + w * z), w * w + x * x - y * y - z * z)
+            dx, dy = self.walk_target[0] - st[0], self.walk_target[1] - st[1]
+            ang, dist = np.arctan2(dy, dx) - yaw, np.hypot(dx, dy)
+            tk[0:3], tk[5], tk[6], tk[14], tk[15] = self.walk_target, 0, self.stop_frames, self.dist, self.angle
+            tk[3], tk[4] = -dist / (1 / 60), np.cos(ang)  # calc_potential :143-158 (scene.dt = 1/60)
+            self._vec.set_task(task_from_float64(tk[None]))
+            s_, c_ = dist * np.sin(ang), dist * np.cos(ang)
+            obs[-2], obs[-1] = s_ / (1 + abs(s_)), c_ / (1 + abs(c_))
+        self.done = done
+        return obs, rew, done, {}
+
+    def get_mirror_indices(self):
+        return H.mirror_indices(self.model, stepper=False)
+
+    @classmethod
+    def mirror_indices(cls):
+        return H.mirror_indices(M.compile_walker3d(M.TASK_WALKER3D_CUSTOM), stepper=False)
+
+
+class Walker3DStepperEnv(EnvBase):
+    """env_locomotion.py:330-840."""
+
+    env_id = "Walker3DStepperEnv-v0"
+    task_id = M.TASK_WALKER3D_STEPPER
+    max_timestep = 1000
+    robot_random_start = True
+    n_steps, step_radius, rendered_step_count = 20, 0.25, 3
+    lookahead, lookbehind, step_param_dim = 2, 1, 5
+
+    def __init__(self, **kwargs):
+        self.random_reward = kwargs.pop("random_reward", False)
+        plank = kwargs.pop("plank_class", None)
+        if self.random_reward:
+            raise NotImplementedError("random_reward (env_locomotion.py:533-547) is not in the GPU stepper yet")
+        if plank not in (None, "LargePlank"):
+            raise NotImplementedError("only plank_class=LargePlank (the reference default) is modelled")
+        kwargs.pop("remove_ground", None)
+        super().__init__(**kwargs)
+        self.curriculum, self.max_curriculum = 0, 9
+        self.terminal_height_curriculum = np.linspace(0.75, 0.45, 10)
+        self.applied_gain_curriculum = np.linspace(1.0, 1.2, 10)
+        self.next_step_index = self.lookbehind
+        self.terrain_info = np.zeros((self.n_steps, 6))
+        self.robot_obs_dim = self.robot.observation_space.shape[0]
+        high = np.inf * np.ones(self.robot_obs_dim + 3 * self.step_param_dim)
+        self.observation_space = gym.spaces.Box(-high, high, dtype=np.float32)
+        self.action_space = self.robot.action_space
+
+    def reset(self):
+        self.timestep, self.done = 0, False
+        cur = min(int(self.curriculum), self.max_curriculum)
+        self.robot.applied_gain = H.applied_gain(cur)
+        q, self.robot.mirrored = H.reset_pose(self.robot.np_random, self.model, self.robot_random_start)
+        self.terrain_info = H.generate_step_placements(self.np_random, cur)
+        self.next_step_index = self.lookbehind
+        self._episode = getattr(self, "_episode", -1) + 1
+        terrain = np.zeros(128, np.float32)
+        terrain[:120] = self.terrain_info.reshape(-1)
+        terrain[120:123] = [0, 1, 2]
+        task = H.task_record(next_step_index=self.next_step_index, curriculum=cur, applied_gain=self.robot.applied_gain,
+                             mirrored=int(self.robot.mirrored), episode=self._episode, draw=122)
+        self._vec.set_param(2, cur)
+        self._push(H.initial_state(self.model, q), task, terrain)
+        obs = self._vec.observe()[0].cpu().numpy().astype(np.float64)
+        self._pull_robot()
+        return obs
+
+    def step(self, action):
+        self.timestep += 1
+        obs, rew, done, nsi = self._step_device(action)
+        self._pull_robot()
+        self.done, self.next_step_index = done, nsi
+        info = {"steps_reached": nsi} if done or self.timestep == self.max_timestep - 1 else {}  # :562-566
+        return obs, rew, done, info
+
+    def get_mirror_indices(self):
+        return H.mirror_indices(self.model, stepper=True)
+
+    @classmethod
+    def mirror_indices(cls):
+        return H.mirror_indices(M.compile_walker3d(M.TASK_WALKER3D_STEPPER), stepper=True)

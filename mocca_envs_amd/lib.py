@@ -9,10 +9,11 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmocca_hip.so")
+# MOCCA_LIB_PATH selects another build of the same HIP library (A/B kernel experiments); never a CPU fallback
+LIB_PATH = os.environ.get("MOCCA_LIB_PATH") or os.path.join(HERE, "libmocca_hip.so")
 
 ABI_VERSION = 1
-PARAM_AUTO_RESET, PARAM_EVAL_MODE, PARAM_CURRICULUM, PARAM_RANDOM_POSE = 0, 1, 2, 3
+PARAM_AUTO_RESET, PARAM_EVAL_MODE, PARAM_CURRICULUM, PARAM_RANDOM_POSE, PARAM_HOST_RETARGET, PARAM_SEED, PARAM_ENV_OFFSET = 0, 1, 2, 3, 4, 5, 6
 
 # every symbol include/mocca.h declares: (name, restype, argtypes)
 _vp, _i, _u64, _sz, _d = C.c_void_p, C.c_int, C.c_uint64, C.c_size_t, C.c_double
@@ -27,6 +28,7 @@ SYMBOLS = {
     "mocca_state_dim": (_i, [_vp]),
     "mocca_reset": (_i, [_vp, _vp, _u64, _vp, _vp]),
     "mocca_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocca_observe": (_i, [_vp, _vp, _vp]),
     "mocca_get_state": (_i, [_vp, _vp, _vp]),
     "mocca_set_state": (_i, [_vp, _vp, _vp]),
     "mocca_get_task": (_i, [_vp, _vp, _vp]),

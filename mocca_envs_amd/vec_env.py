@@ -31,7 +31,8 @@ class VecEnv:
     """
 
     def __init__(self, env_id: str = "Walker3DCustomEnv-v0", n_envs: int = 1, device: Optional[int] = None,
-                 auto_reset: bool = True, seed: int = 0, model_blob: Optional[bytes] = None, **model_kw):
+                 auto_reset: bool = True, seed: int = 0, model_blob: Optional[bytes] = None, env_offset: int = 0,
+                 **model_kw):
         if env_id not in TASKS:
             raise KeyError(f"{env_id!r} has no GPU stepper yet; available: {sorted(TASKS)}")
         if not torch.cuda.is_available():
@@ -61,6 +62,8 @@ class VecEnv:
         self.info = torch.zeros(self.n_envs, dtype=torch.int32, device=self.device)
         self.seed_value = int(seed)
         self.set_param(_lib.PARAM_AUTO_RESET, 1 if auto_reset else 0)
+        self.env_offset = int(env_offset)
+        self.set_param(_lib.PARAM_ENV_OFFSET, self.env_offset)
 
     # ------------------------------------------------------------------
     def _stream(self) -> C.c_void_p:
@@ -83,6 +86,7 @@ class VecEnv:
 
     def seed(self, seed: int):
         self.seed_value = int(seed)
+        self.set_param(_lib.PARAM_SEED, self.seed_value)
         return [seed]
 
     def reset(self, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -102,6 +106,11 @@ class VecEnv:
                                        C.c_void_p(self.rew.data_ptr()), C.c_void_p(self.done.data_ptr()),
                                        C.c_void_p(self.info.data_ptr()), self._stream()), self.h)
         return self.obs, self.rew, self.done, self.info
+
+    def observe(self) -> torch.Tensor:
+        """calc_state() + observation tail of the current state, no stepping (include/mocca.h mocca_observe)."""
+        _lib.check(self.lib.mocca_observe(self.h, C.c_void_p(self.obs.data_ptr()), self._stream()), self.h)
+        return self.obs
 
     # ---- snapshots (saveState/restoreState role; used by the parity tests) ----
     def get_state(self) -> torch.Tensor:

@@ -1,0 +1,123 @@
+"""The single-env gym classes on the GPU: reference draw order, 4-tuple step, TimeLimit, host re-targeting."""
+import copy
+
+import numpy as np
+import pytest
+
+from mocca_envs_amd import host_logic as H
+from mocca_envs_amd import model as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_from(env, task):
+    from mocca_envs_amd.vec_env import task_to_float64
+    from oracle.oracle import Oracle
+    o = Oracle(env.model.to_bytes(), task, 1, "f32")
+    o.reset(seed=0)
+    o.set_state(env._vec.get_state().cpu().numpy().astype(np.float64))
+    o.set_task(task_to_float64(env._vec.get_task()))
+    if task == M.TASK_WALKER3D_STEPPER:
+        o.set_terrain(env._vec.get_terrain().cpu().numpy()[:, :123].astype(np.float64))
+    return o
+
+
+def test_custom_env_episode_uses_the_reference_draw_order():
+    import mocca_envs_amd
+    env = mocca_envs_amd.make("Walker3DCustomEnv-v0")
+    base = env.unwrapped
+    assert base.observation_space.shape == (52,) and base.action_space.shape == (21,)
+    env.seed(5)
+    rng = copy.deepcopy(base.np_random)          # the draws the reference would make, in its order
+    obs = env.reset()
+    dist, angle, stop = H.randomize_target(rng, False)
+    q, mirrored = H.reset_pose(rng, base.model, True)
+    assert obs.shape == (52,) and obs.dtype == np.float64
+    np.testing.assert_allclose(base.walk_target, [dist * np.cos(angle), dist * np.sin(angle), 1.0])
+    assert base.stop_frames == stop and base.robot.mirrored == mirrored
+    np.testing.assert_allclose(base.robot.joint_angles, q, atol=1e-6)
+    # obs tail = softsign(d sin, d cos) of the target seen from the start pose (env_locomotion.py:102-105)
+    s_, c_ = dist * np.sin(angle), dist * np.cos(angle)
+    np.testing.assert_allclose(obs[50:52], [s_ / (1 + abs(s_)), c_ / (1 + abs(c_))], atol=1e-5)
+    # steps agree with the oracle started from the same state
+    orc = _oracle_from(base, M.TASK_WALKER3D_CUSTOM)
+    arng = np.random.default_rng(0)
+    for t in range(5):
+        a = arng.uniform(-1, 1, 21)
+        o, r, d, info = env.step(a)
+        oc, rc, dc, _ = orc.step(a[None].astype(np.float32))
+        assert isinstance(r, float) and isinstance(d, bool) and info == {}
+        np.testing.assert_allclose(o, oc[0], atol=5e-3)
+        assert abs(r - rc[0]) < 5e-2 and d == bool(dc[0] & 1)
+    env.close()
+
+
+def test_custom_env_host_retarget():
+    """close_count reaching stop_frames re-randomises the target from the env's RandomState (:214-222)."""
+    import mocca_envs_amd
+    from mocca_envs_amd.vec_env import task_to_float64, task_from_float64
+    env = mocca_envs_amd.make("Walker3DCustomEnv-v0").unwrapped
+    env.seed(9)
+    env.reset()
+    tk = task_to_float64(env._vec.get_task())
+    st = env._vec.get_state().cpu().numpy()
+    tk[0, 0:2] = st[0, 0:2] + 0.01            # target right under the robot
+    tk[0, 5] = env.stop_frames - 1            # one more close frame triggers the re-target
+    env._vec.set_task(task_from_float64(tk))
+    rng = copy.deepcopy(env.np_random)
+    old = tk[0, 0:3].copy()
+    obs, rew, done, _ = env.step(np.zeros(21))
+    dist, angle, stop = H.randomize_target(rng, False)
+    np.testing.assert_allclose(env.walk_target, old + dist * np.array([np.cos(angle), np.sin(angle), 0]), atol=1e-6)
+    assert env.close_count == 0 and env.stop_frames == stop
+    tk2 = task_to_float64(env._vec.get_task())[0]
+    np.testing.assert_allclose(tk2[0:3], env.walk_target, atol=1e-6)
+    assert abs(obs[50]) <= 1 and abs(obs[51]) <= 1
+    env.close()
+
+
+def test_stepper_env_surface_and_time_limit():
+    import mocca_envs_amd
+    env = mocca_envs_amd.make("Walker3DStepperEnv-v0")
+    base = env.unwrapped
+    assert base.observation_space.shape == (65,)
+    base.set_env_params({"curriculum": 9})
+    assert base.get_env_param("curriculum", 0) == 9
+    env.seed(3)
+    rng = copy.deepcopy(base.np_random)
+    obs = env.reset()
+    q, mirrored = H.reset_pose(rng, base.model, True)
+    table = H.generate_step_placements(rng, 9)
+    np.testing.assert_allclose(base.terrain_info, table)
+    assert abs(base.robot.applied_gain - 1.2) < 1e-12 and obs.shape == (65,)
+    # first target rows of the observation: terrain rows 0,1,2 relative to the base (delta_to_k_targets)
+    np.testing.assert_allclose(obs[50 + 2], table[0, 2] - 1.32, atol=1e-5)
+    orc = _oracle_from(base, M.TASK_WALKER3D_STEPPER)
+    a = np.zeros(21)
+    done = False
+    n = 0
+    while not done and n < 1100:
+        o, r, done, info = env.step(a)
+        oc, rc, dc, ic = orc.step(a[None].astype(np.float32))
+        n += 1
+        if n <= 3:
+            np.testing.assert_allclose(o, oc[0], atol=5e-3)
+    assert done and "steps_reached" in info     # a passive ragdoll falls: terminated well before the cap
+    assert n < 200
+    env.close()
+
+
+def test_shard_offset_reproduces_the_owned_envs():
+    """VecEnv(env_offset=k) == envs k.. of the unsharded batch (bench.py multi-GPU layout)."""
+    import torch
+    from mocca_envs_amd.vec_env import VecEnv
+    acts = torch.rand(30, 1024, 21, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) * 2 - 1
+    full = VecEnv("Walker3DCustomEnv-v0", 1024, auto_reset=True, seed=77)
+    part = VecEnv("Walker3DCustomEnv-v0", 256, auto_reset=True, seed=77, env_offset=512)
+    of, op = full.reset().clone(), part.reset().clone()
+    assert torch.equal(of[512:768], op)
+    for k in range(30):
+        o1, r1, d1, _ = full.step(acts[k])
+        o2, r2, d2, _ = part.step(acts[k, 512:768].contiguous())
+        assert torch.equal(o1[512:768], o2) and torch.equal(r1[512:768], r2) and torch.equal(d1[512:768], d2)
+    full.close(); part.close()
