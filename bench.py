@@ -108,6 +108,11 @@ def main():
     kern_ms = ev0.elapsed_time(ev1) / args.steps  # back-to-back launches: average launch duration incl. launch gaps
 
     if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and args.envs == ENVS_PER_GPU and args.env_id == ENV_ID:
+            # HBM bytes per launch measured offline with rocprofv3 PMC passes (see the file's "method")
+            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         total_envs = args.envs * world
         value = sharding.aggregate_throughput(args.envs, world, args.steps, elapsed)
         achieved = ALGO_BYTES_PER_ENV_STEP * args.envs / (kern_ms * 1e-3) / 1e9
@@ -120,7 +125,7 @@ def main():
                        "envs_per_gpu": args.envs, "parallelism": f"independent env shards x{world}, no collective",
                        "reset_fraction_per_step": reset_frac},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mocca_step_kernel<0>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * args.envs,
                          "note": "path is latency/VALU-bound by construction (SURVEY.md 8d); HBM fraction reported per contract"},

@@ -32,22 +32,36 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   float* obs = a.obs + (size_t)env * a.obs_dim;
 
   load_dyn(st, L, lane, T::NJ, T::NSLOT);
-  TaskRegs t;
-  load_task(tk, t);
-  // apply_action, robots.py:31-40
-  float act_raw = 0.0f;
-  if (lane < T::NJ) {
-    act_raw = a.act[(size_t)env * T::NJ + lane];
-    const float c = act_raw < -1.0f ? -1.0f : (act_raw > 1.0f ? 1.0f : act_raw);
-    L[L_TAU + 1 + lane] = M->gain[lane + 1] * t.gain * c;
+  // apply_action, robots.py:31-40.  Only the two task words the physics needs are read before the substeps;
+  // the rest of the task record is loaded after them so it does not occupy registers across the loop.
+  {
+    const float applied_gain = __uint_as_float(tk[T_GAIN]);
+    if (lane < T::NJ) {
+      const float act_raw = a.act[(size_t)env * T::NJ + lane];
+      const float c = act_raw < -1.0f ? -1.0f : (act_raw > 1.0f ? 1.0f : act_raw);
+      L[L_TAU + 1 + lane] = M->gain[lane + 1] * applied_gain * c;
+    }
   }
   if (lane == 0) { L[L_TAU] = 0.0f; L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
   wsync();
 
   ContactFlags fl = {0, 0, 0, 0};
   const int nsub = M->n_substeps;
+  const int nsi0 = TASK == MOCCA_TASK_WALKER3D_STEPPER ? (int)tk[T_NSI] : 0;
 #pragma unroll 1
-  for (int s = 0; s < nsub; ++s) fl = substep<T, TASK>(M, L, lane, ter, t.nsi);
+  for (int s = 0; s < nsub; ++s) {
+    // launder the model pointer: keeps LICM from hoisting dozens of loop-invariant model loads out of the
+    // substep loop, where they would sit in registers (and spill to scratch) for the whole kernel
+    const MoccaModel* Ms = M;
+    int ln = lane;  // same for lane-derived offsets and predicates (recomputing them costs a few instructions)
+    asm volatile("" : "+s"(Ms), "+v"(ln));
+    fl = substep<T, TASK>(Ms, L, ln, ter, nsi0);
+  }
+  TaskRegs t;
+  load_task(tk, t);
+  // the raw (unclipped) action enters the energy penalty (env_locomotion.py:185-188); re-read it rather than
+  // hold a register across the substeps
+  const float act_raw = lane < T::NJ ? a.act[(size_t)env * T::NJ + lane] : 0.0f;
 
   // ---- calc_state + task logic on the post-step state
   sincos_joints(L, lane, T::NB);
@@ -176,6 +190,9 @@ __global__ __launch_bounds__(64) void mocca_reset_kernel(StepArgs a) {
   float* ter = TASK == MOCCA_TASK_WALKER3D_STEPPER ? a.terrain + (size_t)env * TERRAIN_STRIDE : nullptr;
   TaskRegs t;
   load_task(tk, t);
+  // the raw (unclipped) action enters the energy penalty (env_locomotion.py:185-188); re-read it rather than
+  // hold a register across the substeps
+  const float act_raw = lane < T::NJ ? a.act[(size_t)env * T::NJ + lane] : 0.0f;
   if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
   reset_env<T, TASK>(a, M, L, ter, env + a.env_offset, lane, t, a.obs + (size_t)env * a.obs_dim);
   wsync();
@@ -198,6 +215,9 @@ __global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
   load_dyn(st, L, lane, T::NJ, T::NSLOT);
   TaskRegs t;
   load_task(tk, t);
+  // the raw (unclipped) action enters the energy penalty (env_locomotion.py:185-188); re-read it rather than
+  // hold a register across the substeps
+  const float act_raw = lane < T::NJ ? a.act[(size_t)env * T::NJ + lane] : 0.0f;
   if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
   wsync();
   sincos_joints(L, lane, T::NB);
