@@ -1,0 +1,160 @@
+"""Edge cases of the HIP path against the oracle: row/contact caps, non-finite state, eval mode, TimeLimit,
+odd batch sizes, argument checking.  Needs a real MI355X: -m gpu."""
+import numpy as np
+import pytest
+
+from mocca_envs_amd import model as M
+
+pytestmark = pytest.mark.gpu
+NJ = 21
+
+
+def _pair(env_id, task, n, seed=2, **kw):
+    from mocca_envs_amd.vec_env import VecEnv
+    from oracle.oracle import Oracle
+    env = VecEnv(env_id, n, auto_reset=False, seed=seed, **kw)
+    orc = Oracle(env.model.to_bytes(), task, n, "f32")
+    env.reset(); orc.reset(seed=seed)
+    return env, orc
+
+
+def _sync(env, orc, task=0):
+    from mocca_envs_amd.vec_env import task_from_float64
+    env.set_state(orc.get_state().astype(np.float32))
+    env.set_task(task_from_float64(orc.get_task()))
+    if task:
+        ter = np.zeros((env.n_envs, 128), np.float32); ter[:, :123] = orc.get_terrain(); env.set_terrain(ter)
+
+
+def _close(a, b, tol=5.0):
+    e = np.abs(a - b) / (1e-3 + 1e-3 * np.abs(b))
+    return np.nanmax(e) < tol, np.nanmax(e)
+
+
+def test_contact_and_row_caps_are_applied_identically():
+    """A robot lying 5-8 cm above the plane touches with ~30 points: both sides keep the same max_contacts = 12
+    (terrain slot order) and stay inside the 48-row budget (12 contacts + limit rows) in the first substeps."""
+    import torch
+    env, orc = _pair("Walker3DCustomEnv-v0", 0, 16)
+    rng = np.random.default_rng(0)
+    st = np.zeros_like(orc.get_state())
+    for e in range(16):
+        st[e, 2] = 0.05 + 0.03 * rng.random()
+        pitch = np.pi / 2 * (1 if e % 2 else -1) + rng.normal(0, 0.02)  # face down / face up
+        st[e, 3:7] = [0, np.sin(pitch / 2), 0, np.cos(pitch / 2)]
+        st[e, 13:13 + NJ] = rng.uniform(-0.05, 0.05, NJ)
+    # the caps are really exercised: first substep of the last env has 12 contacts
+    orc.set_state(st)
+    orc.physics_substeps(15, np.zeros(NJ), 1)
+    assert len(orc.last_contacts()) == 12 and orc.last_rows() >= 36
+    orc.set_state(st)
+    a = rng.uniform(-1, 1, (16, NJ)).astype(np.float32)
+    _sync(env, orc)
+    og, rg, dg, _ = env.step(torch.from_numpy(a).cuda())
+    oc, rc, dc, _ = orc.step(a)
+    sg, sc = env.get_state().cpu().numpy(), orc.get_state()
+    assert np.isfinite(sg).all()
+    e = np.abs(sg[:, :55] - sc[:, :55]) / (1e-3 + 1e-3 * np.abs(sc[:, :55]))
+    # violent 5 cm push-out at erp 0.9: fp32 noise is amplified, but a wrong row set would be off by O(1000)
+    assert np.median(e.max(axis=1)) < 2.0 and e.max() < 200.0, (np.median(e.max(axis=1)), e.max())
+    np.testing.assert_array_equal(dg.cpu().numpy(), dc)
+    # warm-start impulses of the kept slots agree, dropped slots are zero on both sides
+    np.testing.assert_array_equal(sg[:, 55:] != 0, sc[:, 55:] != 0)
+
+
+def test_non_finite_state_sets_done_and_auto_reset_recovers():
+    """env_locomotion.py:205-207: a non-finite observation is not an error, it ends the episode."""
+    import torch
+    from mocca_envs_amd.vec_env import VecEnv
+    env = VecEnv("Walker3DCustomEnv-v0", 8, auto_reset=False, seed=1)
+    env.reset()
+    st = env.get_state().cpu().numpy()
+    st[3, 13 + NJ + 4] = np.nan      # one joint speed of env 3
+    st[5, 6] = np.nan                # base orientation of env 5 (an infinite height or speed is clipped to 5: finite)
+    env.set_state(st)
+    obs, rew, done, _ = env.step(torch.zeros(8, NJ, device="cuda"))
+    d = done.cpu().numpy()
+    assert d[3] & 1 and d[5] & 1 and not (d[[0, 1, 2, 4, 6, 7]] & 1).any()
+    assert not torch.isfinite(obs[3]).all()
+    env.set_param(0, 1)              # auto-reset on: the poisoned envs come back finite
+    obs, rew, done, _ = env.step(torch.zeros(8, NJ, device="cuda"))
+    assert torch.isfinite(obs).all() and torch.isfinite(env.get_state()).all()
+    env.close()
+
+
+def test_eval_mode_and_time_limit():
+    import torch
+    from mocca_envs_amd.vec_env import task_to_float64, task_from_float64
+    from oracle.oracle import PARAM_EVAL_MODE
+    env, orc = _pair("Walker3DCustomEnv-v0", 0, 4)
+    env.set_param(1, 1); orc.set_param(PARAM_EVAL_MODE, 1)
+    env.reset(); orc.reset(seed=2)
+    np.testing.assert_allclose(task_to_float64(env.get_task())[:, 14:16], [[4, 0]] * 4)   # dist 4, angle 0
+    a = np.zeros((4, NJ), np.float32)
+    _sync(env, orc)
+    og, _, _, _ = env.step(torch.from_numpy(a).cuda()); oc, _, _, _ = orc.step(a)
+    tg, tc = task_to_float64(env.get_task()), orc.get_task()
+    np.testing.assert_allclose(tg[:, 0:3], tc[:, 0:3], atol=1e-5)                         # target = prev x + 4
+    assert np.allclose(tg[:, 0], 4.0, atol=0.05) and np.allclose(tg[:, 1], 0.0)
+    # TimeLimit: max_episode_steps = 1000 (reference __init__.py:55) -> done bit1
+    tk = orc.get_task(); tk[:, 8] = 999; orc.set_task(tk)
+    _sync(env, orc)
+    _, _, dg, _ = env.step(torch.from_numpy(a).cuda()); _, _, dc, _ = orc.step(a)
+    assert (dg.cpu().numpy() & 2).all() and (dc & 2).all()
+
+
+@pytest.mark.parametrize("cur", [0, 4])
+def test_stepper_standing_on_planks(cur):
+    """Feet on the first plank (soft-contact rows with stiffness/damping erp/cfm, friction 1.2)."""
+    import torch
+    from oracle.oracle import PARAM_CURRICULUM
+    from mocca_envs_amd.vec_env import VecEnv
+    from oracle.oracle import Oracle
+    env = VecEnv("Walker3DStepperEnv-v0", 32, auto_reset=False, seed=4)
+    orc = Oracle(env.model.to_bytes(), 1, 32, "f32")
+    env.set_param(2, cur); orc.set_param(PARAM_CURRICULUM, cur)
+    env.reset(); orc.reset(seed=4)
+    st = orc.get_state(); st[:, 13:13 + NJ] = 0; st[:, 2] = 1.27; orc.set_state(st)   # T-pose, feet on the plank
+    rng = np.random.default_rng(3)
+    touched = 0
+    for t in range(12):
+        _sync(env, orc, 1)
+        a = (0.2 * rng.uniform(-1, 1, (32, NJ))).astype(np.float32)
+        og, rg, dg, ig = env.step(torch.from_numpy(a).cuda())
+        oc, rc, dc, ic = orc.step(a)
+        touched += int(oc[:, 48:50].sum())
+        ok, e = _close(env.get_state().cpu().numpy()[:, :55], orc.get_state()[:, :55], tol=30.0)
+        assert ok, (t, e)
+        np.testing.assert_array_equal(ig.cpu().numpy(), ic)
+    assert touched > 100   # the feet really were in contact with the planks
+
+
+@pytest.mark.parametrize("n", [1, 3, 65])
+def test_odd_batch_sizes(n):
+    import torch
+    env, orc = _pair("Walker3DCustomEnv-v0", 0, n)
+    a = np.random.default_rng(n).uniform(-1, 1, (n, NJ)).astype(np.float32)
+    _sync(env, orc)
+    og, rg, dg, _ = env.step(torch.from_numpy(a).cuda()); oc, rc, dc, _ = orc.step(a)
+    np.testing.assert_allclose(og.cpu().numpy(), oc, atol=5e-3, rtol=5e-3)
+    np.testing.assert_array_equal(dg.cpu().numpy(), dc)
+
+
+def test_argument_checking_and_action_handling():
+    import torch
+    from mocca_envs_amd.vec_env import VecEnv
+    env = VecEnv("Walker3DCustomEnv-v0", 4, auto_reset=False, seed=0)
+    env.reset()
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(4, 20, device="cuda"))
+    with pytest.raises(KeyError):
+        VecEnv("CassieEnv-v0", 4)
+    # out-of-range actions are clipped for the torque (robots.py:33), a float64 / CPU / strided tensor is accepted
+    st0 = env.get_state().clone()
+    big = torch.full((4, NJ), 7.0, dtype=torch.float64)
+    o1 = env.step(big)[0].clone()
+    env.set_state(st0)
+    o2 = env.step(torch.ones(8, NJ, device="cuda")[::2])[0].clone()
+    # same physics (clipped torque); the energy penalty differs but not the observation
+    assert torch.allclose(o1, o2, atol=1e-6)
+    env.close()
