@@ -27,7 +27,9 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
+    # -fno-slp-vectorize: the SLP vectoriser pairs scalar fp32 ops into v_pk_* but pays ~2 v_mov per pair to line
+    # up register pairs; measured on this kernel it ADDS 12 % VALU instructions
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
            "-o", LIB] + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

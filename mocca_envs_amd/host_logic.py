@@ -57,32 +57,30 @@ def reset_pose(np_random, mdl: M.MoccaModel, random_pose: bool = True) -> Tuple[
 
 
 def generate_step_placements(np_random, curriculum: int) -> np.ndarray:
-    """env_locomotion.py:395-441 -> [20, 6] table (x, y, z, phi, x_tilt, y_tilt)."""
-    curriculum = min(curriculum, MAX_CURRICULUM)
-    ratio = curriculum / MAX_CURRICULUM
-    dist_range = np.array([0.65, 1.25])
-    dist_upper = np.linspace(*dist_range, MAX_CURRICULUM + 1)
-    d_range = np.array([dist_range[0], dist_upper[curriculum]])
-    yaw_range = np.array([-20, 20]) * ratio * DEG2RAD
-    pitch_range = np.array([-30, 30]) * ratio * DEG2RAD + np.pi / 2
-    tilt_range = np.array([-15, 15]) * ratio * DEG2RAD
-    n = N_STEPS
-    dr = np_random.uniform(*d_range, size=n)
-    dphi = np_random.uniform(*yaw_range, size=n)
-    dtheta = np_random.uniform(*pitch_range, size=n)
-    x_tilt = np_random.uniform(*tilt_range, size=n)
-    y_tilt = np_random.uniform(*tilt_range, size=n)
-    dr[0], dphi[0], dtheta[0] = 0.0, 0.0, np.pi / 2
-    dr[1:3], dphi[1:3], dtheta[1:3] = INIT_STEP_SEPARATION, 0.0, np.pi / 2
-    x_tilt[0:3] = 0
-    y_tilt[0:3] = 0
-    dphi = np.cumsum(dphi)
-    dx = dr * np.sin(dtheta) * np.cos(dphi)
-    dy = dr * np.sin(dtheta) * np.sin(dphi)
-    dz = dr * np.cos(dtheta)
-    dx_max = np.maximum(np.abs(dx[2:]), STEP_RADIUS * 2.5)
-    dx[2:] = np.sign(dx[2:]) * np.minimum(dx_max, dist_range[1])
-    return np.stack((np.cumsum(dx), np.cumsum(dy), np.cumsum(dz), dphi, x_tilt, y_tilt), axis=1)
+    """Stepping-stone table [20, 6] = (x, y, z, heading, x_tilt, y_tilt), the distribution of
+    env_locomotion.py:395-441: per step a radial distance, a heading increment, a polar angle and two tilts,
+    each uniform in a range that widens with the curriculum; draw order = five blocks of 20."""
+    level = min(int(curriculum), MAX_CURRICULUM)
+    frac = level / MAX_CURRICULUM
+    half_pi = np.pi / 2
+    ranges = (
+        (0.65, np.linspace(0.65, 1.25, MAX_CURRICULUM + 1)[level]),      # radial distance [m]
+        (-20 * frac * DEG2RAD, 20 * frac * DEG2RAD),                      # heading increment
+        (-30 * frac * DEG2RAD + half_pi, 30 * frac * DEG2RAD + half_pi),  # polar angle (pi/2 = level ground)
+        (-15 * frac * DEG2RAD, 15 * frac * DEG2RAD),                      # tilt about x
+        (-15 * frac * DEG2RAD, 15 * frac * DEG2RAD),                      # tilt about y
+    )
+    radial, turn, polar, tilt_x, tilt_y = (np_random.uniform(lo, hi, size=N_STEPS) for lo, hi in ranges)
+    # the robot starts on step 0; steps 1 and 2 lie flat, straight ahead, INIT_STEP_SEPARATION apart
+    radial[:3] = (0.0, INIT_STEP_SEPARATION, INIT_STEP_SEPARATION)
+    turn[:3], polar[:3], tilt_x[:3], tilt_y[:3] = 0.0, half_pi, 0.0, 0.0
+    heading = np.cumsum(turn)
+    ground = radial * np.sin(polar)
+    hop = np.stack((ground * np.cos(heading), ground * np.sin(heading), radial * np.cos(polar)), axis=1)
+    # from the third step on keep consecutive planks from overlapping or drifting apart along x
+    fwd = hop[2:, 0]
+    hop[2:, 0] = np.sign(fwd) * np.clip(np.abs(fwd), 2.5 * STEP_RADIUS, 1.25)
+    return np.column_stack((np.cumsum(hop, axis=0), heading, tilt_x, tilt_y))
 
 
 def applied_gain(curriculum: int) -> float:
