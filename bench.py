@@ -27,18 +27,19 @@ ALGO_BYTES_PER_ENV_STEP = 836 + 2 * 34 * 4
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(seconds_target: float = 12.0):
+def cpu_baseline(env_id: str = ENV_ID, seconds_target: float = 12.0):
     """The CPU oracle (a scalar C port of the same algorithm; PyBullet is not installable here) on one host core."""
     import numpy as np
     from oracle.oracle import Oracle, PARAM_AUTO_RESET
-    from mocca_envs_amd import model as M
-    m = M.compile_walker3d()
+    from mocca_envs_amd.vec_env import TASKS, compile_model_for
+    task = TASKS[env_id]
+    m = compile_model_for(task)
     n = 16
-    orc = Oracle(m.to_bytes(), M.TASK_WALKER3D_CUSTOM, n, "f32")
+    orc = Oracle(m.to_bytes(), task, n, "f32")
     orc.set_param(PARAM_AUTO_RESET, 1)
     orc.reset(seed=0)
     rng = np.random.default_rng(0)
-    tape = rng.uniform(-1, 1, (64, n, 21)).astype(np.float32)
+    tape = rng.uniform(-1, 1, (64, n, orc.act_dim)).astype(np.float32)
     t0 = time.perf_counter()
     steps = 0
     while time.perf_counter() - t0 < seconds_target:
@@ -47,7 +48,7 @@ def cpu_baseline(seconds_target: float = 12.0):
         steps += 64
     dt = time.perf_counter() - t0
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} envs x {steps} steps, auto-reset, U(-1,1) actions, f32 C oracle (oracle/mocca_oracle.c)"}
+            "sample": f"{env_id}: {n} envs x {steps} steps, auto-reset, U(-1,1) actions, f32 C oracle (oracle/mocca_oracle.c)"}
 
 
 def main():
@@ -115,7 +116,12 @@ def main():
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         total_envs = args.envs * world
         value = sharding.aggregate_throughput(args.envs, world, args.steps, elapsed)
-        achieved = ALGO_BYTES_PER_ENV_STEP * args.envs / (kern_ms * 1e-3) / 1e9
+        # per env-step: state + task + action read, state + task + obs + reward + done written
+        sd, td = env.state_dim * 4, 40 * 4
+        algo = (sd + td + env.act_dim * 4) + (sd + td + env.obs_dim * 4 + 5)
+        if args.env_id == ENV_ID:
+            algo = ALGO_BYTES_PER_ENV_STEP  # the figure quoted in DESIGN.md (24-word task record of the metric env)
+        achieved = algo * args.envs / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "env-steps/sec, Walker3DCustomEnv-v0 @ 4096 envs, 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -126,13 +132,13 @@ def main():
                        "reset_fraction_per_step": reset_frac},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "mocca_step_kernel<0>", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * args.envs,
+                         "kernel": "mocca_step_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": algo * args.envs,
                          "note": "path is latency/VALU-bound by construction (SURVEY.md 8d); HBM fraction reported per contract"},
             "kernel_info": env.kernel_info(),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.env_id)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define MOCCA_MODEL_MAGIC 0x41434F4Du /* "MOCA" */
-#define MOCCA_MODEL_VERSION 3u
+#define MOCCA_MODEL_VERSION 4u
 
 #define MOCCA_MAX_BODIES 24
 #define MOCCA_MAX_GEOMS 32
@@ -40,6 +40,8 @@ extern "C" {
 #define MOCCA_MAX_SLOTS 40   /* terrain contact slots (warm-start impulses) */
 #define MOCCA_MAX_PLANKS 3
 #define MOCCA_MAX_TERRAIN_STEPS 20
+#define MOCCA_MAX_CLOSURES 2
+#define MOCCA_MAX_CTRL 16
 
 enum { MOCCA_GEOM_SPHERE = 0, MOCCA_GEOM_CAPSULE = 1 };
 
@@ -47,6 +49,7 @@ enum { MOCCA_GEOM_SPHERE = 0, MOCCA_GEOM_CAPSULE = 1 };
 enum {
   MOCCA_TASK_WALKER3D_CUSTOM = 0,  /* env_locomotion.py:37-282  */
   MOCCA_TASK_WALKER3D_STEPPER = 1, /* env_locomotion.py:330-840 */
+  MOCCA_TASK_CASSIE = 2,           /* env_cassie.py:284-479 (CassieEnv, 3-D) */
 };
 
 typedef struct MoccaModel {
@@ -128,7 +131,30 @@ typedef struct MoccaModel {
   int32_t n_mirror_side;
   int32_t n_mirror_neg;
   int32_t max_contacts;           /* contacts kept per substep (priority: terrain slots, then self pairs) */
-  int32_t max_rows;               /* constraint rows per substep: limits, then 3 per contact */
+  int32_t max_rows;               /* constraint rows per substep: limits, closures, then 3 per contact */
+
+  /* ---- point-to-point loop closures, env_cassie.py:114-137 (createConstraint JOINT_POINT2POINT) ---- */
+  int32_t n_closures;
+  int32_t cl_body_a[MOCCA_MAX_CLOSURES];
+  int32_t cl_body_b[MOCCA_MAX_CLOSURES];
+  float cl_point_a[MOCCA_MAX_CLOSURES][3]; /* pivot in body a's frame */
+  float cl_point_b[MOCCA_MAX_CLOSURES][3];
+
+  /* ---- Cassie low-level PD controller, env_cassie.py:287-319,380-393,433-459 ---- */
+  int32_t n_ctrl;                     /* 12 = 10 powered joints + 2 knee_to_shin springs */
+  int32_t n_llc;                      /* llc_frame_skip: PD + physics iterations per env.step (50) */
+  int32_t ctrl_body[MOCCA_MAX_CTRL];  /* body of controlled joint k (powered joints first, then springs) */
+  float ctrl_kp[MOCCA_MAX_CTRL];
+  float ctrl_kd[MOCCA_MAX_CTRL];
+  float ctrl_base[MOCCA_MAX_CTRL];    /* residual-control offset: base angle for powered joints, 0 for springs */
+  float torque_limit[MOCCA_MAX_BODIES]; /* |torque| cap per body's joint (power_coef), env_cassie.py:41-56,225-230 */
+  int32_t n_ordered;                  /* the reference's `ordered_joints` (14), env_cassie.py:160-199 */
+  int32_t ordered_body[MOCCA_MAX_CTRL];
+  int32_t ctrl_oidx[MOCCA_MAX_CTRL];  /* index of controlled joint k within ordered_body (env_cassie.py:59-60) */
+  float jvel_alpha;                   /* 0.2, env_cassie.py:319 */
+  float alive_height;                 /* 0.6, env_cassie.py:406-412 */
+  float cassie_target[3];             /* (1000, 0, 0), env_cassie.py:366 */
+  int32_t pad2_[3];
 } MoccaModel;
 
 /* ------------------------------------------------------------------------
@@ -150,9 +176,12 @@ typedef struct MoccaModel {
  *  --- stepper only ---
  *  16 i next_step_index 17 i target_reached_count 18 i stop_on_next_step
  *  19 i set_stop_on_next_step 20 i curriculum 21 f applied_gain
- *  22..23 reserved
+ *  22 f prev_body_x  23 reserved
+ *  --- Cassie only ---
+ *  3 f potential (shares linear_potential)  24..37 f jvel[14] (filtered joint speeds, env_cassie.py:451-468)
+ *  38 f initial_z  39 i istep
  */
-#define MOCCA_TASK_WORDS 24
+#define MOCCA_TASK_WORDS 40
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@ REGISTERED = {
     # id -> (entry point, kwargs); max_episode_steps = 1000 for all (reference __init__.py:55,61)
     "Walker3DCustomEnv-v0": ("mocca_envs_amd.envs:Walker3DCustomEnv", {}),
     "Walker3DStepperEnv-v0": ("mocca_envs_amd.envs:Walker3DStepperEnv", {}),
+    "CassieEnv-v0": ("mocca_envs_amd.envs:CassieEnv", {}),
 }
 
 

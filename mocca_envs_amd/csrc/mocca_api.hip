@@ -19,9 +19,8 @@ using namespace mocca;
 // --------------------------------------------------------------------------------------------
 // kernels: one 64-lane workgroup (= one wavefront) per environment
 // --------------------------------------------------------------------------------------------
-template <int TASK>
+template <class T, int TASK>
 __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(StepArgs a) {
-  using T = TopoWalker3D;
   __shared__ float L[L_TOTAL];
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= a.n_envs) return;
@@ -32,6 +31,74 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   float* obs = a.obs + (size_t)env * a.obs_dim;
 
   load_dyn(st, L, lane, T::NJ, T::NSLOT);
+  if constexpr (TASK == MOCCA_TASK_CASSIE) {
+    // ---- CassieEnv.step (env_cassie.py:433-479): 50 x { filter joint speeds, PD torques, one physics step }
+    const int no = M->n_ordered, nctl = M->n_ctrl;
+    float target = 0.0f;  // env_cassie.py:434-443: base angle (residual control) + action, 0 for the springs
+    if (lane < nctl) target = M->ctrl_base[lane] + (lane < nctl - 2 ? a.act[(size_t)env * (nctl - 2) + lane] : 0.0f);
+    if (lane < no) {
+      L[L_JVEL + lane] = __uint_as_float(tk[T_JVEL + lane]);
+      L[L_Q0 + lane] = L[L_Q + M->ordered_body[lane]];
+    }
+    if (lane < MOCCA_MAX_BODIES) L[L_TAU + lane] = 0.0f;
+    if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
+    wsync();
+    const int nllc = M->n_llc;
+#pragma unroll 1
+    for (int it = 0; it < nllc; ++it) {
+      const MoccaModel* Ms = M;
+      int ln = lane;
+      asm volatile("" : "+s"(Ms), "+v"(ln));
+      if (ln < no) {  // :451-453
+        const float al = Ms->jvel_alpha;
+        L[L_JVEL + ln] = (1.0f - al) * L[L_JVEL + ln] + al * L[L_QD + Ms->ordered_body[ln]];
+      }
+      wsync();
+      if (ln < nctl) {  // pd_control :380-393 + torque clip :225-230
+        const int b = Ms->ctrl_body[ln];
+        const float perr = target - L[L_Q + b];
+        float verr = -L[L_JVEL + Ms->ctrl_oidx[ln]];
+        verr = verr < -5.0f ? -5.0f : (verr > 5.0f ? 5.0f : verr);
+        const float tq = Ms->ctrl_kp[ln] * perr + Ms->ctrl_kd[ln] * verr, lim = Ms->torque_limit[b];
+        L[L_TAU + b] = tq < -lim ? -lim : (tq > lim ? lim : tq);
+      }
+      wsync();
+      substep<T, TASK>(Ms, L, ln, nullptr, 0);
+    }
+    TaskRegs t;
+    load_task(tk, t);
+    t.istep += nllc;
+    if (lane < no) {  // :467-468 finite-difference joint velocity over the control step
+      const float jv = (L[L_Q + M->ordered_body[lane]] - L[L_Q0 + lane]) / M->control_dt;
+      tk[T_JVEL + lane] = __float_as_uint(jv);
+    }
+    sincos_joints(L, lane, T::NB);
+    walk_kinematics<T, false>(M, L, lane);
+    wsync();
+    t.t += 1;
+    bool fin;
+    const float height = cassie_obs<T>(M, L, lane, t.initz, obs, &fin);
+    const float old = t.linpot;
+    t.linpot = cassie_potential(M, L);
+    const float alive = height > M->alive_height ? 2.0f : -1.0f;  // compute_rewards :401-414
+    if (!fin || alive < 0.0f) t.done = 1;
+    const int timeout = t.t >= M->max_episode_steps;
+    const int dflag = (t.done ? 1 : 0) | (timeout ? 2 : 0);
+    if (lane == 0) {
+      a.rew[env] = alive + (t.linpot - old);
+      a.done[env] = (uint8_t)dflag;
+      if (a.info) a.info[env] = 0;
+    }
+    if (a.auto_reset && dflag) {
+      wsync();
+      cassie_reset_env<T>(M, L, lane, t, obs);
+      if (lane < MOCCA_MAX_CTRL) tk[T_JVEL + lane] = 0u;
+    }
+    wsync();
+    store_dyn(st, L, lane, T::NJ, T::NSLOT);
+    if (lane == 0) store_task(tk, t);
+    return;
+  }
   // apply_action, robots.py:31-40.  Only the two task words the physics needs are read before the substeps;
   // the rest of the task record is loaded after them so it does not occupy registers across the loop.
   {
@@ -177,9 +244,8 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   if (lane == 0) store_task(tk, t);
 }
 
-template <int TASK>
+template <class T, int TASK>
 __global__ __launch_bounds__(64) void mocca_reset_kernel(StepArgs a) {
-  using T = TopoWalker3D;
   __shared__ float L[L_TOTAL];
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= a.n_envs) return;
@@ -194,16 +260,20 @@ __global__ __launch_bounds__(64) void mocca_reset_kernel(StepArgs a) {
   // hold a register across the substeps
   const float act_raw = lane < T::NJ ? a.act[(size_t)env * T::NJ + lane] : 0.0f;
   if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
-  reset_env<T, TASK>(a, M, L, ter, env + a.env_offset, lane, t, a.obs + (size_t)env * a.obs_dim);
+  if constexpr (TASK == MOCCA_TASK_CASSIE) {
+    cassie_reset_env<T>(M, L, lane, t, a.obs + (size_t)env * a.obs_dim);
+    if (lane < MOCCA_MAX_CTRL) tk[T_JVEL + lane] = 0u;
+  } else {
+    reset_env<T, TASK>(a, M, L, ter, env + a.env_offset, lane, t, a.obs + (size_t)env * a.obs_dim);
+  }
   wsync();
   store_dyn(st, L, lane, T::NJ, T::NSLOT);
   if (lane == 0) store_task(tk, t);
 }
 
 // calc_state + observation tail on the stored state (no physics, no randomness)
-template <int TASK>
+template <class T, int TASK>
 __global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
-  using T = TopoWalker3D;
   __shared__ float L[L_TOTAL];
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= a.n_envs) return;
@@ -224,16 +294,22 @@ __global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
   walk_kinematics<T, false>(M, L, lane);
   wsync();
   constexpr int NBO = 6 + 2 * T::NJ + 2;
-  RobotObs ro = robot_obs<T>(M, L, lane, t.fc0, t.fc1, obs);
-  float dist, ang;
-  if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
-    calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
-    if (lane == 0) softsign_tail(dist, ang, obs + NBO);
+  if constexpr (TASK == MOCCA_TASK_CASSIE) {
+    bool fin;
+    cassie_obs<T>(M, L, lane, t.initz, obs, &fin);
+    t.linpot = cassie_potential(M, L);
   } else {
-    delta_to_k_targets(L, ter, t, ro.rpy[2], lane, obs + NBO);
-    calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+    RobotObs ro = robot_obs<T>(M, L, lane, t.fc0, t.fc1, obs);
+    float dist, ang;
+    if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
+      calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+      if (lane == 0) softsign_tail(dist, ang, obs + NBO);
+    } else {
+      delta_to_k_targets(L, ter, t, ro.rpy[2], lane, obs + NBO);
+      calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+    }
+    t.prevx = L[L_BASE];
   }
-  t.prevx = L[L_BASE];
   if (lane == 0) store_task(tk, t);
 }
 
@@ -263,23 +339,51 @@ static thread_local std::string g_err;
     }                                                                            \
   } while (0)
 
-static int check_topology(const MoccaModel& m, std::string& err) {
-  using T = TopoWalker3D;
-  if (m.n_bodies != T::NB || m.n_joints != T::NJ || m.n_geoms != T::NG || m.n_slots != T::NSLOT) {
-    err = "model blob sizes differ from the compiled topology (TopoWalker3D)";
+template <class T>
+static int check_topology_t(const MoccaModel& m, const char* name, std::string& err) {
+  if (m.n_bodies != T::NB || m.n_joints != T::NJ || m.n_geoms != T::NG || m.n_slots != T::NSLOT || m.n_closures != T::NCLOS) {
+    err = std::string("model blob sizes differ from the compiled topology (") + name + ")";
     return MOCCA_E_TOPOLOGY;
   }
   for (int b = 0; b < T::NB; ++b)
     if (m.parent[b] != T::parent(b) || m.anc_mask[b] != T::anc_mask(b)) {
-      err = "model blob tree differs from the compiled topology (TopoWalker3D)";
+      err = std::string("model blob tree differs from the compiled topology (") + name + ")";
       return MOCCA_E_TOPOLOGY;
     }
-  if (m.max_rows > MAXR || m.max_contacts > MAXC || m.max_rows < 1 || m.n_pairs > MOCCA_MAX_PAIRS || m.n_feet != 2) {
+  if (m.max_rows > MAXR || m.max_contacts > MAXC || m.max_rows < 1 + 3 * T::NCLOS || m.n_pairs > MOCCA_MAX_PAIRS || m.n_feet != 2 ||
+      m.n_ctrl > MOCCA_MAX_CTRL || m.n_ordered > MOCCA_MAX_CTRL) {
     err = "model blob caps exceed the kernel's (max_rows <= 48, max_contacts <= 12, n_feet == 2)";
     return MOCCA_E_ARG;
   }
   return MOCCA_OK;
 }
+static int check_topology(const MoccaModel& m, int task_id, std::string& err) {
+  if (task_id == MOCCA_TASK_CASSIE) return check_topology_t<TopoCassie>(m, "TopoCassie", err);
+  return check_topology_t<TopoWalker3D>(m, "TopoWalker3D", err);
+}
+
+// kernel selection by task id
+template <template <class, int> class Launcher, class... Args>
+static void dispatch(int task_id, Args... args) {
+  if (task_id == MOCCA_TASK_WALKER3D_CUSTOM) Launcher<TopoWalker3D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
+  else if (task_id == MOCCA_TASK_WALKER3D_STEPPER) Launcher<TopoWalker3D, MOCCA_TASK_WALKER3D_STEPPER>::run(args...);
+  else Launcher<TopoCassie, MOCCA_TASK_CASSIE>::run(args...);
+}
+template <class T, int TASK> struct LaunchStep {
+  static void run(int n, hipStream_t s, StepArgs a) { hipLaunchKernelGGL((mocca_step_kernel<T, TASK>), dim3(n), dim3(64), 0, s, a); }
+};
+template <class T, int TASK> struct LaunchReset {
+  static void run(int n, hipStream_t s, StepArgs a) { hipLaunchKernelGGL((mocca_reset_kernel<T, TASK>), dim3(n), dim3(64), 0, s, a); }
+};
+template <class T, int TASK> struct LaunchObserve {
+  static void run(int n, hipStream_t s, StepArgs a) { hipLaunchKernelGGL((mocca_observe_kernel<T, TASK>), dim3(n), dim3(64), 0, s, a); }
+};
+template <class T, int TASK> struct KernelInfo {
+  static void run(hipFuncAttributes* fa, int* nb, hipError_t* e) {
+    *e = hipFuncGetAttributes(fa, (const void*)mocca_step_kernel<T, TASK>);
+    if (*e == hipSuccess) *e = hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, mocca_step_kernel<T, TASK>, 64, 0);
+  }
+};
 
 extern "C" {
 
@@ -293,21 +397,25 @@ int mocca_create(const void* model_blob, size_t nbytes, int task_id, int n_envs,
   *out = nullptr;
   if (!model_blob || nbytes != sizeof(MoccaModel)) { g_err = "model blob has the wrong size"; return MOCCA_E_ARG; }
   if (n_envs <= 0) { g_err = "n_envs must be positive"; return MOCCA_E_ARG; }
-  if (task_id != MOCCA_TASK_WALKER3D_CUSTOM && task_id != MOCCA_TASK_WALKER3D_STEPPER) { g_err = "unknown task id"; return MOCCA_E_ARG; }
+  if (task_id != MOCCA_TASK_WALKER3D_CUSTOM && task_id != MOCCA_TASK_WALKER3D_STEPPER && task_id != MOCCA_TASK_CASSIE) {
+    g_err = "unknown task id"; return MOCCA_E_ARG;
+  }
   mocca_ctx* h = new (std::nothrow) mocca_ctx();
   if (!h) return MOCCA_E_ARG;
   std::memcpy(&h->model, model_blob, sizeof(MoccaModel));
   if (h->model.magic != MOCCA_MODEL_MAGIC || h->model.version != MOCCA_MODEL_VERSION) {
     g_err = "bad model blob magic/version"; delete h; return MOCCA_E_ARG;
   }
-  int rc = check_topology(h->model, g_err);
+  int rc = check_topology(h->model, task_id, g_err);
   if (rc != MOCCA_OK) { delete h; return rc; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
     g_err = "no such HIP device"; delete h; return MOCCA_E_NODEVICE;
   }
   h->task_id = task_id; h->n_envs = n_envs; h->device = device;
-  h->obs_dim = 6 + 2 * h->model.n_joints + h->model.n_feet + (task_id == MOCCA_TASK_WALKER3D_CUSTOM ? 2 : 15);
+  h->obs_dim = task_id == MOCCA_TASK_CASSIE
+                   ? 6 + 2 * h->model.n_ordered + 2
+                   : 6 + 2 * h->model.n_joints + h->model.n_feet + (task_id == MOCCA_TASK_WALKER3D_CUSTOM ? 2 : 15);
   auto fail = [&](const char* what, hipError_t e) {
     g_err = std::string(what) + ": " + hipGetErrorString(e);
     mocca_destroy(h);
@@ -361,7 +469,10 @@ int mocca_destroy(mocca_handle h) {
 
 int mocca_n_envs(mocca_handle h) { return h ? h->n_envs : MOCCA_E_ARG; }
 int mocca_obs_dim(mocca_handle h) { return h ? h->obs_dim : MOCCA_E_ARG; }
-int mocca_act_dim(mocca_handle h) { return h ? h->model.n_joints : MOCCA_E_ARG; }
+int mocca_act_dim(mocca_handle h) {
+  if (!h) return MOCCA_E_ARG;
+  return h->task_id == MOCCA_TASK_CASSIE ? h->model.n_ctrl - 2 : h->model.n_joints;
+}
 int mocca_state_dim(mocca_handle h) { return h ? MOCCA_STATE_DIM(h->model.n_joints, h->model.n_slots) : MOCCA_E_ARG; }
 
 static StepArgs make_args(mocca_handle h) {
@@ -380,10 +491,7 @@ int mocca_reset(mocca_handle h, const uint8_t* mask_dev, uint64_t seed, float* o
   StepArgs a = make_args(h);
   a.mask = mask_dev; a.obs = obs_dev;
   hipStream_t s = (hipStream_t)stream;
-  if (h->task_id == MOCCA_TASK_WALKER3D_CUSTOM)
-    hipLaunchKernelGGL(mocca_reset_kernel<MOCCA_TASK_WALKER3D_CUSTOM>, dim3(h->n_envs), dim3(64), 0, s, a);
-  else
-    hipLaunchKernelGGL(mocca_reset_kernel<MOCCA_TASK_WALKER3D_STEPPER>, dim3(h->n_envs), dim3(64), 0, s, a);
+  dispatch<LaunchReset>(h->task_id, h->n_envs, s, a);
   HIP_TRY(h, hipGetLastError());
   return MOCCA_OK;
 }
@@ -394,10 +502,7 @@ int mocca_step(mocca_handle h, const float* act_dev, float* obs_dev, float* rew_
   StepArgs a = make_args(h);
   a.act = act_dev; a.obs = obs_dev; a.rew = rew_dev; a.done = done_dev; a.info = info_dev;
   hipStream_t s = (hipStream_t)stream;
-  if (h->task_id == MOCCA_TASK_WALKER3D_CUSTOM)
-    hipLaunchKernelGGL(mocca_step_kernel<MOCCA_TASK_WALKER3D_CUSTOM>, dim3(h->n_envs), dim3(64), 0, s, a);
-  else
-    hipLaunchKernelGGL(mocca_step_kernel<MOCCA_TASK_WALKER3D_STEPPER>, dim3(h->n_envs), dim3(64), 0, s, a);
+  dispatch<LaunchStep>(h->task_id, h->n_envs, s, a);
   HIP_TRY(h, hipGetLastError());
   return MOCCA_OK;
 }
@@ -407,10 +512,7 @@ int mocca_observe(mocca_handle h, float* obs_dev, void* stream) {
   StepArgs a = make_args(h);
   a.obs = obs_dev;
   hipStream_t s = (hipStream_t)stream;
-  if (h->task_id == MOCCA_TASK_WALKER3D_CUSTOM)
-    hipLaunchKernelGGL(mocca_observe_kernel<MOCCA_TASK_WALKER3D_CUSTOM>, dim3(h->n_envs), dim3(64), 0, s, a);
-  else
-    hipLaunchKernelGGL(mocca_observe_kernel<MOCCA_TASK_WALKER3D_STEPPER>, dim3(h->n_envs), dim3(64), 0, s, a);
+  dispatch<LaunchObserve>(h->task_id, h->n_envs, s, a);
   HIP_TRY(h, hipGetLastError());
   return MOCCA_OK;
 }
@@ -468,19 +570,14 @@ int mocca_set_param(mocca_handle h, int param_id, double value) {
 int mocca_kernel_info(mocca_handle h, int* vgprs, int* sgprs, int* lds_bytes, int* scratch_bytes, int* max_blocks_per_cu) {
   if (!h) return MOCCA_E_ARG;
   hipFuncAttributes fa;
-  const void* fn = h->task_id == MOCCA_TASK_WALKER3D_CUSTOM
-                       ? (const void*)mocca_step_kernel<MOCCA_TASK_WALKER3D_CUSTOM>
-                       : (const void*)mocca_step_kernel<MOCCA_TASK_WALKER3D_STEPPER>;
-  HIP_TRY(h, hipFuncGetAttributes(&fa, fn));
+  int nb = 0;
+  hipError_t e = hipSuccess;
+  dispatch<KernelInfo>(h->task_id, &fa, &nb, &e);
+  HIP_TRY(h, e);
   if (vgprs) *vgprs = fa.numRegs;
   if (sgprs) *sgprs = 0;
   if (lds_bytes) *lds_bytes = (int)fa.sharedSizeBytes;
   if (scratch_bytes) *scratch_bytes = (int)fa.localSizeBytes;
-  int nb = 0;
-  if (h->task_id == MOCCA_TASK_WALKER3D_CUSTOM)
-    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mocca_step_kernel<MOCCA_TASK_WALKER3D_CUSTOM>, 64, 0));
-  else
-    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mocca_step_kernel<MOCCA_TASK_WALKER3D_STEPPER>, 64, 0));
   if (max_blocks_per_cu) *max_blocks_per_cu = nb;
   return MOCCA_OK;
 }

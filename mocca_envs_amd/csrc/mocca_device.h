@@ -28,6 +28,7 @@
 
 #include "mocca_model.h"
 #include "topo_walker3d.h"
+#include "topo_cassie.h"
 
 #define DI __device__ __forceinline__
 
@@ -39,7 +40,7 @@ constexpr int DYN_STRIDE = 96;      // floats per env in the dynamic-state buffe
 constexpr int TERRAIN_STRIDE = 128; // floats per env in the terrain buffer
 
 // ---- LDS layout, float offsets (one wave = one env) ----
-// [0, L_V)      survives the whole substep (state, torques, new velocity, warm-start impulses)
+// [0, L_V)      survives the whole step (state, torques, new velocity, warm-start impulses)
 // [L_V, end)    one region with two views: the ABA view (joint vectors, articulated inertias, geom points,
 //               contacts) and the solver view (Delassus matrix A[48][48]; Jacobian rows parked in its tail,
 //               row k of J is consumed before row k of A reaches it: 48 k + 47 < 960 + 28 (k + 1) for k <= 47)
@@ -52,7 +53,9 @@ enum : int {
   L_WARM = 116,   // [40] warm-start impulses per terrain slot
   L_FEET = 156,   // [8] feet COM xyz (2x3)
   L_MISC = 164,   // [12]
-  L_V = 176,
+  L_JVEL = 176,   // [16] Cassie: filtered joint speeds of the low-level PD loop (env_cassie.py:451-453)
+  L_Q0 = 192,     // [16] Cassie: joint angles at the start of the env.step (finite-difference jvel, :467-468)
+  L_V = 208,
   // ---- ABA view
   L_SQ = L_V + 0,       // [24] sin q
   L_CQ = L_V + 24,      // [24] cos q
@@ -86,7 +89,8 @@ enum : int { C_BA = 0, C_BB = 1, C_SLOT = 2, C_P = 3, C_N = 6, C_DEPTH = 9, C_MU
 
 // task record words (include/mocca_model.h)
 enum : int { T_WTX = 0, T_WTY, T_WTZ, T_LINPOT, T_ANGPOT, T_CLOSE, T_STOPF, T_DONE, T_T, T_EPISODE, T_DRAW, T_MIRROR,
-             T_FC0, T_FC1, T_DIST, T_ANGLE, T_NSI, T_TRC, T_STOP, T_SETSTOP, T_CUR, T_GAIN, T_PREVX };
+             T_FC0, T_FC1, T_DIST, T_ANGLE, T_NSI, T_TRC, T_STOP, T_SETSTOP, T_CUR, T_GAIN, T_PREVX, T_RES23,
+             T_JVEL = 24, T_INITZ = 38, T_ISTEP = 39 };
 
 struct StepArgs {
   const MoccaModel* model;
@@ -233,7 +237,7 @@ DI void walk_kinematics(const MoccaModel* __restrict__ M, float* L, int lane) {
   }
 #pragma unroll
   for (int k = 0; k < T::MAXD; ++k) {
-    const int j = kPathWalker3D[b][k];
+    const int j = T::path(b, k);
     if (j >= 0) {
       float jp[3], ax[3], Tm[9];
 #pragma unroll
@@ -389,7 +393,7 @@ DI void aba_passes(const MoccaModel* __restrict__ M, float* L, int lane) {
 #pragma unroll 1
   for (int d = T::MAXD; d >= 1; --d) {
     const int s = lane >> 3, i = lane & 7;
-    const int b = (s < T::MAXW) ? (int)kLevelWalker3D[d][s] : -1;
+    const int b = (s < T::MAXW) ? T::level(d, s) : -1;
     const bool valid = b >= 0 && i < 6;
     const int bb = b >= 0 ? b : 0, ii = i < 6 ? i : 0;
     float row[6], S[6], c[6], pAi;
@@ -398,7 +402,7 @@ DI void aba_passes(const MoccaModel* __restrict__ M, float* L, int lane) {
     pAi = L[L_P + 6 * bb + ii];
 #pragma unroll
     for (int k = 0; k < T::MAXCH; ++k) {
-      const int ch = kChildWalker3D[bb][k];
+      const int ch = T::child(bb, k);
       if (ch >= 0) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) row[j] += L[L_M + 36 * ch + 6 * ii + j];
@@ -439,7 +443,7 @@ DI void aba_passes(const MoccaModel* __restrict__ M, float* L, int lane) {
     for (int i = 0; i < 6; ++i) pA[i] = L[L_P + i];
 #pragma unroll
     for (int k = 0; k < T::MAXCH; ++k) {
-      const int ch = kChildWalker3D[0][k];
+      const int ch = T::child(0, k);
       if (ch >= 0) {
 #pragma unroll
         for (int i = 0; i < 6; ++i)
@@ -468,7 +472,7 @@ DI void aba_passes(const MoccaModel* __restrict__ M, float* L, int lane) {
     for (int i = 0; i < 6; ++i) a[i] = L[L_A0 + 24 + i];
 #pragma unroll
     for (int k = 0; k < T::MAXD; ++k) {
-      const int j = kPathWalker3D[b][k];
+      const int j = T::path(b, k);
       if (j >= 0) {
         float U[6], S[6];
 #pragma unroll
@@ -608,7 +612,7 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
 #pragma unroll
       for (int i = 0; i < 3; ++i) { C[i] = L[L_GP + 3 * (2 * g + e) + i]; Cw[i] = C[i] + L[L_BASE + i]; }
       body = M->g_body[g];
-      if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
+      if (TASK != MOCCA_TASK_WALKER3D_STEPPER) {
         gap = Cw[2] - rad;
         mu = M->ground_friction * M->g_friction[g];
       } else {
@@ -756,9 +760,11 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
     nl = __popcll(lm);
     if (nl > maxr) nl = maxr;
   }
+  constexpr int NCL = 3 * T::NCLOS;  // point-to-point closure rows sit between the limit and the contact rows
   int nc = nc_found;
-  if (nc > (maxr - nl) / 3) nc = (maxr - nl) / 3;
-  const int nr = nl + 3 * nc;
+  if (nc > (maxr - nl - NCL) / 3) nc = (maxr - nl - NCL) / 3;
+  if (nc < 0) nc = 0;
+  const int nr = nl + NCL + 3 * nc;
   wsync();
   if (nr == 0) {  // nothing touches, no limit near: nothing to solve (uniform branch)
     if (lane < T::NSLOT) L[L_WARM + lane] = 0.0f;
@@ -769,6 +775,7 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
   const int r = lane;
   int kind = -1, ba = 0, bb = -1, jl = -1, nrm = -1, slot = -1;
   float F[6] = {0, 0, 0, 0, 0, 0}, sgn = 0, bias = 0, cfm = 0, lam = 0, mu = 0;
+  float F2[6] = {0, 0, 0, 0, 0, 0};  // force on body bb (closures: its own pivot; self contacts: same point as F)
   if (r < nl) {
     const int c = reinterpret_cast<int*>(L)[L_ROWD + r];
     const int b = 1 + (c >> 1), side = c & 1;
@@ -776,8 +783,30 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
     const float gap = side == 0 ? q - M->jlo[b] : M->jhi[b] - q;
     kind = 0; jl = b; ba = b; sgn = side == 0 ? 1.0f : -1.0f;
     bias = gap < 0 ? M->erp * (-gap) * idt : -gap * idt;
+  } else if (T::NCLOS > 0 && r < nl + NCL) {
+    // loop closure c, world axis ax: dir . (v(pivot a) - v(pivot b)) = erp (Pb - Pa)/dt, unbounded impulse
+    const int c = (r - nl) / 3, ax = (r - nl) % 3;
+    ba = M->cl_body_a[c]; bb = M->cl_body_b[c];
+    kind = 3;
+    float Pa[3], Pb[3], Ra[9], Rb[9], la[3], lb[3];
+#pragma unroll
+    for (int x = 0; x < 9; ++x) { Ra[x] = L[L_R + 9 * ba + x]; Rb[x] = L[L_R + 9 * bb + x]; }
+#pragma unroll
+    for (int x = 0; x < 3; ++x) { la[x] = M->cl_point_a[c][x]; lb[x] = M->cl_point_b[c][x]; }
+    matvec3(Ra, la, Pa); matvec3(Rb, lb, Pb);
+#pragma unroll
+    for (int x = 0; x < 3; ++x) { Pa[x] += L[L_RR + 3 * ba + x]; Pb[x] += L[L_RR + 3 * bb + x]; }
+    float dir[3] = {ax == 0 ? 1.0f : 0.0f, ax == 1 ? 1.0f : 0.0f, ax == 2 ? 1.0f : 0.0f}, pn[3];
+    cross3(Pa, dir, pn);
+#pragma unroll
+    for (int x = 0; x < 3; ++x) { F[x] = pn[x]; F[3 + x] = dir[x]; }
+    cross3(Pb, dir, pn);
+#pragma unroll
+    for (int x = 0; x < 3; ++x) { F2[x] = pn[x]; F2[3 + x] = dir[x]; }
+    const float e = ax == 0 ? Pb[0] - Pa[0] : (ax == 1 ? Pb[1] - Pa[1] : Pb[2] - Pa[2]);
+    bias = M->erp * e * idt;
   } else if (r < nr) {
-    const int k = r - nl;
+    const int k = r - nl - NCL;
     const int i = k < nc ? k : (k - nc) >> 1;
     const float* ct = L + L_CT + 16 * i;
     float n[3] = {ct[C_N], ct[C_N + 1], ct[C_N + 2]}, P[3] = {ct[C_P], ct[C_P + 1], ct[C_P + 2]}, dir[3];
@@ -797,17 +826,17 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
       const bool second = ((k - nc) & 1) != 0;
 #pragma unroll
       for (int x = 0; x < 3; ++x) dir[x] = second ? t2[x] : t1[x];
-      nrm = nl + i;
+      nrm = nl + NCL + i;
       mu = ct[C_MU];
     }
     float pn[3];
     cross3(P, dir, pn);
 #pragma unroll
-    for (int x = 0; x < 3; ++x) { F[x] = pn[x]; F[3 + x] = dir[x]; }
+    for (int x = 0; x < 3; ++x) { F[x] = pn[x]; F[3 + x] = dir[x]; F2[x] = pn[x]; F2[3 + x] = dir[x]; }
   }
   const unsigned ma = (kind >= 0) ? M->anc_mask[ba] : 0u;
   const unsigned mb = (kind >= 1 && bb >= 0) ? M->anc_mask[bb] : 0u;
-  const float basesign = (kind >= 1 && bb < 0) ? 1.0f : 0.0f;  // base part of J cancels for self contacts
+  const float sa = kind >= 1 ? 1.0f : 0.0f, sb = (kind >= 1 && bb >= 0) ? 1.0f : 0.0f;  // base part: F on a, -F2 on b
 
   // ---- unit response X = M^-1 J^T
   // Jacobian entries go straight to LDS (the J rows sit in the part of the region the ABA no longer
@@ -834,8 +863,9 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
     float S[6], U[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) { S[i] = L[L_S + 6 * b + i]; U[i] = L[L_U + 6 * b + i]; }
-    const float sf = dot6(S, F);
-    float jb = sf * ((ina ? 1.0f : 0.0f) - (inb ? 1.0f : 0.0f));
+    float jb;
+    if (T::NCLOS > 0) jb = (ina ? dot6(S, F) : 0.0f) - (inb ? dot6(S, F2) : 0.0f);
+    else jb = dot6(S, F) * ((ina ? 1.0f : 0.0f) - (inb ? 1.0f : 0.0f));  // F2 == F without closures
     if (b == jl) jb = sgn;
     float pc[6];
 #pragma unroll
@@ -862,7 +892,7 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
     float rhs[6], Ai[21];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const float jb = F[i] * basesign;
+      const float jb = F[i] * sa - F2[i] * sb;
       Jrow[i] = jb;
       w += jb * L[L_NU + i];
       rhs[i] = jb - (pa[i] + pb[i]);
@@ -906,7 +936,7 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
   // warm-start impulses act before the first iteration (normal rows only)
   float lim = 0.0f;  // friction bound mu * lambda_normal, maintained incrementally
 #pragma unroll 1
-  for (int rr = nl; rr < nl + nc; ++rr) {
+  for (int rr = nl + NCL; rr < nl + NCL + nc; ++rr) {
     const float l0 = readlane(lam, rr);
     if (l0 != 0.0f) {
       const float a = lane < MAXR ? L[L_A + MAXR * rr + lane] : 0.0f;
@@ -921,7 +951,7 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
 #pragma unroll 1
     for (int rr = 0; rr < nr; ++rr) {
       const float a = lane < MAXR ? L[L_A + MAXR * rr + lane] : 0.0f;
-      const float lo = kind == 2 ? -lim : 0.0f, hi = kind == 2 ? lim : 1e30f;
+      const float lo = kind == 2 ? -lim : (kind == 3 ? -1e30f : 0.0f), hi = kind == 2 ? lim : 1e30f;
       float nl_ = lam + (bias - w - cfm * lam) * invdiag;
       nl_ = nl_ < lo ? lo : (nl_ > hi ? hi : nl_);
       const float dl = readlane(nl_ - lam, rr);
@@ -1075,8 +1105,8 @@ DI RobotObs robot_obs(const MoccaModel* __restrict__ M, float* L, int lane, floa
 }
 
 struct TaskRegs {  // uniform across the wave
-  float wt[3], linpot, angpot, stopf, fc0, fc1, dist, angle, gain, prevx;
-  int close, done, t, episode, draw, mirrored, nsi, trc, stop, setstop, cur;
+  float wt[3], linpot, angpot, stopf, fc0, fc1, dist, angle, gain, prevx, initz;
+  int close, done, t, episode, draw, mirrored, nsi, trc, stop, setstop, cur, istep;
 };
 DI void load_task(const uint32_t* tk, TaskRegs& t) {
   auto f = [&](int i) { return __uint_as_float(tk[i]); };
@@ -1086,6 +1116,7 @@ DI void load_task(const uint32_t* tk, TaskRegs& t) {
   t.fc0 = f(T_FC0); t.fc1 = f(T_FC1); t.dist = f(T_DIST); t.angle = f(T_ANGLE);
   t.nsi = (int)tk[T_NSI]; t.trc = (int)tk[T_TRC]; t.stop = (int)tk[T_STOP]; t.setstop = (int)tk[T_SETSTOP];
   t.cur = (int)tk[T_CUR]; t.gain = f(T_GAIN); t.prevx = f(T_PREVX);
+  t.initz = f(T_INITZ); t.istep = (int)tk[T_ISTEP];
 }
 DI void store_task(uint32_t* tk, const TaskRegs& t) {
   auto u = [](float x) { return __float_as_uint(x); };
@@ -1095,6 +1126,7 @@ DI void store_task(uint32_t* tk, const TaskRegs& t) {
   tk[T_FC0] = u(t.fc0); tk[T_FC1] = u(t.fc1); tk[T_DIST] = u(t.dist); tk[T_ANGLE] = u(t.angle);
   tk[T_NSI] = (uint32_t)t.nsi; tk[T_TRC] = (uint32_t)t.trc; tk[T_STOP] = (uint32_t)t.stop; tk[T_SETSTOP] = (uint32_t)t.setstop;
   tk[T_CUR] = (uint32_t)t.cur; tk[T_GAIN] = u(t.gain); tk[T_PREVX] = u(t.prevx);
+  tk[T_INITZ] = u(t.initz); tk[T_ISTEP] = (uint32_t)t.istep;
 }
 
 // calc_potential, env_locomotion.py:143-158
@@ -1259,6 +1291,69 @@ DI void reset_env(const StepArgs& a, const MoccaModel* __restrict__ M, float* L,
     calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
   }
   t.prevx = L[L_BASE];
+}
+
+// ---------------- Cassie task layer (env_cassie.py:238-276, 348-479) ----------------
+// Cassie.calc_state + CassieEnv.get_obs on the state in LDS (kinematics done): 6 + 14 + 14 + 2 floats.
+// Returns pelvis z - lowest toe COM z; *finite = every robot_state entry finite.
+template <class T>
+DI float cassie_obs(const MoccaModel* __restrict__ M, const float* L, int lane, float initial_z, float* obs, bool* finite) {
+  const int no = M->n_ordered;
+  float q[4] = {L[L_BASE + 3], L[L_BASE + 4], L[L_BASE + 5], L[L_BASE + 6]}, rpy[3];
+  quat_to_rpy(q, rpy);
+  const float yaw = rpy[2], cy = cosf(-yaw), sy = sinf(-yaw);
+  const float head[6] = {L[L_BASE + 2] - initial_z, cy * L[L_BASE + 7] - sy * L[L_BASE + 8],
+                         sy * L[L_BASE + 7] + cy * L[L_BASE + 8], L[L_BASE + 9], rpy[0], rpy[1]};
+  bool fin = true;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) fin = fin && isfinite(head[i]);
+  bool jf = true;
+  if (lane < no) {
+    const int b = M->ordered_body[lane];
+    const float lo = M->jlo[b], hi = M->jhi[b], mid = 0.5f * (lo + hi);
+    const float nrm = 2 * (L[L_Q + b] - mid) / (hi - lo), sp = L[L_QD + b];  // bullet_utils.py:212-216
+    obs[6 + lane] = nrm;
+    obs[6 + no + lane] = sp;
+    jf = isfinite(nrm) && isfinite(sp);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) obs[i] = head[i];
+    const float tx = M->cassie_target[0], ty = M->cassie_target[1];
+    const float dth = atan2f(ty - L[L_BASE + 1], tx - L[L_BASE]) - yaw, c = cosf(dth), sn = sinf(dth);  // get_obs :416-431
+    obs[6 + 2 * no] = c * tx + sn * ty;
+    obs[6 + 2 * no + 1] = -sn * tx + c * ty;
+  }
+  *finite = fin && (__ballot(!jf) == 0ull);
+  return L[L_BASE + 2] - fminf(L[L_FEET + 2], L[L_FEET + 5]);
+}
+DI float cassie_potential(const MoccaModel* __restrict__ M, const float* L) {  // calc_potential :348-354
+  const float dx = M->cassie_target[0] - L[L_BASE], dy = M->cassie_target[1] - L[L_BASE + 1];
+  return -sqrtf(dx * dx + dy * dy) / M->control_dt;
+}
+// CassieEnv.reset (:362-378): nominal pose, at rest, no randomness
+template <class T>
+DI void cassie_reset_env(const MoccaModel* __restrict__ M, float* L, int lane, TaskRegs& t, float* obs) {
+  const int ep = t.episode + 1;
+  t = TaskRegs{};
+  t.episode = ep;
+  t.gain = 1.0f;
+  if (lane >= 1 && lane < T::NB) { L[L_Q + lane] = M->init_q[lane]; L[L_QD + lane] = 0.0f; }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { L[L_BASE + i] = M->init_pos[i]; L[L_BASE + 7 + i] = 0; L[L_BASE + 10 + i] = 0; }
+    L[L_BASE + 3] = 0; L[L_BASE + 4] = 0; L[L_BASE + 5] = 0; L[L_BASE + 6] = 1.0f;
+  }
+  if (lane < MOCCA_MAX_SLOTS) L[L_WARM + lane] = 0.0f;
+  if (lane < MOCCA_MAX_CTRL) L[L_JVEL + lane] = 0.0f;
+  wsync();
+  t.initz = L[L_BASE + 2];
+  sincos_joints(L, lane, T::NB);
+  walk_kinematics<T, false>(M, L, lane);
+  wsync();
+  bool fin;
+  cassie_obs<T>(M, L, lane, t.initz, obs, &fin);
+  t.linpot = cassie_potential(M, L);
 }
 
 DI void load_dyn(const float* st, float* L, int lane, int nj, int nslots) {

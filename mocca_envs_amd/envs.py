@@ -23,6 +23,23 @@ from . import host_logic as H
 from . import model as M
 
 
+class _CassieRobot:
+    """The attributes of env_cassie.Cassie that trainers touch (env_cassie.py:13-79)."""
+
+    foot_names = ["right_toe", "left_toe"]
+    powered_joint_inds = [0, 1, 2, 3, 6, 7, 8, 9, 10, 13]
+    spring_joint_inds = [4, 11]
+
+    def __init__(self, mdl: M.MoccaModel):
+        self.base_joint_angles = list(M.CASSIE_BASE_ANGLES)
+        self.base_position = tuple(mdl.init_pos)
+        high = np.ones(10)
+        self.action_space = gym.spaces.Box(-high, high, dtype=np.float32)
+        high = np.inf * np.ones((10 + 4) * 2 + 6)
+        self.observation_space = gym.spaces.Box(-high, high, dtype=np.float32)
+        self.body_xyz = np.zeros(3)
+
+
 class _Robot:
     """The attributes of robots.Walker3D that trainers touch (robots.py:13-29,230-290)."""
 
@@ -68,7 +85,7 @@ class EnvBase(gym.Env):
         from .vec_env import VecEnv  # imports torch; needs the HIP library and a GPU (no CPU fallback)
         self._vec = VecEnv(self.env_id, 1, device=device, auto_reset=False)
         self.model = self._vec.model
-        self.robot = _Robot(self.model)
+        self.robot = _CassieRobot(self.model) if self.task_id == M.TASK_CASSIE else _Robot(self.model)
         self.seed()
 
     # ---- gym surface --------------------------------------------------------------------------
@@ -255,3 +272,42 @@ class Walker3DStepperEnv(EnvBase):
     @classmethod
     def mirror_indices(cls):
         return H.mirror_indices(M.compile_walker3d(M.TASK_WALKER3D_STEPPER), stepper=True)
+
+
+class CassieEnv(EnvBase):
+    """env_cassie.py:284-479 (3-D, residual control).  The reference class is not importable in the reference
+    snapshot; this follows its text.  `planar=True` (the 2-D ids) is not modelled."""
+
+    env_id = "CassieEnv-v0"
+    task_id = M.TASK_CASSIE
+    control_step = 0.03
+    llc_frame_skip = 50
+    sim_frame_skip = 1
+
+    def __init__(self, render=False, planar=False, power_coef=1.0, residual_control=True, rsi=True, **kwargs):
+        if planar:
+            raise NotImplementedError("Cassie2D points at a missing URDF directory in the reference (env_cassie.py:280-282)")
+        if power_coef != 1.0 or not residual_control:
+            raise NotImplementedError("only power_coef=1.0, residual_control=True are compiled into the model blob")
+        super().__init__(render=render, **kwargs)
+        self.rsi = rsi
+        high = np.inf * np.ones(self.robot.observation_space.shape[0] + 2)
+        self.observation_space = gym.spaces.Box(-high, high, dtype=np.float32)
+        self.action_space = self.robot.action_space
+
+    def reset(self, istep=0):
+        import torch
+        self.done = False
+        self.walk_target = np.array([1000.0, 0.0, 0.0])
+        obs = self._vec.reset()[0].cpu().numpy().astype(np.float64)   # deterministic: nominal pose at rest
+        self.robot.body_xyz = self._vec.get_state()[0, 0:3].cpu().numpy().astype(np.float64)
+        return obs
+
+    def step(self, a):
+        import torch
+        a = np.asarray(a, dtype=np.float64)
+        assert np.isfinite(a).all()  # env_cassie.py:226
+        obs, rew, done, _ = self._vec.step(torch.from_numpy(a.astype(np.float32)[None]))
+        self.robot.body_xyz = self._vec.get_state()[0, 0:3].cpu().numpy().astype(np.float64)
+        self.done = bool(int(done[0].item()) & 1)
+        return obs[0].cpu().numpy().astype(np.float64), float(rew[0].item()), self.done, {}

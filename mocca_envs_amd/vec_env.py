@@ -18,7 +18,12 @@ from . import model as M
 TASKS = {
     "Walker3DCustomEnv-v0": M.TASK_WALKER3D_CUSTOM,
     "Walker3DStepperEnv-v0": M.TASK_WALKER3D_STEPPER,
+    "CassieEnv-v0": M.TASK_CASSIE,
 }
+
+
+def compile_model_for(task_id: int, **kw) -> M.MoccaModel:
+    return M.compile_cassie() if task_id == M.TASK_CASSIE else M.compile_walker3d(task_id, **kw)
 
 
 class VecEnv:
@@ -42,7 +47,7 @@ class VecEnv:
         self.device_index = torch.cuda.current_device() if device is None else int(device)
         self.device = torch.device("cuda", self.device_index)
         if model_blob is None:
-            self.model = M.compile_walker3d(self.task_id, **model_kw)
+            self.model = compile_model_for(self.task_id, **model_kw)
             model_blob = self.model.to_bytes()
         else:
             self.model = M.MoccaModel.from_bytes(model_blob)
@@ -151,7 +156,7 @@ class VecEnv:
 
 
 # task-record helpers: the device record is 24 x 32-bit words, floats and ints mixed (mocca_model.h)
-TASK_FLOAT_WORDS = (0, 1, 2, 3, 4, 6, 12, 13, 14, 15, 21, 22)
+TASK_FLOAT_WORDS = (0, 1, 2, 3, 4, 6, 12, 13, 14, 15, 21, 22) + tuple(range(24, 39))
 
 
 def task_to_float64(t: torch.Tensor) -> np.ndarray:

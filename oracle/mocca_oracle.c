@@ -177,6 +177,10 @@ typedef struct {
   int32_t next_step_index, target_reached_count, stop_on_next_step, set_stop_on_next_step, curriculum;
   real applied_gain;
   real prev_body_x;
+  /* Cassie (env_cassie.py:433-479) */
+  real jvel[MOCCA_MAX_CTRL];
+  real initial_z;
+  int32_t istep;
 } Task;
 
 typedef struct {
@@ -202,7 +206,7 @@ typedef struct {
   int nr;
   real J[MAX_ROWS][NDOF_MAX], Mi[MAX_ROWS][NDOF_MAX], A[MAX_ROWS][MAX_ROWS];
   real lam[MAX_ROWS], bias[MAX_ROWS], cfm[MAX_ROWS], w[MAX_ROWS];
-  int row_kind[MAX_ROWS]; /* 0 limit, 1 normal, 2 friction */
+  int row_kind[MAX_ROWS]; /* 0 limit, 1 normal, 2 friction, 3 closure */
   int row_normal[MAX_ROWS]; /* friction: index of its normal row */
   real row_mu[MAX_ROWS];
   int row_slot[MAX_ROWS];
@@ -512,7 +516,7 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
       int is_target = 0;
       geom_point(m, w, g, e, C);
       for (int k = 0; k < 3; ++k) Cw[k] = C[k] + s->pos[k];
-      if (o->task_id == MOCCA_TASK_WALKER3D_CUSTOM) {
+      if (o->task_id != MOCCA_TASK_WALKER3D_STEPPER) {
         gap = Cw[2] - rad;
         mu = (real)m->ground_friction * (real)m->g_friction[g];
       } else {
@@ -581,20 +585,27 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
 /* ------------------------------------------------------------------ */
 /* constraint rows + PGS                                               */
 /* ------------------------------------------------------------------ */
-static void contact_jacobian(const MoccaModel *m, const Work *w, int ba, int bb, const real *P, const real *dir, real *J) {
+/* row Jacobian of  dir . (velocity of point Pa of body ba  -  velocity of point Pb of body bb)  ; bb < 0: world */
+static void pair_jacobian(const MoccaModel *m, const Work *w, int ba, const real *Pa, int bb, const real *Pb, const real *dir,
+                          real *J) {
   int nd = 6 + m->n_joints;
   real F[6], pn[3];
-  cross3(P, dir, pn);
+  cross3(Pa, dir, pn);
   for (int k = 0; k < 3; ++k) { F[k] = pn[k]; F[3 + k] = dir[k]; }
   for (int k = 0; k < nd; ++k) J[k] = 0;
   for (int k = 0; k < 6; ++k) J[k] = F[k];
   for (int b = 1; b < m->n_bodies; ++b)
     if (m->anc_mask[ba] & (1u << b)) J[5 + b] = dot6(w->S[b], F);
   if (bb >= 0) {
+    cross3(Pb, dir, pn);
+    for (int k = 0; k < 3; ++k) { F[k] = pn[k]; F[3 + k] = dir[k]; }
     for (int k = 0; k < 6; ++k) J[k] -= F[k];
     for (int b = 1; b < m->n_bodies; ++b)
       if (m->anc_mask[bb] & (1u << b)) J[5 + b] -= dot6(w->S[b], F);
   }
+}
+static void contact_jacobian(const MoccaModel *m, const Work *w, int ba, int bb, const real *P, const real *dir, real *J) {
+  pair_jacobian(m, w, ba, P, bb, P, dir, J);
 }
 
 /* nu = [omega(3) v(3) qd(by body, at 5+b)] */
@@ -613,6 +624,22 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
       w->J[r][5 + b] = sgn;
       w->row_kind[r] = 0; w->row_normal[r] = -1; w->row_mu[r] = 0; w->row_slot[r] = -1;
       w->bias[r] = gap < 0 ? (real)m->erp * (-gap) * idt : -gap * idt;
+      w->cfm[r] = 0; w->lam[r] = 0;
+    }
+  }
+  /* --- point-to-point loop closures (bilateral, 3 rows each), env_cassie.py:114-137 --- */
+  for (int c = 0; c < m->n_closures; ++c) {
+    int ba = m->cl_body_a[c], bb = m->cl_body_b[c];
+    real la[3] = {m->cl_point_a[c][0], m->cl_point_a[c][1], m->cl_point_a[c][2]};
+    real lb[3] = {m->cl_point_b[c][0], m->cl_point_b[c][1], m->cl_point_b[c][2]}, Pa[3], Pb[3];
+    matvec3(w->R[ba], la, Pa); matvec3(w->R[bb], lb, Pb);
+    for (int k = 0; k < 3; ++k) { Pa[k] += w->r[ba][k]; Pb[k] += w->r[bb][k]; }
+    for (int ax = 0; ax < 3 && nr < m->max_rows; ++ax) {
+      real dir[3] = {ax == 0, ax == 1, ax == 2};
+      int r = nr++;
+      pair_jacobian(m, w, ba, Pa, bb, Pb, dir, w->J[r]);
+      w->row_kind[r] = 3; w->row_normal[r] = -1; w->row_mu[r] = 0; w->row_slot[r] = -1;
+      w->bias[r] = (real)m->erp * (Pb[ax] - Pa[ax]) * idt; /* pull pivot a onto pivot b */
       w->cfm[r] = 0; w->lam[r] = 0;
     }
   }
@@ -661,6 +688,7 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
   for (int it = 0; it < m->n_iters; ++it) {
     for (int r = 0; r < nr; ++r) {
       real lo = 0, hi = (real)1e30;
+      if (w->row_kind[r] == 3) lo = (real)-1e30;
       if (w->row_kind[r] == 2) {
         real lim = w->row_mu[r] * w->lam[w->row_normal[r]];
         lo = -lim; hi = lim;
@@ -863,12 +891,107 @@ static void delta_to_k_targets(const Oracle *o, const Dyn *s, Task *tk, const Te
 }
 
 static int obs_dim(const Oracle *o) {
+  if (o->task_id == MOCCA_TASK_CASSIE) return 6 + 2 * o->m.n_ordered + 2; /* env_cassie.py:76-79,344-346 */
   int base = 6 + 2 * o->m.n_joints + o->m.n_feet;
   return o->task_id == MOCCA_TASK_WALKER3D_CUSTOM ? base + 2 : base + 15;
 }
 
+/* ---------------- Cassie task layer, env_cassie.py:238-276,348-479 ---------------- */
+/* Cassie.calc_state + CassieEnv.get_obs; needs kinematics() done.  Returns pelvis z - lowest toe z. */
+static real cassie_obs(Oracle *o, const Dyn *s, const Task *tk, float *obs) {
+  const MoccaModel *m = &o->m;
+  Work *w = &o->wk;
+  int no = m->n_ordered;
+  quat_to_rpy(s->quat, o->body_rpy);
+  real yaw = o->body_rpy[2], cy = cos(-yaw), sy = sin(-yaw);
+  obs[0] = (float)(s->pos[2] - tk->initial_z);
+  obs[1] = (float)(cy * s->vel[0] - sy * s->vel[1]);
+  obs[2] = (float)(sy * s->vel[0] + cy * s->vel[1]);
+  obs[3] = (float)s->vel[2];
+  obs[4] = (float)o->body_rpy[0];
+  obs[5] = (float)o->body_rpy[1];
+  for (int k = 0; k < no; ++k) {
+    int b = m->ordered_body[k];
+    float pos = (float)s->q[b], lo = m->jlo[b], hi = m->jhi[b];
+    float mid = 0.5f * (lo + hi); /* Joint.current_relative_position, bullet_utils.py:212-216 */
+    obs[6 + k] = 2 * (pos - mid) / (hi - lo);
+    obs[6 + no + k] = (float)s->qd[b];
+  }
+  real dx = (real)m->cassie_target[0] - s->pos[0], dy = (real)m->cassie_target[1] - s->pos[1];
+  real dth = atan2(dy, dx) - yaw, c = cos(dth), sn = sin(dth); /* get_obs :416-431 */
+  obs[6 + 2 * no] = (float)(c * (real)m->cassie_target[0] + sn * (real)m->cassie_target[1]);
+  obs[6 + 2 * no + 1] = (float)(-sn * (real)m->cassie_target[0] + c * (real)m->cassie_target[1]);
+  real minz = 1e30;
+  for (int k = 0; k < m->n_feet; ++k) {
+    real z = s->pos[2] + w->comw[m->foot_body[k]][2];
+    if (z < minz) minz = z;
+  }
+  return s->pos[2] - minz;
+}
+static real cassie_potential(const Oracle *o, const Dyn *s) { /* calc_potential :348-354 */
+  real dx = (real)o->m.cassie_target[0] - s->pos[0], dy = (real)o->m.cassie_target[1] - s->pos[1];
+  return -sqrt(dx * dx + dy * dy) / (real)o->m.control_dt;
+}
+static void cassie_reset(Oracle *o, int env, float *obs) { /* CassieEnv.reset :362-378 (no randomness) */
+  const MoccaModel *m = &o->m;
+  Dyn *s = &o->dyn[env];
+  Task *tk = &o->task[env];
+  int ep = tk->episode + 1;
+  memset(tk, 0, sizeof(*tk));
+  tk->episode = ep; tk->applied_gain = 1;
+  for (int b = 1; b <= m->n_joints; ++b) { s->q[b] = m->init_q[b]; s->qd[b] = 0; }
+  for (int k = 0; k < 3; ++k) { s->pos[k] = m->init_pos[k]; s->vel[k] = 0; s->omg[k] = 0; }
+  s->quat[0] = s->quat[1] = s->quat[2] = 0; s->quat[3] = 1;
+  for (int k = 0; k < MOCCA_MAX_SLOTS; ++k) s->warm[k] = 0;
+  tk->initial_z = s->pos[2];
+  kinematics(m, s, &o->wk);
+  cassie_obs(o, s, tk, obs);
+  tk->linear_potential = cassie_potential(o, s);
+}
+static void cassie_step(Oracle *o, int env, const float *act, float *obs, float *rew, uint8_t *done, int32_t *info) {
+  const MoccaModel *m = &o->m;
+  Dyn *s = &o->dyn[env];
+  Task *tk = &o->task[env];
+  Work *w = &o->wk;
+  int nc = m->n_ctrl, no = m->n_ordered, npow = nc - 2;
+  real target[MOCCA_MAX_CTRL], tau[MB], q0[MOCCA_MAX_CTRL];
+  for (int k = 0; k < nc; ++k) target[k] = (real)m->ctrl_base[k] + (k < npow ? (real)act[k] : 0); /* :434-443 */
+  for (int k = 0; k < no; ++k) q0[k] = (real)(float)s->q[m->ordered_body[k]];
+  for (int it = 0; it < m->n_llc; ++it) { /* :450-459 */
+    for (int k = 0; k < no; ++k)
+      tk->jvel[k] = (1 - (real)m->jvel_alpha) * tk->jvel[k] + (real)m->jvel_alpha * (real)(float)s->qd[m->ordered_body[k]];
+    for (int b = 0; b <= m->n_joints; ++b) tau[b] = 0;
+    for (int k = 0; k < nc; ++k) { /* pd_control :380-393, apply_action :225-230 */
+      int b = m->ctrl_body[k], oi = m->ctrl_oidx[k];
+      real perr = target[k] - (real)(float)s->q[b];
+      real verr = 0 - tk->jvel[oi];
+      verr = verr < -5 ? -5 : (verr > 5 ? 5 : verr);
+      real t = (real)m->ctrl_kp[k] * perr + (real)m->ctrl_kd[k] * verr, lim = m->torque_limit[b];
+      tau[b] = t < -lim ? -lim : (t > lim ? lim : t);
+    }
+    tk->istep += 1;
+    substep(o, s, tk, &o->ter[env], tau, w);
+  }
+  for (int k = 0; k < no; ++k) tk->jvel[k] = ((real)(float)s->q[m->ordered_body[k]] - q0[k]) / (real)m->control_dt; /* :467-468 */
+  tk->t += 1;
+  kinematics(m, s, w);
+  real height = cassie_obs(o, s, tk, obs);
+  int finite = 1;
+  for (int i = 0; i < 6 + 2 * no; ++i) if (!isfinite(obs[i])) finite = 0;
+  real old = tk->linear_potential;
+  tk->linear_potential = cassie_potential(o, s);
+  real alive = height > (real)m->alive_height ? 2 : -1; /* :401-414 */
+  if (!finite || alive < 0) tk->done = 1;
+  *rew = (float)(alive + (tk->linear_potential - old));
+  *info = 0;
+  int timeout = tk->t >= m->max_episode_steps;
+  *done = (uint8_t)((tk->done ? 1 : 0) | (timeout ? 2 : 0));
+  if (o->auto_reset && (*done)) cassie_reset(o, env, obs);
+}
+
 /* reset one env.  The pose randomisation follows robots.py:179-210 with Philox draws. */
 static void reset_env(Oracle *o, int env, float *obs) {
+  if (o->task_id == MOCCA_TASK_CASSIE) { cassie_reset(o, env, obs); return; }
   const MoccaModel *m = &o->m;
   Dyn *s = &o->dyn[env];
   Task *tk = &o->task[env];
@@ -937,6 +1060,7 @@ static void reset_env(Oracle *o, int env, float *obs) {
 
 static void step_env(Oracle *o, int env, const float *act, float *obs, float *rew, uint8_t *done, int32_t *info,
                      const int32_t *ext_touch, const int32_t *ext_target) {
+  if (o->task_id == MOCCA_TASK_CASSIE) { cassie_step(o, env, act, obs, rew, done, info); return; }
   const MoccaModel *m = &o->m;
   Dyn *s = &o->dyn[env];
   Task *tk = &o->task[env];
@@ -1085,6 +1209,7 @@ API void orc_destroy(void *h) {
   free(o->dyn); free(o->task); free(o->ter); free(o);
 }
 API int orc_obs_dim(void *h) { return obs_dim((Oracle *)h); }
+API int orc_act_dim(void *h) { Oracle *o = (Oracle *)h; return o->task_id == MOCCA_TASK_CASSIE ? o->m.n_ctrl - 2 : o->m.n_joints; }
 API int orc_state_dim(void *h) { Oracle *o = (Oracle *)h; return MOCCA_STATE_DIM(o->m.n_joints, o->m.n_slots); }
 
 enum { PARAM_AUTO_RESET = 0, PARAM_EVAL_MODE = 1, PARAM_CURRICULUM = 2, PARAM_RANDOM_POSE = 3 };
@@ -1105,7 +1230,7 @@ API void orc_reset(void *h, const uint8_t *mask, uint64_t seed, float *obs) {
 }
 API void orc_step(void *h, const float *act, float *obs, float *rew, uint8_t *done, int32_t *info) {
   Oracle *o = (Oracle *)h;
-  int od = obs_dim(o), nj = o->m.n_joints;
+  int od = obs_dim(o), nj = o->task_id == MOCCA_TASK_CASSIE ? o->m.n_ctrl - 2 : o->m.n_joints;
   for (int e = 0; e < o->n_envs; ++e) {
     int32_t inf = 0;
     step_env(o, e, act + (size_t)e * nj, obs + (size_t)e * od, rew + e, done + e, &inf, NULL, NULL);
@@ -1166,6 +1291,8 @@ API void orc_get_task(void *h, double *t) {
     p[12] = k->feet_contact[0]; p[13] = k->feet_contact[1]; p[14] = k->dist; p[15] = k->angle;
     p[16] = k->next_step_index; p[17] = k->target_reached_count; p[18] = k->stop_on_next_step;
     p[19] = k->set_stop_on_next_step; p[20] = k->curriculum; p[21] = k->applied_gain; p[22] = k->prev_body_x;
+    for (int j = 0; j < 14; ++j) p[24 + j] = k->jvel[j];
+    p[38] = k->initial_z; p[39] = k->istep;
   }
 }
 API void orc_set_task(void *h, const double *t) {
@@ -1180,6 +1307,8 @@ API void orc_set_task(void *h, const double *t) {
     k->dist = (real)p[14]; k->angle = (real)p[15]; k->next_step_index = (int)p[16];
     k->target_reached_count = (int)p[17]; k->stop_on_next_step = (int)p[18]; k->set_stop_on_next_step = (int)p[19];
     k->curriculum = (int)p[20]; k->applied_gain = (real)p[21]; k->prev_body_x = (real)p[22];
+    for (int j = 0; j < 14; ++j) k->jvel[j] = (real)p[24 + j];
+    k->initial_z = (real)p[38]; k->istep = (int)p[39];
   }
 }
 API void orc_get_terrain(void *h, double *t) { /* [N][20][6] + plank_info appended per env [3] */

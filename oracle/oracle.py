@@ -14,7 +14,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-TASK_WORDS = 24
+TASK_WORDS = 40
 TERRAIN_WORDS = 20 * 6 + 3
 
 
@@ -39,7 +39,7 @@ def _load(precision: str) -> C.CDLL:
     lib.orc_create.restype = C.c_void_p
     lib.orc_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.orc_destroy.argtypes = [C.c_void_p]
-    for name in ("orc_obs_dim", "orc_state_dim", "orc_last_rows"):
+    for name in ("orc_obs_dim", "orc_state_dim", "orc_last_rows", "orc_act_dim"):
         getattr(lib, name).argtypes = [C.c_void_p]
         getattr(lib, name).restype = C.c_int
     lib.orc_set_param.argtypes = [C.c_void_p, C.c_int, C.c_double]
@@ -80,6 +80,7 @@ class Oracle:
         self.n_envs = n_envs
         self.obs_dim = self.lib.orc_obs_dim(self.h)
         self.state_dim = self.lib.orc_state_dim(self.h)
+        self.act_dim = self.lib.orc_act_dim(self.h)
         nj = (self.state_dim - 13)
         self.n_joints = None
 
