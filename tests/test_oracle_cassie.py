@@ -54,3 +54,35 @@ def test_pd_loop_and_closures_over_an_episode():
     tk = o.get_task()[0]
     assert tk[39] == 50 * (t + 1)                    # istep counts PD iterations (env_cassie.py:381)
     assert o.last_rows() >= 6                        # 2 closures x 3 rows always present
+
+
+def test_cassie_task_logic_matches_the_reference_code():
+    """tests/golden/make_golden_cassie.py ran the reference's real Cassie / CassieEnv methods (with the missing
+    imports supplied) over THIS oracle's physics; the oracle's own step must then reproduce them: PD loop, joint
+    speed filter, torque clipping, residual targets, observation layout, reward, termination."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cassie_reference.npz"))
+    m = M.compile_cassie()
+    # static facts read from the reference objects
+    assert list(g["ordered_joint_names"]) == M.CASSIE_ORDERED_JOINTS
+    np.testing.assert_allclose([m.torque_limit[m.ordered_body[k]] for k in range(14)], g["torque_limits"], rtol=1e-6)
+    np.testing.assert_allclose([m.jlo[m.ordered_body[k]] for k in range(14)], g["joint_lo"], rtol=1e-6)
+    np.testing.assert_allclose([m.jhi[m.ordered_body[k]] for k in range(14)], g["joint_hi"], rtol=1e-6)
+    np.testing.assert_allclose([m.jdamp[m.ordered_body[k]] for k in range(14)], g["joint_damping"], rtol=1e-6)
+    np.testing.assert_allclose(list(m.ctrl_kp)[:12], g["kp"], rtol=1e-6)
+    np.testing.assert_allclose(list(m.ctrl_kd)[:12], g["kd"], rtol=1e-6)
+    assert abs(m.jvel_alpha - float(g["jvel_alpha"])) < 1e-7 and m.n_llc == int(g["llc_frame_skip"])
+    assert abs(m.dt - float(g["scene_fixedTimeStep"])) < 1e-9 and int(g["n_constraints"]) == m.n_closures
+    assert list(g["powered"]) + list(g["springs"]) == list(m.ctrl_oidx)[:12]
+    np.testing.assert_allclose([m.init_q[m.ordered_body[k]] for k in range(14)], g["base_joint_angles"], rtol=1e-6)
+    for ep in range(2):
+        o = Oracle(m.to_bytes(), M.TASK_CASSIE, 1, "f64")
+        obs = o.reset(seed=0)
+        np.testing.assert_allclose(obs[0], g[f"ep{ep}_obs"][0], atol=1e-5)
+        for t, a in enumerate(g[f"ep{ep}_actions"]):
+            obs, rew, done, _ = o.step(a[None].astype(np.float32))
+            # actions pass through float32 on this side only; 50 PD iterations amplify that to ~1e-4
+            np.testing.assert_allclose(obs[0], g[f"ep{ep}_obs"][t + 1], atol=2e-3, rtol=2e-3, err_msg=f"ep{ep} t{t}")
+            assert abs(rew[0] - g[f"ep{ep}_rew"][t]) < 2e-2, (ep, t, rew[0], g[f"ep{ep}_rew"][t])
+            assert bool(done[0] & 1) == bool(g[f"ep{ep}_done"][t])
+        np.testing.assert_allclose(o.get_state()[0][:49], g[f"ep{ep}_final_state"][:49], atol=2e-3, rtol=2e-3)
