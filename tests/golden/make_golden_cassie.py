@@ -189,7 +189,7 @@ def main():
         phys.reset(seed=0)
         obs0 = env.reset()
         acts, obs_l, rew_l, done_l = [], [obs0], [], []
-        for t in range(8):
+        for t in range(8 if ep == 0 else 30):
             a = (0.25 if ep == 0 else 0.6) * rng.uniform(-1, 1, 10)
             o, r, d, info = env.step(a)
             acts.append(a); obs_l.append(o); rew_l.append(r); done_l.append(d)
