@@ -192,6 +192,8 @@ DI float group8_sum(float t) {
   t += dpp_mov<0x141>(t);  // row_half_mirror
   return t;
 }
+DI int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }  // assert wave-uniformity: value moves to an SGPR
+DI float unif(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 DI float readlane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 DI int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 DI int lane_rank(unsigned long long mask) {  // number of set bits below this lane
@@ -593,9 +595,9 @@ struct ContactFlags { int touch0, touch1, target0, target1; };
 template <class T, int TASK>
 DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, const float* ter, int next_step_index,
                         int* nc_out) {
-  const float margin = M->contact_margin;
+  const float margin = unif(M->contact_margin);
   ContactFlags fl = {0, 0, 0, 0};
-  const int maxc = M->max_contacts;
+  const int maxc = uni(M->max_contacts);
   // ---- terrain: lane -> (geom, end)
   bool active = false;
   float n[3] = {0, 0, 1}, P[3] = {0, 0, 0}, gap = 1e30f, mu = 0, erp = M->erp, cfm = 0;
@@ -666,7 +668,7 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
   }
   if (nc > maxc) nc = maxc;
   // ---- self collisions
-  const int npairs = M->n_pairs;
+  const int npairs = uni(M->n_pairs);
 #pragma unroll 1
   for (int base = 0; base < npairs; base += 64) {
     const int k = base + lane;
@@ -742,8 +744,9 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
 //   6. nu += sum_r X_r lambda_r, summed in row order through LDS
 template <class T>
 DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, int nc_found) {
-  const float dt = M->dt, idt = rcp(dt);
-  const int maxr = M->max_rows;
+  // wave-uniform scalars live in SGPRs: loop control becomes s_cmp/s_cbranch instead of exec-mask bookkeeping
+  const float dt = unif(M->dt), idt = rcp(dt);
+  const int maxr = uni(M->max_rows);
   int nl;
   {
     bool act = false;
@@ -757,11 +760,11 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
     const unsigned long long lm = __ballot(act);
     const int rk = lane_rank(lm);
     if (act && rk < maxr) reinterpret_cast<int*>(L)[L_ROWD + rk] = lane;
-    nl = __popcll(lm);
+    nl = uni(__popcll(lm));
     if (nl > maxr) nl = maxr;
   }
   constexpr int NCL = 3 * T::NCLOS;  // point-to-point closure rows sit between the limit and the contact rows
-  int nc = nc_found;
+  int nc = uni(nc_found);
   if (nc > (maxr - nl - NCL) / 3) nc = (maxr - nl - NCL) / 3;
   if (nc < 0) nc = 0;
   const int nr = nl + NCL + 3 * nc;
@@ -922,6 +925,8 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
   }
   wsync();  // all lanes are done with the ABA view: the A matrix may overwrite it
   // ---- Delassus matrix: A[rr][lane] = J_rr . X_lane (rows of J broadcast from LDS)
+  // lanes >= MAXR own no row: they read/write column MAXR-1 of the dummy area instead of branching around each access
+  const int lc = lane < MAXR ? lane : MAXR - 1;
   float diag = 1.0f;
 #pragma unroll 1
   for (int rr = 0; rr < nr; ++rr) {
@@ -929,35 +934,37 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
 #pragma unroll
     for (int d = 0; d < T::ND; ++d) s += L[L_J + 28 * rr + d] * X[d];
     if (lane < MAXR) L[L_A + MAXR * rr + lane] = s;
-    if (rr == r) diag = s;
+    diag = rr == r ? s : diag;
   }
   const float invdiag = rcp(diag + cfm);
   wsync();
   // warm-start impulses act before the first iteration (normal rows only)
-  float lim = 0.0f;  // friction bound mu * lambda_normal, maintained incrementally
+  // impulse bounds, maintained incrementally: friction rows follow mu * lambda of their normal row
+  float lo = kind == 3 ? -1e30f : 0.0f, hi = kind == 2 ? 0.0f : 1e30f;
 #pragma unroll 1
   for (int rr = nl + NCL; rr < nl + NCL + nc; ++rr) {
     const float l0 = readlane(lam, rr);
     if (l0 != 0.0f) {
-      const float a = lane < MAXR ? L[L_A + MAXR * rr + lane] : 0.0f;
-      w += a * l0;
-      if (nrm == rr) lim = mu * l0;
+      w += L[L_A + MAXR * rr + lc] * l0;
+      const float lm0 = mu * l0;
+      hi = nrm == rr ? lm0 : hi;
+      lo = nrm == rr ? -lm0 : lo;
     }
   }
   // ---- projected Gauss-Seidel, rows in lane order (limits, normals, frictions)
-  const int iters = M->n_iters;
+  const int iters = uni(M->n_iters);
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
 #pragma unroll 1
     for (int rr = 0; rr < nr; ++rr) {
-      const float a = lane < MAXR ? L[L_A + MAXR * rr + lane] : 0.0f;
-      const float lo = kind == 2 ? -lim : (kind == 3 ? -1e30f : 0.0f), hi = kind == 2 ? lim : 1e30f;
-      float nl_ = lam + (bias - w - cfm * lam) * invdiag;
-      nl_ = nl_ < lo ? lo : (nl_ > hi ? hi : nl_);
+      const float a = L[L_A + MAXR * rr + lc];
+      // every lane evaluates its own candidate; only row rr's is broadcast and applied (v_med3 = clamp)
+      const float nl_ = __builtin_amdgcn_fmed3f(lam + (bias - w - cfm * lam) * invdiag, lo, hi);
       const float dl = readlane(nl_ - lam, rr);
-      const float newl = readlane(nl_, rr);
-      if (r == rr) lam = nl_;
-      if (nrm == rr) lim = mu * newl;
+      const float lm = mu * readlane(nl_, rr);
+      lam = r == rr ? nl_ : lam;
+      hi = nrm == rr ? lm : hi;
+      lo = nrm == rr ? -lm : lo;
       w += a * dl;
     }
   }
