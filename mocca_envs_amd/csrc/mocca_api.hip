@@ -31,6 +31,8 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   float* obs = a.obs + (size_t)env * a.obs_dim;
 
   load_dyn(st, L, lane, T::NJ, T::NSLOT);
+  // the lane's root->body path, packed 5 bits per step; the only lane-derived value kept across the substeps
+  const unsigned long long ppk = T::path_packed(lane < T::NB ? lane : 0);
   if constexpr (TASK == MOCCA_TASK_CASSIE) {
     // ---- CassieEnv.step (env_cassie.py:433-479): 50 x { filter joint speeds, PD torques, one physics step }
     const int no = M->n_ordered, nctl = M->n_ctrl;
@@ -48,7 +50,8 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     for (int it = 0; it < nllc; ++it) {
       const MoccaModel* Ms = M;
       int ln = lane;
-      asm volatile("" : "+s"(Ms), "+v"(ln));
+      unsigned long long pk = ppk;
+      asm volatile("" : "+s"(Ms), "+v"(ln), "+v"(pk));
       if (ln < no) {  // :451-453
         const float al = Ms->jvel_alpha;
         L[L_JVEL + ln] = (1.0f - al) * L[L_JVEL + ln] + al * L[L_QD + Ms->ordered_body[ln]];
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
         L[L_TAU + b] = tq < -lim ? -lim : (tq > lim ? lim : tq);
       }
       wsync();
-      substep<T, TASK>(Ms, L, ln, nullptr, 0);
+      substep<T, TASK>(Ms, L, ln, nullptr, 0, pk);
     }
     TaskRegs t;
     load_task(tk, t);
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
       tk[T_JVEL + lane] = __float_as_uint(jv);
     }
     sincos_joints(L, lane, T::NB);
-    walk_kinematics<T, false>(M, L, lane);
+    walk_kinematics<T, false>(M, L, lane, T::path_packed(lane < T::NB ? lane : 0));
     wsync();
     t.t += 1;
     bool fin;
@@ -121,8 +124,9 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     // substep loop, where they would sit in registers (and spill to scratch) for the whole kernel
     const MoccaModel* Ms = M;
     int ln = lane;  // same for lane-derived offsets and predicates (recomputing them costs a few instructions)
-    asm volatile("" : "+s"(Ms), "+v"(ln));
-    fl = substep<T, TASK>(Ms, L, ln, ter, nsi0);
+    unsigned long long pk = ppk;  // laundered too: otherwise every (ppk >> 5k) & 31 and the addresses derived from it
+    asm volatile("" : "+s"(Ms), "+v"(ln), "+v"(pk));  // are hoisted out of the loop and spilled
+    fl = substep<T, TASK>(Ms, L, ln, ter, nsi0, pk);
   }
   TaskRegs t;
   load_task(tk, t);
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
 
   // ---- calc_state + task logic on the post-step state
   sincos_joints(L, lane, T::NB);
-  walk_kinematics<T, false>(M, L, lane);
+  walk_kinematics<T, false>(M, L, lane, T::path_packed(lane < T::NB ? lane : 0));
   wsync();
   t.t += 1;
   constexpr int NBO = 6 + 2 * T::NJ + 2;
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
   if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
   wsync();
   sincos_joints(L, lane, T::NB);
-  walk_kinematics<T, false>(M, L, lane);
+  walk_kinematics<T, false>(M, L, lane, T::path_packed(lane < T::NB ? lane : 0));
   wsync();
   constexpr int NBO = 6 + 2 * T::NJ + 2;
   if constexpr (TASK == MOCCA_TASK_CASSIE) {
@@ -566,6 +570,16 @@ int mocca_set_param(mocca_handle h, int param_id, double value) {
   }
   return MOCCA_OK;
 }
+
+#ifdef MOCCA_STAMPS
+// diagnostic builds only: accumulated s_memtime ticks per phase (lane 0 of every wave), then cleared
+int mocca_debug_stamps(unsigned long long* out32) {
+  unsigned long long zero[32] = {0};
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(mocca::g_stamps), sizeof(zero)) != hipSuccess) return MOCCA_E_HIP;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(mocca::g_stamps), zero, sizeof(zero)) != hipSuccess) return MOCCA_E_HIP;
+  return MOCCA_OK;
+}
+#endif
 
 int mocca_kernel_info(mocca_handle h, int* vgprs, int* sgprs, int* lds_bytes, int* scratch_bytes, int* max_blocks_per_cu) {
   if (!h) return MOCCA_E_ARG;

@@ -34,6 +34,16 @@
 
 namespace mocca {
 
+#ifdef MOCCA_STAMPS  // diagnostic build only (tools/stamps.sh): per-phase cycle shares of one wave's timeline
+__device__ unsigned long long g_stamps[32];
+#define STAMP(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+  if (lane == 0) atomicAdd(&g_stamps[k], t_ - stamp_t0); stamp_t0 = t_; } while (0)
+#define STAMP_BEGIN unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+#else
+#define STAMP(k) do {} while (0)
+#define STAMP_BEGIN do {} while (0)
+#endif
+
 constexpr int MAXR = 48;  // rows held by one wave (MoccaModel.max_rows must be <= MAXR)
 constexpr int MAXC = 12;  // contacts            (MoccaModel.max_contacts <= MAXC)
 constexpr int DYN_STRIDE = 96;      // floats per env in the dynamic-state buffer
@@ -228,7 +238,7 @@ DI float rng_uniform(uint32_t slo, uint32_t shi, uint32_t env, uint32_t episode,
 // lane = body.  Walks root -> body composing joint transforms; with FULL also joint motion vectors,
 // spatial velocities, velocity-product accelerations, link inertia and bias force (ABA pass 1).
 template <class T, bool FULL>
-DI void walk_kinematics(const MoccaModel* __restrict__ M, float* L, int lane) {
+DI void walk_kinematics(const MoccaModel* __restrict__ M, float* L, int lane, unsigned long long ppk) {
   const int b = lane < T::NB ? lane : 0;
   float R[9], r[3] = {0, 0, 0}, v[6], S[6] = {0, 0, 0, 0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
   {
@@ -239,8 +249,8 @@ DI void walk_kinematics(const MoccaModel* __restrict__ M, float* L, int lane) {
   }
 #pragma unroll
   for (int k = 0; k < T::MAXD; ++k) {
-    const int j = T::path(b, k);
-    if (j >= 0) {
+    const int j = (int)((ppk >> (5 * k)) & 31ull);  // the lane's packed path: no table access
+    if (j != 31) {
       float jp[3], ax[3], Tm[9];
 #pragma unroll
       for (int i = 0; i < 3; ++i) { jp[i] = M->jpos[j][i]; ax[i] = M->jaxis[j][i]; }
@@ -338,6 +348,10 @@ DI void walk_kinematics(const MoccaModel* __restrict__ M, float* L, int lane) {
         for (int jx = 0; jx < 6; ++jx) L[L_M + 36 * b + 6 * i + jx] = I[sym(i, jx)];
 #pragma unroll
       for (int i = 0; i < 6; ++i) L[L_P + 6 * b + i] = p[i];
+      // staged for the inward pass (which overwrites both slots with 1/D and u): joint armature and the net joint
+      // torque, so that the level loop reads LDS only -- its global loads were hoisted above all levels and spilled
+      L[L_INVD + b] = M->jarm[b];
+      L[L_UU + b] = L[L_TAU + b] - M->jdamp[b] * L[L_QD + b];
     }
   }
 }
@@ -387,41 +401,57 @@ DI void spd6_inverse_sym(const float* A, float* Ainv) {
 // ABA inward pass (lane = body of the current level) + base solve + outward pass (lane = body).
 // Leaves S, U, 1/D, u, IA0^-1 in LDS for the row sweeps and the new generalised velocity in L_NU.
 template <class T>
-DI void aba_passes(const MoccaModel* __restrict__ M, float* L, int lane) {
+DI void aba_passes(const MoccaModel* __restrict__ M, float* L, int lane, unsigned long long ppk) {
+  STAMP_BEGIN;
   // ---- inward pass, one tree level at a time.  8 lanes per body (lane i < 6 owns row i of the 6x6
   // articulated inertia), up to MAXW = 4 bodies per level: ~45 VALU per level instead of ~260 with one
   // lane per body.  Children are pulled (summed in descending index order, as the oracle does).
   static_assert(T::MAXW * 8 <= 64, "level does not fit a wave");
-#pragma unroll 1
+  static_assert(T::MAXW == 4 && T::MAXCH <= 3, "level pass is written for <= 4 bodies per level, <= 3 children");
+  const int s = lane >> 3, i = lane & 7;
+  const int ii = i < 6 ? i : 0;
+#pragma unroll
   for (int d = T::MAXD; d >= 1; --d) {
-    const int s = lane >> 3, i = lane & 7;
-    const int b = (s < T::MAXW) ? T::level(d, s) : -1;
+    // bodies of this level and their children are compile-time constants selected by the lane's slot
+    const int b = s == 0 ? T::clevel(d, 0) : s == 1 ? T::clevel(d, 1) : s == 2 ? T::clevel(d, 2) : s == 3 ? T::clevel(d, 3) : -1;
     const bool valid = b >= 0 && i < 6;
-    const int bb = b >= 0 ? b : 0, ii = i < 6 ? i : 0;
+    const int bb = b >= 0 ? b : 0;
     float row[6], S[6], c[6], pAi;
 #pragma unroll
     for (int j = 0; j < 6; ++j) { row[j] = L[L_M + 36 * bb + 6 * ii + j]; S[j] = L[L_S + 6 * bb + j]; c[j] = L[L_C + 6 * bb + j]; }
     pAi = L[L_P + 6 * bb + ii];
 #pragma unroll
     for (int k = 0; k < T::MAXCH; ++k) {
-      const int ch = T::child(bb, k);
-      if (ch >= 0) {
+      const int ch = s == 0 ? T::cchild(T::clevel(d, 0), k) : s == 1 ? T::cchild(T::clevel(d, 1), k)
+                   : s == 2 ? T::cchild(T::clevel(d, 2), k) : s == 3 ? T::cchild(T::clevel(d, 3), k) : -1;
+      if (T::cchild(T::clevel(d, 0), k) >= 0 || T::cchild(T::clevel(d, 1), k) >= 0 || T::cchild(T::clevel(d, 2), k) >= 0 ||
+          T::cchild(T::clevel(d, 3), k) >= 0) {  // compile-time: does any body of this level have a k-th child?
+        if (ch >= 0) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) row[j] += L[L_M + 36 * ch + 6 * ii + j];
-        pAi += L[L_P + 6 * ch + ii];
+          for (int j = 0; j < 6; ++j) row[j] += L[L_M + 36 * ch + 6 * ii + j];
+          pAi += L[L_P + 6 * ch + ii];
+        }
       }
     }
     const float Si = i == 0 ? S[0] : i == 1 ? S[1] : i == 2 ? S[2] : i == 3 ? S[3] : i == 4 ? S[4] : S[5];
-    const float Ui = dot6(row, S);
+    const float Ui = valid ? dot6(row, S) : 0.0f;
     const float dsum = group8_sum(valid ? Si * Ui : 0.0f);
     const float psum = group8_sum(valid ? Si * pAi : 0.0f);
-    const float id = rcp(dsum + M->jarm[bb]);
-    const float u = L[L_TAU + bb] - M->jdamp[bb] * L[L_QD + bb] - psum;
-    if (valid) L[L_U + 6 * bb + ii] = Ui;
-    wsync();
+    const float id = rcp(dsum + L[L_INVD + bb]);
+    const float u = L[L_UU + bb] - psum;
+    // all six U_j of the body on every lane of its 8-lane group, by DPP instead of an LDS round trip:
+    // quad broadcasts give the own quad's four values, a half-row mirror brings the other quad's
     float U[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) U[j] = L[L_U + 6 * bb + j];
+    {
+      const float q0 = dpp_mov<0x00>(Ui), q1 = dpp_mov<0x55>(Ui), q2 = dpp_mov<0xAA>(Ui), q3 = dpp_mov<0xFF>(Ui);  // own quad lanes 0..3
+      const float Um = dpp_mov<0x141>(Ui);                                                                       // lane i <- lane 7-i
+      const float m0 = dpp_mov<0x00>(Um), m1 = dpp_mov<0x55>(Um), m2 = dpp_mov<0xAA>(Um), m3 = dpp_mov<0xFF>(Um);
+      // lanes 0-3 (first quad): own = U0..U3, mirrored quad holds (U7,U6,U5,U4) -> U4 = m3, U5 = m2
+      // lanes 4-7 (second quad): own = U4..U7, mirrored quad holds (U3,U2,U1,U0) -> U0 = m3, U1 = m2, U2 = m1, U3 = m0
+      const bool first = i < 4;
+      U[0] = first ? q0 : m3; U[1] = first ? q1 : m2; U[2] = first ? q2 : m1; U[3] = first ? q3 : m0;
+      U[4] = first ? m3 : q0; U[5] = first ? m2 : q1;
+    }
     const float uid = Ui * id;
     float Iac = 0.0f;
 #pragma unroll
@@ -430,10 +460,12 @@ DI void aba_passes(const MoccaModel* __restrict__ M, float* L, int lane) {
 #pragma unroll
       for (int j = 0; j < 6; ++j) L[L_M + 36 * bb + 6 * ii + j] = row[j];
       L[L_P + 6 * bb + ii] = pAi + Iac + uid * u;
+      L[L_U + 6 * bb + ii] = Ui;
       if (i == 0) { L[L_INVD + bb] = id; L[L_UU + bb] = u; }
     }
     wsync();
   }
+  STAMP(10);
   // base: every lane computes the same 6x6 solve (uniform data, broadcast LDS reads)
   {
     float IA[21], pA[6];
@@ -466,6 +498,7 @@ DI void aba_passes(const MoccaModel* __restrict__ M, float* L, int lane) {
     }
     wsync();
   }
+  STAMP(11);
   // outward pass: lane = body, walk from the root accumulating the spatial acceleration
   {
     const int b = lane < T::NB ? lane : 0;
@@ -474,8 +507,8 @@ DI void aba_passes(const MoccaModel* __restrict__ M, float* L, int lane) {
     for (int i = 0; i < 6; ++i) a[i] = L[L_A0 + 24 + i];
 #pragma unroll
     for (int k = 0; k < T::MAXD; ++k) {
-      const int j = T::path(b, k);
-      if (j >= 0) {
+      const int j = (int)((ppk >> (5 * k)) & 31ull);
+      if (j != 31) {
         float U[6], S[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) { a[i] += L[L_C + 6 * j + i]; U[i] = L[L_U + 6 * j + i]; S[i] = L[L_S + 6 * j + i]; }
@@ -497,6 +530,7 @@ DI void aba_passes(const MoccaModel* __restrict__ M, float* L, int lane) {
     }
     wsync();
   }
+  STAMP(12);
 }
 
 // ------------------------------------------------------------------ collision
@@ -595,6 +629,7 @@ struct ContactFlags { int touch0, touch1, target0, target1; };
 template <class T, int TASK>
 DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, const float* ter, int next_step_index,
                         int* nc_out) {
+  STAMP_BEGIN;
   const float margin = unif(M->contact_margin);
   ContactFlags fl = {0, 0, 0, 0};
   const int maxc = uni(M->max_contacts);
@@ -667,6 +702,7 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
     }
   }
   if (nc > maxc) nc = maxc;
+  STAMP(13);
   // ---- self collisions
   const int npairs = uni(M->n_pairs);
 #pragma unroll 1
@@ -728,6 +764,7 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
     nc += __popcll(hm);
     if (nc > maxc) nc = maxc;
   }
+  STAMP(14);
   *nc_out = nc;
   return fl;
 }
@@ -744,6 +781,7 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
 //   6. nu += sum_r X_r lambda_r, summed in row order through LDS
 template <class T>
 DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, int nc_found) {
+  STAMP_BEGIN;
   // wave-uniform scalars live in SGPRs: loop control becomes s_cmp/s_cbranch instead of exec-mask bookkeeping
   const float dt = unif(M->dt), idt = rcp(dt);
   const int maxr = uni(M->max_rows);
@@ -841,6 +879,7 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
   const unsigned mb = (kind >= 1 && bb >= 0) ? M->anc_mask[bb] : 0u;
   const float sa = kind >= 1 ? 1.0f : 0.0f, sb = (kind >= 1 && bb >= 0) ? 1.0f : 0.0f;  // base part: F on a, -F2 on b
 
+  STAMP(5);
   // ---- unit response X = M^-1 J^T
   // Jacobian entries go straight to LDS (the J rows sit in the part of the region the ABA no longer
   // needs: link frames / inertias, not S, U, 1/D, IA0^-1, contacts); w = J nu is accumulated on the fly.
@@ -855,36 +894,65 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) anymask |= (unsigned)__shfl_xor((int)anymask, o, 64);
   anymask = (unsigned)__builtin_amdgcn_readfirstlane((int)anymask);
+  // Rows that act on two bodies (self contacts, loop closures) carry two force paths that merge at the common
+  // ancestor; when the wave has none (the usual case for the walker) a single-path sweep does half the work.
+  const bool two_paths = T::NCLOS > 0 || __ballot(kind >= 1 && bb >= 0) != 0ull;  // wave-uniform
+  if (two_paths) {
 #pragma unroll
-  for (int b = T::NB - 1; b >= 1; --b) {
-    if (!((anymask >> b) & 1u)) {  // wave-uniform
-      Jrow[5 + b] = 0.0f;
-      X[5 + b] = 0.0f;
-      continue;
+    for (int b = T::NB - 1; b >= 1; --b) {
+      if (!((anymask >> b) & 1u)) {  // wave-uniform
+        Jrow[5 + b] = 0.0f;
+        X[5 + b] = 0.0f;
+        continue;
+      }
+      const bool ina = (ma >> b) & 1u, inb = (mb >> b) & 1u;
+      float S[6], U[6];
+  #pragma unroll
+      for (int i = 0; i < 6; ++i) { S[i] = L[L_S + 6 * b + i]; U[i] = L[L_U + 6 * b + i]; }
+      float jb;
+      if (T::NCLOS > 0) jb = (ina ? dot6(S, F) : 0.0f) - (inb ? dot6(S, F2) : 0.0f);
+      else jb = dot6(S, F) * ((ina ? 1.0f : 0.0f) - (inb ? 1.0f : 0.0f));  // F2 == F without closures
+      if (b == jl) jb = sgn;
+      float pc[6];
+  #pragma unroll
+      for (int i = 0; i < 6; ++i) pc[i] = (ina ? pa[i] : 0.0f) + (inb ? pb[i] : 0.0f);
+      const float uu = jb - dot6(S, pc);
+      const float sc = uu * L[L_INVD + b];
+  #pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const float pn = pc[i] + U[i] * sc;
+        pa[i] = ina ? pn : pa[i];
+        pb[i] = ina ? (inb ? 0.0f : pb[i]) : (inb ? pn : pb[i]);
+      }
+      Jrow[5 + b] = jb;
+      w += jb * L[L_NU + 5 + b];
+      X[5 + b] = uu;
+      pin6(pa); pin6(pb); pin1(X[5 + b]); pin1(w);
     }
-    const bool ina = (ma >> b) & 1u, inb = (mb >> b) & 1u;
-    float S[6], U[6];
+  } else {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { S[i] = L[L_S + 6 * b + i]; U[i] = L[L_U + 6 * b + i]; }
-    float jb;
-    if (T::NCLOS > 0) jb = (ina ? dot6(S, F) : 0.0f) - (inb ? dot6(S, F2) : 0.0f);
-    else jb = dot6(S, F) * ((ina ? 1.0f : 0.0f) - (inb ? 1.0f : 0.0f));  // F2 == F without closures
-    if (b == jl) jb = sgn;
-    float pc[6];
+    for (int b = T::NB - 1; b >= 1; --b) {
+      if (!((anymask >> b) & 1u)) {  // wave-uniform
+        Jrow[5 + b] = 0.0f;
+        X[5 + b] = 0.0f;
+        continue;
+      }
+      const bool ina = (ma >> b) & 1u;
+      float S[6], U[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) pc[i] = (ina ? pa[i] : 0.0f) + (inb ? pb[i] : 0.0f);
-    const float uu = jb - dot6(S, pc);
-    const float sc = uu * L[L_INVD + b];
+      for (int i = 0; i < 6; ++i) { S[i] = L[L_S + 6 * b + i]; U[i] = L[L_U + 6 * b + i]; }
+      float jb = ina ? dot6(S, F) : 0.0f;
+      if (b == jl) jb = sgn;
+      // off the row's path no force arrives (pa is only ever advanced on the path): u_b = 0 there
+      const float uu = ina ? jb - dot6(S, pa) : 0.0f;
+      const float sc = uu * L[L_INVD + b];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const float pn = pc[i] + U[i] * sc;
-      pa[i] = ina ? pn : pa[i];
-      pb[i] = ina ? (inb ? 0.0f : pb[i]) : (inb ? pn : pb[i]);
+      for (int i = 0; i < 6; ++i) pa[i] += U[i] * sc;  // sc == 0 off the path
+      Jrow[5 + b] = jb;
+      w += jb * L[L_NU + 5 + b];
+      X[5 + b] = uu;
+      pin6(pa); pin1(X[5 + b]); pin1(w);
     }
-    Jrow[5 + b] = jb;
-    w += jb * L[L_NU + 5 + b];
-    X[5 + b] = uu;
-    pin6(pa); pin6(pb); pin1(X[5 + b]); pin1(w);
   }
   // Launder the LDS pointer: otherwise the compiler keeps all 21 bodies' S/U loads of the inward sweep live
   // for the outward sweep (273 VGPRs); re-reading 13 broadcast floats per body costs far less than the occupancy.
@@ -923,6 +991,7 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
       pin6(acc[b]); pin1(X[5 + b]);
     }
   }
+  STAMP(6);
   wsync();  // all lanes are done with the ABA view: the A matrix may overwrite it
   // ---- Delassus matrix: A[rr][lane] = J_rr . X_lane (rows of J broadcast from LDS)
   // lanes >= MAXR own no row: they read/write column MAXR-1 of the dummy area instead of branching around each access
@@ -938,6 +1007,7 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
   }
   const float invdiag = rcp(diag + cfm);
   wsync();
+  STAMP(7);
   // warm-start impulses act before the first iteration (normal rows only)
   // impulse bounds, maintained incrementally: friction rows follow mu * lambda of their normal row
   float lo = kind == 3 ? -1e30f : 0.0f, hi = kind == 2 ? 0.0f : 1e30f;
@@ -968,6 +1038,7 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
       w += a * dl;
     }
   }
+  STAMP(8);
   // ---- apply: nu += sum_r X_r lambda_r, summed in row order through LDS
   wsync();
   if (r < nr) {
@@ -984,6 +1055,7 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
     L[L_NU + lane] += s;
   }
   wsync();
+  STAMP(9);
 }
 
 // ------------------------------------------------------------------ integration
@@ -1034,10 +1106,13 @@ DI void sincos_joints(float* L, int lane, int nb) {
 
 // one physics substep (what stepSimulation does numSubSteps times, bullet_utils.py:346-353)
 template <class T, int TASK>
-DI ContactFlags substep(const MoccaModel* __restrict__ M, float* L, int lane, const float* ter, int next_step_index) {
+DI ContactFlags substep(const MoccaModel* __restrict__ M, float* L, int lane, const float* ter, int next_step_index,
+                        unsigned long long ppk) {
   sincos_joints(L, lane, T::NB);
-  walk_kinematics<T, true>(M, L, lane);
+  STAMP_BEGIN;
+  walk_kinematics<T, true>(M, L, lane, ppk);
   wsync();
+  STAMP(0);
   geom_points<T>(M, L, lane);
   wsync();
   int nc = 0;
@@ -1046,13 +1121,25 @@ DI ContactFlags substep(const MoccaModel* __restrict__ M, float* L, int lane, co
 #else
   ContactFlags fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc);
 #endif
+  STAMP(1);
 #ifndef MOCCA_SKIP_ABA
-  aba_passes<T>(M, L, lane);
+  aba_passes<T>(M, L, lane, ppk);
 #endif
+  STAMP(2);
 #ifndef MOCCA_SKIP_SOLVE
   solve_constraints<T>(M, L, lane, nc);
 #endif
+  STAMP(3);
+#ifdef MOCCA_DUMMY_VALU  // experiment: is the kernel VALU-issue-bound?  (tools/ab.sh variants)
+  {
+    float x = (float)lane;
+#pragma unroll 1
+    for (int i = 0; i < MOCCA_DUMMY_VALU; ++i) { x = fmaf(x, 1.0001f, 0.5f); x = fmaf(x, 0.9999f, -0.5f); x = fmaf(x, 1.0001f, 0.5f); x = fmaf(x, 0.9999f, -0.5f); }
+    asm volatile("" :: "v"(x));
+  }
+#endif
   integrate<T>(M, L, lane);
+  STAMP(4);
   return fl;
 }
 
@@ -1283,7 +1370,7 @@ DI void reset_env(const StepArgs& a, const MoccaModel* __restrict__ M, float* L,
   if (lane < MOCCA_MAX_SLOTS) L[L_WARM + lane] = 0.0f;
   wsync();
   sincos_joints(L, lane, T::NB);
-  walk_kinematics<T, false>(M, L, lane);
+  walk_kinematics<T, false>(M, L, lane, T::path_packed(lane < T::NB ? lane : 0));
   wsync();
   const int nbo = 6 + 2 * T::NJ + 2;
   RobotObs ro = robot_obs<T>(M, L, lane, 0.0f, 0.0f, obs);
@@ -1356,7 +1443,7 @@ DI void cassie_reset_env(const MoccaModel* __restrict__ M, float* L, int lane, T
   wsync();
   t.initz = L[L_BASE + 2];
   sincos_joints(L, lane, T::NB);
-  walk_kinematics<T, false>(M, L, lane);
+  walk_kinematics<T, false>(M, L, lane, T::path_packed(lane < T::NB ? lane : 0));
   wsync();
   bool fin;
   cassie_obs<T>(M, L, lane, t.initz, obs, &fin);

@@ -797,6 +797,8 @@ def topology_header(m: MoccaModel, name: str = "Walker3D") -> str:
     lines += ["  %s," % arr((l if d > 0 else []) + [-1] * (maxw - (len(l) if d > 0 else 0))) for d, l in enumerate(levels)]
     lines += [
         "};",
+        "__device__ static const unsigned long long kPathPk%s[%d] = %s;" % (
+            name, nb, arr(["0x%xull" % sum(((path[b][k] if path[b][k] >= 0 else 31) << (5 * k)) for k in range(maxd)) for b in range(nb)])),
         "struct Topo%s {" % name,
         "  static constexpr int NB = %d;        // bodies incl. floating base" % nb,
         "  static constexpr int NJ = %d;        // hinges" % (nb - 1),
@@ -816,6 +818,15 @@ def topology_header(m: MoccaModel, name: str = "Walker3D") -> str:
         "  static __device__ __forceinline__ int path(int b, int k) { return kPath%s[b][k]; }" % name,
         "  static __device__ __forceinline__ int child(int b, int k) { return kChild%s[b][k]; }" % name,
         "  static __device__ __forceinline__ int level(int d, int s) { return kLevel%s[d][s]; }" % name,
+        "  // compile-time versions: with the loops over k / d unrolled these cost a few VALU ops and NO memory access",
+        "  // (a dependent global table load per tree level / path step is what dominated the latency-bound phases)",
+        "  static constexpr int clevel(int d, int s) { constexpr int t[%d][%d] = {%s}; return t[d][s]; }"
+        % (maxd + 1, maxw, ", ".join(arr((l if d > 0 else []) + [-1] * (maxw - (len(l) if d > 0 else 0))) for d, l in enumerate(levels))),
+        "  static constexpr int cchild(int b, int k) { constexpr int t[%d][%d] = {%s}; return b < 0 ? -1 : t[b][k]; }"
+        % (nb, maxc, ", ".join(arr(sorted(c, reverse=True) + [-1] * (maxc - len(c))) for c in children)),
+        "  // the lane's own root->body path, 5 bits per step (31 = none): loaded once per kernel, two VGPRs, then",
+        "  // every path step is a v_bfe -- no table access inside the walks",
+        "  static __device__ __forceinline__ unsigned long long path_packed(int b) { return kPathPk%s[b]; }" % name,
         "};",
         "",
     ]
