@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define MOCCA_MODEL_MAGIC 0x41434F4Du /* "MOCA" */
-#define MOCCA_MODEL_VERSION 4u
+#define MOCCA_MODEL_VERSION 5u
 
 #define MOCCA_MAX_BODIES 24
 #define MOCCA_MAX_GEOMS 32
@@ -155,6 +155,11 @@ typedef struct MoccaModel {
   float alive_height;                 /* 0.6, env_cassie.py:406-412 */
   float cassie_target[3];             /* (1000, 0, 0), env_cassie.py:366 */
   int32_t pad2_[3];
+
+  /* ---- derived lookup tables (model.py finalize_tables): one 16-byte load instead of chains of dependent loads ---- */
+  float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | terrain<<24), bits(anc_mask[body]) */
+  float gp_tab[2 * MOCCA_MAX_GEOMS][4];     /* geom end point in its body frame (x, y, z), bits(body) */
+  float pair_tab[MOCCA_MAX_PAIRS][4];       /* bits(geom_a | geom_b<<8 | body_a<<16 | body_b<<24), radius_a, radius_b, friction_a*friction_b */
 } MoccaModel;
 
 /* ------------------------------------------------------------------------

@@ -95,7 +95,7 @@ static_assert(L_J % 4 == 0 && L_V % 4 == 0, "16-byte alignment of broadcast rows
 static_assert(L_J >= L_R, "J rows may be written while S, U, 1/D, IA0^-1 and the contacts are still being read");
 
 // contact record fields
-enum : int { C_BA = 0, C_BB = 1, C_SLOT = 2, C_P = 3, C_N = 6, C_DEPTH = 9, C_MU = 10, C_ERP = 11, C_CFM = 12 };
+enum : int { C_BA = 0, C_BB = 1, C_SLOT = 2, C_P = 3, C_N = 6, C_DEPTH = 9, C_MU = 10, C_ERP = 11, C_CFM = 12, C_MA = 13, C_MB = 14 };
 
 // task record words (include/mocca_model.h)
 enum : int { T_WTX = 0, T_WTY, T_WTZ, T_LINPOT, T_ANGPOT, T_CLOSE, T_STOPF, T_DONE, T_T, T_EPISODE, T_DRAW, T_MIRROR,
@@ -610,10 +610,9 @@ DI void seg_seg(const float* p1, const float* q1, const float* p2, const float* 
 template <class T>
 DI void geom_points(const MoccaModel* __restrict__ M, float* L, int lane) {
   if (lane < 2 * T::NG) {
-    const int g = lane >> 1, e = lane & 1, b = M->g_body[g];
-    float pl[3], R[9], pw[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) pl[i] = e ? M->g_p2[g][i] : M->g_p1[g][i];
+    const float4 t = *reinterpret_cast<const float4*>(M->gp_tab[lane]);  // point (body frame) + body id, one load
+    const int b = __float_as_int(t.w);
+    float pl[3] = {t.x, t.y, t.z}, R[9], pw[3];
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = L[L_R + 9 * b + i];
     matvec3(R, pl, pw);
@@ -637,21 +636,21 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
   bool active = false;
   float n[3] = {0, 0, 1}, P[3] = {0, 0, 0}, gap = 1e30f, mu = 0, erp = M->erp, cfm = 0;
   int body = -1, slot = lane, is_target = 0;
+  unsigned bmask = 0u;
   if (lane < T::NSLOT) {
-    // slot -> geom: geoms are few, scan the prefix table
-    int g = 0;
-#pragma unroll 1
-    for (int k = 0; k < T::NG; ++k) if (M->g_slot[k] <= lane) g = k;
-    const int e = lane - M->g_slot[g];
-    if (M->g_terrain[g]) {
+    const float4 st = *reinterpret_cast<const float4*>(M->slot_tab[lane]);  // radius, friction, ids, ancestor mask
+    const int ids = __float_as_int(st.z);
+    const int g = (ids >> 8) & 0xFF, e = (ids >> 16) & 0xFF;
+    bmask = __float_as_uint(st.w);
+    if (ids >> 24) {
       float C[3], Cw[3];
-      const float rad = M->g_radius[g];
+      const float rad = st.x, gfric = st.y;
 #pragma unroll
       for (int i = 0; i < 3; ++i) { C[i] = L[L_GP + 3 * (2 * g + e) + i]; Cw[i] = C[i] + L[L_BASE + i]; }
-      body = M->g_body[g];
+      body = ids & 0xFF;
       if (TASK != MOCCA_TASK_WALKER3D_STEPPER) {
         gap = Cw[2] - rad;
-        mu = M->ground_friction * M->g_friction[g];
+        mu = M->ground_friction * gfric;
       } else {
         const float h[3] = {M->plank_half[0], M->plank_half[1], M->plank_half[2]};
         const float cz = M->plank_com_z;
@@ -672,7 +671,7 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
             is_target = (lz >= h[2] * 0.8f) && (k == next_step_index % MOCCA_MAX_PLANKS);
           }
         }
-        mu = M->plank_friction * M->g_friction[g];
+        mu = M->plank_friction * gfric;
         const float kk = M->plank_stiffness, cc = M->plank_damping, dt = M->dt;
         erp = dt * kk / (dt * kk + cc);
         cfm = 1.0f / (dt * kk + cc) / dt;
@@ -699,6 +698,7 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
 #pragma unroll
       for (int i = 0; i < 3; ++i) { ct[C_P + i] = P[i]; ct[C_N + i] = n[i]; }
       ct[C_DEPTH] = -gap; ct[C_MU] = mu; ct[C_ERP] = erp; ct[C_CFM] = cfm;
+      ct[C_MA] = __uint_as_float(bmask); ct[C_MB] = __uint_as_float(0u);
     }
   }
   if (nc > maxc) nc = maxc;
@@ -714,8 +714,11 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
     int ga = 0, gb = 0;
     float a1[3], a2[3], b1[3], b2[3];
     bool near = false;
+    float4 pt = {0, 0, 0, 0};
     if (k < npairs) {
-      ga = M->pair_a[k]; gb = M->pair_b[k];
+      pt = *reinterpret_cast<const float4*>(M->pair_tab[k]);  // geoms, bodies, radii, friction: one load
+      const int ids = __float_as_int(pt.x);
+      ga = ids & 0xFF; gb = (ids >> 8) & 0xFF;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         a1[i] = L[L_GP + 6 * ga + i]; a2[i] = L[L_GP + 6 * ga + 3 + i];
@@ -725,7 +728,7 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
       float dm[3], ha[3], hb[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) { dm[i] = 0.5f * ((a1[i] + a2[i]) - (b1[i] + b2[i])); ha[i] = 0.5f * (a2[i] - a1[i]); hb[i] = 0.5f * (b2[i] - b1[i]); }
-      const float reach = sqrtf(dot3(ha, ha)) + sqrtf(dot3(hb, hb)) + M->g_radius[ga] + M->g_radius[gb] + margin;
+      const float reach = sqrtf(dot3(ha, ha)) + sqrtf(dot3(hb, hb)) + pt.y + pt.z + margin;
       near = dot3(dm, dm) < reach * reach;
     }
     if (__ballot(near) == 0ull) continue;  // wave-uniform: nothing close in this batch of 64 pairs
@@ -733,7 +736,7 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
       float ca[3], cb[3];
       seg_seg(a1, a2, b1, b2, ca, cb);
       float d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
-      const float dist = sqrtf(dot3(d, d)), ra = M->g_radius[ga], rb = M->g_radius[gb];
+      const float dist = sqrtf(dot3(d, d)), ra = pt.y, rb = pt.z;
       g2 = dist - ra - rb;
       hit = g2 < margin && dist > 1e-9f;
       if (hit) {
@@ -743,8 +746,9 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
           nn[i] = d[i] * id;
           PP[i] = 0.5f * ((ca[i] - ra * d[i] * id) + (cb[i] + rb * d[i] * id));
         }
-        ba = M->g_body[ga]; bb = M->g_body[gb];
-        mu2 = M->g_friction[ga] * M->g_friction[gb];
+        const int ids2 = __float_as_int(pt.x);
+        ba = (ids2 >> 16) & 0xFF; bb = (ids2 >> 24) & 0xFF;
+        mu2 = pt.w;
       }
     }
     const unsigned long long hm = __ballot(hit);
@@ -760,6 +764,7 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
 #pragma unroll
       for (int i = 0; i < 3; ++i) { ct[C_P + i] = PP[i]; ct[C_N + i] = nn[i]; }
       ct[C_DEPTH] = -g2; ct[C_MU] = mu2; ct[C_ERP] = M->erp; ct[C_CFM] = 0.0f;
+      ct[C_MA] = __uint_as_float(M->anc_mask[ba]); ct[C_MB] = __uint_as_float(M->anc_mask[bb]);  // rare path
     }
     nc += __popcll(hm);
     if (nc > maxc) nc = maxc;
@@ -875,8 +880,15 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
 #pragma unroll
     for (int x = 0; x < 3; ++x) { F[x] = pn[x]; F[3 + x] = dir[x]; F2[x] = pn[x]; F2[3 + x] = dir[x]; }
   }
-  const unsigned ma = (kind >= 0) ? M->anc_mask[ba] : 0u;
-  const unsigned mb = (kind >= 1 && bb >= 0) ? M->anc_mask[bb] : 0u;
+  // ancestor masks travel with the contact records; limit / closure rows use the compile-time table (few distinct bodies)
+  unsigned ma = 0u, mb = 0u;
+  if (kind == 1 || kind == 2) {
+    const float* ct = L + L_CT + 16 * ((r - nl - NCL) < nc ? (r - nl - NCL) : ((r - nl - NCL - nc) >> 1));
+    ma = __float_as_uint(ct[C_MA]); mb = __float_as_uint(ct[C_MB]);
+  } else if (kind >= 0) {
+    ma = M->anc_mask[ba];
+    mb = (kind == 3) ? M->anc_mask[bb] : 0u;
+  }
   const float sa = kind >= 1 ? 1.0f : 0.0f, sb = (kind >= 1 && bb >= 0) ? 1.0f : 0.0f;  // base part: F on a, -F2 on b
 
   STAMP(5);

@@ -29,7 +29,7 @@ MAX_PAIRS = 192
 MAX_FEET = 2
 MAX_SLOTS = 40
 MAGIC = 0x41434F4D
-VERSION = 4
+VERSION = 5
 
 GEOM_SPHERE, GEOM_CAPSULE = 0, 1
 TASK_WALKER3D_CUSTOM, TASK_WALKER3D_STEPPER, TASK_CASSIE = 0, 1, 2
@@ -128,6 +128,9 @@ class MoccaModel(C.Structure):
         ("alive_height", C.c_float),
         ("cassie_target", C.c_float * 3),
         ("pad2_", C.c_int32 * 3),
+        ("slot_tab", (C.c_float * 4) * MAX_SLOTS),
+        ("gp_tab", (C.c_float * 4) * (2 * MAX_GEOMS)),
+        ("pair_tab", (C.c_float * 4) * MAX_PAIRS),
     ]
 
     def to_bytes(self) -> bytes:
@@ -141,6 +144,32 @@ class MoccaModel(C.Structure):
         if m.magic != MAGIC or m.version != VERSION:
             raise ValueError("bad model blob magic/version")
         return m
+
+    def finalize_tables(self) -> "MoccaModel":
+        """Fill the derived lookup tables from the primary fields (call after any edit of geoms / pairs)."""
+        def bits(i: int) -> float:
+            return float(np.array([i & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0])
+        for g in range(self.n_geoms):
+            ne = 2 if self.g_type[g] == GEOM_CAPSULE else 1
+            b = self.g_body[g]
+            for e in range(2):
+                p = self.g_p2[g] if e else self.g_p1[g]
+                for k in range(3):
+                    self.gp_tab[2 * g + e][k] = p[k]
+                self.gp_tab[2 * g + e][3] = bits(b)
+            for e in range(ne):
+                sl = self.g_slot[g] + e
+                self.slot_tab[sl][0] = self.g_radius[g]
+                self.slot_tab[sl][1] = self.g_friction[g]
+                self.slot_tab[sl][2] = bits(b | (g << 8) | (e << 16) | ((1 if self.g_terrain[g] else 0) << 24))
+                self.slot_tab[sl][3] = bits(self.anc_mask[b])
+        for k in range(self.n_pairs):
+            ga, gb = self.pair_a[k], self.pair_b[k]
+            self.pair_tab[k][0] = bits(ga | (gb << 8) | (self.g_body[ga] << 16) | (self.g_body[gb] << 24))
+            self.pair_tab[k][1] = self.g_radius[ga]
+            self.pair_tab[k][2] = self.g_radius[gb]
+            self.pair_tab[k][3] = self.g_friction[ga] * self.g_friction[gb]
+        return self
 
     @property
     def state_dim(self) -> int:
@@ -553,7 +582,7 @@ def compile_model(
         m.mirror_left[k] = v
     for k, v in enumerate(mirror_neg):
         m.mirror_neg[k] = v
-    return m
+    return m.finalize_tables()
 
 
 WALKER3D_JOINT_NAMES = [
@@ -742,7 +771,7 @@ def compile_cassie() -> MoccaModel:
     m.jvel_alpha = min(10 / 50, 1)                                           # env_cassie.py:319
     m.alive_height = 0.6                                                     # env_cassie.py:406-412
     m.cassie_target[0], m.cassie_target[1], m.cassie_target[2] = 1000.0, 0.0, 0.0  # env_cassie.py:366
-    return m
+    return m.finalize_tables()
 
 
 def joint_limits(m: MoccaModel) -> Tuple[np.ndarray, np.ndarray]:
