@@ -33,7 +33,7 @@ def cpu_baseline(env_id: str = ENV_ID, seconds_target: float = 12.0):
     from oracle.oracle import Oracle, PARAM_AUTO_RESET
     from mocca_envs_amd.vec_env import TASKS, compile_model_for
     task = TASKS[env_id]
-    m = compile_model_for(task)
+    m = compile_model_for(env_id)
     n = 16
     orc = Oracle(m.to_bytes(), task, n, "f32")
     orc.set_param(PARAM_AUTO_RESET, 1)
@@ -127,7 +127,8 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.env_id}, {args.envs} envs/GPU, flat ground, U(-1,1) action tape, auto-reset",
+            "config": {"workload": f"{args.env_id}, {args.envs} envs/GPU, "
+                                   f"{'20 stepping planks' if 'Stepper' in args.env_id else 'flat ground'}, U(-1,1) action tape, auto-reset",
                        "envs_per_gpu": args.envs, "parallelism": f"independent env shards x{world}, no collective",
                        "reset_fraction_per_step": reset_frac},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define MOCCA_MODEL_MAGIC 0x41434F4Du /* "MOCA" */
-#define MOCCA_MODEL_VERSION 5u
+#define MOCCA_MODEL_VERSION 6u
 
 #define MOCCA_MAX_BODIES 24
 #define MOCCA_MAX_GEOMS 32
@@ -154,7 +154,8 @@ typedef struct MoccaModel {
   float jvel_alpha;                   /* 0.2, env_cassie.py:319 */
   float alive_height;                 /* 0.6, env_cassie.py:406-412 */
   float cassie_target[3];             /* (1000, 0, 0), env_cassie.py:366 */
-  int32_t pad2_[3];
+  float init_quat[4];                  /* base orientation at reset, xyzw (robots.py:199-200; "crawl" pose :316-318) */
+  int32_t pad2_[1];
 
   /* ---- derived lookup tables (model.py finalize_tables): one 16-byte load instead of chains of dependent loads ---- */
   float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | terrain<<24), bits(anc_mask[body]) */

@@ -14,6 +14,8 @@ REGISTERED = {
     "Walker3DCustomEnv-v0": ("mocca_envs_amd.envs:Walker3DCustomEnv", {}),
     "Walker3DStepperEnv-v0": ("mocca_envs_amd.envs:Walker3DStepperEnv", {}),
     "CassieEnv-v0": ("mocca_envs_amd.envs:CassieEnv", {}),
+    "Child3DCustomEnv-v0": ("mocca_envs_amd.envs:Child3DCustomEnv", {}),
+    "MikeStepperEnv-v0": ("mocca_envs_amd.envs:MikeStepperEnv", {}),
 }
 
 

@@ -345,7 +345,7 @@ static thread_local std::string g_err;
 
 template <class T>
 static int check_topology_t(const MoccaModel& m, const char* name, std::string& err) {
-  if (m.n_bodies != T::NB || m.n_joints != T::NJ || m.n_geoms != T::NG || m.n_slots != T::NSLOT || m.n_closures != T::NCLOS) {
+  if (m.n_bodies != T::NB || m.n_joints != T::NJ || m.n_geoms > T::NG || m.n_slots > T::NSLOT || m.n_closures != T::NCLOS) {
     err = std::string("model blob sizes differ from the compiled topology (") + name + ")";
     return MOCCA_E_TOPOLOGY;
   }

@@ -1377,7 +1377,8 @@ DI void reset_env(const StepArgs& a, const MoccaModel* __restrict__ M, float* L,
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) { L[L_BASE + i] = M->init_pos[i]; L[L_BASE + 7 + i] = 0; L[L_BASE + 10 + i] = 0; }
-    L[L_BASE + 3] = 0; L[L_BASE + 4] = 0; L[L_BASE + 5] = 0; L[L_BASE + 6] = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) L[L_BASE + 3 + i] = M->init_quat[i];
   }
   if (lane < MOCCA_MAX_SLOTS) L[L_WARM + lane] = 0.0f;
   wsync();
@@ -1448,7 +1449,8 @@ DI void cassie_reset_env(const MoccaModel* __restrict__ M, float* L, int lane, T
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) { L[L_BASE + i] = M->init_pos[i]; L[L_BASE + 7 + i] = 0; L[L_BASE + 10 + i] = 0; }
-    L[L_BASE + 3] = 0; L[L_BASE + 4] = 0; L[L_BASE + 5] = 0; L[L_BASE + 6] = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) L[L_BASE + 3 + i] = M->init_quat[i];
   }
   if (lane < MOCCA_MAX_SLOTS) L[L_WARM + lane] = 0.0f;
   if (lane < MOCCA_MAX_CTRL) L[L_JVEL + lane] = 0.0f;

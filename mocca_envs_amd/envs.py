@@ -190,8 +190,7 @@ class Walker3DCustomEnv(EnvBase):
             self.dist, self.angle, self.stop_frames = H.randomize_target(self.np_random, self.eval_mode)
             self.walk_target = self.walk_target + self.dist * np.array([np.cos(self.angle), np.sin(self.angle), 0.0])
             st = self._vec.get_state()[0].cpu().numpy().astype(np.float64)
-            x, y, z, w = st[3:7]
-            yaw = np.arctan2(2 * (x * y + w * z), w * w + x * x - y * y - z * z)
+            yaw = H.yaw_from_quat(*st[3:7])
             dx, dy = self.walk_target[0] - st[0], self.walk_target[1] - st[1]
             ang, dist = np.arctan2(dy, dx) - yaw, np.hypot(dx, dy)
             tk[0:3], tk[5], tk[6], tk[14], tk[15] = self.walk_target, 0, self.stop_frames, self.dist, self.angle
@@ -207,7 +206,15 @@ class Walker3DCustomEnv(EnvBase):
 
     @classmethod
     def mirror_indices(cls):
-        return H.mirror_indices(M.compile_walker3d(M.TASK_WALKER3D_CUSTOM), stepper=False)
+        from .vec_env import compile_model_for
+        return H.mirror_indices(compile_model_for(cls.env_id), stepper=False)
+
+
+class Child3DCustomEnv(Walker3DCustomEnv):
+    """env_locomotion.py:317-327: Child3D (robots.py:326-335) from the "crawl" pose, fallen below 0.1 m."""
+
+    env_id = "Child3DCustomEnv-v0"
+    termination_height = 0.1
 
 
 class Walker3DStepperEnv(EnvBase):
@@ -271,7 +278,14 @@ class Walker3DStepperEnv(EnvBase):
 
     @classmethod
     def mirror_indices(cls):
-        return H.mirror_indices(M.compile_walker3d(M.TASK_WALKER3D_STEPPER), stepper=True)
+        from .vec_env import compile_model_for
+        return H.mirror_indices(compile_model_for(cls.env_id), stepper=True)
+
+
+class MikeStepperEnv(Walker3DStepperEnv):
+    """env_locomotion.py:843-851: Mike (robots.py:474-510) starting at (0.3, 0, 1.0)."""
+
+    env_id = "MikeStepperEnv-v0"
 
 
 class CassieEnv(EnvBase):

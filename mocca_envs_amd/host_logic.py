@@ -91,11 +91,22 @@ def terminal_height(curriculum: int) -> float:
     return float(np.linspace(0.75, 0.45, MAX_CURRICULUM + 1)[min(curriculum, MAX_CURRICULUM)])  # :368
 
 
+def yaw_from_quat(x: float, y: float, z: float, w: float) -> float:
+    """Yaw of getEulerFromQuaternion (robots.py:57), including Bullet's clamp at the pitch = +-90 degree singularity,
+    which Child3D's "crawl" pose starts on."""
+    sarg = -2.0 * (x * z - w * y)
+    if sarg <= -0.99999:
+        return float(2 * np.arctan2(x, -y))
+    if sarg >= 0.99999:
+        return float(2 * np.arctan2(-x, y))
+    return float(np.arctan2(2 * (x * y + w * z), w * w + x * x - y * y - z * z))
+
+
 def initial_state(mdl: M.MoccaModel, q: np.ndarray) -> np.ndarray:
-    """robots.py:196-204: base at init_pos, identity orientation, at rest -> dynamic state record."""
+    """robots.py:196-204: base at init_pos / init_quat, at rest -> dynamic state record."""
     st = np.zeros(mdl.state_dim, dtype=np.float32)
     st[0:3] = list(mdl.init_pos)
-    st[6] = 1.0
+    st[3:7] = list(mdl.init_quat)
     st[13:13 + mdl.n_joints] = q
     return st
 

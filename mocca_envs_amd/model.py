@@ -29,7 +29,7 @@ MAX_PAIRS = 192
 MAX_FEET = 2
 MAX_SLOTS = 40
 MAGIC = 0x41434F4D
-VERSION = 5
+VERSION = 6
 
 GEOM_SPHERE, GEOM_CAPSULE = 0, 1
 TASK_WALKER3D_CUSTOM, TASK_WALKER3D_STEPPER, TASK_CASSIE = 0, 1, 2
@@ -127,7 +127,8 @@ class MoccaModel(C.Structure):
         ("jvel_alpha", C.c_float),
         ("alive_height", C.c_float),
         ("cassie_target", C.c_float * 3),
-        ("pad2_", C.c_int32 * 3),
+        ("init_quat", C.c_float * 4),
+        ("pad2_", C.c_int32 * 1),
         ("slot_tab", (C.c_float * 4) * MAX_SLOTS),
         ("gp_tab", (C.c_float * 4) * (2 * MAX_GEOMS)),
         ("pair_tab", (C.c_float * 4) * MAX_PAIRS),
@@ -452,6 +453,8 @@ def compile_model(
     joint_damping: float = 0.0,
     joint_armature: float = 0.0,
     self_collision: bool = True,
+    init_quat_xyzw: Sequence[float] = (0.0, 0.0, 0.0, 1.0),
+    link_mass: Optional[Dict[str, float]] = None,
 ) -> MoccaModel:
     flat, bl_parent, _ = _flatten(root, base_ref)
     nb = len(flat)
@@ -485,6 +488,10 @@ def compile_model(
             parts.append(_geom_inertial(gg))
             geoms.append((b, gg, bl))
         mass, com, I = _compose_inertial(parts)
+        if link_mass and fb.name in link_mass:
+            # changeDynamics(mass=...) on a link (robots.py:507-510): Bullet re-derives the link's local inertia from its
+            # collision shape at the new mass, i.e. scales it with the mass.                    [UNVERIFIED-BULLET]
+            I, mass = I * (link_mass[fb.name] / mass), link_mass[fb.name]
         m.mass[b] = mass
         for k in range(3):
             m.com[b][k] = com[k]
@@ -569,6 +576,8 @@ def compile_model(
 
     for k in range(3):
         m.init_pos[k] = init_pos[k]
+    for k in range(4):
+        m.init_quat[k] = init_quat_xyzw[k]
     m.control_dt = 1.0 / 60.0       # env_locomotion.py:39
     m.termination_height = 0.7      # env_locomotion.py:44
     m.electricity_cost = 4.5        # env_locomotion.py:54
@@ -625,6 +634,50 @@ def compile_walker3d(task: int = TASK_WALKER3D_CUSTOM, **kw) -> MoccaModel:
         **kw,
     )
     return m
+
+
+def walker3d_crawl() -> Dict[str, float]:
+    """robots.py:309-315 ("crawl")."""
+    q = np.zeros(21)
+    q[[13, 17]] = np.pi / 2
+    q[[14, 18]] = np.pi / 2
+    q[[16, 20]] = np.pi / 3
+    q[[5, 10]] = -np.pi / 2
+    q[[6, 11]] = -120 * DEG
+    q[[7, 12]] = -20 * DEG
+    return {n: float(v) for n, v in zip(WALKER3D_JOINT_NAMES, q)}
+
+
+_WALKER3D_MIRROR = dict(mirror_right=[3, 4, 5, 6, 7, 13, 14, 15, 16], mirror_left=[8, 9, 10, 11, 12, 17, 18, 19, 20],
+                        mirror_neg=[0, 2])  # robots.py:282-288 (inherited by Child3D and Mike)
+
+
+def compile_child3d(**kw) -> MoccaModel:
+    """Child3D for Child3DCustomEnv (robots.py:326-335, env_locomotion.py:317-324): the Walker3D tree at child scale,
+    gains x0.4, starting on all fours 0.38 m up with the base pitched 90 degrees, fallen below 0.1 m."""
+    from .mjcf_tables import child3d_description
+    kw.setdefault("joint_damping", 0.1)     # child3d.xml:4
+    kw.setdefault("joint_armature", 0.01)
+    h = math.sqrt(0.5)
+    m = compile_model(child3d_description(), foot_names=["right_foot", "left_foot"], init_q_by_name=walker3d_crawl(),
+                      init_pos=(0.0, 0.0, 0.38),                 # robots.py:335
+                      init_quat_xyzw=(0.0, h, 0.0, h),           # getQuaternionFromEuler([0, 90 deg, 0]), robots.py:316-318
+                      **_WALKER3D_MIRROR, **kw)
+    m.termination_height = 0.1                                   # env_locomotion.py:320
+    return m.finalize_tables()
+
+
+def compile_mike(**kw) -> MoccaModel:
+    """Mike for MikeStepperEnv (robots.py:474-510, env_locomotion.py:843-845): Walker3D tree, passive abdomen, halved
+    arm gains, waist link forced to 8 kg, starting at (0.3, 0, 1.0)."""
+    from .mjcf_tables import mike_description
+    kw.setdefault("joint_damping", 0.1)     # mike.xml:4
+    kw.setdefault("joint_armature", 0.01)
+    return compile_model(mike_description(), foot_names=["right_foot", "left_foot"],
+                         init_q_by_name=walker3d_running_start(),  # env_locomotion.py:360
+                         init_pos=(0.3, 0.0, 1.0),               # env_locomotion.py:845
+                         link_mass={"abdomen_y": 8.0},           # the link carrying MJCF body "waist", robots.py:507-510
+                         **_WALKER3D_MIRROR, **kw)
 
 
 # --------------------------------------------------------------------------
@@ -766,6 +819,7 @@ def compile_cassie() -> MoccaModel:
     m.ground_friction = 0.8
     m.limit_slack, m.max_contacts, m.max_rows = 0.05, 12, 48
     m.init_pos[0], m.init_pos[1], m.init_pos[2] = 0.0, 0.0, 1.085            # env_cassie.py:17
+    m.init_quat[3] = 1.0
     m.control_dt = 0.03
     m.max_episode_steps = 1000                                               # __init__.py:18-22
     m.jvel_alpha = min(10 / 50, 1)                                           # env_cassie.py:319

@@ -19,11 +19,26 @@ TASKS = {
     "Walker3DCustomEnv-v0": M.TASK_WALKER3D_CUSTOM,
     "Walker3DStepperEnv-v0": M.TASK_WALKER3D_STEPPER,
     "CassieEnv-v0": M.TASK_CASSIE,
+    # same tree as Walker3D (child3d.xml / mike.xml): new model blobs on the Walker3D kernels
+    "Child3DCustomEnv-v0": M.TASK_WALKER3D_CUSTOM,
+    "MikeStepperEnv-v0": M.TASK_WALKER3D_STEPPER,
 }
 
+_MODELS = {
+    "Walker3DCustomEnv-v0": lambda **kw: M.compile_walker3d(M.TASK_WALKER3D_CUSTOM, **kw),
+    "Walker3DStepperEnv-v0": lambda **kw: M.compile_walker3d(M.TASK_WALKER3D_STEPPER, **kw),
+    "CassieEnv-v0": lambda **kw: M.compile_cassie(**kw),
+    "Child3DCustomEnv-v0": M.compile_child3d,
+    "MikeStepperEnv-v0": M.compile_mike,
+}
+_DEFAULT_ENV_OF_TASK = {M.TASK_WALKER3D_CUSTOM: "Walker3DCustomEnv-v0", M.TASK_WALKER3D_STEPPER: "Walker3DStepperEnv-v0",
+                        M.TASK_CASSIE: "CassieEnv-v0"}
 
-def compile_model_for(task_id: int, **kw) -> M.MoccaModel:
-    return M.compile_cassie() if task_id == M.TASK_CASSIE else M.compile_walker3d(task_id, **kw)
+
+def compile_model_for(env_or_task, **kw) -> M.MoccaModel:
+    """Model blob of a registered env id (or, for the three task ids, of the task's original robot)."""
+    env_id = env_or_task if isinstance(env_or_task, str) else _DEFAULT_ENV_OF_TASK[int(env_or_task)]
+    return _MODELS[env_id](**kw)
 
 
 class VecEnv:
@@ -47,7 +62,7 @@ class VecEnv:
         self.device_index = torch.cuda.current_device() if device is None else int(device)
         self.device = torch.device("cuda", self.device_index)
         if model_blob is None:
-            self.model = compile_model_for(self.task_id, **model_kw)
+            self.model = compile_model_for(env_id, **model_kw)
             model_blob = self.model.to_bytes()
         else:
             self.model = M.MoccaModel.from_bytes(model_blob)

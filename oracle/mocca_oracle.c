@@ -941,7 +941,7 @@ static void cassie_reset(Oracle *o, int env, float *obs) { /* CassieEnv.reset :3
   tk->episode = ep; tk->applied_gain = 1;
   for (int b = 1; b <= m->n_joints; ++b) { s->q[b] = m->init_q[b]; s->qd[b] = 0; }
   for (int k = 0; k < 3; ++k) { s->pos[k] = m->init_pos[k]; s->vel[k] = 0; s->omg[k] = 0; }
-  s->quat[0] = s->quat[1] = s->quat[2] = 0; s->quat[3] = 1;
+  for (int k = 0; k < 4; ++k) s->quat[k] = m->init_quat[k];
   for (int k = 0; k < MOCCA_MAX_SLOTS; ++k) s->warm[k] = 0;
   tk->initial_z = s->pos[2];
   kinematics(m, s, &o->wk);
@@ -1035,7 +1035,7 @@ static void reset_env(Oracle *o, int env, float *obs) {
     s->qd[b] = 0;
   }
   for (int k = 0; k < 3; ++k) { s->pos[k] = m->init_pos[k]; s->vel[k] = 0; s->omg[k] = 0; }
-  s->quat[0] = s->quat[1] = s->quat[2] = 0; s->quat[3] = 1;
+  for (int k = 0; k < 4; ++k) s->quat[k] = m->init_quat[k];
   for (int k = 0; k < MOCCA_MAX_SLOTS; ++k) s->warm[k] = 0;
   kinematics(m, s, &o->wk);
   int jal; float spd[MB];

@@ -1,0 +1,114 @@
+"""Child3DCustomEnv / MikeStepperEnv: model blobs and oracle task logic vs golden vectors captured from the reference's
+own classes (tests/golden/make_golden_variants.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from mocca_envs_amd import model as M
+from oracle.oracle import Oracle, PARAM_CURRICULUM
+
+NJ = 21
+
+
+@pytest.fixture(scope="module")
+def vg():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "variants_reference.npz"), allow_pickle=False)
+
+
+def _constants(m, vg, tag):
+    assert list(vg[f"{tag}_joint_names"]) == M.WALKER3D_JOINT_NAMES
+    lo, hi = M.joint_limits(m)
+    np.testing.assert_allclose(lo, vg[f"{tag}_joint_lo"], atol=1e-6)
+    np.testing.assert_allclose(hi, vg[f"{tag}_joint_hi"], atol=1e-6)
+    gains = np.array([m.gain[b] for b in range(1, NJ + 1)], np.float64)
+    np.testing.assert_allclose(gains, vg[f"{tag}_gains"], rtol=1e-6)
+    np.testing.assert_allclose([m.init_q[b] for b in range(1, NJ + 1)], vg[f"{tag}_base_joint_angles"], atol=1e-6)
+    np.testing.assert_allclose(list(m.init_quat), vg[f"{tag}_base_orientation"], atol=1e-6)
+    np.testing.assert_array_equal(list(m.mirror_right)[:m.n_mirror_side], vg[f"{tag}_mirror_right_act"])
+    np.testing.assert_array_equal(list(m.mirror_left)[:m.n_mirror_side], vg[f"{tag}_mirror_left_act"])
+    np.testing.assert_array_equal(list(m.mirror_neg)[:m.n_mirror_neg], vg[f"{tag}_mirror_neg_act"])
+
+
+def test_child3d_constants(vg):
+    m = M.compile_child3d()
+    assert str(vg["child_mjcf"]) == "child3d.xml"
+    _constants(m, vg, "child")
+    np.testing.assert_allclose(list(m.init_pos), vg["child_base_position"], atol=1e-7)
+    assert abs(m.termination_height - float(vg["child_termination_height"])) < 1e-7
+    assert int(vg["child_obs_dim"]) == 6 + 2 * NJ + 2 + 2
+    assert len(vg["child_mass_links"]) == 0
+    w = M.compile_walker3d()
+    assert list(m.parent[:22]) == list(w.parent[:22])      # same tree: the Walker3D kernels serve it
+    assert m.n_geoms <= w.n_geoms and m.n_slots <= w.n_slots
+
+
+def test_mike_constants(vg):
+    m = M.compile_mike()
+    assert str(vg["mike_mjcf"]) == "mike.xml"
+    _constants(m, vg, "mike")
+    np.testing.assert_allclose(list(m.init_pos), vg["mike_init_position"], atol=1e-7)
+    assert int(vg["mike_obs_dim"]) == 6 + 2 * NJ + 2 + 15
+    # changeDynamics(waist, mass=8), robots.py:507-510: the link named "waist" is the one abdomen_y drives
+    assert list(vg["mike_mass_links"]) == ["waist"] and list(vg["mike_mass_values"]) == [8.0]
+    assert abs(m.mass[2] - 8.0) < 1e-6 and M.WALKER3D_JOINT_NAMES[1] == "abdomen_y"
+    raw = M.compile_model(__import__("mocca_envs_amd.mjcf_tables", fromlist=["x"]).mike_description(), ["right_foot", "left_foot"],
+                          {}, (0, 0, 1), [], [], [])
+    np.testing.assert_allclose(np.array(m.inertia[2]) * raw.mass[2] / 8.0, np.array(raw.inertia[2]), rtol=1e-5)
+    w = M.compile_walker3d()
+    assert list(m.parent[:22]) == list(w.parent[:22])
+    assert m.n_geoms <= w.n_geoms and m.n_slots <= w.n_slots
+    for ep in range(int(vg["mike_n_episodes"])):
+        g = float(vg[f"mike_ep{ep}_applied_gain"])
+        gains = np.array([m.gain[b] for b in range(1, NJ + 1)], np.float64)
+        np.testing.assert_allclose(gains * g * np.clip(vg[f"mike_ep{ep}_torque_act"], -1, 1), vg[f"mike_ep{ep}_torque_out"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("prec,tol", [("f64", 2e-6), ("f32", 2e-5)])
+def test_child3d_episodes(vg, prec, tol):
+    m = M.compile_child3d()
+    for ep in range(int(vg["child_n_episodes"])):
+        g = lambda k: vg[f"child_ep{ep}_{k}"]
+        orc = Oracle(m.to_bytes(), M.TASK_WALKER3D_CUSTOM, 1, prec)
+        orc.set_tape(g("tape"))
+        obs0 = orc.reset(seed=0)
+        st = orc.get_state()[0]
+        np.testing.assert_allclose(st[13:13 + NJ], g("reset_q"), atol=tol, err_msg="crawl pose")
+        np.testing.assert_allclose(st[0:3], g("reset_base_pos"), atol=tol)
+        np.testing.assert_allclose(st[3:7], g("reset_base_quat"), atol=tol)       # pitched 90 degrees, never mirrored
+        tk = orc.get_task()[0]
+        assert int(tk[11]) == int(g("reset_mirrored"))
+        np.testing.assert_allclose(tk[0:3], g("reset_walk_target"), atol=tol)
+        # obs[0] (height) involves the feet, which the fake client reports at the origin at reset
+        np.testing.assert_allclose(obs0[0, 1:], g("reset_obs")[1:], atol=10 * tol)
+        states, touch, actions = g("states"), g("touch"), g("actions")
+        for t in range(len(states)):
+            full = np.zeros((1, orc.state_dim))
+            full[0, :55] = states[t]
+            orc.set_state(full)
+            o, r, d, _ = orc.task_step(actions[t][None], touch[t][None])
+            np.testing.assert_allclose(o[0], g("obs")[t], atol=20 * tol, err_msg=f"ep{ep} t{t} obs")
+            assert (d[0] & 1) == int(g("done")[t]), f"ep{ep} t{t} done (height {o[0][0]})"
+            np.testing.assert_allclose(r[0], g("rew")[t], atol=2e3 * tol, err_msg=f"ep{ep} t{t} reward")
+        # the script must exercise the 0.1 m line itself: heights in (0.1, 0.7) stay alive, heights below 0.1 fall
+        h, tall = g("obs")[:, 0], g("terms")[:, 3]
+        assert ((h > 0.1) & (h < 0.7) & (tall == 2)).sum() > 10 and ((h < 0.1) & (tall == -1)).sum() > 3
+
+
+@pytest.mark.parametrize("prec,tol", [("f64", 2e-6), ("f32", 2e-5)])
+def test_mike_reset(vg, prec, tol):
+    m = M.compile_mike()
+    for ep in range(int(vg["mike_n_episodes"])):
+        g = lambda k: vg[f"mike_ep{ep}_{k}"]
+        orc = Oracle(m.to_bytes(), M.TASK_WALKER3D_STEPPER, 1, prec)
+        orc.set_param(PARAM_CURRICULUM, int(g("curriculum")))
+        orc.set_tape(g("tape"))
+        obs0 = orc.reset(seed=0)
+        st = orc.get_state()[0]
+        np.testing.assert_allclose(st[13:13 + NJ], g("reset_q"), atol=tol)
+        np.testing.assert_allclose(st[0:3], g("reset_base_pos"), atol=tol)
+        np.testing.assert_allclose(st[3:7], g("reset_base_quat"), atol=tol)
+        np.testing.assert_allclose(orc.get_terrain()[0][:120].reshape(20, 6), g("terrain"), atol=10 * tol)
+        tk = orc.get_task()[0]
+        assert abs(tk[21] - float(g("applied_gain"))) < 1e-6 and int(tk[11]) == int(g("reset_mirrored"))
+        np.testing.assert_allclose(obs0[0, 1:], g("reset_obs")[1:], atol=20 * tol)

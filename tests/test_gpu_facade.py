@@ -121,3 +121,28 @@ def test_shard_offset_reproduces_the_owned_envs():
         o2, r2, d2, _ = part.step(acts[k, 512:768].contiguous())
         assert torch.equal(o1[512:768], o2) and torch.equal(r1[512:768], r2) and torch.equal(d1[512:768], d2)
     full.close(); part.close()
+
+
+@pytest.mark.parametrize("env_id,obs_dim,z0", [("Child3DCustomEnv-v0", 52, 0.38), ("MikeStepperEnv-v0", 65, 1.0)])
+def test_same_tree_variants(env_id, obs_dim, z0):
+    """Child3D / Mike run on the Walker3D kernels with their own model blobs (env_locomotion.py:317-327, :843-851)."""
+    import mocca_envs_amd
+    env = mocca_envs_amd.make(env_id)
+    base = env.unwrapped
+    assert base.observation_space.shape == (obs_dim,) and base.action_space.shape == (21,)
+    env.seed(11)
+    obs = env.reset()
+    st = base._vec.get_state()[0].cpu().numpy()
+    np.testing.assert_allclose(st[0:3], list(base.model.init_pos), atol=1e-6)
+    assert abs(st[2] - z0) < 1e-6
+    np.testing.assert_allclose(st[3:7], list(base.model.init_quat), atol=1e-6)
+    assert obs.shape == (obs_dim,) and np.isfinite(obs).all()
+    orc = _oracle_from(base, base.task_id)
+    arng = np.random.default_rng(3)
+    for t in range(5):
+        a = arng.uniform(-1, 1, 21)
+        o, r, d, info = env.step(a)
+        oc, rc, dc, _ = orc.step(a[None].astype(np.float32))
+        np.testing.assert_allclose(o, oc[0], atol=5e-3)
+        assert abs(r - rc[0]) < 5e-2 and d == bool(dc[0] & 1)
+    env.close()
