@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
       const float jv = (L[L_Q + M->ordered_body[lane]] - L[L_Q0 + lane]) / M->control_dt;
       tk[T_JVEL + lane] = __float_as_uint(jv);
     }
-    sincos_joints(L, lane, T::NB);
+    stage_joints<T>(M, L, lane);
     walk_kinematics<T, false>(M, L, lane, T::path_packed(lane < T::NB ? lane : 0));
     wsync();
     t.t += 1;
@@ -135,8 +135,12 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   const float act_raw = lane < T::NJ ? a.act[(size_t)env * T::NJ + lane] : 0.0f;
 
   // ---- calc_state + task logic on the post-step state
-  sincos_joints(L, lane, T::NB);
-  walk_kinematics<T, false>(M, L, lane, T::path_packed(lane < T::NB ? lane : 0));
+  {
+    int lo = lane;  // laundered: the walk's lane-derived body index would otherwise be kept (spilled) from kernel entry
+    asm volatile("" : "+v"(lo));
+    stage_joints<T>(M, L, lo);
+    walk_kinematics<T, false>(M, L, lo, ppk);
+  }
   wsync();
   t.t += 1;
   constexpr int NBO = 6 + 2 * T::NJ + 2;
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
   const float act_raw = lane < T::NJ ? a.act[(size_t)env * T::NJ + lane] : 0.0f;
   if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
   wsync();
-  sincos_joints(L, lane, T::NB);
+  stage_joints<T>(M, L, lane);
   walk_kinematics<T, false>(M, L, lane, T::path_packed(lane < T::NB ? lane : 0));
   wsync();
   constexpr int NBO = 6 + 2 * T::NJ + 2;
@@ -572,11 +576,10 @@ int mocca_set_param(mocca_handle h, int param_id, double value) {
 }
 
 #ifdef MOCCA_STAMPS
-// diagnostic builds only: accumulated s_memtime ticks per phase (lane 0 of every wave), then cleared
-int mocca_debug_stamps(unsigned long long* out32) {
-  unsigned long long zero[32] = {0};
-  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(mocca::g_stamps), sizeof(zero)) != hipSuccess) return MOCCA_E_HIP;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(mocca::g_stamps), zero, sizeof(zero)) != hipSuccess) return MOCCA_E_HIP;
+// diagnostic builds only: the raw s_memtime marks (STAMP_SLOTS per wave) of the most recent launch
+int mocca_debug_stamps(unsigned long long* out, int n_waves) {
+  if (n_waves > mocca::STAMP_WAVES) n_waves = mocca::STAMP_WAVES;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mocca::g_stamps), (size_t)n_waves * mocca::STAMP_SLOTS * 8) != hipSuccess) return MOCCA_E_HIP;
   return MOCCA_OK;
 }
 #endif

@@ -34,11 +34,12 @@
 
 namespace mocca {
 
-#ifdef MOCCA_STAMPS  // diagnostic build only (tools/stamps.sh): per-phase cycle shares of one wave's timeline
-__device__ unsigned long long g_stamps[32];
-#define STAMP(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
-  if (lane == 0) atomicAdd(&g_stamps[k], t_ - stamp_t0); stamp_t0 = t_; } while (0)
-#define STAMP_BEGIN unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+#ifdef MOCCA_STAMPS  // diagnostic build only (tools/stamps.py): raw s_memtime marks of the last substep of every wave
+// Plain fire-and-forget stores, no waits and no atomics (an atomic + s_waitcnt per mark cost more than the small phases).
+constexpr int STAMP_SLOTS = 32, STAMP_WAVES = 8192;
+__device__ unsigned long long g_stamps[STAMP_WAVES * STAMP_SLOTS];
+#define STAMP(k) do { if (lane == 0 && blockIdx.x < STAMP_WAVES) g_stamps[blockIdx.x * STAMP_SLOTS + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP_BEGIN do {} while (0)
 #else
 #define STAMP(k) do {} while (0)
 #define STAMP_BEGIN do {} while (0)
@@ -67,8 +68,8 @@ enum : int {
   L_Q0 = 192,     // [16] Cassie: joint angles at the start of the env.step (finite-difference jvel, :467-468)
   L_V = 208,
   // ---- ABA view
-  L_SQ = L_V + 0,       // [24] sin q
-  L_CQ = L_V + 24,      // [24] cos q
+  L_SQ = L_V + 0,       // [24] (free)
+  L_CQ = L_V + 24,      // [24] (free)
   L_S = L_V + 48,       // [NB][6] joint motion vectors about the base origin, world axes
   L_U = L_V + 180,      // [NB][6] IA S
   L_INVD = L_V + 312,   // [24] 1 / (S.U + armature)
@@ -83,6 +84,11 @@ enum : int {
   L_M = L_V + 1168,     // [NB][36] link / articulated inertias, full 6x6 rows (lane = row in the inward pass)
   L_P = L_V + 1960,     // [NB][6]  bias forces
   L_ABA_END = L_V + 2092,
+  // per-joint walk records, 16 floats each: [jrot * Rot(axis, q)](9) jpos(3) axis(3) qd(1).  Rebuilt by stage_joints()
+  // before every walk; joints 1..8 sit where U will be written later in the substep (the walks run first), the rest
+  // in the slack between the end of the ABA view and the end of the solver view.
+  L_JR0 = L_V + 180 - 16,           // record j in 1..8   at L_JR0 + 16 j   (= L_U .. L_U + 128)
+  L_JR1 = L_V + 2092 - 16 * 9,      // record j in 9..    at L_JR1 + 16 j
   // ---- solver view
   L_A = L_V,            // [MAXR][MAXR] Delassus matrix, row = updated row, column = lane
   L_J = L_V + 960,      // [MAXR][28] Jacobian rows (tail of the A region)
@@ -90,6 +96,7 @@ enum : int {
   L_TOTAL = L_V + MAXR * MAXR + 28,  // + one dummy J row for lanes that own no row
 };
 static_assert(L_ABA_END <= L_TOTAL, "ABA view must fit");
+static_assert(L_JR1 + 16 * MOCCA_MAX_BODIES <= L_TOTAL && (L_JR0 % 4) == 0 && (L_JR1 % 4) == 0, "joint records must fit, 16-byte aligned");
 static_assert(L_J + (MAXR + 1) * 28 <= L_TOTAL, "Jacobian rows (+ dummy) must fit the tail of the A region");
 static_assert(L_J % 4 == 0 && L_V % 4 == 0, "16-byte alignment of broadcast rows");
 static_assert(L_J >= L_R, "J rows may be written while S, U, 1/D, IA0^-1 and the contacts are still being read");
@@ -209,6 +216,17 @@ DI int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 DI int lane_rank(unsigned long long mask) {  // number of set bits below this lane
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
+// OR over the wave, result uniform (SGPR): DPP butterflies inside each row of 16, then one readlane per row --
+// no LDS crossbar round trips (six dependent ds_bpermute cost ~900 cycles)
+template <int CTRL>
+DI unsigned dpp_or(unsigned v) { return v | (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
+DI unsigned wave_or(unsigned v) {
+  v = dpp_or<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_or<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_or<0x141>(v);  // row_half_mirror
+  v = dpp_or<0x140>(v);  // row_mirror: every lane now holds its row's OR
+  return (unsigned)(readlane_i((int)v, 0) | readlane_i((int)v, 16) | readlane_i((int)v, 32) | readlane_i((int)v, 48));
+}
 DI float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -239,8 +257,17 @@ DI float rng_uniform(uint32_t slo, uint32_t shi, uint32_t env, uint32_t episode,
 // spatial velocities, velocity-product accelerations, link inertia and bias force (ABA pass 1).
 template <class T, bool FULL>
 DI void walk_kinematics(const MoccaModel* __restrict__ M, float* L, int lane, unsigned long long ppk) {
+  asm volatile("" : "+v"(lane));  // the body index is recomputed per walk: CSE across walks kept it live from kernel entry (spilled)
   const int b = lane < T::NB ? lane : 0;
   float R[9], r[3] = {0, 0, 0}, v[6], S[6] = {0, 0, 0, 0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
+  // the body's own constants are fetched before the walk so that their latency hides behind it
+  const float cl[3] = {M->com[b][0], M->com[b][1], M->com[b][2]};
+  float inl[6] = {0, 0, 0, 0, 0, 0}, ms = 0, jarm = 0, jdamp = 0;
+  if (FULL) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) inl[i] = M->inertia[b][i];
+    ms = M->mass[b]; jarm = M->jarm[b]; jdamp = M->jdamp[b];
+  }
   {
     float q[4] = {L[L_BASE + 3], L[L_BASE + 4], L[L_BASE + 5], L[L_BASE + 6]};
     quat_to_mat(q, R);
@@ -251,34 +278,21 @@ DI void walk_kinematics(const MoccaModel* __restrict__ M, float* L, int lane, un
   for (int k = 0; k < T::MAXD; ++k) {
     const int j = (int)((ppk >> (5 * k)) & 31ull);  // the lane's packed path: no table access
     if (j != 31) {
-      float jp[3], ax[3], Tm[9];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { jp[i] = M->jpos[j][i]; ax[i] = M->jaxis[j][i]; }
-      // most hinges carry an identity rest rotation; only test the diagonal, the compiler keeps one branch
-      const float j0 = M->jrot[j][0], j4 = M->jrot[j][4], j8 = M->jrot[j][8];
-      if (j0 == 1.0f && j4 == 1.0f && j8 == 1.0f) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Tm[i] = R[i];
-      } else {
-        float jr[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) jr[i] = M->jrot[j][i];
-        matmul3(R, jr, Tm);
-      }
-      float a[3], off[3], Rq[9];
-      matvec3(Tm, ax, a);
-      const float s = L[L_SQ + j], cq = L[L_CQ + j], t = 1.0f - cq;
-      Rq[0] = cq + t * ax[0] * ax[0];          Rq[1] = t * ax[0] * ax[1] - s * ax[2];   Rq[2] = t * ax[0] * ax[2] + s * ax[1];
-      Rq[3] = t * ax[0] * ax[1] + s * ax[2];   Rq[4] = cq + t * ax[1] * ax[1];          Rq[5] = t * ax[1] * ax[2] - s * ax[0];
-      Rq[6] = t * ax[0] * ax[2] - s * ax[1];   Rq[7] = t * ax[1] * ax[2] + s * ax[0];   Rq[8] = cq + t * ax[2] * ax[2];
+      // the joint's record was staged by stage_joints(): four 16-byte LDS reads, none of them on the dependent chain
+      const float4* jr = reinterpret_cast<const float4*>(L + (j <= 8 ? L_JR0 : L_JR1) + 16 * j);
+      const float4 r0 = jr[0], r1 = jr[1], r2 = jr[2], r3 = jr[3];
+      const float Tl[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
+      const float jp[3] = {r2.y, r2.z, r2.w}, ax[3] = {r3.x, r3.y, r3.z};
+      float a[3], off[3];
       matvec3(R, jp, off);
-      matmul3(Tm, Rq, R);
+      matmul3(R, Tl, R);
+      matvec3(R, ax, a);  // Rot(axis, q) leaves the axis in place: world axis = new frame * axis
 #pragma unroll
       for (int i = 0; i < 3; ++i) r[i] += off[i];
       if (FULL) {
         float ra[3], vJ[6];
         cross3(r, a, ra);
-        const float qd = L[L_QD + j];
+        const float qd = r3.w;
 #pragma unroll
         for (int i = 0; i < 3; ++i) { S[i] = a[i]; S[3 + i] = ra[i]; }
 #pragma unroll
@@ -294,7 +308,7 @@ DI void walk_kinematics(const MoccaModel* __restrict__ M, float* L, int lane, un
     for (int i = 0; i < 9; ++i) L[L_R + 9 * b + i] = R[i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) L[L_RR + 3 * b + i] = r[i];
-    float cl[3] = {M->com[b][0], M->com[b][1], M->com[b][2]}, cw[3];
+    float cw[3];
     matvec3(R, cl, cw);
 #pragma unroll
     for (int i = 0; i < 3; ++i) cw[i] += r[i];
@@ -309,8 +323,7 @@ DI void walk_kinematics(const MoccaModel* __restrict__ M, float* L, int lane, un
 #pragma unroll
       for (int i = 0; i < 6; ++i) { L[L_S + 6 * b + i] = S[i]; L[L_C + 6 * b + i] = c[i]; }
       // spatial inertia about the base origin, world axes
-      const float ixx = M->inertia[b][0], iyy = M->inertia[b][1], izz = M->inertia[b][2];
-      const float ixy = M->inertia[b][3], ixz = M->inertia[b][4], iyz = M->inertia[b][5];
+      const float ixx = inl[0], iyy = inl[1], izz = inl[2], ixy = inl[3], ixz = inl[4], iyz = inl[5];
       float Il[9] = {ixx, ixy, ixz, ixy, iyy, iyz, ixz, iyz, izz}, Tm[9], Iw[9];
       matmul3(R, Il, Tm);
 #pragma unroll
@@ -318,7 +331,7 @@ DI void walk_kinematics(const MoccaModel* __restrict__ M, float* L, int lane, un
 #pragma unroll
         for (int jx = i; jx < 3; ++jx)
           Iw[3 * i + jx] = Tm[3 * i] * R[3 * jx] + Tm[3 * i + 1] * R[3 * jx + 1] + Tm[3 * i + 2] * R[3 * jx + 2];
-      const float ms = M->mass[b], cc = dot3(cw, cw);
+      const float cc = dot3(cw, cw);
       float I[21];
 #pragma unroll
       for (int i = 0; i < 3; ++i)
@@ -350,8 +363,8 @@ DI void walk_kinematics(const MoccaModel* __restrict__ M, float* L, int lane, un
       for (int i = 0; i < 6; ++i) L[L_P + 6 * b + i] = p[i];
       // staged for the inward pass (which overwrites both slots with 1/D and u): joint armature and the net joint
       // torque, so that the level loop reads LDS only -- its global loads were hoisted above all levels and spilled
-      L[L_INVD + b] = M->jarm[b];
-      L[L_UU + b] = L[L_TAU + b] - M->jdamp[b] * L[L_QD + b];
+      L[L_INVD + b] = jarm;
+      L[L_UU + b] = L[L_TAU + b] - jdamp * L[L_QD + b];
     }
   }
 }
@@ -704,35 +717,52 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
   if (nc > maxc) nc = maxc;
   STAMP(13);
   // ---- self collisions
+  // pass 1: conservative broad phase over every candidate pair (bounding spheres around the segment midpoints); the
+  // survivors are compacted in pair order into a 16-bit list (the U area is not written until the ABA runs).
+  // pass 2: narrow phase over the survivors only -- typically one batch of 64 instead of ceil(n_pairs / 64).
   const int npairs = uni(M->n_pairs);
+  unsigned short* cand = reinterpret_cast<unsigned short*>(L + L_U);
+  static_assert(2 * (L_INVD - L_U) >= MOCCA_MAX_PAIRS, "candidate list must hold every pair");
+  int ncand = 0;
 #pragma unroll 1
   for (int base = 0; base < npairs; base += 64) {
     const int k = base + lane;
+    bool near = false;
+    if (k < npairs) {
+      const float4 pt = *reinterpret_cast<const float4*>(M->pair_tab[k]);  // geoms, bodies, radii, friction: one load
+      const int ids = __float_as_int(pt.x);
+      const int ga = ids & 0xFF, gb = (ids >> 8) & 0xFF;
+      float dm[3], ha[3], hb[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float a1 = L[L_GP + 6 * ga + i], a2 = L[L_GP + 6 * ga + 3 + i], b1 = L[L_GP + 6 * gb + i], b2 = L[L_GP + 6 * gb + 3 + i];
+        dm[i] = 0.5f * ((a1 + a2) - (b1 + b2)); ha[i] = 0.5f * (a2 - a1); hb[i] = 0.5f * (b2 - b1);
+      }
+      const float reach = sqrtf(dot3(ha, ha)) + sqrtf(dot3(hb, hb)) + pt.y + pt.z + margin;
+      near = dot3(dm, dm) < reach * reach;
+    }
+    const unsigned long long nm = __ballot(near);
+    if (near) cand[ncand + lane_rank(nm)] = (unsigned short)k;
+    ncand += __popcll(nm);
+  }
+  ncand = uni(ncand);
+  wsync();
+#pragma unroll 1
+  for (int base = 0; base < ncand; base += 64) {
     bool hit = false;
     float nn[3] = {0, 0, 0}, PP[3] = {0, 0, 0}, g2 = 0, mu2 = 0;
     int ba = -1, bb = -1;
-    int ga = 0, gb = 0;
-    float a1[3], a2[3], b1[3], b2[3];
-    bool near = false;
-    float4 pt = {0, 0, 0, 0};
-    if (k < npairs) {
-      pt = *reinterpret_cast<const float4*>(M->pair_tab[k]);  // geoms, bodies, radii, friction: one load
+    if (base + lane < ncand) {
+      const int k = cand[base + lane];
+      const float4 pt = *reinterpret_cast<const float4*>(M->pair_tab[k]);
       const int ids = __float_as_int(pt.x);
-      ga = ids & 0xFF; gb = (ids >> 8) & 0xFF;
+      const int ga = ids & 0xFF, gb = (ids >> 8) & 0xFF;
+      float a1[3], a2[3], b1[3], b2[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         a1[i] = L[L_GP + 6 * ga + i]; a2[i] = L[L_GP + 6 * ga + 3 + i];
         b1[i] = L[L_GP + 6 * gb + i]; b2[i] = L[L_GP + 6 * gb + 3 + i];
       }
-      // broad phase (conservative): bounding spheres around the segment midpoints
-      float dm[3], ha[3], hb[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { dm[i] = 0.5f * ((a1[i] + a2[i]) - (b1[i] + b2[i])); ha[i] = 0.5f * (a2[i] - a1[i]); hb[i] = 0.5f * (b2[i] - b1[i]); }
-      const float reach = sqrtf(dot3(ha, ha)) + sqrtf(dot3(hb, hb)) + pt.y + pt.z + margin;
-      near = dot3(dm, dm) < reach * reach;
-    }
-    if (__ballot(near) == 0ull) continue;  // wave-uniform: nothing close in this batch of 64 pairs
-    if (near) {
       float ca[3], cb[3];
       seg_seg(a1, a2, b1, b2, ca, cb);
       float d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
@@ -746,8 +776,7 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
           nn[i] = d[i] * id;
           PP[i] = 0.5f * ((ca[i] - ra * d[i] * id) + (cb[i] + rb * d[i] * id));
         }
-        const int ids2 = __float_as_int(pt.x);
-        ba = (ids2 >> 16) & 0xFF; bb = (ids2 >> 24) & 0xFF;
+        ba = (ids >> 16) & 0xFF; bb = (ids >> 24) & 0xFF;
         mu2 = pt.w;
       }
     }
@@ -812,6 +841,7 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
   if (nc < 0) nc = 0;
   const int nr = nl + NCL + 3 * nc;
   wsync();
+  STAMP(16);
   if (nr == 0) {  // nothing touches, no limit near: nothing to solve (uniform branch)
     if (lane < T::NSLOT) L[L_WARM + lane] = 0.0f;
     wsync();
@@ -819,7 +849,7 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
   }
   // ---- my row
   const int r = lane;
-  int kind = -1, ba = 0, bb = -1, jl = -1, nrm = -1, slot = -1;
+  int kind = -1, ba = 0, bb = -1, jl = -1, slot = -1;
   float F[6] = {0, 0, 0, 0, 0, 0}, sgn = 0, bias = 0, cfm = 0, lam = 0, mu = 0;
   float F2[6] = {0, 0, 0, 0, 0, 0};  // force on body bb (closures: its own pivot; self contacts: same point as F)
   if (r < nl) {
@@ -872,7 +902,6 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
       const bool second = ((k - nc) & 1) != 0;
 #pragma unroll
       for (int x = 0; x < 3; ++x) dir[x] = second ? t2[x] : t1[x];
-      nrm = nl + NCL + i;
       mu = ct[C_MU];
     }
     float pn[3];
@@ -880,6 +909,7 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
 #pragma unroll
     for (int x = 0; x < 3; ++x) { F[x] = pn[x]; F[3 + x] = dir[x]; F2[x] = pn[x]; F2[3 + x] = dir[x]; }
   }
+  STAMP(17);
   // ancestor masks travel with the contact records; limit / closure rows use the compile-time table (few distinct bodies)
   unsigned ma = 0u, mb = 0u;
   if (kind == 1 || kind == 2) {
@@ -902,13 +932,11 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
   float* Jrow = L + L_J + 28 * (r < MAXR ? r : MAXR);
   float pa[6] = {0, 0, 0, 0, 0, 0}, pb[6] = {0, 0, 0, 0, 0, 0};
   // bodies on no row's path (typically the arms) have zero Jacobian entries and carry no force: skip them
-  unsigned anymask = ma | mb;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) anymask |= (unsigned)__shfl_xor((int)anymask, o, 64);
-  anymask = (unsigned)__builtin_amdgcn_readfirstlane((int)anymask);
+  const unsigned anymask = wave_or(ma | mb);
   // Rows that act on two bodies (self contacts, loop closures) carry two force paths that merge at the common
   // ancestor; when the wave has none (the usual case for the walker) a single-path sweep does half the work.
   const bool two_paths = T::NCLOS > 0 || __ballot(kind >= 1 && bb >= 0) != 0ull;  // wave-uniform
+  STAMP(18);
   if (two_paths) {
 #pragma unroll
     for (int b = T::NB - 1; b >= 1; --b) {
@@ -968,6 +996,7 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
   }
   // Launder the LDS pointer: otherwise the compiler keeps all 21 bodies' S/U loads of the inward sweep live
   // for the outward sweep (273 VGPRs); re-reading 13 broadcast floats per body costs far less than the occupancy.
+  STAMP(19);
   const float* L2 = L;
   asm volatile("" : "+v"(L2));
   float a0[6];
@@ -1009,7 +1038,7 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
   // lanes >= MAXR own no row: they read/write column MAXR-1 of the dummy area instead of branching around each access
   const int lc = lane < MAXR ? lane : MAXR - 1;
   float diag = 1.0f;
-#pragma unroll 1
+#pragma unroll 2
   for (int rr = 0; rr < nr; ++rr) {
     float s = 0;
 #pragma unroll
@@ -1021,33 +1050,50 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
   wsync();
   STAMP(7);
   // warm-start impulses act before the first iteration (normal rows only)
-  // impulse bounds, maintained incrementally: friction rows follow mu * lambda of their normal row
-  float lo = kind == 3 ? -1e30f : 0.0f, hi = kind == 2 ? 0.0f : 1e30f;
 #pragma unroll 1
   for (int rr = nl + NCL; rr < nl + NCL + nc; ++rr) {
     const float l0 = readlane(lam, rr);
-    if (l0 != 0.0f) {
-      w += L[L_A + MAXR * rr + lc] * l0;
-      const float lm0 = mu * l0;
-      hi = nrm == rr ? lm0 : hi;
-      lo = nrm == rr ? -lm0 : lo;
-    }
+    if (l0 != 0.0f) w += L[L_A + MAXR * rr + lc] * l0;
   }
-  // ---- projected Gauss-Seidel, rows in lane order (limits, normals, frictions)
+  STAMP(20);
+  // ---- projected Gauss-Seidel, rows in lane order (limits, closures, normals, then frictions).
+  // Every lane evaluates its own candidate, only row rr's is broadcast and applied (v_med3 = clamp):
+  //   lam + (bias - w - cfm lam) / (A_rr + cfm) = (lam c1 + c0) - w invdiag.
+  // Limit / closure / normal rows have fixed bounds; a friction row's bound is mu * (current impulse of its normal row),
+  // looked up when the friction row is visited (its normal's index is wave-uniform then) instead of being pushed to
+  // every friction lane whenever a normal row changes.  The loop is instruction-issue bound: ~13 instructions per row visit.
   const int iters = uni(M->n_iters);
+  const float c1 = 1.0f - cfm * invdiag, c0 = bias * invdiag;
+  const float lo0 = kind == 3 ? -1e30f : 0.0f;
+  const int r_fr = nl + NCL + nc;  // first friction row
+  const float* Acol = L + L_A + lc;
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
+    // the next row's A entry is fetched one visit ahead (row nr of A is the dummy J row: readable, unused)
+    float a = Acol[0];
 #pragma unroll 1
-    for (int rr = 0; rr < nr; ++rr) {
-      const float a = L[L_A + MAXR * rr + lc];
-      // every lane evaluates its own candidate; only row rr's is broadcast and applied (v_med3 = clamp)
-      const float nl_ = __builtin_amdgcn_fmed3f(lam + (bias - w - cfm * lam) * invdiag, lo, hi);
+    for (int rr = 0; rr < r_fr; ++rr) {
+      const float an = Acol[MAXR * (rr + 1)];
+      const float nl_ = __builtin_amdgcn_fmed3f(fmaf(-w, invdiag, fmaf(lam, c1, c0)), lo0, 1e30f);
       const float dl = readlane(nl_ - lam, rr);
-      const float lm = mu * readlane(nl_, rr);
       lam = r == rr ? nl_ : lam;
-      hi = nrm == rr ? lm : hi;
-      lo = nrm == rr ? -lm : lo;
-      w += a * dl;
+      w = fmaf(a, dl, w);
+      a = an;
+    }
+#pragma unroll 1
+    for (int i = 0; i < nc; ++i) {  // the two friction rows of contact i share the bound mu * lam[normal row of i]
+      const float lm = mu * readlane(lam, nl + NCL + i);
+      const int rr = r_fr + 2 * i;
+      const float a1 = Acol[MAXR * (rr + 1)], a2 = Acol[MAXR * (rr + 2)];
+      float nl_ = __builtin_amdgcn_fmed3f(fmaf(-w, invdiag, fmaf(lam, c1, c0)), -lm, lm);
+      float dl = readlane(nl_ - lam, rr);
+      lam = r == rr ? nl_ : lam;
+      w = fmaf(a, dl, w);
+      nl_ = __builtin_amdgcn_fmed3f(fmaf(-w, invdiag, fmaf(lam, c1, c0)), -lm, lm);
+      dl = readlane(nl_ - lam, rr + 1);
+      lam = r == rr + 1 ? nl_ : lam;
+      w = fmaf(a1, dl, w);
+      a = a2;
     }
   }
   STAMP(8);
@@ -1106,12 +1152,30 @@ DI void integrate(const MoccaModel* __restrict__ M, float* L, int lane) {
   wsync();
 }
 
-DI void sincos_joints(float* L, int lane, int nb) {
-  if (lane >= 1 && lane < nb) {
-    float s, c;
-    sincosf(L[L_Q + lane], &s, &c);
-    L[L_SQ + lane] = s;
-    L[L_CQ + lane] = c;
+// lane = joint: sin/cos of the joint angle and everything a path walk needs about the joint, as one 16-float LDS
+// record (layout at L_JR0).  Every lane of a walk visits up to MAXD joints; staging keeps the model's global loads and the
+// Rodrigues formula out of that loop (they were re-done per (lane, path step), with the load latency on the chain).
+template <class T>
+DI void stage_joints(const MoccaModel* __restrict__ M, float* L, int lane) {
+  if (lane >= 1 && lane < T::NB) {
+    const int j = lane;
+    float s, cq;
+    sincosf(L[L_Q + j], &s, &cq);
+    const float t = 1.0f - cq;
+    float ax[3], jr[9], Rq[9], Tl[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ax[i] = M->jaxis[j][i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) jr[i] = M->jrot[j][i];
+    Rq[0] = cq + t * ax[0] * ax[0];          Rq[1] = t * ax[0] * ax[1] - s * ax[2];   Rq[2] = t * ax[0] * ax[2] + s * ax[1];
+    Rq[3] = t * ax[0] * ax[1] + s * ax[2];   Rq[4] = cq + t * ax[1] * ax[1];          Rq[5] = t * ax[1] * ax[2] - s * ax[0];
+    Rq[6] = t * ax[0] * ax[2] - s * ax[1];   Rq[7] = t * ax[1] * ax[2] + s * ax[0];   Rq[8] = cq + t * ax[2] * ax[2];
+    matmul3(jr, Rq, Tl);
+    float4* rec = reinterpret_cast<float4*>(L + (j <= 8 ? L_JR0 : L_JR1) + 16 * j);
+    rec[0] = make_float4(Tl[0], Tl[1], Tl[2], Tl[3]);
+    rec[1] = make_float4(Tl[4], Tl[5], Tl[6], Tl[7]);
+    rec[2] = make_float4(Tl[8], M->jpos[j][0], M->jpos[j][1], M->jpos[j][2]);
+    rec[3] = make_float4(ax[0], ax[1], ax[2], L[L_QD + j]);
   }
   wsync();
 }
@@ -1120,13 +1184,15 @@ DI void sincos_joints(float* L, int lane, int nb) {
 template <class T, int TASK>
 DI ContactFlags substep(const MoccaModel* __restrict__ M, float* L, int lane, const float* ter, int next_step_index,
                         unsigned long long ppk) {
-  sincos_joints(L, lane, T::NB);
-  STAMP_BEGIN;
+  STAMP(30);
+  stage_joints<T>(M, L, lane);
+  STAMP(29);
   walk_kinematics<T, true>(M, L, lane, ppk);
   wsync();
   STAMP(0);
   geom_points<T>(M, L, lane);
   wsync();
+  STAMP(15);
   int nc = 0;
 #ifdef MOCCA_SKIP_COLLIDE  // profiling builds only (tools/ablate.sh): results are wrong by construction
   ContactFlags fl = {0, 0, 0, 0};
@@ -1382,7 +1448,7 @@ DI void reset_env(const StepArgs& a, const MoccaModel* __restrict__ M, float* L,
   }
   if (lane < MOCCA_MAX_SLOTS) L[L_WARM + lane] = 0.0f;
   wsync();
-  sincos_joints(L, lane, T::NB);
+  stage_joints<T>(M, L, lane);
   walk_kinematics<T, false>(M, L, lane, T::path_packed(lane < T::NB ? lane : 0));
   wsync();
   const int nbo = 6 + 2 * T::NJ + 2;
@@ -1456,7 +1522,7 @@ DI void cassie_reset_env(const MoccaModel* __restrict__ M, float* L, int lane, T
   if (lane < MOCCA_MAX_CTRL) L[L_JVEL + lane] = 0.0f;
   wsync();
   t.initz = L[L_BASE + 2];
-  sincos_joints(L, lane, T::NB);
+  stage_joints<T>(M, L, lane);
   walk_kinematics<T, false>(M, L, lane, T::path_packed(lane < T::NB ? lane : 0));
   wsync();
   bool fin;

@@ -1,5 +1,7 @@
-"""Per-phase share of a wave's timeline (diagnostic build -DMOCCA_STAMPS; never quote its run time, only shares)."""
+"""Per-phase timeline of one wave's last physics substep (diagnostic build -DMOCCA_STAMPS: raw s_memtime marks, plain
+stores, no waits).  Reports the mean over waves that executed every phase.  usage: stamps.py [env-id] [n_envs]"""
 import ctypes as C, os, subprocess, sys
+import numpy as np
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, R)
 so = "/tmp/libmocca_stamps.so"
@@ -13,17 +15,25 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 env = VecEnv(env_id, n, auto_reset=True, seed=1000)
 env.reset()
 tape = torch.rand(64, n, env.act_dim, device="cuda") * 2 - 1
-for i in range(20): env.step(tape[i % 64])
-torch.cuda.synchronize()
-lib = C.CDLL(so); buf = (C.c_ulonglong * 32)()
-lib.mocca_debug_stamps(buf)
-for i in range(50): env.step(tape[i % 64])
-torch.cuda.synchronize()
-lib.mocca_debug_stamps(buf)
-v = list(buf)
-names = ["kinematics walk", "geom points + collide", "ABA passes", "constraint solve (all)", "integrate",
-         "  solve: row setup", "  solve: response sweeps", "  solve: Delassus build", "  solve: warm start + PGS", "  solve: apply", "  aba: inward levels", "  aba: base 6x6", "  aba: outward walk",
-         "  collide: terrain", "  collide: self pairs"]
-tot = sum(v[:5])
-for k, nm in enumerate(names):
-    print(f"{nm:32s} {100.0 * v[k] / tot:6.2f} %   {v[k] / (50 * n * (50 if 'Cassie' in env_id else 4)):9.0f} ticks/substep/wave")
+lib = C.CDLL(so)
+SEQ = [(30, "substep start"), (29, "stage joints"), (0, "kinematics walk"), (15, "geom points"), (13, "collide: terrain"),
+       (14, "collide: self pairs"), (1, "collide: epilogue"), (10, "aba: inward levels"), (11, "aba: base 6x6"),
+       (12, "aba: outward walk"), (2, "aba: epilogue"), (16, "rows: limit compaction"), (17, "rows: build row"),
+       (5, "rows: ancestor masks"), (18, "sweeps: anymask reduction"), (19, "sweeps: inward"), (6, "sweeps: base + outward"),
+       (7, "Delassus build"), (20, "pgs: warm start"), (8, "pgs: iterations"), (9, "apply"), (3, "solve: epilogue"), (4, "integrate")]
+acc = np.zeros(len(SEQ) - 1); cnt = 0
+nw = min(n, 8192)
+for rep in range(40):
+    env.step(tape[rep % 64])
+    torch.cuda.synchronize()
+    if rep < 20: continue
+    buf = np.zeros((nw, 32), np.uint64)
+    lib.mocca_debug_stamps(buf.ctypes.data_as(C.c_void_p), nw)
+    t = buf[:, [k for k, _ in SEQ]].astype(np.int64)
+    d = np.diff(t, axis=1)
+    ok = (d >= 0).all(axis=1) & (d.sum(axis=1) < 10_000_000)   # waves whose last substep ran every phase, in order
+    acc += d[ok].sum(axis=0); cnt += ok.sum()
+mean = acc / cnt
+print(f"{env_id}, {n} envs: mean s_memtime ticks per phase of the last substep ({cnt} wave samples); total {mean.sum():.0f}")
+for (k, nm), v in zip(SEQ[1:], mean):
+    print(f"  {nm:28s} {v:9.0f}  {100 * v / mean.sum():6.2f} %")
