@@ -24,7 +24,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   __shared__ float L[L_TOTAL];
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= a.n_envs) return;
-  const MoccaModel* __restrict__ M = a.model;
+  ModelP M = (ModelP)a.model;
   float* st = a.dyn + (size_t)env * DYN_STRIDE;
   uint32_t* tk = a.task + (size_t)env * MOCCA_TASK_WORDS;
   float* ter = TASK == MOCCA_TASK_WALKER3D_STEPPER ? a.terrain + (size_t)env * TERRAIN_STRIDE : nullptr;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     const int nllc = M->n_llc;
 #pragma unroll 1
     for (int it = 0; it < nllc; ++it) {
-      const MoccaModel* Ms = M;
+      ModelP Ms = M;
       int ln = lane;
       unsigned long long pk = ppk;
       asm volatile("" : "+s"(Ms), "+v"(ln), "+v"(pk));
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   for (int s = 0; s < nsub; ++s) {
     // launder the model pointer: keeps LICM from hoisting dozens of loop-invariant model loads out of the
     // substep loop, where they would sit in registers (and spill to scratch) for the whole kernel
-    const MoccaModel* Ms = M;
+    ModelP Ms = M;
     int ln = lane;  // same for lane-derived offsets and predicates (recomputing them costs a few instructions)
     unsigned long long pk = ppk;  // laundered too: otherwise every (ppk >> 5k) & 31 and the addresses derived from it
     asm volatile("" : "+s"(Ms), "+v"(ln), "+v"(pk));  // are hoisted out of the loop and spilled
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64) void mocca_reset_kernel(StepArgs a) {
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= a.n_envs) return;
   if (a.mask && !a.mask[env]) return;
-  const MoccaModel* __restrict__ M = a.model;
+  ModelP M = (ModelP)a.model;
   float* st = a.dyn + (size_t)env * DYN_STRIDE;
   uint32_t* tk = a.task + (size_t)env * MOCCA_TASK_WORDS;
   float* ter = TASK == MOCCA_TASK_WALKER3D_STEPPER ? a.terrain + (size_t)env * TERRAIN_STRIDE : nullptr;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
   __shared__ float L[L_TOTAL];
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= a.n_envs) return;
-  const MoccaModel* __restrict__ M = a.model;
+  ModelP M = (ModelP)a.model;
   const float* st = a.dyn + (size_t)env * DYN_STRIDE;
   uint32_t* tk = a.task + (size_t)env * MOCCA_TASK_WORDS;
   const float* ter = TASK == MOCCA_TASK_WALKER3D_STEPPER ? a.terrain + (size_t)env * TERRAIN_STRIDE : nullptr;

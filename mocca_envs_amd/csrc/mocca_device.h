@@ -45,6 +45,15 @@ __device__ unsigned long long g_stamps[STAMP_WAVES * STAMP_SLOTS];
 #define STAMP_BEGIN do {} while (0)
 #endif
 
+// The model blob is read-only for every kernel: it is addressed through the constant address space, so that
+// wave-uniform reads become scalar loads (SGPR results, no VALU) and per-lane reads become global loads off an SGPR
+// base.  (A generic pointer -- which is what a laundered kernel argument degrades to -- makes every access a flat load:
+// 64-bit address arithmetic on the VALU, a wait on both memory counters, and a v_readfirstlane for uniform values.)
+#define MOCCA_AS_CONST __attribute__((address_space(4)))
+typedef const MOCCA_AS_CONST MoccaModel* ModelP;
+typedef float f4_t __attribute__((ext_vector_type(4)));  // native vector: loadable through any address space
+typedef const MOCCA_AS_CONST f4_t* CF4P;
+
 constexpr int MAXR = 48;  // rows held by one wave (MoccaModel.max_rows must be <= MAXR)
 constexpr int MAXC = 12;  // contacts            (MoccaModel.max_contacts <= MAXC)
 constexpr int DYN_STRIDE = 96;      // floats per env in the dynamic-state buffer
@@ -256,7 +265,7 @@ DI float rng_uniform(uint32_t slo, uint32_t shi, uint32_t env, uint32_t episode,
 // lane = body.  Walks root -> body composing joint transforms; with FULL also joint motion vectors,
 // spatial velocities, velocity-product accelerations, link inertia and bias force (ABA pass 1).
 template <class T, bool FULL>
-DI void walk_kinematics(const MoccaModel* __restrict__ M, float* L, int lane, unsigned long long ppk) {
+DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
   asm volatile("" : "+v"(lane));  // the body index is recomputed per walk: CSE across walks kept it live from kernel entry (spilled)
   const int b = lane < T::NB ? lane : 0;
   float R[9], r[3] = {0, 0, 0}, v[6], S[6] = {0, 0, 0, 0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
@@ -414,7 +423,7 @@ DI void spd6_inverse_sym(const float* A, float* Ainv) {
 // ABA inward pass (lane = body of the current level) + base solve + outward pass (lane = body).
 // Leaves S, U, 1/D, u, IA0^-1 in LDS for the row sweeps and the new generalised velocity in L_NU.
 template <class T>
-DI void aba_passes(const MoccaModel* __restrict__ M, float* L, int lane, unsigned long long ppk) {
+DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
   STAMP_BEGIN;
   // ---- inward pass, one tree level at a time.  8 lanes per body (lane i < 6 owns row i of the 6x6
   // articulated inertia), up to MAXW = 4 bodies per level: ~45 VALU per level instead of ~260 with one
@@ -621,9 +630,9 @@ DI void seg_seg(const float* p1, const float* q1, const float* p2, const float* 
 
 // world (base-origin relative) end points of every geom: lane = geom end
 template <class T>
-DI void geom_points(const MoccaModel* __restrict__ M, float* L, int lane) {
+DI void geom_points(ModelP M, float* L, int lane) {
   if (lane < 2 * T::NG) {
-    const float4 t = *reinterpret_cast<const float4*>(M->gp_tab[lane]);  // point (body frame) + body id, one load
+    const f4_t t = *(CF4P)(M->gp_tab[lane]);  // point (body frame) + body id, one load
     const int b = __float_as_int(t.w);
     float pl[3] = {t.x, t.y, t.z}, R[9], pw[3];
 #pragma unroll
@@ -639,7 +648,7 @@ struct ContactFlags { int touch0, touch1, target0, target1; };
 // lane = terrain contact slot, then self-collision pairs strided over the wave.
 // Contacts are compacted in slot order, then pair order (the oracle's priority), up to max_contacts.
 template <class T, int TASK>
-DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, const float* ter, int next_step_index,
+DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next_step_index,
                         int* nc_out) {
   STAMP_BEGIN;
   const float margin = unif(M->contact_margin);
@@ -651,7 +660,7 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
   int body = -1, slot = lane, is_target = 0;
   unsigned bmask = 0u;
   if (lane < T::NSLOT) {
-    const float4 st = *reinterpret_cast<const float4*>(M->slot_tab[lane]);  // radius, friction, ids, ancestor mask
+    const f4_t st = *(CF4P)(M->slot_tab[lane]);  // radius, friction, ids, ancestor mask
     const int ids = __float_as_int(st.z);
     const int g = (ids >> 8) & 0xFF, e = (ids >> 16) & 0xFF;
     bmask = __float_as_uint(st.w);
@@ -729,7 +738,7 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
     const int k = base + lane;
     bool near = false;
     if (k < npairs) {
-      const float4 pt = *reinterpret_cast<const float4*>(M->pair_tab[k]);  // geoms, bodies, radii, friction: one load
+      const f4_t pt = *(CF4P)(M->pair_tab[k]);  // geoms, bodies, radii, friction: one load
       const int ids = __float_as_int(pt.x);
       const int ga = ids & 0xFF, gb = (ids >> 8) & 0xFF;
       float dm[3], ha[3], hb[3];
@@ -754,7 +763,7 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
     int ba = -1, bb = -1;
     if (base + lane < ncand) {
       const int k = cand[base + lane];
-      const float4 pt = *reinterpret_cast<const float4*>(M->pair_tab[k]);
+      const f4_t pt = *(CF4P)(M->pair_tab[k]);
       const int ids = __float_as_int(pt.x);
       const int ga = ids & 0xFF, gb = (ids >> 8) & 0xFF;
       float a1[3], a2[3], b1[3], b2[3];
@@ -814,7 +823,7 @@ DI ContactFlags collide(const MoccaModel* __restrict__ M, float* L, int lane, co
 //   5. projected Gauss-Seidel in row order; per row update one LDS read, one readlane pair
 //   6. nu += sum_r X_r lambda_r, summed in row order through LDS
 template <class T>
-DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, int nc_found) {
+DI void solve_constraints(ModelP M, float* L, int lane, int nc_found) {
   STAMP_BEGIN;
   // wave-uniform scalars live in SGPRs: loop control becomes s_cmp/s_cbranch instead of exec-mask bookkeeping
   const float dt = unif(M->dt), idt = rcp(dt);
@@ -997,8 +1006,9 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
   // Launder the LDS pointer: otherwise the compiler keeps all 21 bodies' S/U loads of the inward sweep live
   // for the outward sweep (273 VGPRs); re-reading 13 broadcast floats per body costs far less than the occupancy.
   STAMP(19);
-  const float* L2 = L;
-  asm volatile("" : "+v"(L2));
+  int l2off = 0;  // an opaque zero offset, not an opaque pointer: a laundered pointer turns generic and its reads
+  asm volatile("" : "+v"(l2off));  // become flat loads (VALU address math, both memory counters) instead of ds_read
+  const float* L2 = L + l2off;
   float a0[6];
   {
     float rhs[6], Ai[21];
@@ -1118,7 +1128,7 @@ DI void solve_constraints(const MoccaModel* __restrict__ M, float* L, int lane, 
 
 // ------------------------------------------------------------------ integration
 template <class T>
-DI void integrate(const MoccaModel* __restrict__ M, float* L, int lane) {
+DI void integrate(ModelP M, float* L, int lane) {
   const float dt = M->dt;
   if (lane >= 1 && lane < T::NB) {
     float v = L[L_NU + 5 + lane];
@@ -1156,7 +1166,7 @@ DI void integrate(const MoccaModel* __restrict__ M, float* L, int lane) {
 // record (layout at L_JR0).  Every lane of a walk visits up to MAXD joints; staging keeps the model's global loads and the
 // Rodrigues formula out of that loop (they were re-done per (lane, path step), with the load latency on the chain).
 template <class T>
-DI void stage_joints(const MoccaModel* __restrict__ M, float* L, int lane) {
+DI void stage_joints(ModelP M, float* L, int lane) {
   if (lane >= 1 && lane < T::NB) {
     const int j = lane;
     float s, cq;
@@ -1182,7 +1192,7 @@ DI void stage_joints(const MoccaModel* __restrict__ M, float* L, int lane) {
 
 // one physics substep (what stepSimulation does numSubSteps times, bullet_utils.py:346-353)
 template <class T, int TASK>
-DI ContactFlags substep(const MoccaModel* __restrict__ M, float* L, int lane, const float* ter, int next_step_index,
+DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next_step_index,
                         unsigned long long ppk) {
   STAMP(30);
   stage_joints<T>(M, L, lane);
@@ -1239,7 +1249,7 @@ struct RobotObs { float rpy[3]; int jal; float spd; float height; bool finite; }
 // WalkerBase.calc_state (robots.py:42-95): writes obs[0 .. 6+2NJ+2) ; needs kinematics done (L_FEET).
 // lane j < NJ keeps its scaled joint speed in the return value for the energy term.
 template <class T>
-DI RobotObs robot_obs(const MoccaModel* __restrict__ M, float* L, int lane, float fc0, float fc1, float* obs) {
+DI RobotObs robot_obs(ModelP M, float* L, int lane, float fc0, float fc1, float* obs) {
   RobotObs ro;
   float q[4] = {L[L_BASE + 3], L[L_BASE + 4], L[L_BASE + 5], L[L_BASE + 6]};
   quat_to_rpy(q, ro.rpy);
@@ -1302,7 +1312,7 @@ DI void store_task(uint32_t* tk, const TaskRegs& t) {
 }
 
 // calc_potential, env_locomotion.py:143-158
-DI void calc_potential(const MoccaModel* __restrict__ M, const float* L, TaskRegs& t, float yaw, float* dist, float* ang) {
+DI void calc_potential(ModelP M, const float* L, TaskRegs& t, float yaw, float* dist, float* ang) {
   const float dx = t.wt[0] - L[L_BASE], dy = t.wt[1] - L[L_BASE + 1];
   *ang = atan2f(dy, dx) - yaw;
   *dist = sqrtf(dx * dx + dy * dy);
@@ -1399,7 +1409,7 @@ DI void generate_terrain(const StepArgs& a, int env, TaskRegs& t, float* L, floa
 
 // env.reset() for one env (lane-parallel); leaves the new state in LDS and writes obs.
 template <class T, int TASK>
-DI void reset_env(const StepArgs& a, const MoccaModel* __restrict__ M, float* L, float* ter, int env, int lane, TaskRegs& t,
+DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, int lane, TaskRegs& t,
                   float* obs) {
   const int ep = t.episode + 1, cur = t.cur;
   t = TaskRegs{};
@@ -1470,7 +1480,7 @@ DI void reset_env(const StepArgs& a, const MoccaModel* __restrict__ M, float* L,
 // Cassie.calc_state + CassieEnv.get_obs on the state in LDS (kinematics done): 6 + 14 + 14 + 2 floats.
 // Returns pelvis z - lowest toe COM z; *finite = every robot_state entry finite.
 template <class T>
-DI float cassie_obs(const MoccaModel* __restrict__ M, const float* L, int lane, float initial_z, float* obs, bool* finite) {
+DI float cassie_obs(ModelP M, const float* L, int lane, float initial_z, float* obs, bool* finite) {
   const int no = M->n_ordered;
   float q[4] = {L[L_BASE + 3], L[L_BASE + 4], L[L_BASE + 5], L[L_BASE + 6]}, rpy[3];
   quat_to_rpy(q, rpy);
@@ -1500,13 +1510,13 @@ DI float cassie_obs(const MoccaModel* __restrict__ M, const float* L, int lane, 
   *finite = fin && (__ballot(!jf) == 0ull);
   return L[L_BASE + 2] - fminf(L[L_FEET + 2], L[L_FEET + 5]);
 }
-DI float cassie_potential(const MoccaModel* __restrict__ M, const float* L) {  // calc_potential :348-354
+DI float cassie_potential(ModelP M, const float* L) {  // calc_potential :348-354
   const float dx = M->cassie_target[0] - L[L_BASE], dy = M->cassie_target[1] - L[L_BASE + 1];
   return -sqrtf(dx * dx + dy * dy) / M->control_dt;
 }
 // CassieEnv.reset (:362-378): nominal pose, at rest, no randomness
 template <class T>
-DI void cassie_reset_env(const MoccaModel* __restrict__ M, float* L, int lane, TaskRegs& t, float* obs) {
+DI void cassie_reset_env(ModelP M, float* L, int lane, TaskRegs& t, float* obs) {
   const int ep = t.episode + 1;
   t = TaskRegs{};
   t.episode = ep;
