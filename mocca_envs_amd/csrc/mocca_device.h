@@ -432,6 +432,11 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
   static_assert(T::MAXW == 4 && T::MAXCH <= 3, "level pass is written for <= 4 bodies per level, <= 3 children");
   const int s = lane >> 3, i = lane & 7;
   const int ii = i < 6 ? i : 0;
+  // A body sits in the slot of its "carried" child (topo_*.h: clevel / ccarry), so along a serial chain the articulated
+  // inertia row and bias of the child stay in registers (crow, cpA) and a level costs no LDS round trip: the level's
+  // own link data has static addresses and nothing on the chain waits for it.  Only children in another slot (the
+  // second leg at the pelvis, the limbs at the base) travel through LDS.
+  float crow[6] = {0, 0, 0, 0, 0, 0}, cpA = 0.0f;
 #pragma unroll
   for (int d = T::MAXD; d >= 1; --d) {
     // bodies of this level and their children are compile-time constants selected by the lane's slot
@@ -440,20 +445,21 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
     const int bb = b >= 0 ? b : 0;
     float row[6], S[6], c[6], pAi;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { row[j] = L[L_M + 36 * bb + 6 * ii + j]; S[j] = L[L_S + 6 * bb + j]; c[j] = L[L_C + 6 * bb + j]; }
-    pAi = L[L_P + 6 * bb + ii];
+    for (int j = 0; j < 6; ++j) { row[j] = L[L_M + 36 * bb + 6 * ii + j] + crow[j]; S[j] = L[L_S + 6 * bb + j]; c[j] = L[L_C + 6 * bb + j]; }
+    pAi = L[L_P + 6 * bb + ii] + cpA;
 #pragma unroll
     for (int k = 0; k < T::MAXCH; ++k) {
-      const int ch = s == 0 ? T::cchild(T::clevel(d, 0), k) : s == 1 ? T::cchild(T::clevel(d, 1), k)
-                   : s == 2 ? T::cchild(T::clevel(d, 2), k) : s == 3 ? T::cchild(T::clevel(d, 3), k) : -1;
-      if (T::cchild(T::clevel(d, 0), k) >= 0 || T::cchild(T::clevel(d, 1), k) >= 0 || T::cchild(T::clevel(d, 2), k) >= 0 ||
-          T::cchild(T::clevel(d, 3), k) >= 0) {  // compile-time: does any body of this level have a k-th child?
+      // the k-th child of the slot's body, unless it is the carried one
+#define MOCCA_LDS_CHILD(sl) (T::cchild(T::clevel(d, sl), k) != T::ccarry(T::clevel(d, sl)) ? T::cchild(T::clevel(d, sl), k) : -1)
+      const int ch = s == 0 ? MOCCA_LDS_CHILD(0) : s == 1 ? MOCCA_LDS_CHILD(1) : s == 2 ? MOCCA_LDS_CHILD(2) : s == 3 ? MOCCA_LDS_CHILD(3) : -1;
+      if (MOCCA_LDS_CHILD(0) >= 0 || MOCCA_LDS_CHILD(1) >= 0 || MOCCA_LDS_CHILD(2) >= 0 || MOCCA_LDS_CHILD(3) >= 0) {  // compile-time
         if (ch >= 0) {
 #pragma unroll
           for (int j = 0; j < 6; ++j) row[j] += L[L_M + 36 * ch + 6 * ii + j];
           pAi += L[L_P + 6 * ch + ii];
         }
       }
+#undef MOCCA_LDS_CHILD
     }
     const float Si = i == 0 ? S[0] : i == 1 ? S[1] : i == 2 ? S[2] : i == 3 ? S[3] : i == 4 ? S[4] : S[5];
     const float Ui = valid ? dot6(row, S) : 0.0f;
@@ -478,14 +484,26 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
     float Iac = 0.0f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) { row[j] -= uid * U[j]; Iac += row[j] * c[j]; }
+    const float pOut = pAi + Iac + uid * u;
+    // is any body of this level consumed through LDS (its parent carries another child, or is the base)?
+#define MOCCA_VIA_LDS(sl) (T::clevel(d, sl) >= 0 && T::ccarry(T::parent(T::clevel(d, sl) >= 0 ? T::clevel(d, sl) : 0)) != T::clevel(d, sl))
+    const bool store_m = MOCCA_VIA_LDS(0) || MOCCA_VIA_LDS(1) || MOCCA_VIA_LDS(2) || MOCCA_VIA_LDS(3);
     if (valid) {
+      if (store_m) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) L[L_M + 36 * bb + 6 * ii + j] = row[j];
-      L[L_P + 6 * bb + ii] = pAi + Iac + uid * u;
+        for (int j = 0; j < 6; ++j) L[L_M + 36 * bb + 6 * ii + j] = row[j];
+        L[L_P + 6 * bb + ii] = pOut;
+      }
       L[L_U + 6 * bb + ii] = Ui;
       if (i == 0) { L[L_INVD + bb] = id; L[L_UU + bb] = u; }
     }
-    wsync();
+    // what the slot hands to the next level in registers: its result if the body there carries it, else nothing
+    const bool fw = valid && (s == 0 ? !MOCCA_VIA_LDS(0) : s == 1 ? !MOCCA_VIA_LDS(1) : s == 2 ? !MOCCA_VIA_LDS(2) : !MOCCA_VIA_LDS(3));
+#undef MOCCA_VIA_LDS
+#pragma unroll
+    for (int j = 0; j < 6; ++j) crow[j] = fw ? row[j] : 0.0f;
+    cpA = fw ? pOut : 0.0f;
+    if (store_m) wsync();
   }
   STAMP(10);
   // base: every lane computes the same 6x6 solve (uniform data, broadcast LDS reads)

@@ -851,8 +851,27 @@ def topology_header(m: MoccaModel, name: str = "Walker3D") -> str:
     maxd = max(depth)
     children = [[c for c in range(nb) if parent[c] == b] for b in range(nb)]
     maxc = max(len(c) for c in children)
-    levels = [[b for b in range(nb) if depth[b] == d] for d in range(maxd + 1)]
-    maxw = max(len(l) for l in levels[1:])
+    # Level tables for the ABA inward pass (8 lanes per body, one slot of 8 lanes per body of a level).  A body keeps
+    # the slot of one of its children ("carried" child) so that a serial chain -- a leg, an arm -- stays on the same
+    # lanes from leaf to root and its articulated inertia travels in registers; other children go through LDS.
+    by_depth = [[b for b in range(nb) if depth[b] == d] for d in range(maxd + 1)]
+    maxw = max(len(l) for l in by_depth[1:])
+    slot_of, carry = {}, [-1] * nb
+    levels = [[-1] * maxw for _ in range(maxd + 1)]
+    for d in range(maxd, 0, -1):
+        taken = set()
+        for b in by_depth[d]:                       # continuations first: inherit the slot of the lowest-index child
+            for c in sorted(children[b]):
+                if slot_of[c] not in taken:
+                    slot_of[b], carry[b] = slot_of[c], c
+                    taken.add(slot_of[c])
+                    break
+        for b in by_depth[d]:                       # leaves and bodies whose children's slots were all taken
+            if b not in slot_of:
+                slot_of[b] = min(set(range(maxw)) - taken)
+                taken.add(slot_of[b])
+        for b in by_depth[d]:
+            levels[d][slot_of[b]] = b
     path = []
     for b in range(nb):
         p, cur = [], b
@@ -877,7 +896,7 @@ def topology_header(m: MoccaModel, name: str = "Walker3D") -> str:
     # children in DESCENDING order: the oracle accumulates b = nb-1 .. 1 into parent[b]
     lines += ["  %s," % arr(sorted(c, reverse=True) + [-1] * (maxc - len(c))) for c in children]
     lines += ["};", "__device__ static const signed char kLevel%s[%d][%d] = {" % (name, maxd + 1, maxw)]
-    lines += ["  %s," % arr((l if d > 0 else []) + [-1] * (maxw - (len(l) if d > 0 else 0))) for d, l in enumerate(levels)]
+    lines += ["  %s," % arr(l) for l in levels]
     lines += [
         "};",
         "__device__ static const unsigned long long kPathPk%s[%d] = %s;" % (
@@ -904,7 +923,9 @@ def topology_header(m: MoccaModel, name: str = "Walker3D") -> str:
         "  // compile-time versions: with the loops over k / d unrolled these cost a few VALU ops and NO memory access",
         "  // (a dependent global table load per tree level / path step is what dominated the latency-bound phases)",
         "  static constexpr int clevel(int d, int s) { constexpr int t[%d][%d] = {%s}; return t[d][s]; }"
-        % (maxd + 1, maxw, ", ".join(arr((l if d > 0 else []) + [-1] * (maxw - (len(l) if d > 0 else 0))) for d, l in enumerate(levels))),
+        % (maxd + 1, maxw, ", ".join(arr(l) for l in levels)),
+        "  // the child whose articulated inertia stays in registers (same slot, next level), -1 if none",
+        "  static constexpr int ccarry(int b) { constexpr int t[%d] = %s; return b < 0 ? -1 : t[b]; }" % (nb, arr(carry)),
         "  static constexpr int cchild(int b, int k) { constexpr int t[%d][%d] = {%s}; return b < 0 ? -1 : t[b][k]; }"
         % (nb, maxc, ", ".join(arr(sorted(c, reverse=True) + [-1] * (maxc - len(c))) for c in children)),
         "  // the lane's own root->body path, 5 bits per step (31 = none): loaded once per kernel, two VGPRs, then",
