@@ -461,12 +461,17 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
       }
 #undef MOCCA_LDS_CHILD
     }
-    const float Si = i == 0 ? S[0] : i == 1 ? S[1] : i == 2 ? S[2] : i == 3 ? S[3] : i == 4 ? S[4] : S[5];
-    const float Ui = valid ? dot6(row, S) : 0.0f;
-    const float dsum = group8_sum(valid ? Si * Ui : 0.0f);
-    const float psum = group8_sum(valid ? Si * pAi : 0.0f);
-    const float id = rcp(dsum + L[L_INVD + bb]);
-    const float u = L[L_UU + bb] - psum;
+    // Branch-free on purpose: idle lanes (rows 6, 7 of a group, empty slots) run the same arithmetic on harmless data
+    // and are kept out of the sums / the stores only.  Under `valid ? ... : 0` the compiler sank the LDS reads into
+    // conditional blocks, each with its own wait, and nothing of the next level could be fetched ahead.
+    const float Si = i < 6 ? L[L_S + 6 * bb + ii] : 0.0f;  // the lane's own component of S (0 for the two idle lanes)
+    const float Ui = dot6(row, S);
+    const float dsum = group8_sum(Si * Ui);
+    const float psum = group8_sum(Si * pAi);
+    float arm = L[L_INVD + bb], unet = L[L_UU + bb];  // staged by the walk: joint armature, net joint torque
+    pin1(arm); pin1(unet);                           // fetched with the level's other reads, not inside the store branch
+    const float id = rcp(dsum + arm);
+    const float u = unet - psum;
     // all six U_j of the body on every lane of its 8-lane group, by DPP instead of an LDS round trip:
     // quad broadcasts give the own quad's four values, a half-row mirror brings the other quad's
     float U[6];
