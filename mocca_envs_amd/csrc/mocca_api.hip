@@ -115,6 +115,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   if (lane == 0) { L[L_TAU] = 0.0f; L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
   wsync();
 
+  STAMP(28);  // kernel prologue done
   ContactFlags fl = {0, 0, 0, 0};
   const int nsub = M->n_substeps;
   const int nsi0 = TASK == MOCCA_TASK_WALKER3D_STEPPER ? (int)tk[T_NSI] : 0;
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     asm volatile("" : "+s"(Ms), "+v"(ln), "+v"(pk));  // are hoisted out of the loop and spilled
     fl = substep<T, TASK>(Ms, L, ln, ter, nsi0, pk);
   }
+  STAMP(27);  // substeps done
   TaskRegs t;
   load_task(tk, t);
   // the raw (unclipped) action enters the energy penalty (env_locomotion.py:185-188); re-read it rather than
@@ -243,6 +245,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     a.done[env] = (uint8_t)dflag;
     if (a.info) a.info[env] = info;
   }
+  STAMP(26);  // observation + reward done
   if (a.auto_reset && dflag) {
     wsync();
     reset_env<T, TASK>(a, M, L, ter, env + a.env_offset, lane, t, obs);
@@ -250,6 +253,10 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   wsync();
   store_dyn(st, L, lane, T::NJ, T::NSLOT);
   if (lane == 0) store_task(tk, t);
+  STAMP(25);  // reset (if any) + write-back done
+#ifdef MOCCA_STAMPS
+  if (lane == 0 && blockIdx.x < STAMP_WAVES) g_stamps[blockIdx.x * STAMP_SLOTS + 24] = (unsigned long long)(a.auto_reset && dflag);
+#endif
 }
 
 template <class T, int TASK>

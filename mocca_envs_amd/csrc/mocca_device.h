@@ -54,6 +54,11 @@ typedef const MOCCA_AS_CONST MoccaModel* ModelP;
 typedef float f4_t __attribute__((ext_vector_type(4)));  // native vector: loadable through any address space
 typedef const MOCCA_AS_CONST f4_t* CF4P;
 
+#ifndef MOCCA_PRIO_T3  // row-count thresholds of the issue priorities 3 / 2 / 1 (solve_constraints)
+#define MOCCA_PRIO_T3 36
+#define MOCCA_PRIO_T2 26
+#define MOCCA_PRIO_T1 18
+#endif
 constexpr int MAXR = 48;  // rows held by one wave (MoccaModel.max_rows must be <= MAXR)
 constexpr int MAXC = 12;  // contacts            (MoccaModel.max_contacts <= MAXC)
 constexpr int DYN_STRIDE = 96;      // floats per env in the dynamic-state buffer
@@ -872,6 +877,14 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found) {
   if (nc > (maxr - nl - NCL) / 3) nc = (maxr - nl - NCL) / 3;
   if (nc < 0) nc = 0;
   const int nr = nl + NCL + 3 * nc;
+  // Load balancing across the waves of a SIMD: the launch lasts as long as its slowest wave, and a wave's cost grows with
+  // its row count (an env lying on the ground has 48 rows, a standing one ~20).  Issue priority follows the row count,
+  // so heavy waves run at nearly their stand-alone speed while light ones -- which have slack -- yield.  nr is in an
+  // SGPR: each branch is s_cmp / s_cbranch around one s_setprio (which ignores EXEC).
+  if (nr > MOCCA_PRIO_T3) __builtin_amdgcn_s_setprio(3);
+  else if (nr > MOCCA_PRIO_T2) __builtin_amdgcn_s_setprio(2);
+  else if (nr > MOCCA_PRIO_T1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
   wsync();
   STAMP(16);
   if (nr == 0) {  // nothing touches, no limit near: nothing to solve (uniform branch)

@@ -21,7 +21,7 @@ SEQ = [(30, "substep start"), (29, "stage joints"), (0, "kinematics walk"), (15,
        (12, "aba: outward walk"), (2, "aba: epilogue"), (16, "rows: limit compaction"), (17, "rows: build row"),
        (5, "rows: ancestor masks"), (18, "sweeps: anymask reduction"), (19, "sweeps: inward"), (6, "sweeps: base + outward"),
        (7, "Delassus build"), (20, "pgs: warm start"), (8, "pgs: iterations"), (9, "apply"), (3, "solve: epilogue"), (4, "integrate")]
-acc = np.zeros(len(SEQ) - 1); cnt = 0
+acc = np.zeros(len(SEQ) - 1); cnt = 0; tot_all = []; slow = np.zeros(len(SEQ) - 1); nslow = 0
 nw = min(n, 8192)
 for rep in range(40):
     env.step(tape[rep % 64])
@@ -33,7 +33,26 @@ for rep in range(40):
     d = np.diff(t, axis=1)
     ok = (d >= 0).all(axis=1) & (d.sum(axis=1) < 10_000_000)   # waves whose last substep ran every phase, in order
     acc += d[ok].sum(axis=0); cnt += ok.sum()
+    tt = d[ok].sum(axis=1); tot_all.append(tt)
+    thr = np.percentile(tt, 99)
+    slow += d[ok][tt >= thr].sum(axis=0); nslow += (tt >= thr).sum()
 mean = acc / cnt
 print(f"{env_id}, {n} envs: mean s_memtime ticks per phase of the last substep ({cnt} wave samples); total {mean.sum():.0f}")
 for (k, nm), v in zip(SEQ[1:], mean):
     print(f"  {nm:28s} {v:9.0f}  {100 * v / mean.sum():6.2f} %")
+tt = np.concatenate(tot_all)
+print("per-wave substep total: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % tuple(np.percentile(tt, [10, 50, 90, 99, 100])))
+print("slowest 1 % of waves, mean ticks per phase:")
+for (k, nm), v in zip(SEQ[1:], slow / nslow):
+    print(f"  {nm:28s} {v:9.0f}")
+# whole-kernel view of the last launch: prologue -> substeps -> obs/reward -> reset + write-back
+t = buf.astype(np.int64)
+t0 = t[:, 28].min()
+sub, ob, rs = t[:, 27] - t[:, 28], t[:, 26] - t[:, 27], t[:, 25] - t[:, 26]
+was_reset = t[:, 24] != 0
+end = t[:, 25] - t0
+print("whole kernel, last launch: wave end time after the first wave's prologue: p50 %.0f p90 %.0f p99 %.0f max %.0f ticks" % tuple(np.percentile(end, [50, 90, 99, 100])))
+print("  substeps: mean %.0f p99 %.0f max %.0f | obs+reward: mean %.0f | tail (reset + write-back): no reset %.0f, reset %.0f (%d waves reset)"
+      % (sub.mean(), np.percentile(sub, 99), sub.max(), ob.mean(), rs[~was_reset].mean(), rs[was_reset].mean() if was_reset.any() else 0, was_reset.sum()))
+late = np.argsort(end)[-8:]
+print("  the 8 last waves: end", end[late], "substeps", sub[late], "reset", was_reset[late].astype(int))
