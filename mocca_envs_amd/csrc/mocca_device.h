@@ -88,7 +88,7 @@ enum : int {
   L_U = L_V + 180,      // [NB][6] IA S
   L_INVD = L_V + 312,   // [24] 1 / (S.U + armature)
   L_UU = L_V + 336,     // [24] u = tau - S.pA
-  L_A0 = L_V + 360,     // [24] IA0^-1 (sym 21) ; [8] base spatial acceleration
+  L_A0 = L_V + 360,     // [24] Cholesky factor of IA0 (sym 21, see chol6_factor) ; [8] base spatial acceleration
   L_GP = L_V + 392,     // [NG][2][3] geom end points rel. base origin (136)
   L_CT = L_V + 528,     // [MAXC][16] contact records (192)
   L_ROWD = L_V + 720,   // [48] compacted limit-row candidates (int)
@@ -227,6 +227,17 @@ DI int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }  // assert wave-
 DI float unif(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 DI float readlane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 DI int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+// lane l (wave-uniform) of `old` takes the uniform value v: one v_writelane, no compare / select on every lane
+DI float writelane(float v, int l, float old) {
+  // two SGPR sources exceed the constant bus; the lane select travels in M0 (exempt)
+  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(v), "s"(l) : "m0");
+  return old;
+}
+template <int LANE>
+DI float writelane_c(float v, float old) {  // immediate lane select
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(v), "n"(LANE));
+  return old;
+}
 DI int lane_rank(unsigned long long mask) {  // number of set bits below this lane
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
@@ -383,46 +394,45 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
   }
 }
 
-// 6x6 SPD inverse via Cholesky on symmetric storage; all indices static.  v_rsq/v_rcp (1 ulp) instead of
-// IEEE sqrt/div: the 18 divisions would otherwise be a third of the instructions of the whole ABA base solve.
-DI void spd6_inverse_sym(const float* A, float* Ainv) {
-  float Lm[6][6], idg[6];
+// 6x6 SPD system through its Cholesky factor, symmetric storage, all indices static: F[sym(i, j)] = L_ij (i > j),
+// F[sym(j, j)] = 1 / L_jj.  The factor is what is kept (not the explicit inverse): factor + two triangular solves are a
+// third of the instructions of factor + inversion + product, and every consumer only ever applies the inverse to a vector.
+// v_rsq (1 ulp) instead of IEEE sqrt/div.
+DI void chol6_factor(const float* A, float* F) {
+  float Lm[6][6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     float s = A[sym(j, j)];
 #pragma unroll
     for (int k = 0; k < j; ++k) s -= Lm[j][k] * Lm[j][k];
     const float id = rsq(s);
-    idg[j] = id;
+    F[sym(j, j)] = id;
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       float t = A[sym(i, j)];
 #pragma unroll
       for (int k = 0; k < j; ++k) t -= Lm[i][k] * Lm[j][k];
       Lm[i][j] = t * id;
+      F[sym(i, j)] = Lm[i][j];
     }
   }
-  float Li[6][6];
+}
+DI void chol6_solve(const float* F, const float* b, float* x) {
+  float y[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    Li[j][j] = idg[j];
+    float t = b[j];
 #pragma unroll
-    for (int i = j + 1; i < 6; ++i) {
-      float t = 0;
-#pragma unroll
-      for (int k = j; k < i; ++k) t -= Lm[i][k] * Li[k][j];
-      Li[i][j] = t * idg[i];
-    }
+    for (int k = 0; k < j; ++k) t -= F[sym(j, k)] * y[k];
+    y[j] = t * F[sym(j, j)];
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
+  for (int i = 5; i >= 0; --i) {
+    float t = y[i];
 #pragma unroll
-    for (int j = i; j < 6; ++j) {
-      float t = 0;
-#pragma unroll
-      for (int k = j; k < 6; ++k) t += Li[k][i] * Li[k][j];
-      Ainv[sym(i, j)] = t;
-    }
+    for (int k = i + 1; k < 6; ++k) t -= F[sym(k, i)] * x[k];
+    x[i] = t * F[sym(i, i)];
+  }
 }
 
 // ABA inward pass (lane = body of the current level) + base solve + outward pass (lane = body).
@@ -538,8 +548,8 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
       }
     }
     float Ai[21], a0[6];
-    spd6_inverse_sym(IA, Ai);
-    symmv6(Ai, pA, a0);
+    chol6_factor(IA, Ai);
+    chol6_solve(Ai, pA, a0);
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < 21; ++i) L[L_A0 + i] = Ai[i];
@@ -840,6 +850,28 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
   return fl;
 }
 
+// One PGS visit of fixed-bound row RR, then the next (compile-time recursion = guaranteed full unrolling with a
+// wave-uniform early exit; the optimiser keeps a `#pragma unroll` loop with a break rolled).  With RR an immediate, the
+// readlane / writelane index and the LDS offset are constants and the A entry of the next visit is fetched one visit
+// ahead with no register shuffling.  See solve_constraints for the y formulation.
+template <int RR>
+DI void pgs_fixed_rows(const float* Acol, float a, float a1, int r_fr, float& y, float& lam, float invdiag, float lo0) {
+  if constexpr (RR < MAXR) {
+    if (RR >= r_fr) return;
+    // A entries travel two visits ahead: a (this visit) was pinned at the end of the previous one, a1 (next visit) is
+    // pinned at the end of this one, a2 is issued now.  Without the pins the optimiser sinks each read into the visit
+    // that uses it (the early exit does not need it), and every visit then waits a full LDS round trip.
+    const float a2 = Acol[MAXR * (RR + 2 < MAXR ? RR + 2 : MAXR)];  // row MAXR is the dummy J row: readable, unused
+    const float as = a * invdiag;
+    const float nl_ = __builtin_amdgcn_fmed3f(y, lo0, 1e30f);
+    const float dl = readlane(nl_ - lam, RR);
+    lam = writelane_c<RR>(readlane(nl_, RR), lam);
+    y = fmaf(-as, dl, y);
+    pin1(a1);
+    pgs_fixed_rows<RR + 1>(Acol, a1, a2, r_fr, y, lam, invdiag, lo0);
+  }
+}
+
 // ------------------------------------------------------------------ constraint rows + PGS
 // lane = row.  See oracle solve_constraints() for the reference formulation.
 //   1. limit-row candidates are compacted with a ballot; contacts come from collide()
@@ -1057,7 +1089,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found) {
     }
 #pragma unroll
     for (int i = 0; i < 21; ++i) Ai[i] = L2[L_A0 + i];
-    symmv6(Ai, rhs, a0);
+    chol6_solve(Ai, rhs, a0);
 #pragma unroll
     for (int i = 0; i < 6; ++i) X[i] = a0[i];
   }
@@ -1094,6 +1126,12 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found) {
   }
   const float invdiag = rcp(diag + cfm);
   wsync();
+  // The solver works on A with a ZERO diagonal: each lane keeps y = (bias - sum_{r' != c} A[r'][c] lam_r') / (A_cc + cfm),
+  // the value its own impulse would take if unclamped.  A visit of row rr then is
+  //     new = clamp(y_rr);  d = new - lam_rr;  lam_rr = new;  y_c -= A[rr][c] / (A_cc + cfm) * d   for every lane c
+  // and lane rr needs no special case (its own column entry is the zeroed diagonal): no v_cmp / v_cndmask per visit.
+  if (r < nr) L[L_A + MAXR * r + r] = 0.0f;
+  wsync();
   STAMP(7);
   // warm-start impulses act before the first iteration (normal rows only)
 #pragma unroll 1
@@ -1103,42 +1141,33 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found) {
   }
   STAMP(20);
   // ---- projected Gauss-Seidel, rows in lane order (limits, closures, normals, then frictions).
-  // Every lane evaluates its own candidate, only row rr's is broadcast and applied (v_med3 = clamp):
-  //   lam + (bias - w - cfm lam) / (A_rr + cfm) = (lam c1 + c0) - w invdiag.
   // Limit / closure / normal rows have fixed bounds; a friction row's bound is mu * (current impulse of its normal row),
   // looked up when the friction row is visited (its normal's index is wave-uniform then) instead of being pushed to
-  // every friction lane whenever a normal row changes.  The loop is instruction-issue bound: ~13 instructions per row visit.
+  // every friction lane whenever a normal row changes.  The loop is instruction-issue bound: 11 instructions per visit of
+  // a fixed-bound row (ds_read, mul, med3, sub, 2 readlane, writelane, fma, wait, 2 for the uniform exit test).
   const int iters = uni(M->n_iters);
-  const float c1 = 1.0f - cfm * invdiag, c0 = bias * invdiag;
   const float lo0 = kind == 3 ? -1e30f : 0.0f;
   const int r_fr = nl + NCL + nc;  // first friction row
   const float* Acol = L + L_A + lc;
+  float y = (bias - w) * invdiag;
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
-    // the next row's A entry is fetched one visit ahead (row nr of A is the dummy J row: readable, unused)
-    float a = Acol[0];
-#pragma unroll 1
-    for (int rr = 0; rr < r_fr; ++rr) {
-      const float an = Acol[MAXR * (rr + 1)];
-      const float nl_ = __builtin_amdgcn_fmed3f(fmaf(-w, invdiag, fmaf(lam, c1, c0)), lo0, 1e30f);
-      const float dl = readlane(nl_ - lam, rr);
-      lam = r == rr ? nl_ : lam;
-      w = fmaf(a, dl, w);
-      a = an;
-    }
+    pgs_fixed_rows<0>(Acol, Acol[0], Acol[MAXR], r_fr, y, lam, invdiag, lo0);
+    float a = Acol[MAXR * r_fr];
 #pragma unroll 1
     for (int i = 0; i < nc; ++i) {  // the two friction rows of contact i share the bound mu * lam[normal row of i]
       const float lm = mu * readlane(lam, nl + NCL + i);
       const int rr = r_fr + 2 * i;
       const float a1 = Acol[MAXR * (rr + 1)], a2 = Acol[MAXR * (rr + 2)];
-      float nl_ = __builtin_amdgcn_fmed3f(fmaf(-w, invdiag, fmaf(lam, c1, c0)), -lm, lm);
+      const float as = a * invdiag, as1 = a1 * invdiag;
+      float nl_ = __builtin_amdgcn_fmed3f(y, -lm, lm);
       float dl = readlane(nl_ - lam, rr);
-      lam = r == rr ? nl_ : lam;
-      w = fmaf(a, dl, w);
-      nl_ = __builtin_amdgcn_fmed3f(fmaf(-w, invdiag, fmaf(lam, c1, c0)), -lm, lm);
+      lam = writelane(readlane(nl_, rr), rr, lam);
+      y = fmaf(-as, dl, y);
+      nl_ = __builtin_amdgcn_fmed3f(y, -lm, lm);
       dl = readlane(nl_ - lam, rr + 1);
-      lam = r == rr + 1 ? nl_ : lam;
-      w = fmaf(a1, dl, w);
+      lam = writelane(readlane(nl_, rr + 1), rr + 1, lam);
+      y = fmaf(-as1, dl, y);
       a = a2;
     }
   }
