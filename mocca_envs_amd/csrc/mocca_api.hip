@@ -116,6 +116,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   wsync();
 
   STAMP(28);  // kernel prologue done
+  if constexpr (TASK == MOCCA_TASK_WALKER3D_STEPPER) stage_planks(M, L, lane, ter);
   ContactFlags fl = {0, 0, 0, 0};
   const int nsub = M->n_substeps;
   const int nsi0 = TASK == MOCCA_TASK_WALKER3D_STEPPER ? (int)tk[T_NSI] : 0;

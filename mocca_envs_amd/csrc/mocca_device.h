@@ -78,6 +78,8 @@ enum : int {
   L_WARM = 116,   // [40] warm-start impulses per terrain slot
   L_FEET = 156,   // [8] feet COM xyz (2x3)
   L_MISC = 164,   // [12]
+  L_PLANK = 164,  // [3][12] Stepper: frames of the three live planks (rotation 9, box centre 3), built once per env.step;
+                  //         overlays L_MISC / L_JVEL / L_Q0 (the last two are Cassie-only)
   L_JVEL = 176,   // [16] Cassie: filtered joint speeds of the low-level PD loop (env_cassie.py:451-453)
   L_Q0 = 192,     // [16] Cassie: joint angles at the start of the env.step (finite-difference jvel, :467-468)
   L_V = 208,
@@ -611,10 +613,15 @@ DI void euler_to_mat(float roll, float pitch, float yaw, float* R) {
   R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
   R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
 }
-DI float sphere_box(const float* C, float rad, const float* bc, const float* Rb, const float* h, float* n) {
-  float d[3] = {C[0] - bc[0], C[1] - bc[1], C[2] - bc[2]}, l[3], q[3];
+// sphere centre in the box frame
+DI void box_local(const float* C, const float* bc, const float* Rb, float* l) {
+  const float d[3] = {C[0] - bc[0], C[1] - bc[1], C[2] - bc[2]};
 #pragma unroll
   for (int i = 0; i < 3; ++i) l[i] = Rb[i] * d[0] + Rb[3 + i] * d[1] + Rb[6 + i] * d[2];
+}
+// signed gap and world normal of a sphere (centre l in the box frame) against an oriented box
+DI float sphere_box(const float* l, float rad, const float* Rb, const float* h, float* n) {
+  float q[3];
   bool inside = true;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -681,6 +688,24 @@ DI void geom_points(ModelP M, float* L, int lane) {
   }
 }
 
+// Stepper: rotation and box centre of the three live planks (bullet_objects.py:77-83 offset included), once per env.step.
+// They were rebuilt from the terrain table -- six sin/cos and seven global reads -- per (lane, plank, substep).
+DI void stage_planks(ModelP M, float* L, int lane, const float* ter) {
+  if (lane < MOCCA_MAX_PLANKS) {
+    const int row = (int)ter[120 + lane];
+    const float* ti = ter + 6 * row;
+    float Rb[9];
+    euler_to_mat(ti[4], ti[5], ti[3], Rb);
+    const float cz = M->plank_com_z, dz = -M->plank_half[2] - cz;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) L[L_PLANK + 12 * lane + i] = Rb[i];
+    L[L_PLANK + 12 * lane + 9] = ti[0] + Rb[2] * dz;
+    L[L_PLANK + 12 * lane + 10] = ti[1] + Rb[5] * dz;
+    L[L_PLANK + 12 * lane + 11] = ti[2] + Rb[8] * dz + cz;
+  }
+  wsync();
+}
+
 struct ContactFlags { int touch0, touch1, target0, target1; };
 
 // lane = terrain contact slot, then self-collision pairs strided over the wave.
@@ -713,16 +738,20 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
         mu = M->ground_friction * gfric;
       } else {
         const float h[3] = {M->plank_half[0], M->plank_half[1], M->plank_half[2]};
-        const float cz = M->plank_com_z;
 #pragma unroll 1
         for (int k = 0; k < MOCCA_MAX_PLANKS; ++k) {
-          const int row = (int)ter[120 + k];
-          const float* ti = ter + 6 * row;
-          float Rb[9], bc[3], nn[3];
-          euler_to_mat(ti[4], ti[5], ti[3], Rb);
-          const float dz = -h[2] - cz;
-          bc[0] = ti[0] + Rb[2] * dz; bc[1] = ti[1] + Rb[5] * dz; bc[2] = ti[2] + Rb[8] * dz + cz;
-          const float gk = sphere_box(Cw, rad, bc, Rb, h, nn);
+          float Rb[9], bc[3], nn[3];  // staged by stage_planks(): the planks do not move during the substeps
+#pragma unroll
+          for (int i = 0; i < 9; ++i) Rb[i] = L[L_PLANK + 12 * k + i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) bc[i] = L[L_PLANK + 12 * k + 9 + i];
+          float lb[3];
+          box_local(Cw, bc, Rb, lb);
+          // wave-uniform skip: no contact point of this env is within reach of plank k (exact: such a plank can neither
+          // activate a slot nor win the minimum against one that does)
+          const float reach = rad + margin;
+          if (__ballot(fabsf(lb[0]) < h[0] + reach && fabsf(lb[1]) < h[1] + reach && fabsf(lb[2]) < h[2] + reach) == 0ull) continue;
+          const float gk = sphere_box(lb, rad, Rb, h, nn);
           if (gk < gap) {
             gap = gk;
             n[0] = nn[0]; n[1] = nn[1]; n[2] = nn[2];
