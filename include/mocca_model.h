@@ -47,8 +47,8 @@ enum { MOCCA_GEOM_SPHERE = 0, MOCCA_GEOM_CAPSULE = 1 };
 
 /* task ids accepted by mocca_create() */
 enum {
-  MOCCA_TASK_WALKER3D_CUSTOM = 0,  /* env_locomotion.py:37-282  */
-  MOCCA_TASK_WALKER3D_STEPPER = 1, /* env_locomotion.py:330-840 */
+  MOCCA_TASK_WALKER3D_CUSTOM = 0,  /* env_locomotion.py:37-282; also Child3DCustomEnv (:317-327) with a Child3D blob   */
+  MOCCA_TASK_WALKER3D_STEPPER = 1, /* env_locomotion.py:330-840; also MikeStepperEnv (:843-851) with a Mike blob       */
   MOCCA_TASK_CASSIE = 2,           /* env_cassie.py:284-479 (CassieEnv, 3-D) */
 };
 
