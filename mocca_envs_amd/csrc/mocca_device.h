@@ -280,13 +280,19 @@ DI float rng_uniform(uint32_t slo, uint32_t shi, uint32_t env, uint32_t episode,
 }
 
 // ------------------------------------------------------------------ kinematics
-// lane = body.  Walks root -> body composing joint transforms; with FULL also joint motion vectors,
-// spatial velocities, velocity-product accelerations, link inertia and bias force (ABA pass 1).
+// Kinematics in two phases.
+//  1. lane = (body, row): three lanes per body, each composing ONE ROW of the body's rotation along the root -> body path
+//     (row' = row * [jrot Rot(axis, q)], 9 FMA per step instead of 27, the offset r_i = row . jpos one component each).
+//     The rows of a rotation chain never mix, so the three lanes need no exchange.  21 bodies x 3 = 63 lanes.
+//     Each group also leaves its joint's world axis a = R_body * axis (component i on lane i).
+//  2. lane = body: joint motion vector S = (a, r x a), then -- FULL only -- the spatial velocity as a plain sum of
+//     S_j qd_j along the path (no rotation chain any more), the velocity-product acceleration, link inertia, bias force.
+// One lane per body for everything cost ~90 VALU per path step; this costs ~20 + ~12.
 template <class T, bool FULL>
 DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
-  asm volatile("" : "+v"(lane));  // the body index is recomputed per walk: CSE across walks kept it live from kernel entry (spilled)
+  asm volatile("" : "+v"(lane));  // lane-derived indices are recomputed per walk: CSE across walks kept them live from kernel entry (spilled)
+  static_assert(3 * (T::NB - 1) <= 63, "three lanes per body must fit the wave (lane 63 writes the base)");
   const int b = lane < T::NB ? lane : 0;
-  float R[9], r[3] = {0, 0, 0}, v[6], S[6] = {0, 0, 0, 0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
   // the body's own constants are fetched before the walk so that their latency hides behind it
   const float cl[3] = {M->com[b][0], M->com[b][1], M->com[b][2]};
   float inl[6] = {0, 0, 0, 0, 0, 0}, ms = 0, jarm = 0, jdamp = 0;
@@ -295,46 +301,86 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
     for (int i = 0; i < 6; ++i) inl[i] = M->inertia[b][i];
     ms = M->mass[b]; jarm = M->jarm[b]; jdamp = M->jdamp[b];
   }
+  // ---- phase 1
   {
-    float q[4] = {L[L_BASE + 3], L[L_BASE + 4], L[L_BASE + 5], L[L_BASE + 6]};
-    quat_to_mat(q, R);
+    const int g = (lane * 43) >> 7;          // lane / 3 for lane < 64
+    const int ri = lane - 3 * g;             // row of the rotation this lane owns
+    const int bg = g + 1 < T::NB ? g + 1 : 0;  // the group's body (0 = idle group)
+    // the group's packed path: fetched from the lane that owns body bg in the lane = body layout
+    const unsigned plo = (unsigned)__shfl((int)(unsigned)ppk, bg, 64), phi = (unsigned)__shfl((int)(unsigned)(ppk >> 32), bg, 64);
+    const unsigned long long pk3 = ((unsigned long long)phi << 32) | plo;
+    float Rb[9];
+    {
+      float q[4] = {L[L_BASE + 3], L[L_BASE + 4], L[L_BASE + 5], L[L_BASE + 6]};
+      quat_to_mat(q, Rb);
+    }
+    float row[3] = {ri == 0 ? Rb[0] : ri == 1 ? Rb[3] : Rb[6], ri == 0 ? Rb[1] : ri == 1 ? Rb[4] : Rb[7], ri == 0 ? Rb[2] : ri == 1 ? Rb[5] : Rb[8]};
+    float rr = 0.0f;
+#pragma unroll
+    for (int k = 0; k < T::MAXD; ++k) {
+      const int j = (int)((pk3 >> (5 * k)) & 31ull);
+      if (j != 31) {
+        // the joint's record was staged by stage_joints(): 16-byte LDS reads, none of them on the dependent chain
+        const float4* jr = reinterpret_cast<const float4*>(L + (j <= 8 ? L_JR0 : L_JR1) + 16 * j);
+        const float4 r0 = jr[0], r1 = jr[1], r2 = jr[2];
+        rr += row[0] * r2.y + row[1] * r2.z + row[2] * r2.w;  // offset of the joint in the parent frame
+        const float n0 = row[0] * r0.x + row[1] * r0.w + row[2] * r1.z;
+        const float n1 = row[0] * r0.y + row[1] * r1.x + row[2] * r1.w;
+        const float n2 = row[0] * r0.z + row[1] * r1.y + row[2] * r2.x;
+        row[0] = n0; row[1] = n1; row[2] = n2;
+      }
+    }
+    if (bg > 0) {
+      const float4 r3 = reinterpret_cast<const float4*>(L + (bg <= 8 ? L_JR0 : L_JR1) + 16 * bg)[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) L[L_R + 9 * bg + 3 * ri + i] = row[i];
+      L[L_RR + 3 * bg + ri] = rr;
+      L[L_S + 6 * bg + ri] = row[0] * r3.x + row[1] * r3.y + row[2] * r3.z;  // world axis: Rot(axis, q) leaves the axis in place
+    }
+    if (lane == 63) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) L[L_R + i] = Rb[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) L[L_RR + i] = 0.0f;
+    }
+  }
+  wsync();
+  // ---- phase 2
+  float R[9], r[3], v[6], S[6] = {0, 0, 0, 0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = L[L_R + 9 * b + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r[i] = L[L_RR + 3 * b + i];
+  if (FULL) {
+    if (lane >= 1 && lane < T::NB) {
+      float a[3] = {L[L_S + 6 * b], L[L_S + 6 * b + 1], L[L_S + 6 * b + 2]}, ra[3];
+      cross3(r, a, ra);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { S[i] = a[i]; S[3 + i] = ra[i]; L[L_S + 6 * b + 3 + i] = ra[i]; }
+    }
+    wsync();
 #pragma unroll
     for (int k = 0; k < 3; ++k) { v[k] = L[L_BASE + 10 + k]; v[3 + k] = L[L_BASE + 7 + k]; }
-  }
 #pragma unroll
-  for (int k = 0; k < T::MAXD; ++k) {
-    const int j = (int)((ppk >> (5 * k)) & 31ull);  // the lane's packed path: no table access
-    if (j != 31) {
-      // the joint's record was staged by stage_joints(): four 16-byte LDS reads, none of them on the dependent chain
-      const float4* jr = reinterpret_cast<const float4*>(L + (j <= 8 ? L_JR0 : L_JR1) + 16 * j);
-      const float4 r0 = jr[0], r1 = jr[1], r2 = jr[2], r3 = jr[3];
-      const float Tl[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
-      const float jp[3] = {r2.y, r2.z, r2.w}, ax[3] = {r3.x, r3.y, r3.z};
-      float a[3], off[3];
-      matvec3(R, jp, off);
-      matmul3(R, Tl, R);
-      matvec3(R, ax, a);  // Rot(axis, q) leaves the axis in place: world axis = new frame * axis
+    for (int k = 0; k < T::MAXD; ++k) {
+      const int j = (int)((ppk >> (5 * k)) & 31ull);  // the lane's packed path: no table access
+      if (j != 31 && j != b) {  // ancestors; the body's own joint follows below
+        const float qd = L[L_QD + j];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) r[i] += off[i];
-      if (FULL) {
-        float ra[3], vJ[6];
-        cross3(r, a, ra);
-        const float qd = r3.w;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { S[i] = a[i]; S[3 + i] = ra[i]; }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) vJ[i] = S[i] * qd;
-        crm(v, vJ, c);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) v[i] += vJ[i];
+        for (int i = 0; i < 6; ++i) v[i] += L[L_S + 6 * j + i] * qd;
       }
+    }
+    if (lane >= 1 && lane < T::NB) {
+      float vJ[6];
+      const float qd = L[L_QD + b];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) vJ[i] = S[i] * qd;
+      crm(v, vJ, c);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) v[i] += vJ[i];
     }
   }
   if (lane < T::NB) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) L[L_R + 9 * b + i] = R[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) L[L_RR + 3 * b + i] = r[i];
     float cw[3];
     matvec3(R, cl, cw);
 #pragma unroll
@@ -348,7 +394,7 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
       }
     if (FULL) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) { L[L_S + 6 * b + i] = S[i]; L[L_C + 6 * b + i] = c[i]; }
+      for (int i = 0; i < 6; ++i) L[L_C + 6 * b + i] = c[i];  // (S of the base is never read)
       // spatial inertia about the base origin, world axes
       const float ixx = inl[0], iyy = inl[1], izz = inl[2], ixy = inl[3], ixz = inl[4], iyz = inl[5];
       float Il[9] = {ixx, ixy, ixz, ixy, iyy, iyz, ixz, iyz, izz}, Tm[9], Iw[9];
