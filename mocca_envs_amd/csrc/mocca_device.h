@@ -925,6 +925,42 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
   return fl;
 }
 
+// Delassus matrix by symmetry: A[r][c] = J_r . X_c = A[c][r], so lane c only evaluates the rows (c + t) mod nr for
+// t = 0 .. nr / 2 (a circulant schedule covers every unordered pair once) and writes each value to both places.
+// Step t of every lane reads a DIFFERENT J row (stride 28 floats: the 16-byte reads of 16 consecutive lanes tile all 64
+// banks, no conflicts beyond the four passes a b128 read takes anyway).  Values stay in registers until every J row has
+// been read -- A overlays the J rows.  Compile-time recursion: v[TT] must be a static register.
+template <class T, int TT>
+DI void delassus_dots(const float* L, const float* X, int c, int nr, int tmax, float* v) {
+  if constexpr (TT <= MAXR / 2) {
+    if (TT > tmax) return;
+    int rho = c + TT;
+    rho = rho >= nr ? rho - nr : rho;
+    const float* Jr = L + L_J + 28 * rho;
+    float s = 0;
+#pragma unroll
+    for (int d = 0; d < T::ND; ++d) s += Jr[d] * X[d];
+    v[TT] = s;
+    pin1(v[TT]);  // keeps the steps in order: hoisting the next steps' 28-register J rows above this point spills
+    delassus_dots<T, TT + 1>(L, X, c, nr, tmax, v);
+  }
+}
+template <int TT>
+DI void delassus_store(float* L, int c, int nr, int tmax, const float* v) {
+  if constexpr (TT <= MAXR / 2) {
+    if (TT > tmax) return;
+    int rho = c + TT;
+    rho = rho >= nr ? rho - nr : rho;
+    if (TT == 0) {
+      L[L_A + (MAXR + 1) * c] = 0.0f;  // the solver works on a zero diagonal (see solve_constraints); the value stays in v[0]
+    } else {
+      L[L_A + MAXR * rho + c] = v[TT];
+      L[L_A + MAXR * c + rho] = v[TT];
+    }
+    delassus_store<TT + 1>(L, c, nr, tmax, v);
+  }
+}
+
 // One PGS visit of fixed-bound row RR, then the next (compile-time recursion = guaranteed full unrolling with a
 // wave-uniform early exit; the optimiser keeps a `#pragma unroll` loop with a break rolled).  With RR an immediate, the
 // readlane / writelane index and the LDS offset are constants and the A entry of the next visit is fetched one visit
@@ -1187,25 +1223,23 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found) {
   }
   STAMP(6);
   wsync();  // all lanes are done with the ABA view: the A matrix may overwrite it
-  // ---- Delassus matrix: A[rr][lane] = J_rr . X_lane (rows of J broadcast from LDS)
-  // lanes >= MAXR own no row: they read/write column MAXR-1 of the dummy area instead of branching around each access
+  // ---- Delassus matrix A = J M^-1 J^T, half of it computed, mirrored on store (delassus_dots / delassus_store)
+  // lanes >= MAXR own no row: they read column MAXR-1 of the dummy area instead of branching around each access
   const int lc = lane < MAXR ? lane : MAXR - 1;
-  float diag = 1.0f;
-#pragma unroll 2
-  for (int rr = 0; rr < nr; ++rr) {
-    float s = 0;
-#pragma unroll
-    for (int d = 0; d < T::ND; ++d) s += L[L_J + 28 * rr + d] * X[d];
-    if (lane < MAXR) L[L_A + MAXR * rr + lane] = s;
-    diag = rr == r ? s : diag;
+  float diag;
+  {
+    float av[MAXR / 2 + 1];
+    const int cc = r < nr ? r : 0, tmax = nr >> 1;
+    delassus_dots<T, 0>(L, X, cc, nr, tmax, av);
+    diag = r < nr ? av[0] : 1.0f;
+    wsync();  // every J row has been read: A may overwrite them
+    if (r < nr) delassus_store<0>(L, cc, nr, tmax, av);
   }
   const float invdiag = rcp(diag + cfm);
-  wsync();
   // The solver works on A with a ZERO diagonal: each lane keeps y = (bias - sum_{r' != c} A[r'][c] lam_r') / (A_cc + cfm),
   // the value its own impulse would take if unclamped.  A visit of row rr then is
   //     new = clamp(y_rr);  d = new - lam_rr;  lam_rr = new;  y_c -= A[rr][c] / (A_cc + cfm) * d   for every lane c
   // and lane rr needs no special case (its own column entry is the zeroed diagonal): no v_cmp / v_cndmask per visit.
-  if (r < nr) L[L_A + MAXR * r + r] = 0.0f;
   wsync();
   STAMP(7);
   // warm-start impulses act before the first iteration (normal rows only)
