@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define MOCCA_MODEL_MAGIC 0x41434F4Du /* "MOCA" */
-#define MOCCA_MODEL_VERSION 6u
+#define MOCCA_MODEL_VERSION 7u
 
 #define MOCCA_MAX_BODIES 24
 #define MOCCA_MAX_GEOMS 32
@@ -45,9 +45,15 @@ extern "C" {
 
 enum { MOCCA_GEOM_SPHERE = 0, MOCCA_GEOM_CAPSULE = 1 };
 
+/* MoccaModel.task_flags */
+enum {
+  MOCCA_TASKF_NEVER_DONE = 1,      /* Walker2DCustomEnv.step forces done = False (env_locomotion.py:302-309); TimeLimit still applies */
+  MOCCA_TASKF_RESET_TAIL_ZERO = 2, /* Walker2DCustomEnv.reset returns [robot_state, 0, 0] (env_locomotion.py:299-300)            */
+};
+
 /* task ids accepted by mocca_create() */
 enum {
-  MOCCA_TASK_WALKER3D_CUSTOM = 0,  /* env_locomotion.py:37-282; also Child3DCustomEnv (:317-327) with a Child3D blob   */
+  MOCCA_TASK_WALKER3D_CUSTOM = 0,  /* env_locomotion.py:37-282; also Child3DCustomEnv (:317-327), Walker2D / Crab2DCustomEnv (:285-314) by blob */
   MOCCA_TASK_WALKER3D_STEPPER = 1, /* env_locomotion.py:330-840; also MikeStepperEnv (:843-851) with a Mike blob       */
   MOCCA_TASK_CASSIE = 2,           /* env_cassie.py:284-479 (CassieEnv, 3-D) */
 };
@@ -155,7 +161,7 @@ typedef struct MoccaModel {
   float alive_height;                 /* 0.6, env_cassie.py:406-412 */
   float cassie_target[3];             /* (1000, 0, 0), env_cassie.py:366 */
   float init_quat[4];                  /* base orientation at reset, xyzw (robots.py:199-200; "crawl" pose :316-318) */
-  int32_t pad2_[1];
+  int32_t task_flags;                 /* MOCCA_TASKF_*: quirks of the planar Custom envs (env_locomotion.py:285-314) */
 
   /* ---- derived lookup tables (model.py finalize_tables): one 16-byte load instead of chains of dependent loads ---- */
   float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | terrain<<24), bits(anc_mask[body]) */

@@ -16,6 +16,8 @@ REGISTERED = {
     "CassieEnv-v0": ("mocca_envs_amd.envs:CassieEnv", {}),
     "Child3DCustomEnv-v0": ("mocca_envs_amd.envs:Child3DCustomEnv", {}),
     "MikeStepperEnv-v0": ("mocca_envs_amd.envs:MikeStepperEnv", {}),
+    "Walker2DCustomEnv-v0": ("mocca_envs_amd.envs:Walker2DCustomEnv", {}),
+    "Crab2DCustomEnv-v0": ("mocca_envs_amd.envs:Crab2DCustomEnv", {}),
 }
 
 

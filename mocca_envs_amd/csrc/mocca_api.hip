@@ -179,6 +179,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     }
     rew = progress + bonus - energy + tall - posture - joints;                         // :121-122
     if (lane == 0) softsign_tail(dist, ang, obs + NBO);
+    if (M->task_flags & MOCCA_TASKF_NEVER_DONE) t.done = 0;                            // Walker2DCustomEnv.step, :302-309
   } else {
     // env_locomotion.py:515-568
     t.setstop = (t.nsi == 6 || t.nsi == 7 || t.nsi == 13 || t.nsi == 14);             // :522
@@ -336,6 +337,7 @@ struct mocca_ctx {
   MoccaModel model;
   int task_id = 0, n_envs = 0, device = 0, obs_dim = 0;
   MoccaModel* d_model = nullptr;
+  int topo = 0;  // TOPO_*
   float* d_dyn = nullptr;
   uint32_t* d_task = nullptr;
   float* d_terrain = nullptr;
@@ -373,17 +375,28 @@ static int check_topology_t(const MoccaModel& m, const char* name, std::string& 
   }
   return MOCCA_OK;
 }
-static int check_topology(const MoccaModel& m, int task_id, std::string& err) {
-  if (task_id == MOCCA_TASK_CASSIE) return check_topology_t<TopoCassie>(m, "TopoCassie", err);
+// compiled topologies: the tree of the blob selects the kernel instance
+enum { TOPO_WALKER3D = 0, TOPO_CASSIE = 1, TOPO_WALKER2D = 2, TOPO_CRAB2D = 3 };
+static int check_topology(const MoccaModel& m, int task_id, int* topo, std::string& err) {
+  if (task_id == MOCCA_TASK_CASSIE) { *topo = TOPO_CASSIE; return check_topology_t<TopoCassie>(m, "TopoCassie", err); }
+  if (task_id == MOCCA_TASK_WALKER3D_CUSTOM && m.n_bodies == TopoWalker2D::NB) {
+    *topo = TOPO_WALKER2D; return check_topology_t<TopoWalker2D>(m, "TopoWalker2D", err);
+  }
+  if (task_id == MOCCA_TASK_WALKER3D_CUSTOM && m.n_bodies == TopoCrab2D::NB) {
+    *topo = TOPO_CRAB2D; return check_topology_t<TopoCrab2D>(m, "TopoCrab2D", err);
+  }
+  *topo = TOPO_WALKER3D;
   return check_topology_t<TopoWalker3D>(m, "TopoWalker3D", err);
 }
 
-// kernel selection by task id
+// kernel selection by (topology, task id)
 template <template <class, int> class Launcher, class... Args>
-static void dispatch(int task_id, Args... args) {
-  if (task_id == MOCCA_TASK_WALKER3D_CUSTOM) Launcher<TopoWalker3D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
-  else if (task_id == MOCCA_TASK_WALKER3D_STEPPER) Launcher<TopoWalker3D, MOCCA_TASK_WALKER3D_STEPPER>::run(args...);
-  else Launcher<TopoCassie, MOCCA_TASK_CASSIE>::run(args...);
+static void dispatch(int topo, int task_id, Args... args) {
+  if (topo == TOPO_CASSIE) Launcher<TopoCassie, MOCCA_TASK_CASSIE>::run(args...);
+  else if (topo == TOPO_WALKER2D) Launcher<TopoWalker2D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
+  else if (topo == TOPO_CRAB2D) Launcher<TopoCrab2D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
+  else if (task_id == MOCCA_TASK_WALKER3D_CUSTOM) Launcher<TopoWalker3D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
+  else Launcher<TopoWalker3D, MOCCA_TASK_WALKER3D_STEPPER>::run(args...);
 }
 template <class T, int TASK> struct LaunchStep {
   static void run(int n, hipStream_t s, StepArgs a) { hipLaunchKernelGGL((mocca_step_kernel<T, TASK>), dim3(n), dim3(64), 0, s, a); }
@@ -422,7 +435,7 @@ int mocca_create(const void* model_blob, size_t nbytes, int task_id, int n_envs,
   if (h->model.magic != MOCCA_MODEL_MAGIC || h->model.version != MOCCA_MODEL_VERSION) {
     g_err = "bad model blob magic/version"; delete h; return MOCCA_E_ARG;
   }
-  int rc = check_topology(h->model, task_id, g_err);
+  int rc = check_topology(h->model, task_id, &h->topo, g_err);
   if (rc != MOCCA_OK) { delete h; return rc; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
@@ -507,7 +520,7 @@ int mocca_reset(mocca_handle h, const uint8_t* mask_dev, uint64_t seed, float* o
   StepArgs a = make_args(h);
   a.mask = mask_dev; a.obs = obs_dev;
   hipStream_t s = (hipStream_t)stream;
-  dispatch<LaunchReset>(h->task_id, h->n_envs, s, a);
+  dispatch<LaunchReset>(h->topo, h->task_id, h->n_envs, s, a);
   HIP_TRY(h, hipGetLastError());
   return MOCCA_OK;
 }
@@ -518,7 +531,7 @@ int mocca_step(mocca_handle h, const float* act_dev, float* obs_dev, float* rew_
   StepArgs a = make_args(h);
   a.act = act_dev; a.obs = obs_dev; a.rew = rew_dev; a.done = done_dev; a.info = info_dev;
   hipStream_t s = (hipStream_t)stream;
-  dispatch<LaunchStep>(h->task_id, h->n_envs, s, a);
+  dispatch<LaunchStep>(h->topo, h->task_id, h->n_envs, s, a);
   HIP_TRY(h, hipGetLastError());
   return MOCCA_OK;
 }
@@ -528,7 +541,7 @@ int mocca_observe(mocca_handle h, float* obs_dev, void* stream) {
   StepArgs a = make_args(h);
   a.obs = obs_dev;
   hipStream_t s = (hipStream_t)stream;
-  dispatch<LaunchObserve>(h->task_id, h->n_envs, s, a);
+  dispatch<LaunchObserve>(h->topo, h->task_id, h->n_envs, s, a);
   HIP_TRY(h, hipGetLastError());
   return MOCCA_OK;
 }
@@ -597,7 +610,7 @@ int mocca_kernel_info(mocca_handle h, int* vgprs, int* sgprs, int* lds_bytes, in
   hipFuncAttributes fa;
   int nb = 0;
   hipError_t e = hipSuccess;
-  dispatch<KernelInfo>(h->task_id, &fa, &nb, &e);
+  dispatch<KernelInfo>(h->topo, h->task_id, &fa, &nb, &e);
   HIP_TRY(h, e);
   if (vgprs) *vgprs = fa.numRegs;
   if (sgprs) *sgprs = 0;

@@ -29,6 +29,8 @@
 #include "mocca_model.h"
 #include "topo_walker3d.h"
 #include "topo_cassie.h"
+#include "topo_walker2d.h"
+#include "topo_crab2d.h"
 
 #define DI __device__ __forceinline__
 
@@ -1235,7 +1237,9 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found) {
     wsync();  // every J row has been read: A may overwrite them
     if (r < nr) delassus_store<0>(L, cc, nr, tmax, av);
   }
-  const float invdiag = rcp(diag + cfm);
+  // a row with a vanishing Jacobian (out-of-plane friction of a planar mechanism's self contact) gets zero gain, as in
+  // Bullet (jacDiagABInv = 0 below SIMD_EPSILON), instead of 0 * inf
+  const float invdiag = diag + cfm > 1e-12f ? rcp(diag + cfm) : 0.0f;
   // The solver works on A with a ZERO diagonal: each lane keeps y = (bias - sum_{r' != c} A[r'][c] lam_r') / (A_cc + cfm),
   // the value its own impulse would take if unclamped.  A visit of row rr then is
   //     new = clamp(y_rr);  d = new - lam_rr;  lam_rr = new;  y_c -= A[rr][c] / (A_cc + cfm) * d   for every lane c
@@ -1640,7 +1644,10 @@ DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, in
   float dist, ang;
   if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
     calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
-    if (lane == 0) softsign_tail(dist, ang, obs + nbo);
+    if (lane == 0) {
+      softsign_tail(dist, ang, obs + nbo);
+      if (M->task_flags & MOCCA_TASKF_RESET_TAIL_ZERO) { obs[nbo] = 0.0f; obs[nbo + 1] = 0.0f; }  // Walker2DCustomEnv.reset, :299-300
+    }
   } else {
     generate_terrain(a, env, t, L, ter, lane);
     t.nsi = 1;

@@ -217,6 +217,29 @@ class Child3DCustomEnv(Walker3DCustomEnv):
     termination_height = 0.1
 
 
+class Walker2DCustomEnv(Walker3DCustomEnv):
+    """env_locomotion.py:285-309: the planar walker; reset returns [robot_state, 0, 0] and step never reports done."""
+
+    env_id = "Walker2DCustomEnv-v0"
+    robot_init_position = [0, 0, 1.35]
+
+    def reset(self):
+        obs = super().reset()
+        obs[-2:] = 0.0                      # :299-300
+        return obs
+
+    def step(self, action):
+        obs, rew, _, info = super().step(action)
+        self.done = False                   # :303-305 (the device record is cleared the same way: MOCCA_TASKF_NEVER_DONE)
+        return obs, rew, False, info
+
+
+class Crab2DCustomEnv(Walker2DCustomEnv):
+    """env_locomotion.py:312-314."""
+
+    env_id = "Crab2DCustomEnv-v0"
+
+
 class Walker3DStepperEnv(EnvBase):
     """env_locomotion.py:330-840."""
 

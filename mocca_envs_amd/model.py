@@ -29,11 +29,12 @@ MAX_PAIRS = 192
 MAX_FEET = 2
 MAX_SLOTS = 40
 MAGIC = 0x41434F4D
-VERSION = 6
+VERSION = 7
 
 GEOM_SPHERE, GEOM_CAPSULE = 0, 1
 TASK_WALKER3D_CUSTOM, TASK_WALKER3D_STEPPER, TASK_CASSIE = 0, 1, 2
 TASK_WORDS = 40
+TASKF_NEVER_DONE, TASKF_RESET_TAIL_ZERO = 1, 2  # MoccaModel.task_flags (include/mocca_model.h)
 MAX_CLOSURES = 2
 MAX_CTRL = 16
 STATE_BASE = 13
@@ -128,7 +129,7 @@ class MoccaModel(C.Structure):
         ("alive_height", C.c_float),
         ("cassie_target", C.c_float * 3),
         ("init_quat", C.c_float * 4),
-        ("pad2_", C.c_int32 * 1),
+        ("task_flags", C.c_int32),
         ("slot_tab", (C.c_float * 4) * MAX_SLOTS),
         ("gp_tab", (C.c_float * 4) * (2 * MAX_GEOMS)),
         ("pair_tab", (C.c_float * 4) * MAX_PAIRS),
@@ -436,8 +437,16 @@ def _bullet_ancestors(bl_parent: List[int], a: int) -> set:
     return out
 
 
-TERRAIN_GROUP = 2           # btBroadphaseProxy::StaticFilter      [UNVERIFIED-BULLET]
-TERRAIN_MASK = ~2 & 0xFFFF  # AllFilter ^ StaticFilter             [UNVERIFIED-BULLET]
+# MJCF contype / conaffinity become Bullet's collision filter group / mask.  MuJoCo lets two geoms collide when
+# (contype_a & conaffinity_b) OR (contype_b & conaffinity_a); with Bullet's default AND rule walker2d.xml
+# (contype 1, conaffinity 0 -- "no self collision, but stand on the floor") could not touch the ground plane at all, yet
+# PyBullet's 2-D walkers do.  The OR rule is therefore what is modelled, for terrain and for self pairs.  [UNVERIFIED-BULLET]
+TERRAIN_GROUP = 2           # btBroadphaseProxy::StaticFilter
+TERRAIN_MASK = ~2 & 0xFFFF  # AllFilter ^ StaticFilter
+
+
+def filters_collide(group_a: int, mask_a: int, group_b: int, mask_b: int) -> bool:
+    return bool(group_a & mask_b) or bool(group_b & mask_a)
 
 
 def compile_model(
@@ -509,7 +518,7 @@ def compile_model(
             m.g_p2[gi][k] = g.p2[k]
         m.g_slot[gi] = slot
         slot += 1 if g.kind == GEOM_SPHERE else 2
-        m.g_terrain[gi] = int(bool(g.group & TERRAIN_MASK) and bool(TERRAIN_GROUP & g.mask))
+        m.g_terrain[gi] = int(filters_collide(g.group, g.mask, TERRAIN_GROUP, TERRAIN_MASK))
     assert slot <= MAX_SLOTS
     m.n_slots = slot
 
@@ -525,7 +534,7 @@ def compile_model(
                     continue
                 if li in _bullet_ancestors(bl_parent, lj) or lj in _bullet_ancestors(bl_parent, li):
                     continue
-                if not ((gi_.group & gj_.mask) and (gj_.group & gi_.mask)):
+                if not filters_collide(gi_.group, gi_.mask, gj_.group, gj_.mask):
                     continue
                 if bi == bj:
                     continue  # rigidly attached in our tree (e.g. head vs torso): cannot move relative
@@ -678,6 +687,40 @@ def compile_mike(**kw) -> MoccaModel:
                          init_pos=(0.3, 0.0, 1.0),               # env_locomotion.py:845
                          link_mass={"abdomen_y": 8.0},           # the link carrying MJCF body "waist", robots.py:507-510
                          **_WALKER3D_MIRROR, **kw)
+
+
+def _compile_planar(description, damping: float, armature: float, self_collision: bool, mirror_right, mirror_left, **kw) -> MoccaModel:
+    """Walker2D / Crab2D for the planar Custom envs (env_locomotion.py:285-314).
+
+    The MJCF root carries slide-x / slide-z / hinge-y "ignore*" joints (robots.py:163-165): in Bullet the pelvis is a
+    link behind them on a world-fixed base.  Here the pelvis is the floating base: every hinge axis is +-y and every
+    geom lies in the y = 0 plane, so the motion stays planar by symmetry; what differs from the 3-D walkers is that no
+    base damping acts (Bullet damps the multibody BASE, which is the fixed anchor there).  The reported base point is
+    the pelvis link's COM (robot_body = parts["pelvis"], robots.py:105-106; getLinkState()[0]).
+    Start height: the rest pose of the file (feet just above the ground).  What robot_init_position = [0, 0, 1.35]
+    (env_locomotion.py:287) does to a fixed-base multibody whose MJCF body sits at z = -1.35 cannot be observed without
+    PyBullet.                                                                                     [UNVERIFIED-BULLET]
+    """
+    root = description()
+    kw.setdefault("joint_damping", damping)
+    kw.setdefault("joint_armature", armature)
+    m = compile_model(root, foot_names=["foot", "foot_left"], init_q_by_name={}, init_pos=root.pos,
+                      mirror_right=mirror_right, mirror_left=mirror_left, mirror_neg=[], self_collision=self_collision, **kw)
+    m.lin_damp = m.ang_damp = 0.0
+    m.task_flags = TASKF_NEVER_DONE | TASKF_RESET_TAIL_ZERO
+    return m.finalize_tables()
+
+
+def compile_walker2d(**kw) -> MoccaModel:
+    """robots.py:338-369; loaded without the self-collision flags (:358)."""
+    from .mjcf_tables import walker2d_description
+    return _compile_planar(walker2d_description, 0.1, 0.01, False, [1, 2, 3], [4, 5, 6], **kw)
+
+
+def compile_crab2d(**kw) -> MoccaModel:
+    """robots.py:372-404; crab2d.xml:4 armature 1, damping 1; self-collision flags on (:390-394)."""
+    from .mjcf_tables import crab2d_description
+    return _compile_planar(crab2d_description, 1.0, 1.0, True, [0, 1, 2], [3, 4, 5], **kw)
 
 
 # --------------------------------------------------------------------------
@@ -855,7 +898,7 @@ def topology_header(m: MoccaModel, name: str = "Walker3D") -> str:
     # the slot of one of its children ("carried" child) so that a serial chain -- a leg, an arm -- stays on the same
     # lanes from leaf to root and its articulated inertia travels in registers; other children go through LDS.
     by_depth = [[b for b in range(nb) if depth[b] == d] for d in range(maxd + 1)]
-    maxw = max(len(l) for l in by_depth[1:])
+    maxw = max(4, max(len(l) for l in by_depth[1:]))  # the level pass is written for four 8-lane slots
     slot_of, carry = {}, [-1] * nb
     levels = [[-1] * maxw for _ in range(maxd + 1)]
     for d in range(maxd, 0, -1):
@@ -944,6 +987,10 @@ def write_topology_headers(outdir: Optional[str] = None) -> None:
         f.write(topology_header(compile_walker3d(), "Walker3D"))
     with open(os.path.join(outdir, "topo_cassie.h"), "w") as f:
         f.write(topology_header(compile_cassie(), "Cassie"))
+    with open(os.path.join(outdir, "topo_walker2d.h"), "w") as f:
+        f.write(topology_header(compile_walker2d(), "Walker2D"))
+    with open(os.path.join(outdir, "topo_crab2d.h"), "w") as f:
+        f.write(topology_header(compile_crab2d(), "Crab2D"))
 
 
 if __name__ == "__main__":

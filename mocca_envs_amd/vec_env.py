@@ -22,6 +22,9 @@ TASKS = {
     # same tree as Walker3D (child3d.xml / mike.xml): new model blobs on the Walker3D kernels
     "Child3DCustomEnv-v0": M.TASK_WALKER3D_CUSTOM,
     "MikeStepperEnv-v0": M.TASK_WALKER3D_STEPPER,
+    # planar robots (walker2d.xml / crab2d.xml): own topologies, Custom task with the quirks of env_locomotion.py:285-314
+    "Walker2DCustomEnv-v0": M.TASK_WALKER3D_CUSTOM,
+    "Crab2DCustomEnv-v0": M.TASK_WALKER3D_CUSTOM,
 }
 
 _MODELS = {
@@ -30,6 +33,8 @@ _MODELS = {
     "CassieEnv-v0": lambda **kw: M.compile_cassie(**kw),
     "Child3DCustomEnv-v0": M.compile_child3d,
     "MikeStepperEnv-v0": M.compile_mike,
+    "Walker2DCustomEnv-v0": M.compile_walker2d,
+    "Crab2DCustomEnv-v0": M.compile_crab2d,
 }
 _DEFAULT_ENV_OF_TASK = {M.TASK_WALKER3D_CUSTOM: "Walker3DCustomEnv-v0", M.TASK_WALKER3D_STEPPER: "Walker3DStepperEnv-v0",
                         M.TASK_CASSIE: "CassieEnv-v0"}

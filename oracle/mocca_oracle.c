@@ -693,7 +693,11 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
         real lim = w->row_mu[r] * w->lam[w->row_normal[r]];
         lo = -lim; hi = lim;
       }
-      real dl = (w->bias[r] - w->w[r] - w->cfm[r] * w->lam[r]) / (w->A[r][r] + w->cfm[r]);
+      /* a row whose Jacobian vanishes (e.g. the out-of-plane friction direction of a self contact of a planar
+       * mechanism) has A_rr = 0: Bullet gives such a row a zero gain (jacDiagABInv = 0 when the denominator is below
+       * SIMD_EPSILON) instead of dividing */
+      real den = w->A[r][r] + w->cfm[r];
+      real dl = den > (real)1e-12 ? (w->bias[r] - w->w[r] - w->cfm[r] * w->lam[r]) / den : 0;
       real nl = w->lam[r] + dl;
       nl = nl < lo ? lo : (nl > hi ? hi : nl);
       dl = nl - w->lam[r];
@@ -1045,6 +1049,7 @@ static void reset_env(Oracle *o, int env, float *obs) {
     real dist, ang;
     calc_potential(o, s, tk, &dist, &ang);
     softsign_tail(dist, ang, obs + nb);
+    if (m->task_flags & MOCCA_TASKF_RESET_TAIL_ZERO) { obs[nb] = 0; obs[nb + 1] = 0; } /* Walker2DCustomEnv.reset, :299-300 */
   } else {
     /* env_locomotion.py:481-513: calc_feet_state() on the fresh pose finds no contacts (planks
      * not yet placed relative to a robot at rest above them): feet_contact = 0 */
@@ -1116,6 +1121,7 @@ static void step_env(Oracle *o, int env, const float *act, float *obs, float *re
     }
     *rew = (float)(progress + target_bonus - energy + tall - posture - joints); /* :121-122 */
     softsign_tail(dist, ang, obs + nb);
+    if (m->task_flags & MOCCA_TASKF_NEVER_DONE) tk->done = 0; /* Walker2DCustomEnv.step, :302-309 */
     *info = 0;
   } else {
     /* env_locomotion.py:515-568 */

@@ -20,21 +20,57 @@ import make_golden as G  # noqa: E402
 
 
 class FakeBulletAnyMJCF(G.FakeBullet):
+    root_link = None  # name of the link the robot reports as its body (planar robots: "pelvis")
+
     def loadMJCF(self, path, flags=0):
         self.joints = []
         self.mjcf_path = path
-        self._parse_walker(path)
+        self.mjcf_flags = flags
+        self._parse_any(path)
         self.q, self.qd = np.zeros(len(self.joints)), np.zeros(len(self.joints))
         return (self.ROBOT,)
 
+    def restoreState(self, *a, **k): pass
 
-def make_env(cls_name, **kw):
+    def _parse_any(self, path):
+        """Links in file order; the root body's "ignore*" joints are real joints (without a range) of the fake client."""
+        import math
+        import xml.etree.ElementTree as ET
+        nfix = [0]
+
+        def rec(body, is_root):
+            js = body.findall("joint")
+            for k, j in enumerate(js):
+                rng = j.get("range")
+                lo, hi = [float(v) * math.pi / 180 for v in rng.split()] if rng else (0.0, -1.0)
+                link = body.get("name") if k == len(js) - 1 else "link_dummy_%s" % j.get("name")
+                self.joints.append((j.get("name"), link, lo, hi))
+            if not js and not is_root:
+                self.joints.append(("jointfix_%d" % nfix[0], body.get("name"), 0.0, -1.0))
+                nfix[0] += 1
+            for ch in body.findall("body"):
+                rec(ch, False)
+
+        root = ET.parse(path).getroot().find("worldbody").find("body")
+        rec(root, not root.findall("joint"))
+
+    def getLinkState(self, body, link, computeLinkVelocity=0):
+        if self.root_link is not None and self.joints[link][1] == self.root_link:
+            p, q = tuple(self.base_pos), tuple(self.base_quat)
+            v, w = tuple(self.base_vel), (0.0, 0.0, 0.0)
+        else:
+            p, q, v, w = tuple(self.link_pos.get(link, np.zeros(3))), (0, 0, 0, 1), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0)
+        return (p, q, None, None, None, None, v, w) if computeLinkVelocity else (p, q, None, None, None, None)
+
+
+def make_env(cls_name, root_link=None, **kw):
     import mocca_envs.env_base as env_base
     import mocca_envs.env_locomotion as loco
     holder = {}
 
     def factory(*a, **k):
         holder["p"] = FakeBulletAnyMJCF()
+        holder["p"].root_link = root_link
         return holder["p"]
 
     env_base.BulletClient = factory
@@ -159,6 +195,64 @@ def main():
         rob.apply_action(a)
         out[f"mike_ep{ep}_torque_act"], out[f"mike_ep{ep}_torque_out"] = a, p.torques.copy()
     out["mike_n_episodes"] = np.array(2)
+
+    # ---------------- Walker2DCustomEnv / Crab2DCustomEnv (env_locomotion.py:285-314)
+    for tag, cls, compile_fn in (("walker2d", "Walker2DCustomEnv", M.compile_walker2d), ("crab2d", "Crab2DCustomEnv", M.compile_crab2d)):
+        env, p = make_env(cls, root_link="pelvis")
+        rob = env.robot
+        robot_constants(out, tag, env, p)
+        n2 = len(rob.ordered_joints)
+        out[f"{tag}_load_flags"] = np.array(p.mjcf_flags)
+        out[f"{tag}_self_collision"] = np.array(int(bool(p.mjcf_flags & p.URDF_USE_SELF_COLLISION)))
+        out[f"{tag}_init_position"] = np.array(env.robot_init_position, dtype=np.float64)
+        out[f"{tag}_termination_height"] = np.array(env.termination_height)
+        joint_ids = rob.ordered_joint_ids
+        foot_links = [rob.parts[f].bodyPartIndex for f in rob.foot_names]
+        mdl = compile_fn()
+        orc = Oracle(mdl.to_bytes(), M.TASK_WALKER3D_CUSTOM, 1, "f64")
+        lo, hi = out[f"{tag}_joint_lo"], out[f"{tag}_joint_hi"]
+        sd = 13 + 2 * n2
+
+        def push_state2(st, touch, p=p, orc=orc, mdl=mdl, joint_ids=joint_ids, foot_links=foot_links, n2=n2, sd=sd):
+            full = np.zeros((1, orc.state_dim))
+            full[0, :sd] = st
+            orc.set_state(full)
+            fr = orc.link_frames(0, mdl.n_bodies)
+            p.base_pos, p.base_quat, p.base_vel = st[0:3].copy(), st[3:7].copy(), st[7:10].copy()
+            for k, jid in enumerate(joint_ids):
+                p.q[jid], p.qd[jid] = st[13 + k], st[13 + n2 + k]
+            for k, fl in enumerate(foot_links):
+                p.link_pos[fl] = fr[mdl.foot_body[k], 12:15].copy()
+            p.contacts = {fl: ([(G.FakeBullet.PLANE, -1)] if touch[k] else []) for k, fl in enumerate(foot_links)}
+
+        env.seed(80)
+        env.robot.np_random = env.np_random
+        tape = env.np_random.tape.copy()
+        p.base_pos = np.array(mdl.init_pos, dtype=np.float64)   # the fake's link pose is whatever the script says
+        obs0 = env.reset()
+        rec = dict(tape=tape[:640], reset_obs=obs0, reset_q=np.array([p.q[j] for j in joint_ids]), reset_mirrored=int(rob.mirrored),
+                   reset_walk_target=env.walk_target.copy())
+        rng = np.random.default_rng(500)
+        states, touches, actions, obs_l, rew_l, done_l, terms = [], [], [], [], [], [], []
+        for t in range(40):
+            st = np.zeros(sd)
+            pitch = rng.normal(0.1, 0.4)
+            st[0:3] = [0.03 * t, 0.0, rng.uniform(0.3, 1.2)]      # heights on both sides of 0.7: done must stay False
+            st[3:7] = G.quat_from_euler(0.0, pitch, 0.0)
+            st[7:10] = [rng.normal(0, 1), 0.0, rng.normal(0, 1)]
+            st[11] = rng.normal(0, 1)
+            st[13:13 + n2] = lo + (hi - lo) * rng.uniform(-0.02, 1.02, n2)
+            st[13 + n2:sd] = rng.normal(0, 3.0, n2)
+            touch = (rng.random(2) < 0.6).astype(np.int32)
+            a = rng.uniform(-1.5, 1.5, n2)
+            p.on_step = (lambda st=st, touch=touch: push_state2(st, touch))
+            o, r, dn, _ = env.step(a)
+            states.append(st); touches.append(touch); actions.append(a); obs_l.append(o); rew_l.append(r); done_l.append(dn)
+            terms.append([env.progress, env.target_bonus, env.energy_penalty, env.tall_bonus, env.posture_penalty, env.joints_penalty])
+        rec.update(states=np.array(states), touch=np.array(touches), actions=np.array(actions), obs=np.array(obs_l),
+                   rew=np.array(rew_l), done=np.array(done_l).astype(np.int32), terms=np.array(terms))
+        for k, v in rec.items():
+            out[f"{tag}_ep0_{k}"] = np.asarray(v)
 
     path = os.path.join(HERE, "variants_reference.npz")
     np.savez_compressed(path, **out)

@@ -123,15 +123,20 @@ def test_shard_offset_reproduces_the_owned_envs():
     full.close(); part.close()
 
 
-@pytest.mark.parametrize("env_id,obs_dim,z0", [("Child3DCustomEnv-v0", 52, 0.38), ("MikeStepperEnv-v0", 65, 1.0)])
+@pytest.mark.parametrize("env_id,obs_dim,z0", [("Child3DCustomEnv-v0", 52, 0.38), ("MikeStepperEnv-v0", 65, 1.0),
+                                               ("Walker2DCustomEnv-v0", 24, 1.05), ("Crab2DCustomEnv-v0", 22, 1.06)])
 def test_same_tree_variants(env_id, obs_dim, z0):
-    """Child3D / Mike run on the Walker3D kernels with their own model blobs (env_locomotion.py:317-327, :843-851)."""
+    """Child3D / Mike run on the Walker3D kernels with their own model blobs (env_locomotion.py:317-327, :843-851);
+    Walker2D / Crab2D on their own topologies (:285-314: reset tail zero, never done)."""
     import mocca_envs_amd
     env = mocca_envs_amd.make(env_id)
     base = env.unwrapped
-    assert base.observation_space.shape == (obs_dim,) and base.action_space.shape == (21,)
+    nj = base.model.n_joints
+    assert base.observation_space.shape == (obs_dim,) and base.action_space.shape == (nj,)
     env.seed(11)
     obs = env.reset()
+    if "2D" in env_id:
+        assert obs[-2] == 0.0 and obs[-1] == 0.0
     st = base._vec.get_state()[0].cpu().numpy()
     np.testing.assert_allclose(st[0:3], list(base.model.init_pos), atol=1e-6)
     assert abs(st[2] - z0) < 1e-6
@@ -140,7 +145,7 @@ def test_same_tree_variants(env_id, obs_dim, z0):
     orc = _oracle_from(base, base.task_id)
     arng = np.random.default_rng(3)
     for t in range(5):
-        a = arng.uniform(-1, 1, 21)
+        a = arng.uniform(-1, 1, nj)
         o, r, d, info = env.step(a)
         oc, rc, dc, _ = orc.step(a[None].astype(np.float32))
         np.testing.assert_allclose(o, oc[0], atol=5e-3)

@@ -8,7 +8,9 @@ pytestmark = pytest.mark.gpu
 
 TASKS = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER),
          # same tree, other model blobs (child3d.xml from the crawl pose, mike.xml): same kernels
-         ("Child3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM), ("MikeStepperEnv-v0", M.TASK_WALKER3D_STEPPER)]
+         ("Child3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM), ("MikeStepperEnv-v0", M.TASK_WALKER3D_STEPPER),
+         # planar robots: own topologies (7 / 6 hinges), Custom task
+         ("Walker2DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM), ("Crab2DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM)]
 
 # fp32 tolerance of one teacher-forced env.step() (4 substeps, up to 48 PGS rows).  Errors are measured in
 # units of (1e-3 + 1e-3 |x|): joint speeds reach 100 rad/s under random actions, hence the relative part.
@@ -89,14 +91,19 @@ def test_teacher_forced_steps(env_id, task):
             o64.set_terrain(o32.get_terrain())
         _sync_from(env, o32, task)
         scale = 1.0 if t % 4 else 0.3  # calmer actions keep some envs standing so contact rows matter
-        a = (scale * rng.uniform(-1, 1, (128, 21))).astype(np.float32)
+        a = (scale * rng.uniform(-1, 1, (128, env.act_dim))).astype(np.float32)
         og, rg, dg, ig = env.step(torch.from_numpy(a).cuda())
         oc, rc, dc, ic = o32.step(a)
         o6, r6, d6, _ = o64.step(a)
         og, rg, dg, ig = og.cpu().numpy(), rg.cpu().numpy(), dg.cpu().numpy(), ig.cpu().numpy()
         sg, sc, s6 = env.get_state().cpu().numpy(), o32.get_state(), o64.get_state()
         ok = np.isfinite(sc).all(axis=1) & np.isfinite(s6).all(axis=1)
-        e_state = _err_units(sg[ok], sc[ok]).max(axis=1)
+        # dynamic state proper; the persisted warm-start impulses are compared through their sum (the total support
+        # impulse): redundant contacts -- two capsules sharing an end point at a joint, the planar robots' coplanar
+        # legs -- make the split between rows non-unique, so rounding moves impulse from one slot to its twin
+        nd_ = 13 + 2 * env.act_dim
+        e_state = _err_units(sg[ok][:, :nd_], sc[ok][:, :nd_]).max(axis=1)
+        e_state = np.maximum(e_state, _err_units(sg[ok][:, nd_:].sum(axis=1), sc[ok][:, nd_:].sum(axis=1)))
         e_obs = _err_units(og[ok], oc[ok]).max(axis=1)
         assert e_state.max() < 50 and e_obs.max() < 50, f"t={t}: gross mismatch {e_state.max()} {e_obs.max()}"
         errs["state"].append(e_state); errs["obs"].append(e_obs)
@@ -107,8 +114,9 @@ def test_teacher_forced_steps(env_id, task):
             thr = env.model.termination_height if task == 0 else 0.45
             assert (np.abs(oc[mism, 0] - thr) < 1e-3).all(), f"t={t} done flags differ away from the threshold"
         np.testing.assert_array_equal(ig[ok & ~mism], ic[ok & ~mism])
-        err_gpu.append(_err_units(sg[ok][:, :55], s6[ok][:, :55]).max(axis=1))
-        err_f32.append(_err_units(sc[ok][:, :55], s6[ok][:, :55]).max(axis=1))
+        nd = 13 + 2 * env.act_dim
+        err_gpu.append(_err_units(sg[ok][:, :nd], s6[ok][:, :nd]).max(axis=1))
+        err_f32.append(_err_units(sc[ok][:, :nd], s6[ok][:, :nd]).max(axis=1))
         if dc.any():
             m = (dc != 0).astype(np.uint8)
             o32.reset(seed=9, mask=m)
@@ -119,7 +127,10 @@ def test_teacher_forced_steps(env_id, task):
           f"p99 {np.percentile(eg, 99):.3g} | f32 oracle median {np.median(ec):.3g} p99 {np.percentile(ec, 99):.3g}; "
           f"reward abs err median {np.median(cat['rew']):.2e} p99 {np.percentile(cat['rew'], 99):.2e}")
     for k in ("state", "obs"):
-        assert np.median(cat[k]) < 0.1, k          # typical error ~1e-5 absolute
+        # typical error ~1e-5 absolute; the planar robots carry structurally redundant rows (coplanar legs, out-of-plane
+        # friction directions with zero gain), whose impulse split is rounding-dependent: twice the allowance, while the
+        # comparison against the f64 oracle below stays as strict as for the 3-D robots
+        assert np.median(cat[k]) < (0.2 if "2D" in env_id else 0.1), k
         assert np.percentile(cat[k], 99) < 2.0, k  # 99 % within 2e-3 (1 + |x|)
     # reward contains d(potential)/dt = (difference of O(100) numbers) * 60 in fp32
     assert np.median(cat["rew"]) < 1e-3 and np.percentile(cat["rew"], 99) < 5e-2

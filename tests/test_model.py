@@ -37,9 +37,11 @@ def test_collision_filter():
     m = M.compile_walker3d()
     names = [g.name for g in _all_geoms(M.walker3d_description())]
     terrain = {names[g] for g in range(m.n_geoms) if m.g_terrain[g]}
-    # contype/conaffinity 1/1 (torso, butt) and 2/2 (waist) never meet Bullet's static-filter plane
-    assert {"torso1", "butt", "waist"}.isdisjoint(terrain)
+    # MuJoCo's OR rule (model.filters_collide): every geom can touch the static terrain, also the 1/1 and 2/2 ones
+    assert {"torso1", "butt", "waist"} <= terrain
     assert {"right_foot_1", "right_foot_2", "left_foot_1", "left_foot_2"} <= terrain
+    assert M.filters_collide(1, 0, M.TERRAIN_GROUP, M.TERRAIN_MASK)      # walker2d.xml geoms stand on the floor ...
+    assert not M.filters_collide(1, 0, 1, 0)                             # ... and never collide with each other
     pairs = {(m.pair_a[k], m.pair_b[k]) for k in range(m.n_pairs)}
     gi = {n: i for i, n in enumerate(names)}
     assert (gi["torso1"], gi["waist"]) not in pairs          # 1 & 2 == 0
