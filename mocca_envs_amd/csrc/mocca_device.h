@@ -231,10 +231,15 @@ DI int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }  // assert wave-
 DI float unif(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 DI float readlane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 DI int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-// lane l (wave-uniform) of `old` takes the uniform value v: one v_writelane, no compare / select on every lane
-DI float writelane(float v, int l, float old) {
-  // two SGPR sources exceed the constant bus; the lane select travels in M0 (exempt)
-  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(v), "s"(l) : "m0");
+// lane l (wave-uniform, dynamic) of `old` takes the value its own lane holds in v: the one-lane exec mask is built on
+// the scalar unit (v_writelane with two SGPR sources would exceed the constant bus, and M0 is reserved)
+DI float setlane(float v, int l, float old) {
+  unsigned long long m, saved;  // two pairs: s_and_saveexec with source == destination does not mask anything
+  asm volatile("s_lshl_b64 %1, 1, %4\n\t"
+               "s_and_saveexec_b64 %2, %1\n\t"
+               "v_mov_b32 %0, %3\n\t"
+               "s_mov_b64 exec, %2"
+               : "+v"(old), "=&s"(m), "=&s"(saved) : "v"(v), "s"(l) : "scc");  // both scalar ops write SCC
   return old;
 }
 template <int LANE>
@@ -1275,11 +1280,11 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found) {
       const float as = a * invdiag, as1 = a1 * invdiag;
       float nl_ = __builtin_amdgcn_fmed3f(y, -lm, lm);
       float dl = readlane(nl_ - lam, rr);
-      lam = writelane(readlane(nl_, rr), rr, lam);
+      lam = setlane(nl_, rr, lam);
       y = fmaf(-as, dl, y);
       nl_ = __builtin_amdgcn_fmed3f(y, -lm, lm);
       dl = readlane(nl_ - lam, rr + 1);
-      lam = writelane(readlane(nl_, rr + 1), rr + 1, lam);
+      lam = setlane(nl_, rr + 1, lam);
       y = fmaf(-as1, dl, y);
       a = a2;
     }
