@@ -195,3 +195,29 @@ def test_properties_at_full_size():
     q = sa[:, 13:34].cpu().numpy()
     assert (q > lo - 0.35).all() and (q < hi + 0.35).all()  # ERP 0.9 + 100 rad/s impacts: bounded overshoot
     assert (sa[:, 34:55].abs() <= 100.0 + 1e-3).all()      # max_qd clamp
+
+
+@pytest.mark.parametrize("env_id", ["Walker2DCustomEnv-v0", "Crab2DCustomEnv-v0"])
+def test_planar_robots_stay_in_their_plane_at_full_size(env_id):
+    """The planar robots are simulated with a 6-DoF floating base and no planar constraint: every hinge is about +-y and
+    every geom lies in the y = 0 plane, so y, roll and yaw must stay EXACTLY zero (bit-zero), for 4096 envs under random
+    actions, through ground contacts and (Crab2D) self collisions.  done never fires; only the TimeLimit bit may."""
+    import torch
+    from mocca_envs_amd.vec_env import VecEnv
+    n = 4096
+    env = VecEnv(env_id, n, auto_reset=True, seed=5)
+    obs = env.reset()
+    assert (obs[:, -2:] == 0).all()                      # env_locomotion.py:299-300
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for k in range(300):
+        a = torch.rand(n, env.act_dim, device="cuda", generator=g) * 2 - 1
+        obs, r, d, _ = env.step(a)
+        assert int((d & 1).sum()) == 0                   # :302-309
+    st = env.get_state()
+    assert torch.isfinite(st).all() and torch.isfinite(obs).all()
+    assert (st[:, 1] == 0).all()                                     # base y
+    assert (st[:, 3] == 0).all() and (st[:, 5] == 0).all()           # quaternion x, z: pitch only
+    assert (st[:, 8] == 0).all()                                     # v_y
+    assert (st[:, 10] == 0).all() and (st[:, 12] == 0).all()         # omega_x, omega_z
+    assert torch.allclose(st[:, 3:7].norm(dim=1), torch.ones(n, device="cuda"), atol=1e-5)
+    env.close()
