@@ -117,7 +117,7 @@ static_assert(L_ABA_END <= L_TOTAL, "ABA view must fit");
 static_assert(L_JR1 + 16 * MOCCA_MAX_BODIES <= L_TOTAL && (L_JR0 % 4) == 0 && (L_JR1 % 4) == 0, "joint records must fit, 16-byte aligned");
 static_assert(L_J + (MAXR + 1) * 28 <= L_TOTAL, "Jacobian rows (+ dummy) must fit the tail of the A region");
 static_assert(L_J % 4 == 0 && L_V % 4 == 0, "16-byte alignment of broadcast rows");
-static_assert(L_J >= L_R, "J rows may be written while S, U, 1/D, IA0^-1 and the contacts are still being read");
+static_assert(L_J >= L_R, "J rows may be written while S, U, 1/D, the factor of IA0 and the contacts are still being read");
 
 // contact record fields
 enum : int { C_BA = 0, C_BB = 1, C_SLOT = 2, C_P = 3, C_N = 6, C_DEPTH = 9, C_MU = 10, C_ERP = 11, C_CFM = 12, C_MA = 13, C_MB = 14 };
@@ -491,7 +491,7 @@ DI void chol6_solve(const float* F, const float* b, float* x) {
 }
 
 // ABA inward pass (lane = body of the current level) + base solve + outward pass (lane = body).
-// Leaves S, U, 1/D, u, IA0^-1 in LDS for the row sweeps and the new generalised velocity in L_NU.
+// Leaves S, U, 1/D, u, the factor of IA0 in LDS for the row sweeps and the new generalised velocity in L_NU.
 template <class T>
 DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
   STAMP_BEGIN;
@@ -995,10 +995,12 @@ DI void pgs_fixed_rows(const float* Acol, float a, float a1, int r_fr, float& y,
 //   1. limit-row candidates are compacted with a ballot; contacts come from collide()
 //   2. every lane builds its row (force direction, bias, bounds) in registers
 //   3. unit-impulse response X = M^-1 J^T by an inward sweep along the row's path(s) and an outward
-//      sweep over the tree, re-using S, U, 1/D and IA0^-1 of the ABA (unrolled over bodies so the
+//      sweep over the tree, re-using S, U, 1/D and the factor of IA0 of the ABA (unrolled over bodies so the
 //      per-lane arrays stay in VGPRs)
-//   4. Delassus matrix A[r][c] = J_r . X_c: rows of J are broadcast from LDS, lane c keeps X_c
-//   5. projected Gauss-Seidel in row order; per row update one LDS read, one readlane pair
+//   4. Delassus matrix A[r][c] = J_r . X_c, by symmetry: lane c evaluates half of its column and mirrors the values
+//      (delassus_dots / delassus_store); the diagonal stays in a register and is stored as zero
+//   5. projected Gauss-Seidel in row order on the zero-diagonal matrix: every lane carries its own unclamped impulse,
+//      a visit is clamp, subtract, readlane, one-lane commit, fma (pgs_fixed_rows + the friction loop)
 //   6. nu += sum_r X_r lambda_r, summed in row order through LDS
 template <class T>
 DI void solve_constraints(ModelP M, float* L, int lane, int nc_found) {
@@ -1119,7 +1121,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found) {
   STAMP(5);
   // ---- unit response X = M^-1 J^T
   // Jacobian entries go straight to LDS (the J rows sit in the part of the region the ABA no longer
-  // needs: link frames / inertias, not S, U, 1/D, IA0^-1, contacts); w = J nu is accumulated on the fly.
+  // needs: link frames / inertias, not S, U, 1/D, the factor of IA0, contacts); w = J nu is accumulated on the fly.
   float X[T::ND];  // X holds u_b during the inward sweep, then the response
   float w = 0;
   // stores are unconditional (idle lanes write unused rows / the dummy row): a branch per body makes the
