@@ -504,6 +504,17 @@ int mocca_act_dim(mocca_handle h) {
 }
 int mocca_state_dim(mocca_handle h) { return h ? MOCCA_STATE_DIM(h->model.n_joints, h->model.n_slots) : MOCCA_E_ARG; }
 
+// The handle's buffers live on h->device: launches and copies are issued with that device current, whatever the
+// caller's current device is (restored on return).  hipGetDevice / hipSetDevice are thread-local bookkeeping.
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev); else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 static StepArgs make_args(mocca_handle h) {
   StepArgs a{};
   a.model = h->d_model; a.dyn = h->d_dyn; a.task = h->d_task; a.terrain = h->d_terrain;
@@ -517,6 +528,7 @@ static StepArgs make_args(mocca_handle h) {
 int mocca_reset(mocca_handle h, const uint8_t* mask_dev, uint64_t seed, float* obs_dev, void* stream) {
   if (!h || !obs_dev) return MOCCA_E_ARG;
   h->seed = seed;
+  DeviceGuard guard(h->device);
   StepArgs a = make_args(h);
   a.mask = mask_dev; a.obs = obs_dev;
   hipStream_t s = (hipStream_t)stream;
@@ -528,6 +540,7 @@ int mocca_reset(mocca_handle h, const uint8_t* mask_dev, uint64_t seed, float* o
 int mocca_step(mocca_handle h, const float* act_dev, float* obs_dev, float* rew_dev, uint8_t* done_dev, int32_t* info_dev,
                void* stream) {
   if (!h || !act_dev || !obs_dev || !rew_dev || !done_dev) return MOCCA_E_ARG;
+  DeviceGuard guard(h->device);
   StepArgs a = make_args(h);
   a.act = act_dev; a.obs = obs_dev; a.rew = rew_dev; a.done = done_dev; a.info = info_dev;
   hipStream_t s = (hipStream_t)stream;
@@ -538,6 +551,7 @@ int mocca_step(mocca_handle h, const float* act_dev, float* obs_dev, float* rew_
 
 int mocca_observe(mocca_handle h, float* obs_dev, void* stream) {
   if (!h || !obs_dev) return MOCCA_E_ARG;
+  DeviceGuard guard(h->device);
   StepArgs a = make_args(h);
   a.obs = obs_dev;
   hipStream_t s = (hipStream_t)stream;
@@ -548,6 +562,7 @@ int mocca_observe(mocca_handle h, float* obs_dev, void* stream) {
 
 int mocca_get_state(mocca_handle h, float* state_dev, void* stream) {
   if (!h || !state_dev) return MOCCA_E_ARG;
+  DeviceGuard guard(h->device);
   const size_t w = (size_t)mocca_state_dim(h) * sizeof(float);
   HIP_TRY(h, hipMemcpy2DAsync(state_dev, w, h->d_dyn, DYN_STRIDE * sizeof(float), w, h->n_envs, hipMemcpyDeviceToDevice,
                               (hipStream_t)stream));
@@ -555,6 +570,7 @@ int mocca_get_state(mocca_handle h, float* state_dev, void* stream) {
 }
 int mocca_set_state(mocca_handle h, const float* state_dev, void* stream) {
   if (!h || !state_dev) return MOCCA_E_ARG;
+  DeviceGuard guard(h->device);
   const size_t w = (size_t)mocca_state_dim(h) * sizeof(float);
   HIP_TRY(h, hipMemcpy2DAsync(h->d_dyn, DYN_STRIDE * sizeof(float), state_dev, w, w, h->n_envs, hipMemcpyDeviceToDevice,
                               (hipStream_t)stream));
@@ -562,21 +578,25 @@ int mocca_set_state(mocca_handle h, const float* state_dev, void* stream) {
 }
 int mocca_get_task(mocca_handle h, uint32_t* task_dev, void* stream) {
   if (!h || !task_dev) return MOCCA_E_ARG;
+  DeviceGuard guard(h->device);
   HIP_TRY(h, hipMemcpyAsync(task_dev, h->d_task, (size_t)h->n_envs * MOCCA_TASK_WORDS * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return MOCCA_OK;
 }
 int mocca_set_task(mocca_handle h, const uint32_t* task_dev, void* stream) {
   if (!h || !task_dev) return MOCCA_E_ARG;
+  DeviceGuard guard(h->device);
   HIP_TRY(h, hipMemcpyAsync(h->d_task, task_dev, (size_t)h->n_envs * MOCCA_TASK_WORDS * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return MOCCA_OK;
 }
 int mocca_get_terrain(mocca_handle h, float* terrain_dev, void* stream) {
   if (!h || !terrain_dev) return MOCCA_E_ARG;
+  DeviceGuard guard(h->device);
   HIP_TRY(h, hipMemcpyAsync(terrain_dev, h->d_terrain, (size_t)h->n_envs * TERRAIN_STRIDE * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return MOCCA_OK;
 }
 int mocca_set_terrain(mocca_handle h, const float* terrain_dev, void* stream) {
   if (!h || !terrain_dev) return MOCCA_E_ARG;
+  DeviceGuard guard(h->device);
   HIP_TRY(h, hipMemcpyAsync(h->d_terrain, terrain_dev, (size_t)h->n_envs * TERRAIN_STRIDE * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return MOCCA_OK;
 }
