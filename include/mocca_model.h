@@ -31,12 +31,12 @@ extern "C" {
 #endif
 
 #define MOCCA_MODEL_MAGIC 0x41434F4Du /* "MOCA" */
-#define MOCCA_MODEL_VERSION 7u
+#define MOCCA_MODEL_VERSION 8u
 
 #define MOCCA_MAX_BODIES 24
 #define MOCCA_MAX_GEOMS 32
 #define MOCCA_MAX_PAIRS 192
-#define MOCCA_MAX_FEET 2
+#define MOCCA_MAX_FEET 4
 #define MOCCA_MAX_SLOTS 40   /* terrain contact slots (warm-start impulses) */
 #define MOCCA_MAX_PLANKS 3
 #define MOCCA_MAX_TERRAIN_STEPS 20
@@ -189,6 +189,8 @@ typedef struct MoccaModel {
  *  16 i next_step_index 17 i target_reached_count 18 i stop_on_next_step
  *  19 i set_stop_on_next_step 20 i curriculum 21 f applied_gain
  *  22 f prev_body_x  23 reserved
+ *  --- quadrupeds only (n_feet == 4) ---
+ *  24 f feet_contact[2]  25 f feet_contact[3]
  *  --- Cassie only ---
  *  3 f potential (shares linear_potential)  24..37 f jvel[14] (filtered joint speeds, env_cassie.py:451-468)
  *  38 f initial_z  39 i istep

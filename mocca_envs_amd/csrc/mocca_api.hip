@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   }
   STAMP(27);  // substeps done
   TaskRegs t;
-  load_task(tk, t);
+  load_task(tk, t, T::NFEET > 2);
   // the raw (unclipped) action enters the energy penalty (env_locomotion.py:185-188); re-read it rather than
   // hold a register across the substeps
   const float act_raw = lane < T::NJ ? a.act[(size_t)env * T::NJ + lane] : 0.0f;
@@ -146,13 +146,14 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   }
   wsync();
   t.t += 1;
-  constexpr int NBO = 6 + 2 * T::NJ + 2;
+  constexpr int NBO = 6 + 2 * T::NJ + T::NFEET;
   float rew = 0.0f;
   int info = 0;
   if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
     if (a.eval_mode) { t.wt[0] = t.prevx + 4.0f; t.wt[1] = 0.0f; t.wt[2] = 1.0f; }  // env_locomotion.py:115-116
     t.fc0 = (float)fl.touch0; t.fc1 = (float)fl.touch1;                                // robots.py:74-86
-    RobotObs ro = robot_obs<T>(M, L, lane, t.fc0, t.fc1, obs);
+    t.fc2 = (float)fl.touch2; t.fc3 = (float)fl.touch3;
+    RobotObs ro = robot_obs<T>(M, L, lane, t.fc0, t.fc1, obs, t.fc2, t.fc3);
     if (!ro.finite) t.done = 1;                                                        // :205-207
     const float old = t.linpot;
     float dist, ang;
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   }
   wsync();
   store_dyn(st, L, lane, T::NJ, T::NSLOT);
-  if (lane == 0) store_task(tk, t);
+  if (lane == 0) store_task(tk, t, T::NFEET > 2);
   STAMP(25);  // reset (if any) + write-back done
 #ifdef MOCCA_STAMPS
   if (lane == 0 && blockIdx.x < STAMP_WAVES) g_stamps[blockIdx.x * STAMP_SLOTS + 24] = (unsigned long long)(a.auto_reset && dflag);
@@ -272,10 +273,7 @@ __global__ __launch_bounds__(64) void mocca_reset_kernel(StepArgs a) {
   uint32_t* tk = a.task + (size_t)env * MOCCA_TASK_WORDS;
   float* ter = TASK == MOCCA_TASK_WALKER3D_STEPPER ? a.terrain + (size_t)env * TERRAIN_STRIDE : nullptr;
   TaskRegs t;
-  load_task(tk, t);
-  // the raw (unclipped) action enters the energy penalty (env_locomotion.py:185-188); re-read it rather than
-  // hold a register across the substeps
-  const float act_raw = lane < T::NJ ? a.act[(size_t)env * T::NJ + lane] : 0.0f;
+  load_task(tk, t, T::NFEET > 2);
   if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
   if constexpr (TASK == MOCCA_TASK_CASSIE) {
     cassie_reset_env<T>(M, L, lane, t, a.obs + (size_t)env * a.obs_dim);
@@ -285,7 +283,7 @@ __global__ __launch_bounds__(64) void mocca_reset_kernel(StepArgs a) {
   }
   wsync();
   store_dyn(st, L, lane, T::NJ, T::NSLOT);
-  if (lane == 0) store_task(tk, t);
+  if (lane == 0) store_task(tk, t, T::NFEET > 2);
 }
 
 // calc_state + observation tail on the stored state (no physics, no randomness)
@@ -301,22 +299,19 @@ __global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
   float* obs = a.obs + (size_t)env * a.obs_dim;
   load_dyn(st, L, lane, T::NJ, T::NSLOT);
   TaskRegs t;
-  load_task(tk, t);
-  // the raw (unclipped) action enters the energy penalty (env_locomotion.py:185-188); re-read it rather than
-  // hold a register across the substeps
-  const float act_raw = lane < T::NJ ? a.act[(size_t)env * T::NJ + lane] : 0.0f;
+  load_task(tk, t, T::NFEET > 2);
   if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
   wsync();
   stage_joints<T>(M, L, lane);
   walk_kinematics<T, false>(M, L, lane, T::path_packed(lane < T::NB ? lane : 0));
   wsync();
-  constexpr int NBO = 6 + 2 * T::NJ + 2;
+  constexpr int NBO = 6 + 2 * T::NJ + T::NFEET;
   if constexpr (TASK == MOCCA_TASK_CASSIE) {
     bool fin;
     cassie_obs<T>(M, L, lane, t.initz, obs, &fin);
     t.linpot = cassie_potential(M, L);
   } else {
-    RobotObs ro = robot_obs<T>(M, L, lane, t.fc0, t.fc1, obs);
+    RobotObs ro = robot_obs<T>(M, L, lane, t.fc0, t.fc1, obs, t.fc2, t.fc3);
     float dist, ang;
     if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
       calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
@@ -327,7 +322,7 @@ __global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
     }
     t.prevx = L[L_BASE];
   }
-  if (lane == 0) store_task(tk, t);
+  if (lane == 0) store_task(tk, t, T::NFEET > 2);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -368,9 +363,9 @@ static int check_topology_t(const MoccaModel& m, const char* name, std::string& 
       err = std::string("model blob tree differs from the compiled topology (") + name + ")";
       return MOCCA_E_TOPOLOGY;
     }
-  if (m.max_rows > MAXR || m.max_contacts > MAXC || m.max_rows < 1 + 3 * T::NCLOS || m.n_pairs > MOCCA_MAX_PAIRS || m.n_feet != 2 ||
+  if (m.max_rows > MAXR || m.max_contacts > MAXC || m.max_rows < 1 + 3 * T::NCLOS || m.n_pairs > MOCCA_MAX_PAIRS || m.n_feet != T::NFEET ||
       m.n_ctrl > MOCCA_MAX_CTRL || m.n_ordered > MOCCA_MAX_CTRL) {
-    err = "model blob caps exceed the kernel's (max_rows <= 48, max_contacts <= 12, n_feet == 2)";
+    err = "model blob caps exceed the kernel's (max_rows <= 48, max_contacts <= 12, n_feet as compiled)";
     return MOCCA_E_ARG;
   }
   return MOCCA_OK;

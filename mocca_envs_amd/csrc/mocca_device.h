@@ -78,7 +78,7 @@ enum : int {
   L_NU = 72,      // [28] omega(3) v(3) qd(at 5+body)
   L_BASE = 100,   // [16] pos3 quat4 vel3 omg3
   L_WARM = 116,   // [40] warm-start impulses per terrain slot
-  L_FEET = 156,   // [8] feet COM xyz (2x3)
+  L_FEET = 156,   // [12] feet COM xyz (NFEET x 3; a quadruped's last two reach into L_MISC, which only the Stepper uses)
   L_MISC = 164,   // [12]
   L_PLANK = 164,  // [3][12] Stepper: frames of the three live planks (rotation 9, box centre 3), built once per env.step;
                   //         overlays L_MISC / L_JVEL / L_Q0 (the last two are Cassie-only)
@@ -125,7 +125,7 @@ enum : int { C_BA = 0, C_BB = 1, C_SLOT = 2, C_P = 3, C_N = 6, C_DEPTH = 9, C_MU
 // task record words (include/mocca_model.h)
 enum : int { T_WTX = 0, T_WTY, T_WTZ, T_LINPOT, T_ANGPOT, T_CLOSE, T_STOPF, T_DONE, T_T, T_EPISODE, T_DRAW, T_MIRROR,
              T_FC0, T_FC1, T_DIST, T_ANGLE, T_NSI, T_TRC, T_STOP, T_SETSTOP, T_CUR, T_GAIN, T_PREVX, T_RES23,
-             T_JVEL = 24, T_INITZ = 38, T_ISTEP = 39 };
+             T_JVEL = 24, T_FC2 = 24, T_FC3 = 25 /* quadrupeds; Cassie's jvel otherwise */, T_INITZ = 38, T_ISTEP = 39 };
 
 struct StepArgs {
   const MoccaModel* model;
@@ -394,7 +394,7 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
     for (int i = 0; i < 3; ++i) cw[i] += r[i];
     // feet COM (getLinkState[0], bullet_utils.py:106) for the observation
 #pragma unroll
-    for (int f = 0; f < MOCCA_MAX_FEET; ++f)
+    for (int f = 0; f < T::NFEET; ++f)
       if (b == M->foot_body[f]) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) L[L_FEET + 3 * f + i] = cw[i] + L[L_BASE + i];
@@ -759,7 +759,7 @@ DI void stage_planks(ModelP M, float* L, int lane, const float* ter) {
   wsync();
 }
 
-struct ContactFlags { int touch0, touch1, target0, target1; };
+struct ContactFlags { int touch0, touch1, target0, target1, touch2, touch3, body_touch; };  // feet 2, 3: quadrupeds; body_touch: a non-foot link on the terrain
 
 // lane = terrain contact slot, then self-collision pairs strided over the wave.
 // Contacts are compacted in slot order, then pair order (the oracle's priority), up to max_contacts.
@@ -768,7 +768,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
                         int* nc_out) {
   STAMP_BEGIN;
   const float margin = unif(M->contact_margin);
-  ContactFlags fl = {0, 0, 0, 0};
+  ContactFlags fl = {0, 0, 0, 0, 0, 0, 0};
   const int maxc = uni(M->max_contacts);
   // ---- terrain: lane -> (geom, end)
   bool active = false;
@@ -828,6 +828,13 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
     const int f0 = M->foot_body[0], f1 = M->foot_body[1];
     fl.touch0 = __ballot(active && body == f0) != 0ull;
     fl.touch1 = __ballot(active && body == f1) != 0ull;
+    if constexpr (T::NFEET > 2) {
+      const int f2 = M->foot_body[2], f3 = M->foot_body[3];
+      fl.touch2 = __ballot(active && body == f2) != 0ull;
+      fl.touch3 = __ballot(active && body == f3) != 0ull;
+      // LaikagoCustomEnv ends the episode when anything but a foot meets the ground (env_locomotion.py:880-890)
+      fl.body_touch = __ballot(active && body != f0 && body != f1 && body != f2 && body != f3) != 0ull;
+    }
     fl.target0 = __ballot(active && body == f0 && is_target) != 0ull;
     fl.target1 = __ballot(active && body == f1 && is_target) != 0ull;
   }
@@ -1390,7 +1397,7 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
   STAMP(15);
   int nc = 0;
 #ifdef MOCCA_SKIP_COLLIDE  // profiling builds only (tools/ablate.sh): results are wrong by construction
-  ContactFlags fl = {0, 0, 0, 0};
+  ContactFlags fl = {0, 0, 0, 0, 0, 0, 0};
 #else
   ContactFlags fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc);
 #endif
@@ -1431,16 +1438,17 @@ DI void quat_to_rpy(const float* q, float* rpy) {  // pybullet.getEulerFromQuate
 
 struct RobotObs { float rpy[3]; int jal; float spd; float height; bool finite; };
 
-// WalkerBase.calc_state (robots.py:42-95): writes obs[0 .. 6+2NJ+2) ; needs kinematics done (L_FEET).
+// WalkerBase.calc_state (robots.py:42-95): writes obs[0 .. 6+2NJ+NFEET) ; needs kinematics done (L_FEET).
 // lane j < NJ keeps its scaled joint speed in the return value for the energy term.
 template <class T>
-DI RobotObs robot_obs(ModelP M, float* L, int lane, float fc0, float fc1, float* obs) {
+DI RobotObs robot_obs(ModelP M, float* L, int lane, float fc0, float fc1, float* obs, float fc2 = 0.0f, float fc3 = 0.0f) {
   RobotObs ro;
   float q[4] = {L[L_BASE + 3], L[L_BASE + 4], L[L_BASE + 5], L[L_BASE + 6]};
   quat_to_rpy(q, ro.rpy);
   const float yaw = ro.rpy[2], cy = cosf(-yaw), sy = sinf(-yaw);
   const float vx = cy * L[L_BASE + 7] - sy * L[L_BASE + 8], vy = sy * L[L_BASE + 7] + cy * L[L_BASE + 8], vz = L[L_BASE + 9];
-  const float minz = fminf(L[L_FEET + 2], L[L_FEET + 5]);
+  float minz = fminf(L[L_FEET + 2], L[L_FEET + 5]);
+  if constexpr (T::NFEET > 2) minz = fminf(minz, fminf(L[L_FEET + 8], L[L_FEET + 11]));
   const float height = L[L_BASE + 2] - minz;
   auto clip5 = [](float x) { return x > 5.f ? 5.f : (x < -5.f ? -5.f : x); };
   float nrm = 0, sp = 0;
@@ -1463,6 +1471,7 @@ DI RobotObs robot_obs(ModelP M, float* L, int lane, float fc0, float fc1, float*
     for (int i = 0; i < 6; ++i) obs[i] = clip5(head[i]);
     obs[6 + 2 * T::NJ] = fc0;
     obs[6 + 2 * T::NJ + 1] = fc1;
+    if constexpr (T::NFEET > 2) { obs[6 + 2 * T::NJ + 2] = fc2; obs[6 + 2 * T::NJ + 3] = fc3; }
   }
   ro.jal = __popcll(__ballot(lane < T::NJ && fabsf(nrm) > 0.99f));
   ro.spd = sp;
@@ -1472,25 +1481,27 @@ DI RobotObs robot_obs(ModelP M, float* L, int lane, float fc0, float fc1, float*
 }
 
 struct TaskRegs {  // uniform across the wave
-  float wt[3], linpot, angpot, stopf, fc0, fc1, dist, angle, gain, prevx, initz;
+  float wt[3], linpot, angpot, stopf, fc0, fc1, fc2, fc3, dist, angle, gain, prevx, initz;
   int close, done, t, episode, draw, mirrored, nsi, trc, stop, setstop, cur, istep;
 };
-DI void load_task(const uint32_t* tk, TaskRegs& t) {
+DI void load_task(const uint32_t* tk, TaskRegs& t, bool quadruped = false) {
   auto f = [&](int i) { return __uint_as_float(tk[i]); };
   t.wt[0] = f(T_WTX); t.wt[1] = f(T_WTY); t.wt[2] = f(T_WTZ); t.linpot = f(T_LINPOT); t.angpot = f(T_ANGPOT);
   t.close = (int)tk[T_CLOSE]; t.stopf = f(T_STOPF); t.done = (int)tk[T_DONE]; t.t = (int)tk[T_T];
   t.episode = (int)tk[T_EPISODE]; t.draw = (int)tk[T_DRAW]; t.mirrored = (int)tk[T_MIRROR];
   t.fc0 = f(T_FC0); t.fc1 = f(T_FC1); t.dist = f(T_DIST); t.angle = f(T_ANGLE);
+  t.fc2 = quadruped ? f(T_FC2) : 0.0f; t.fc3 = quadruped ? f(T_FC3) : 0.0f;
   t.nsi = (int)tk[T_NSI]; t.trc = (int)tk[T_TRC]; t.stop = (int)tk[T_STOP]; t.setstop = (int)tk[T_SETSTOP];
   t.cur = (int)tk[T_CUR]; t.gain = f(T_GAIN); t.prevx = f(T_PREVX);
   t.initz = f(T_INITZ); t.istep = (int)tk[T_ISTEP];
 }
-DI void store_task(uint32_t* tk, const TaskRegs& t) {
+DI void store_task(uint32_t* tk, const TaskRegs& t, bool quadruped = false) {
   auto u = [](float x) { return __float_as_uint(x); };
   tk[T_WTX] = u(t.wt[0]); tk[T_WTY] = u(t.wt[1]); tk[T_WTZ] = u(t.wt[2]); tk[T_LINPOT] = u(t.linpot); tk[T_ANGPOT] = u(t.angpot);
   tk[T_CLOSE] = (uint32_t)t.close; tk[T_STOPF] = u(t.stopf); tk[T_DONE] = (uint32_t)t.done; tk[T_T] = (uint32_t)t.t;
   tk[T_EPISODE] = (uint32_t)t.episode; tk[T_DRAW] = (uint32_t)t.draw; tk[T_MIRROR] = (uint32_t)t.mirrored;
   tk[T_FC0] = u(t.fc0); tk[T_FC1] = u(t.fc1); tk[T_DIST] = u(t.dist); tk[T_ANGLE] = u(t.angle);
+  if (quadruped) { tk[T_FC2] = u(t.fc2); tk[T_FC3] = u(t.fc3); }
   tk[T_NSI] = (uint32_t)t.nsi; tk[T_TRC] = (uint32_t)t.trc; tk[T_STOP] = (uint32_t)t.stop; tk[T_SETSTOP] = (uint32_t)t.setstop;
   tk[T_CUR] = (uint32_t)t.cur; tk[T_GAIN] = u(t.gain); tk[T_PREVX] = u(t.prevx);
   tk[T_INITZ] = u(t.initz); tk[T_ISTEP] = (uint32_t)t.istep;
@@ -1646,7 +1657,7 @@ DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, in
   stage_joints<T>(M, L, lane);
   walk_kinematics<T, false>(M, L, lane, T::path_packed(lane < T::NB ? lane : 0));
   wsync();
-  const int nbo = 6 + 2 * T::NJ + 2;
+  const int nbo = 6 + 2 * T::NJ + T::NFEET;
   RobotObs ro = robot_obs<T>(M, L, lane, 0.0f, 0.0f, obs);
   float dist, ang;
   if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {

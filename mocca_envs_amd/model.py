@@ -26,10 +26,10 @@ import numpy as np
 MAX_BODIES = 24
 MAX_GEOMS = 32
 MAX_PAIRS = 192
-MAX_FEET = 2
+MAX_FEET = 4
 MAX_SLOTS = 40
 MAGIC = 0x41434F4D
-VERSION = 7
+VERSION = 8
 
 GEOM_SPHERE, GEOM_CAPSULE = 0, 1
 TASK_WALKER3D_CUSTOM, TASK_WALKER3D_STEPPER, TASK_CASSIE = 0, 1, 2
@@ -955,6 +955,7 @@ def topology_header(m: MoccaModel, name: str = "Walker3D") -> str:
         "  static constexpr int NSLOT = %d;     // terrain contact slots" % m.n_slots,
         "  static constexpr int NPAIR = %d;     // self-collision candidate pairs" % m.n_pairs,
         "  static constexpr int NCLOS = %d;     // point-to-point loop closures" % m.n_closures,
+        "  static constexpr int NFEET = %d;     // feet (entries of the observation, robots.py:74-86)" % m.n_feet,
         "  // constexpr functions (implicitly __host__ __device__ under hipcc) fold after unrolling",
         "  static constexpr int parent(int b) { constexpr int t[%d] = %s; return t[b]; }" % (nb, arr(parent)),
         "  static constexpr int depth(int b) { constexpr int t[%d] = %s; return t[b]; }" % (nb, arr(depth)),

@@ -172,7 +172,7 @@ typedef struct {
   int32_t close_count;
   real stop_frames;
   int32_t done, t, episode, draw, mirrored;
-  real feet_contact[2];
+  real feet_contact[MOCCA_MAX_FEET];
   real dist, angle;
   int32_t next_step_index, target_reached_count, stop_on_next_step, set_stop_on_next_step, curriculum;
   real applied_gain;
@@ -1079,7 +1079,7 @@ static void step_env(Oracle *o, int env, const float *act, float *obs, float *re
     a = a < -1 ? -1 : (a > 1 ? 1 : a);
     tau[b] = (real)m->gain[b] * tk->applied_gain * a;
   }
-  int touch[MOCCA_MAX_FEET] = {0, 0}, target[MOCCA_MAX_FEET] = {0, 0};
+  int touch[MOCCA_MAX_FEET] = {0}, target[MOCCA_MAX_FEET] = {0};
   if (!ext_touch) {
     for (int k = 0; k < m->n_substeps; ++k) substep(o, s, tk, tr, tau, w);
     /* contact queries after stepSimulation see the manifolds of the LAST substep's collision pass */
@@ -1298,6 +1298,7 @@ API void orc_get_task(void *h, double *t) {
     p[16] = k->next_step_index; p[17] = k->target_reached_count; p[18] = k->stop_on_next_step;
     p[19] = k->set_stop_on_next_step; p[20] = k->curriculum; p[21] = k->applied_gain; p[22] = k->prev_body_x;
     for (int j = 0; j < 14; ++j) p[24 + j] = k->jvel[j];
+    if (o->m.n_feet > 2) { p[24] = k->feet_contact[2]; p[25] = k->feet_contact[3]; } /* quadrupeds: words shared with Cassie's jvel */
     p[38] = k->initial_z; p[39] = k->istep;
   }
 }
@@ -1314,6 +1315,7 @@ API void orc_set_task(void *h, const double *t) {
     k->target_reached_count = (int)p[17]; k->stop_on_next_step = (int)p[18]; k->set_stop_on_next_step = (int)p[19];
     k->curriculum = (int)p[20]; k->applied_gain = (real)p[21]; k->prev_body_x = (real)p[22];
     for (int j = 0; j < 14; ++j) k->jvel[j] = (real)p[24 + j];
+    if (o->m.n_feet > 2) { k->feet_contact[2] = (real)p[24]; k->feet_contact[3] = (real)p[25]; }
     k->initial_z = (real)p[38]; k->istep = (int)p[39];
   }
 }
