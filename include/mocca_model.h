@@ -49,11 +49,13 @@ enum { MOCCA_GEOM_SPHERE = 0, MOCCA_GEOM_CAPSULE = 1 };
 enum {
   MOCCA_TASKF_NEVER_DONE = 1,      /* Walker2DCustomEnv.step forces done = False (env_locomotion.py:302-309); TimeLimit still applies */
   MOCCA_TASKF_RESET_TAIL_ZERO = 2, /* Walker2DCustomEnv.reset returns [robot_state, 0, 0] (env_locomotion.py:299-300)            */
+  MOCCA_TASKF_BODY_CONTACT = 4,    /* LaikagoCustomEnv.calc_base_reward: tall_bonus = 0, and -1 + done as soon as a non-foot link
+                                      touches the ground (env_locomotion.py:877-890)                                              */
 };
 
 /* task ids accepted by mocca_create() */
 enum {
-  MOCCA_TASK_WALKER3D_CUSTOM = 0,  /* env_locomotion.py:37-282; also Child3DCustomEnv (:317-327), Walker2D / Crab2DCustomEnv (:285-314) by blob */
+  MOCCA_TASK_WALKER3D_CUSTOM = 0,  /* env_locomotion.py:37-282; also Child3D (:317-327), Walker2D / Crab2D (:285-314), Laikago (:854-890) by blob */
   MOCCA_TASK_WALKER3D_STEPPER = 1, /* env_locomotion.py:330-840; also MikeStepperEnv (:843-851) with a Mike blob       */
   MOCCA_TASK_CASSIE = 2,           /* env_cassie.py:284-479 (CassieEnv, 3-D) */
 };
@@ -93,6 +95,7 @@ typedef struct MoccaModel {
   int32_t g_type[MOCCA_MAX_GEOMS];
   int32_t g_slot[MOCCA_MAX_GEOMS];    /* first terrain slot of this geom */
   int32_t g_terrain[MOCCA_MAX_GEOMS]; /* 1 if the filter lets it touch static terrain */
+  int32_t g_foot[MOCCA_MAX_GEOMS];    /* index into foot_body if the geom belongs to that foot's LINK (robots.py:74-86), else -1 */
   float g_radius[MOCCA_MAX_GEOMS];
   float g_p1[MOCCA_MAX_GEOMS][3]; /* body frame; sphere centre / capsule end 1 */
   float g_p2[MOCCA_MAX_GEOMS][3]; /* capsule end 2 (= p1 for spheres) */
@@ -102,6 +105,9 @@ typedef struct MoccaModel {
   int32_t pair_b[MOCCA_MAX_PAIRS];
 
   int32_t foot_body[MOCCA_MAX_FEET]; /* robots.py:232 foot_names order: right, left */
+  float foot_point[MOCCA_MAX_FEET][3]; /* the foot LINK's centre of mass in the frame of foot_body (getLinkState()[0],
+                                          bullet_utils.py:106): the body's own COM, except where the foot link is a fixed child
+                                          merged into its parent (Laikago's toes) */
 
   /* ---- physics parameters (bullet_utils.py:340-350, env_base.py:78-83) ---- */
   float gravity;        /* 9.8 */

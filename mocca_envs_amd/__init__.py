@@ -18,6 +18,7 @@ REGISTERED = {
     "MikeStepperEnv-v0": ("mocca_envs_amd.envs:MikeStepperEnv", {}),
     "Walker2DCustomEnv-v0": ("mocca_envs_amd.envs:Walker2DCustomEnv", {}),
     "Crab2DCustomEnv-v0": ("mocca_envs_amd.envs:Crab2DCustomEnv", {}),
+    "LaikagoCustomEnv-v0": ("mocca_envs_amd.envs:LaikagoCustomEnv", {}),
 }
 
 

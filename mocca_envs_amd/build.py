@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libmocca_hip.so")
 SOURCES = ["mocca_api.hip"]
-DEPS = ["mocca_api.hip", "mocca_device.h", "topo_walker3d.h", "topo_cassie.h", "topo_walker2d.h", "topo_crab2d.h"]
+DEPS = ["mocca_api.hip", "mocca_device.h", "topo_walker3d.h", "topo_cassie.h", "topo_walker2d.h", "topo_crab2d.h", "topo_laikago.h"]
 
 
 def _stale() -> bool:

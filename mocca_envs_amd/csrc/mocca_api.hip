@@ -167,8 +167,12 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     const float e2 = wave_sum(lane < T::NJ ? act_raw * act_raw : 0.0f);
     const float energy = M->electricity_cost * (e1 / T::NJ) + M->stall_torque_cost * (e2 / T::NJ);
     const float joints = M->joints_at_limit_cost * (float)ro.jal;
-    const float tall = ro.height > M->termination_height ? 2.0f : -1.0f;
+    float tall = ro.height > M->termination_height ? 2.0f : -1.0f;
     if (tall < 0) t.done = 1;
+    if (M->task_flags & MOCCA_TASKF_BODY_CONTACT) {                                    // LaikagoCustomEnv, :877-890
+      tall = 0.0f;
+      if (fl.body_touch) { tall = -1.0f; t.done = 1; }
+    }
     float bonus = 0.0f;
     if (dist < 0.15f) { t.close += 1; bonus = 2.0f; }                                  // :198-202
     if ((float)t.close >= t.stopf && !a.host_retarget) {                               // :214-222
@@ -371,7 +375,7 @@ static int check_topology_t(const MoccaModel& m, const char* name, std::string& 
   return MOCCA_OK;
 }
 // compiled topologies: the tree of the blob selects the kernel instance
-enum { TOPO_WALKER3D = 0, TOPO_CASSIE = 1, TOPO_WALKER2D = 2, TOPO_CRAB2D = 3 };
+enum { TOPO_WALKER3D = 0, TOPO_CASSIE = 1, TOPO_WALKER2D = 2, TOPO_CRAB2D = 3, TOPO_LAIKAGO = 4 };
 static int check_topology(const MoccaModel& m, int task_id, int* topo, std::string& err) {
   if (task_id == MOCCA_TASK_CASSIE) { *topo = TOPO_CASSIE; return check_topology_t<TopoCassie>(m, "TopoCassie", err); }
   if (task_id == MOCCA_TASK_WALKER3D_CUSTOM && m.n_bodies == TopoWalker2D::NB) {
@@ -379,6 +383,9 @@ static int check_topology(const MoccaModel& m, int task_id, int* topo, std::stri
   }
   if (task_id == MOCCA_TASK_WALKER3D_CUSTOM && m.n_bodies == TopoCrab2D::NB) {
     *topo = TOPO_CRAB2D; return check_topology_t<TopoCrab2D>(m, "TopoCrab2D", err);
+  }
+  if (task_id == MOCCA_TASK_WALKER3D_CUSTOM && m.n_bodies == TopoLaikago::NB) {
+    *topo = TOPO_LAIKAGO; return check_topology_t<TopoLaikago>(m, "TopoLaikago", err);
   }
   *topo = TOPO_WALKER3D;
   return check_topology_t<TopoWalker3D>(m, "TopoWalker3D", err);
@@ -390,6 +397,7 @@ static void dispatch(int topo, int task_id, Args... args) {
   if (topo == TOPO_CASSIE) Launcher<TopoCassie, MOCCA_TASK_CASSIE>::run(args...);
   else if (topo == TOPO_WALKER2D) Launcher<TopoWalker2D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
   else if (topo == TOPO_CRAB2D) Launcher<TopoCrab2D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
+  else if (topo == TOPO_LAIKAGO) Launcher<TopoLaikago, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
   else if (task_id == MOCCA_TASK_WALKER3D_CUSTOM) Launcher<TopoWalker3D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
   else Launcher<TopoWalker3D, MOCCA_TASK_WALKER3D_STEPPER>::run(args...);
 }

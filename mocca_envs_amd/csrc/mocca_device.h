@@ -31,6 +31,7 @@
 #include "topo_cassie.h"
 #include "topo_walker2d.h"
 #include "topo_crab2d.h"
+#include "topo_laikago.h"
 
 #define DI __device__ __forceinline__
 
@@ -392,12 +393,15 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
     matvec3(R, cl, cw);
 #pragma unroll
     for (int i = 0; i < 3; ++i) cw[i] += r[i];
-    // feet COM (getLinkState[0], bullet_utils.py:106) for the observation
+    // COM of each foot LINK (getLinkState[0], bullet_utils.py:106) for the observation
 #pragma unroll
     for (int f = 0; f < T::NFEET; ++f)
       if (b == M->foot_body[f]) {
+        const float fp[3] = {M->foot_point[f][0], M->foot_point[f][1], M->foot_point[f][2]};  // uniform: scalar loads
+        float fw[3];
+        matvec3(R, fp, fw);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) L[L_FEET + 3 * f + i] = cw[i] + L[L_BASE + i];
+        for (int i = 0; i < 3; ++i) L[L_FEET + 3 * f + i] = fw[i] + r[i] + L[L_BASE + i];
       }
     if (FULL) {
 #pragma unroll
@@ -499,7 +503,7 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
   // articulated inertia), up to MAXW = 4 bodies per level: ~45 VALU per level instead of ~260 with one
   // lane per body.  Children are pulled (summed in descending index order, as the oracle does).
   static_assert(T::MAXW * 8 <= 64, "level does not fit a wave");
-  static_assert(T::MAXW == 4 && T::MAXCH <= 3, "level pass is written for <= 4 bodies per level, <= 3 children");
+  static_assert(T::MAXW == 4 && T::MAXCH <= 4, "level pass is written for <= 4 bodies per level, <= 4 children");
   const int s = lane >> 3, i = lane & 7;
   const int ii = i < 6 ? i : 0;
   // A body sits in the slot of its "carried" child (topo_*.h: clevel / ccarry), so along a serial chain the articulated
@@ -773,14 +777,15 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
   // ---- terrain: lane -> (geom, end)
   bool active = false;
   float n[3] = {0, 0, 1}, P[3] = {0, 0, 0}, gap = 1e30f, mu = 0, erp = M->erp, cfm = 0;
-  int body = -1, slot = lane, is_target = 0;
+  int body = -1, slot = lane, is_target = 0, gfoot = -1;
   unsigned bmask = 0u;
   if (lane < T::NSLOT) {
     const f4_t st = *(CF4P)(M->slot_tab[lane]);  // radius, friction, ids, ancestor mask
     const int ids = __float_as_int(st.z);
     const int g = (ids >> 8) & 0xFF, e = (ids >> 16) & 0xFF;
     bmask = __float_as_uint(st.w);
-    if (ids >> 24) {
+    if ((ids >> 24) & 1) {  // flags: bit 24 terrain, bits 25.. foot index + 1
+      gfoot = ((ids >> 25) & 7) - 1;
       float C[3], Cw[3];
       const float rad = st.x, gfric = st.y;
 #pragma unroll
@@ -825,18 +830,16 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
   }
   unsigned long long am = __ballot(active);
   {
-    const int f0 = M->foot_body[0], f1 = M->foot_body[1];
-    fl.touch0 = __ballot(active && body == f0) != 0ull;
-    fl.touch1 = __ballot(active && body == f1) != 0ull;
+    fl.touch0 = __ballot(active && gfoot == 0) != 0ull;
+    fl.touch1 = __ballot(active && gfoot == 1) != 0ull;
     if constexpr (T::NFEET > 2) {
-      const int f2 = M->foot_body[2], f3 = M->foot_body[3];
-      fl.touch2 = __ballot(active && body == f2) != 0ull;
-      fl.touch3 = __ballot(active && body == f3) != 0ull;
-      // LaikagoCustomEnv ends the episode when anything but a foot meets the ground (env_locomotion.py:880-890)
-      fl.body_touch = __ballot(active && body != f0 && body != f1 && body != f2 && body != f3) != 0ull;
+      fl.touch2 = __ballot(active && gfoot == 2) != 0ull;
+      fl.touch3 = __ballot(active && gfoot == 3) != 0ull;
+      // LaikagoCustomEnv ends the episode when anything but a foot link meets the ground (env_locomotion.py:880-890)
+      fl.body_touch = __ballot(active && gfoot < 0) != 0ull;
     }
-    fl.target0 = __ballot(active && body == f0 && is_target) != 0ull;
-    fl.target1 = __ballot(active && body == f1 && is_target) != 0ull;
+    fl.target0 = __ballot(active && gfoot == 0 && is_target) != 0ull;
+    fl.target1 = __ballot(active && gfoot == 1 && is_target) != 0ull;
   }
   int nc = __popcll(am);
   {

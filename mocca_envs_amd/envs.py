@@ -52,6 +52,8 @@ class _Robot:
         self.action_dim = mdl.n_joints
         high = np.ones(self.action_dim)
         self.action_space = gym.spaces.Box(-high, high, dtype=np.float32)
+        if mdl.n_feet == 4:
+            self.foot_names = ["toeFR", "toeFL", "toeRR", "toeRL"]   # robots.py:559
         self.state_dim = 6 + self.action_dim * 2 + len(self.foot_names)
         high = np.inf * np.ones(self.state_dim)
         self.observation_space = gym.spaces.Box(-high, high, dtype=np.float32)
@@ -61,7 +63,7 @@ class _Robot:
         self.body_xyz = np.zeros(3)
         self.joint_angles = np.zeros(self.action_dim)
         self.joint_speeds = np.zeros(self.action_dim)
-        self.feet_contact = np.zeros(2, dtype=np.float32)
+        self.feet_contact = np.zeros(len(self.foot_names), dtype=np.float32)
 
 
 class EnvBase(gym.Env):
@@ -238,6 +240,23 @@ class Crab2DCustomEnv(Walker2DCustomEnv):
     """env_locomotion.py:312-314."""
 
     env_id = "Crab2DCustomEnv-v0"
+
+
+class LaikagoCustomEnv(Walker3DCustomEnv):
+    """env_locomotion.py:854-890: the quadruped; 8 substeps of 1/480 s, no random start pose, tall_bonus 0, and the
+    episode ends as soon as anything but a foot touches the ground."""
+
+    env_id = "LaikagoCustomEnv-v0"
+    sim_frame_skip = 8
+    termination_height = 0
+    robot_random_start = False
+    robot_init_position = [0, 0, 0.56]
+
+    def __init__(self, **kwargs):
+        kwargs.pop("random_reward", False)
+        kwargs.pop("plank_class", None)
+        super().__init__(**kwargs)
+        self.curriculum, self.max_curriculum = 0, 9
 
 
 class Walker3DStepperEnv(EnvBase):

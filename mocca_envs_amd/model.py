@@ -34,7 +34,7 @@ VERSION = 8
 GEOM_SPHERE, GEOM_CAPSULE = 0, 1
 TASK_WALKER3D_CUSTOM, TASK_WALKER3D_STEPPER, TASK_CASSIE = 0, 1, 2
 TASK_WORDS = 40
-TASKF_NEVER_DONE, TASKF_RESET_TAIL_ZERO = 1, 2  # MoccaModel.task_flags (include/mocca_model.h)
+TASKF_NEVER_DONE, TASKF_RESET_TAIL_ZERO, TASKF_BODY_CONTACT = 1, 2, 4  # MoccaModel.task_flags (include/mocca_model.h)
 MAX_CLOSURES = 2
 MAX_CTRL = 16
 STATE_BASE = 13
@@ -71,6 +71,7 @@ class MoccaModel(C.Structure):
         ("g_type", C.c_int32 * MAX_GEOMS),
         ("g_slot", C.c_int32 * MAX_GEOMS),
         ("g_terrain", C.c_int32 * MAX_GEOMS),
+        ("g_foot", C.c_int32 * MAX_GEOMS),
         ("g_radius", C.c_float * MAX_GEOMS),
         ("g_p1", (C.c_float * 3) * MAX_GEOMS),
         ("g_p2", (C.c_float * 3) * MAX_GEOMS),
@@ -78,6 +79,7 @@ class MoccaModel(C.Structure):
         ("pair_a", C.c_int32 * MAX_PAIRS),
         ("pair_b", C.c_int32 * MAX_PAIRS),
         ("foot_body", C.c_int32 * MAX_FEET),
+        ("foot_point", (C.c_float * 3) * MAX_FEET),
         ("gravity", C.c_float),
         ("dt", C.c_float),
         ("n_substeps", C.c_int32),
@@ -163,7 +165,7 @@ class MoccaModel(C.Structure):
                 sl = self.g_slot[g] + e
                 self.slot_tab[sl][0] = self.g_radius[g]
                 self.slot_tab[sl][1] = self.g_friction[g]
-                self.slot_tab[sl][2] = bits(b | (g << 8) | (e << 16) | ((1 if self.g_terrain[g] else 0) << 24))
+                self.slot_tab[sl][2] = bits(b | (g << 8) | (e << 16) | ((1 if self.g_terrain[g] else 0) << 24) | ((self.g_foot[g] + 1) << 25))
                 self.slot_tab[sl][3] = bits(self.anc_mask[b])
         for k in range(self.n_pairs):
             ga, gb = self.pair_a[k], self.pair_b[k]
@@ -560,6 +562,11 @@ def compile_model(
     for k, fn in enumerate(foot_names):
         fbdy = find_body(root, fn)
         m.foot_body[k] = names.index(fbdy.hinges[-1].name)
+    for gi in range(m.n_geoms):   # MJCF feet: every geom of the foot body belongs to the foot link
+        m.g_foot[gi] = next((k for k in range(m.n_feet) if m.foot_body[k] == m.g_body[gi]), -1)
+    for k in range(m.n_feet):     # ... and the foot link is the body itself: its COM is what getLinkState reports
+        for i in range(3):
+            m.foot_point[k][i] = m.com[m.foot_body[k]][i]
 
     # physics parameters
     m.gravity = 9.8                 # env_base.py:80
@@ -828,6 +835,11 @@ def compile_cassie() -> MoccaModel:
     m.n_pairs = 0
     m.n_feet = 2
     m.foot_body[0], m.foot_body[1] = names.index("toe_joint_right"), names.index("toe_joint_left")  # env_cassie.py:72
+    for gi in range(m.n_geoms):
+        m.g_foot[gi] = next((k for k in range(2) if m.foot_body[k] == m.g_body[gi]), -1)
+    for k in range(2):
+        for i in range(3):
+            m.foot_point[k][i] = m.com[m.foot_body[k]][i]
     # ordered joints, controller
     m.n_ordered = len(CASSIE_ORDERED_JOINTS)
     for k, n in enumerate(CASSIE_ORDERED_JOINTS):
@@ -868,6 +880,121 @@ def compile_cassie() -> MoccaModel:
     m.jvel_alpha = min(10 / 50, 1)                                           # env_cassie.py:319
     m.alive_height = 0.6                                                     # env_cassie.py:406-412
     m.cassie_target[0], m.cassie_target[1], m.cassie_target[2] = 1000.0, 0.0, 0.0  # env_cassie.py:366
+    return m.finalize_tables()
+
+
+LAIKAGO_JOINTS = ["%s_%s" % (leg, j) for leg in ("FR", "FL", "RR", "RL")
+                  for j in ("hip_motor_2_chassis_joint", "upper_leg_2_hip_motor_joint", "lower_leg_2_upper_leg_joint")]  # robots.py:561-574
+LAIKAGO_FEET = ["toeFR", "toeFL", "toeRR", "toeRL"]                                                       # robots.py:559
+LAIKAGO_SHAPE_MARGIN = 0.001  # collision margin PyBullet gives URDF mesh shapes; enters the box inertia  [UNVERIFIED-BULLET]
+
+
+def compile_laikago() -> MoccaModel:
+    """Laikago for LaikagoCustomEnv (robots.py:554-656, env_locomotion.py:854-890) from mocca_envs_amd/laikago_table.py.
+
+    * The URDF is y-up; its chassis INERTIAL frame (rpy -1.57 -1.57 0) is what stands the robot up: PyBullet's base pose is
+      the pose of that frame, and the env resets it to the identity.  The model's base frame therefore is the chassis
+      inertial frame (origin at its COM), everything else is expressed in it.
+    * The file's inertia tensors are zero and the robot is loaded without URDF_USE_INERTIA_FROM_FILE (robots.py:595-600):
+      every link gets the box inertia of its collision shape's bounding box in its inertial frame (what Bullet's
+      calculateLocalInertia does for convex hulls / compounds), spheres 0.4 m r^2.                [UNVERIFIED-BULLET]
+    * Ground contact: the four toe spheres (the feet) and 28 support points of the link meshes' convex hulls (radius-0
+      spheres, no foot index): touching the ground with any of those ends the episode.  Mesh-mesh self collision
+      (URDF_USE_SELF_COLLISION) is not modelled.
+    """
+    from . import laikago_table as LT
+    kids: Dict[str, list] = {}
+    for j in LT.JOINTS:
+        kids.setdefault(j["parent"], []).append(j)
+    bodies = []  # dict(name, parent, jpos, jrot, axis, lo, hi, parts[], geoms[])
+
+    def visit(link, body, R, t):
+        e = LT.LINKS[link]
+        Ri = R @ _rpy_mat(e["rpy"])
+        if e["mass"] > 0.0:
+            if e["sphere"] is not None:
+                I = np.eye(3) * 0.4 * e["mass"] * e["sphere"]["radius"] ** 2
+            else:
+                hx, hy, hz = (h + LAIKAGO_SHAPE_MARGIN for h in e["box_half"])
+                I = Ri @ np.diag([hy * hy + hz * hz, hx * hx + hz * hz, hx * hx + hy * hy]) @ Ri.T * (e["mass"] / 3.0)
+            bodies[body]["parts"].append((e["mass"], R @ np.asarray(e["com"], float) + t, I))
+        fr = e["friction"] if e["friction"] is not None else 1.0
+        if e["sphere"] is not None:
+            bodies[body]["geoms"].append((R @ np.asarray(e["sphere"]["center"], float) + t, e["sphere"]["radius"], fr, link))
+        for p in e["points"]:
+            bodies[body]["geoms"].append((R @ np.asarray(p, float) + t, 0.0, fr, None))
+        for j in kids.get(link, []):
+            Rj, tj = R @ _rpy_mat(j["rpy"]), R @ np.asarray(j["xyz"], float) + t
+            if j["type"] == "fixed":
+                visit(j["child"], body, Rj, tj)
+            else:
+                bodies.append(dict(name=j["name"], parent=body, jpos=tj, jrot=Rj, axis=np.asarray(j["axis"], float),
+                                   lo=j["lower"], hi=j["upper"], parts=[], geoms=[]))
+                visit(j["child"], len(bodies) - 1, np.eye(3), np.zeros(3))
+
+    ch = LT.LINKS["chassis"]
+    R0 = _rpy_mat(ch["rpy"]).T
+    bodies.append(dict(name="chassis", parent=-1, jpos=np.zeros(3), jrot=np.eye(3), axis=None, lo=0, hi=0, parts=[], geoms=[]))
+    visit("chassis", 0, R0, -R0 @ np.asarray(ch["com"], float))
+    names = [b["name"] for b in bodies]
+    assert names[1:] == LAIKAGO_JOINTS, names      # URDF order == ordered_joints order (robots.py:609-626)
+    nb = len(bodies)
+    m = MoccaModel()
+    m.magic, m.version = MAGIC, VERSION
+    m.n_bodies, m.n_joints = nb, nb - 1
+    g = 0
+    m.n_feet = 4
+    for b, bd in enumerate(bodies):
+        m.parent[b] = bd["parent"]
+        if b:
+            m.anc_mask[b] = m.anc_mask[bd["parent"]] | (1 << b)
+            m.depth[b] = m.depth[bd["parent"]] + 1
+            for k in range(3):
+                m.jpos[b][k] = bd["jpos"][k]
+                m.jaxis[b][k] = bd["axis"][k] / np.linalg.norm(bd["axis"])
+            for k in range(9):
+                m.jrot[b][k] = bd["jrot"].reshape(-1)[k]
+            m.jlo[b], m.jhi[b] = bd["lo"], bd["hi"]
+            m.gain[b] = 40.0                                                          # robots.py:561-574, base_power 1
+            m.init_q[b] = -math.pi / 6 if bd["name"].endswith("lower_leg_2_upper_leg_joint") else 0.0   # "running_start", :654-655
+        mass, com, I = _compose_inertial(bd["parts"])
+        m.mass[b] = mass
+        for k in range(3):
+            m.com[b][k] = com[k]
+        for k, (i, j) in enumerate([(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)]):
+            m.inertia[b][k] = I[i, j]
+        for p, rad, fr, toe in bd["geoms"]:
+            m.g_body[g], m.g_type[g], m.g_radius[g], m.g_slot[g], m.g_terrain[g] = b, GEOM_SPHERE, rad, g, 1
+            m.g_friction[g] = fr
+            m.g_foot[g] = LAIKAGO_FEET.index(toe) if toe in LAIKAGO_FEET else -1
+            if toe in LAIKAGO_FEET:      # the foot link is the toe, a fixed child: its COM is the sphere centre
+                m.foot_body[LAIKAGO_FEET.index(toe)] = b
+                for k in range(3):
+                    m.foot_point[LAIKAGO_FEET.index(toe)][k] = p[k]
+            for k in range(3):
+                m.g_p1[g][k] = m.g_p2[g][k] = p[k]
+            g += 1
+    assert g <= MAX_GEOMS
+    m.n_geoms = m.n_slots = g
+    m.n_pairs = 0
+    # physics: control_step 1/60, sim_frame_skip 8 (env_locomotion.py:856-858) -> 8 substeps of 1/480 s
+    m.gravity, m.dt, m.n_substeps, m.n_iters, m.erp = 9.8, 1.0 / 480.0, 8, 5, 0.9
+    m.contact_margin, m.lin_damp, m.ang_damp, m.max_qd, m.warmstart = 0.02, 0.04, 0.04, 100.0, 0.85
+    m.ground_friction = 0.8
+    m.limit_slack, m.max_contacts, m.max_rows = 0.05, 12, 48
+    m.init_pos[0], m.init_pos[1], m.init_pos[2] = 0.0, 0.0, 0.56                      # env_locomotion.py:864
+    m.init_quat[3] = 1.0
+    m.control_dt = 1.0 / 60.0
+    m.termination_height = 0.0                                                        # :862
+    m.electricity_cost, m.stall_torque_cost, m.joints_at_limit_cost = 4.5, 0.225, 0.1
+    m.max_episode_steps = 1000
+    right, left = [0, 1, 2, 6, 7, 8], [3, 4, 5, 9, 10, 11]                            # robots.py:578-580
+    m.n_mirror_side, m.n_mirror_neg = len(right), 0
+    for k, v in enumerate(right):
+        m.mirror_right[k] = v
+    for k, v in enumerate(left):
+        m.mirror_left[k] = v
+    m.task_flags = TASKF_BODY_CONTACT
     return m.finalize_tables()
 
 
@@ -992,6 +1119,8 @@ def write_topology_headers(outdir: Optional[str] = None) -> None:
         f.write(topology_header(compile_walker2d(), "Walker2D"))
     with open(os.path.join(outdir, "topo_crab2d.h"), "w") as f:
         f.write(topology_header(compile_crab2d(), "Crab2D"))
+    with open(os.path.join(outdir, "topo_laikago.h"), "w") as f:
+        f.write(topology_header(compile_laikago(), "Laikago"))
 
 
 if __name__ == "__main__":

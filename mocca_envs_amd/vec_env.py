@@ -25,7 +25,11 @@ TASKS = {
     # planar robots (walker2d.xml / crab2d.xml): own topologies, Custom task with the quirks of env_locomotion.py:285-314
     "Walker2DCustomEnv-v0": M.TASK_WALKER3D_CUSTOM,
     "Crab2DCustomEnv-v0": M.TASK_WALKER3D_CUSTOM,
+    # quadruped (laikago_toes_limits.urdf): own topology, four feet, Custom task ending on body contact
+    "LaikagoCustomEnv-v0": M.TASK_WALKER3D_CUSTOM,
 }
+# class attributes of the reference envs that are device parameters here
+_DEFAULT_PARAMS = {"LaikagoCustomEnv-v0": {_lib.PARAM_RANDOM_POSE: 0}}   # robot_random_start = False, env_locomotion.py:863
 
 _MODELS = {
     "Walker3DCustomEnv-v0": lambda **kw: M.compile_walker3d(M.TASK_WALKER3D_CUSTOM, **kw),
@@ -35,6 +39,7 @@ _MODELS = {
     "MikeStepperEnv-v0": M.compile_mike,
     "Walker2DCustomEnv-v0": M.compile_walker2d,
     "Crab2DCustomEnv-v0": M.compile_crab2d,
+    "LaikagoCustomEnv-v0": M.compile_laikago,
 }
 _DEFAULT_ENV_OF_TASK = {M.TASK_WALKER3D_CUSTOM: "Walker3DCustomEnv-v0", M.TASK_WALKER3D_STEPPER: "Walker3DStepperEnv-v0",
                         M.TASK_CASSIE: "CassieEnv-v0"}
@@ -89,6 +94,8 @@ class VecEnv:
         self.set_param(_lib.PARAM_AUTO_RESET, 1 if auto_reset else 0)
         self.env_offset = int(env_offset)
         self.set_param(_lib.PARAM_ENV_OFFSET, self.env_offset)
+        for pid, val in _DEFAULT_PARAMS.get(env_id, {}).items():
+            self.set_param(pid, val)
 
     # ------------------------------------------------------------------
     def _stream(self) -> C.c_void_p:

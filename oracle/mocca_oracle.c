@@ -202,6 +202,7 @@ typedef struct {
   real c_erp[MAX_CONTACTS], c_cfm[MAX_CONTACTS];
   int foot_touch[MOCCA_MAX_FEET];        /* any terrain contact of foot k this substep */
   int foot_target[MOCCA_MAX_FEET];       /* foot k touches the cover of the target plank */
+  int body_touch;                        /* some non-foot geom touches the terrain */
   /* rows */
   int nr;
   real J[MAX_ROWS][NDOF_MAX], Mi[MAX_ROWS][NDOF_MAX], A[MAX_ROWS][MAX_ROWS];
@@ -505,6 +506,7 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
   const MoccaModel *m = &o->m;
   w->nc = 0;
   for (int k = 0; k < m->n_feet; ++k) w->foot_touch[k] = w->foot_target[k] = 0;
+  w->body_touch = 0;
   real margin = m->contact_margin;
   /* terrain */
   for (int g = 0; g < m->n_geoms; ++g) {
@@ -543,8 +545,8 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
         cfm = 1 / (dt * kk + cc) / dt;
       }
       if (gap < margin) {
-        for (int k = 0; k < m->n_feet; ++k)
-          if (m->g_body[g] == m->foot_body[k]) { w->foot_touch[k] = 1; if (is_target) w->foot_target[k] = 1; }
+        if (m->g_foot[g] >= 0) { w->foot_touch[m->g_foot[g]] = 1; if (is_target) w->foot_target[m->g_foot[g]] = 1; }
+        else w->body_touch = 1; /* a non-foot link on the terrain (LaikagoCustomEnv, env_locomotion.py:880-890) */
         if (w->nc < m->max_contacts) {
           int i = w->nc++;
           w->c_a[i] = m->g_body[g]; w->c_b[i] = -1; w->c_slot[i] = m->g_slot[g] + e;
@@ -799,7 +801,9 @@ static void calc_robot_state(Oracle *o, const Dyn *s, const Task *tk, float *out
   real minz = 1e30;
   for (int k = 0; k < m->n_feet; ++k) {
     int b = m->foot_body[k];
-    for (int i = 0; i < 3; ++i) o->feet_xyz[k][i] = s->pos[i] + w->comw[b][i]; /* getLinkState[0], bullet_utils.py:106 */
+    real fp[3] = {m->foot_point[k][0], m->foot_point[k][1], m->foot_point[k][2]}, fw[3];
+    matvec3(w->R[b], fp, fw); /* the foot LINK's centre of mass: getLinkState[0], bullet_utils.py:106 */
+    for (int i = 0; i < 3; ++i) o->feet_xyz[k][i] = s->pos[i] + w->r[b][i] + fw[i];
     if (o->feet_xyz[k][2] < minz) minz = o->feet_xyz[k][2];
   }
   out[0] = (float)(s->pos[2] - minz); /* robots.py:88-89 */
@@ -1064,7 +1068,7 @@ static void reset_env(Oracle *o, int env, float *obs) {
 }
 
 static void step_env(Oracle *o, int env, const float *act, float *obs, float *rew, uint8_t *done, int32_t *info,
-                     const int32_t *ext_touch, const int32_t *ext_target) {
+                     const int32_t *ext_touch, const int32_t *ext_target, const int32_t *ext_body) {
   if (o->task_id == MOCCA_TASK_CASSIE) { cassie_step(o, env, act, obs, rew, done, info); return; }
   const MoccaModel *m = &o->m;
   Dyn *s = &o->dyn[env];
@@ -1079,14 +1083,16 @@ static void step_env(Oracle *o, int env, const float *act, float *obs, float *re
     a = a < -1 ? -1 : (a > 1 ? 1 : a);
     tau[b] = (real)m->gain[b] * tk->applied_gain * a;
   }
-  int touch[MOCCA_MAX_FEET] = {0}, target[MOCCA_MAX_FEET] = {0};
+  int touch[MOCCA_MAX_FEET] = {0}, target[MOCCA_MAX_FEET] = {0}, body_touch = 0;
   if (!ext_touch) {
     for (int k = 0; k < m->n_substeps; ++k) substep(o, s, tk, tr, tau, w);
     /* contact queries after stepSimulation see the manifolds of the LAST substep's collision pass */
     for (int k = 0; k < m->n_feet; ++k) { touch[k] = w->foot_touch[k]; target[k] = w->foot_target[k]; }
+    body_touch = w->body_touch;
   } else {
     /* task-only step (golden tests): the caller injected the post-physics state and the contacts */
     for (int k = 0; k < m->n_feet; ++k) { touch[k] = ext_touch[k]; target[k] = ext_target[k]; }
+    body_touch = ext_body ? *ext_body : 0;
   }
   tk->t += 1;
   kinematics(m, s, w);
@@ -1111,6 +1117,10 @@ static void step_env(Oracle *o, int env, const float *act, float *obs, float *re
     joints = (real)m->joints_at_limit_cost * jal;
     tall = obs[0] > m->termination_height ? 2 : -1;
     if (tall < 0) tk->done = 1;
+    if (m->task_flags & MOCCA_TASKF_BODY_CONTACT) { /* LaikagoCustomEnv.calc_base_reward, :877-890 */
+      tall = 0;
+      if (body_touch) { tall = -1; tk->done = 1; }
+    }
     if (dist < (real)0.15) { tk->close_count += 1; target_bonus = 2; } /* :198-202 */
     if (tk->close_count >= tk->stop_frames) { /* :214-222 */
       tk->close_count = 0;
@@ -1239,7 +1249,7 @@ API void orc_step(void *h, const float *act, float *obs, float *rew, uint8_t *do
   int od = obs_dim(o), nj = o->task_id == MOCCA_TASK_CASSIE ? o->m.n_ctrl - 2 : o->m.n_joints;
   for (int e = 0; e < o->n_envs; ++e) {
     int32_t inf = 0;
-    step_env(o, e, act + (size_t)e * nj, obs + (size_t)e * od, rew + e, done + e, &inf, NULL, NULL);
+    step_env(o, e, act + (size_t)e * nj, obs + (size_t)e * od, rew + e, done + e, &inf, NULL, NULL, NULL);
     if (info) info[e] = inf;
   }
 }
@@ -1251,7 +1261,19 @@ API void orc_task_step(void *h, const float *act, const int32_t *touch, const in
   int od = obs_dim(o), nj = o->m.n_joints;
   for (int e = 0; e < o->n_envs; ++e) {
     int32_t inf = 0;
-    step_env(o, e, act + (size_t)e * nj, obs + (size_t)e * od, rew + e, done + e, &inf, touch + 2 * e, target + 2 * e);
+    step_env(o, e, act + (size_t)e * nj, obs + (size_t)e * od, rew + e, done + e, &inf, touch + 2 * e, target + 2 * e, NULL);
+    if (info) info[e] = inf;
+  }
+}
+/* the same for any foot count: touch / target are [N][n_feet], body_touch [N] (non-foot link on the ground) or NULL */
+API void orc_task_step_feet(void *h, const float *act, const int32_t *touch, const int32_t *target, const int32_t *body_touch,
+                            float *obs, float *rew, uint8_t *done, int32_t *info) {
+  Oracle *o = (Oracle *)h;
+  int od = obs_dim(o), nj = o->m.n_joints, nf = o->m.n_feet;
+  for (int e = 0; e < o->n_envs; ++e) {
+    int32_t inf = 0;
+    step_env(o, e, act + (size_t)e * nj, obs + (size_t)e * od, rew + e, done + e, &inf, touch + nf * e, target + nf * e,
+             body_touch ? body_touch + e : NULL);
     if (info) info[e] = inf;
   }
 }

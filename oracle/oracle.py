@@ -49,6 +49,7 @@ def _load(precision: str) -> C.CDLL:
                  "orc_get_terrain", "orc_set_terrain"):
         getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p]
     lib.orc_task_step.argtypes = [C.c_void_p] * 8
+    lib.orc_task_step_feet.argtypes = [C.c_void_p] * 9
     lib.orc_set_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.orc_physics_substeps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     lib.orc_forward_dynamics.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -81,8 +82,8 @@ class Oracle:
         self.obs_dim = self.lib.orc_obs_dim(self.h)
         self.state_dim = self.lib.orc_state_dim(self.h)
         self.act_dim = self.lib.orc_act_dim(self.h)
-        nj = (self.state_dim - 13)
-        self.n_joints = None
+        from mocca_envs_amd.model import MoccaModel   # layout only (the oracle may import the product, never the reverse)
+        self.n_feet = MoccaModel.from_bytes(model_blob).n_feet
 
     def close(self):
         if self.h:
@@ -114,16 +115,21 @@ class Oracle:
         self.lib.orc_step(self.h, _p(act), _p(obs), _p(rew), _p(done), _p(info))
         return obs, rew, done, info
 
-    def task_step(self, act: np.ndarray, touch: np.ndarray, target: Optional[np.ndarray] = None):
-        """Task logic only on the injected post-physics state (golden tests)."""
+    def task_step(self, act: np.ndarray, touch: np.ndarray, target: Optional[np.ndarray] = None,
+                  body_touch: Optional[np.ndarray] = None):
+        """Task logic only on the injected post-physics state (golden tests).  touch / target: [N][n_feet] foot contact
+        query results; body_touch [N]: a non-foot link touches the ground (LaikagoCustomEnv)."""
         act = np.ascontiguousarray(act, np.float32)
-        touch = np.ascontiguousarray(touch, np.int32).reshape(self.n_envs, 2)
-        target = np.zeros_like(touch) if target is None else np.ascontiguousarray(target, np.int32).reshape(self.n_envs, 2)
+        nf = self.n_feet
+        touch = np.ascontiguousarray(touch, np.int32).reshape(self.n_envs, nf)
+        target = np.zeros_like(touch) if target is None else np.ascontiguousarray(target, np.int32).reshape(self.n_envs, nf)
+        body = None if body_touch is None else np.ascontiguousarray(body_touch, np.int32).reshape(self.n_envs)
         obs = np.zeros((self.n_envs, self.obs_dim), np.float32)
         rew = np.zeros(self.n_envs, np.float32)
         done = np.zeros(self.n_envs, np.uint8)
         info = np.zeros(self.n_envs, np.int32)
-        self.lib.orc_task_step(self.h, _p(act), _p(touch), _p(target), _p(obs), _p(rew), _p(done), _p(info))
+        self.lib.orc_task_step_feet(self.h, _p(act), _p(touch), _p(target), _p(body) if body is not None else None,
+                                    _p(obs), _p(rew), _p(done), _p(info))
         return obs, rew, done, info
 
     def set_tape(self, tape: Optional[np.ndarray]):

@@ -63,26 +63,63 @@ class FakeBulletAnyMJCF(G.FakeBullet):
         return (p, q, None, None, None, None, v, w) if computeLinkVelocity else (p, q, None, None, None, None)
 
 
+class FakeBulletURDFRobot(FakeBulletAnyMJCF):
+    """The robot comes from loadURDF (Laikago, robots.py:584-600): joints in file order with their types and limits."""
+    JOINT_REVOLUTE, JOINT_PRISMATIC, JOINT_FIXED = 0, 1, 4
+    robot_urdf = None
+
+    def loadURDF(self, f, basePosition=None, baseOrientation=None, useFixedBase=False, globalScaling=1.0, flags=0):
+        if not f.endswith(self.robot_urdf):
+            return super().loadURDF(f, basePosition, baseOrientation, useFixedBase, globalScaling)
+        import xml.etree.ElementTree as ET
+        self.mjcf_path, self.mjcf_flags, self.joints, self.jtypes = f, flags, [], []
+        for j in ET.parse(f).getroot().findall("joint"):
+            lim = j.find("limit")
+            lo, hi = (float(lim.get("lower")), float(lim.get("upper"))) if lim is not None else (0.0, -1.0)
+            self.joints.append((j.get("name"), j.find("child").get("link"), lo, hi))
+            self.jtypes.append(self.JOINT_FIXED if j.get("type") == "fixed" else self.JOINT_REVOLUTE)
+        self.q, self.qd = np.zeros(len(self.joints)), np.zeros(len(self.joints))
+        return self.ROBOT
+
+    def getJointInfo(self, body, j):
+        info = list(super().getJointInfo(body, j))
+        if body == self.ROBOT:
+            info[2] = self.jtypes[j]
+        return tuple(info)
+
+    def getContactPoints(self, bodyA=None, linkIndexA=None):
+        if linkIndexA is not None:
+            return super().getContactPoints(bodyA, linkIndexA)
+        return [(0, bodyA, bB, lA, lB) for lA, lst in self.contacts.items() for (bB, lB) in lst]   # every link of the body
+
+
 def make_env(cls_name, root_link=None, **kw):
     import mocca_envs.env_base as env_base
     import mocca_envs.env_locomotion as loco
     holder = {}
 
     def factory(*a, **k):
-        holder["p"] = FakeBulletAnyMJCF()
+        holder["p"] = FakeBulletURDFRobot() if kw.get("_urdf") else FakeBulletAnyMJCF()
         holder["p"].root_link = root_link
+        holder["p"].robot_urdf = kw.get("_urdf")
         return holder["p"]
 
     env_base.BulletClient = factory
-    return getattr(loco, cls_name)(**kw), holder["p"]
+    return getattr(loco, cls_name)(**{k: v for k, v in kw.items() if not k.startswith("_")}), holder["p"]
 
 
 def robot_constants(out, tag, env, p):
     rob = env.robot
     out[f"{tag}_mjcf"] = np.array(os.path.basename(p.mjcf_path))
-    out[f"{tag}_joint_names"] = np.array([j.joint_name for j in rob.ordered_joints])
-    out[f"{tag}_joint_lo"] = np.array([j.lowerLimit for j in rob.ordered_joints])
-    out[f"{tag}_joint_hi"] = np.array([j.upperLimit for j in rob.ordered_joints])
+    if hasattr(rob, "ordered_joints"):
+        out[f"{tag}_joint_names"] = np.array([j.joint_name for j in rob.ordered_joints])
+        out[f"{tag}_joint_lo"] = np.array([j.lowerLimit for j in rob.ordered_joints])
+        out[f"{tag}_joint_hi"] = np.array([j.upperLimit for j in rob.ordered_joints])
+    else:   # Laikago keeps ids only (robots.py:609-626); limits as its to_radians sees them: theta = -1 / +1
+        n = len(rob.ordered_joint_ids)
+        out[f"{tag}_joint_names"] = np.array([p.joints[j][0] for j in rob.ordered_joint_ids])
+        out[f"{tag}_joint_lo"] = np.asarray(rob.to_radians(-np.ones(n)), dtype=np.float64)
+        out[f"{tag}_joint_hi"] = np.asarray(rob.to_radians(np.ones(n)), dtype=np.float64)
     out[f"{tag}_gains"] = np.array(rob.ordered_joint_base_gains, dtype=np.float64)
     out[f"{tag}_base_joint_angles"] = np.array(rob.base_joint_angles, dtype=np.float64)
     out[f"{tag}_base_position"] = np.array(rob.base_position, dtype=np.float64)
@@ -253,6 +290,78 @@ def main():
                    rew=np.array(rew_l), done=np.array(done_l).astype(np.int32), terms=np.array(terms))
         for k, v in rec.items():
             out[f"{tag}_ep0_{k}"] = np.asarray(v)
+
+    # ---------------- LaikagoCustomEnv (env_locomotion.py:854-890)
+    env, p = make_env("LaikagoCustomEnv", _urdf="laikago_toes_limits.urdf")
+    rob = env.robot
+    robot_constants(out, "laikago", env, p)
+    n2 = len(rob.ordered_joint_ids)
+    out["laikago_init_position"] = np.array(env.robot_init_position, dtype=np.float64)
+    out["laikago_termination_height"] = np.array(env.termination_height)
+    out["laikago_random_start"] = np.array(int(env.robot_random_start))
+    out["laikago_physics_fixedTimeStep"] = np.array(p.physics["fixedTimeStep"])
+    out["laikago_physics_numSubSteps"] = np.array(p.physics["numSubSteps"])
+    out["laikago_foot_names"] = np.array(rob.foot_names)
+    joint_ids = rob.ordered_joint_ids
+    foot_links = [rob.parts[f].bodyPartIndex for f in rob.foot_names]
+    chassis_link, knee_link = -1, rob.parts["FR_lower_leg"].bodyPartIndex
+    mdl = M.compile_laikago()
+    orc = Oracle(mdl.to_bytes(), M.TASK_WALKER3D_CUSTOM, 1, "f64")
+    lo, hi = out["laikago_joint_lo"], out["laikago_joint_hi"]
+    sd = 13 + 2 * n2
+
+    def push_state4(st, touch, body):
+        full = np.zeros((1, orc.state_dim))
+        full[0, :sd] = st
+        orc.set_state(full)
+        fr = orc.link_frames(0, mdl.n_bodies)
+        p.base_pos, p.base_quat, p.base_vel = st[0:3].copy(), st[3:7].copy(), st[7:10].copy()
+        for k, jid in enumerate(joint_ids):
+            p.q[jid], p.qd[jid] = st[13 + k], st[13 + n2 + k]
+        # the foot LINK is the toe: a fixed child of the lower leg whose origin is the toe sphere's centre
+        for k, fl in enumerate(foot_links):
+            gi = [g for g in range(mdl.n_geoms) if mdl.g_foot[g] == k][0]
+            R = fr[mdl.foot_body[k], 0:9].reshape(3, 3)
+            p.link_pos[fl] = R @ np.array([mdl.g_p1[gi][i] for i in range(3)]) + fr[mdl.foot_body[k], 9:12]   # (world: includes the base position)
+        p.contacts = {fl: ([(G.FakeBullet.PLANE, -1)] if touch[k] else []) for k, fl in enumerate(foot_links)}
+        if body == 1:
+            p.contacts[chassis_link] = [(G.FakeBullet.PLANE, -1)]
+        elif body == 2:
+            p.contacts[knee_link] = [(G.FakeBullet.PLANE, -1)]
+
+    for ep in range(2):
+        env.seed(90 + ep)
+        env.robot.np_random = env.np_random
+        tape = env.np_random.tape.copy()
+        p.contacts = {}
+        p.link_pos = {}
+        obs0 = env.reset()
+        rec = dict(tape=tape[:640], reset_obs=obs0, reset_q=np.array([p.q[j] for j in joint_ids]), reset_mirrored=int(rob.mirrored),
+                   reset_base_pos=np.array(p.base_pos), reset_base_quat=np.array(p.base_quat), reset_walk_target=env.walk_target.copy())
+        rng = np.random.default_rng(600 + ep)
+        states, touches, bodies, actions, obs_l, rew_l, done_l, terms = [], [], [], [], [], [], [], []
+        T = 50
+        for t in range(T):
+            st = np.zeros(sd)
+            st[0:3] = [0.02 * t, rng.normal(0, 0.02), rng.uniform(0.3, 0.55)]
+            st[3:7] = G.quat_from_euler(rng.normal(0, 0.2), rng.normal(0, 0.25), rng.normal(0, 0.3))
+            st[7:10] = rng.normal(0, 0.5, 3)
+            st[10:13] = rng.normal(0, 0.5, 3)
+            st[13:13 + n2] = lo + (hi - lo) * rng.uniform(-0.02, 1.02, n2)
+            st[13 + n2:sd] = rng.normal(0, 3.0, n2)
+            touch = (rng.random(4) < 0.6).astype(np.int32)
+            body = 0 if t < T - 1 else (1 + ep)          # the last frame: chassis (ep 0) / a lower leg (ep 1) on the ground
+            a = rng.uniform(-1.5, 1.5, n2)
+            p.on_step = (lambda st=st, touch=touch, body=body: push_state4(st, touch, body))
+            o, r, dn, _ = env.step(a)
+            states.append(st); touches.append(touch); bodies.append(int(body > 0)); actions.append(a)
+            obs_l.append(o); rew_l.append(r); done_l.append(dn)
+            terms.append([env.progress, env.target_bonus, env.energy_penalty, env.tall_bonus, env.posture_penalty, env.joints_penalty])
+        rec.update(states=np.array(states), touch=np.array(touches), body=np.array(bodies), actions=np.array(actions),
+                   obs=np.array(obs_l), rew=np.array(rew_l), done=np.array(done_l).astype(np.int32), terms=np.array(terms))
+        for k, v in rec.items():
+            out[f"laikago_ep{ep}_{k}"] = np.asarray(v)
+    out["laikago_n_episodes"] = np.array(2)
 
     path = os.path.join(HERE, "variants_reference.npz")
     np.savez_compressed(path, **out)

@@ -168,3 +168,59 @@ def test_planar_episode(vg, tag, compile_fn, xml, prec, tol):
         np.testing.assert_allclose(r[0], g("rew")[t], atol=2e3 * tol, err_msg=f"t{t} reward")
     tall = g("terms")[:, 3]
     assert (tall == -1).sum() > 3 and (tall == 2).sum() > 3      # the script does cross the 0.7 m line; done stays 0
+
+
+def test_laikago_constants(vg):
+    from mocca_envs_amd import host_logic as H
+    m = M.compile_laikago()
+    nj = m.n_joints
+    assert list(vg["laikago_joint_names"]) == M.LAIKAGO_JOINTS and list(vg["laikago_foot_names"]) == M.LAIKAGO_FEET
+    lo, hi = M.joint_limits(m)
+    np.testing.assert_allclose(lo, vg["laikago_joint_lo"], atol=1e-6)
+    np.testing.assert_allclose(hi, vg["laikago_joint_hi"], atol=1e-6)
+    np.testing.assert_allclose([m.gain[b] for b in range(1, nj + 1)], vg["laikago_gains"], rtol=1e-6)
+    np.testing.assert_allclose([m.init_q[b] for b in range(1, nj + 1)], vg["laikago_base_joint_angles"], atol=1e-6)   # "running_start"
+    np.testing.assert_allclose(list(m.init_pos), vg["laikago_init_position"], atol=1e-7)
+    np.testing.assert_allclose(list(m.init_quat), vg["laikago_base_orientation"], atol=1e-7)
+    assert int(vg["laikago_obs_dim"]) == 6 + 2 * nj + 4 + 2 and m.n_feet == 4
+    assert abs(m.termination_height - float(vg["laikago_termination_height"])) < 1e-7
+    assert int(vg["laikago_random_start"]) == 0
+    assert m.n_substeps == int(vg["laikago_physics_numSubSteps"])
+    assert abs(m.dt * m.n_substeps - float(vg["laikago_physics_fixedTimeStep"])) < 1e-9
+    assert m.task_flags == M.TASKF_BODY_CONTACT
+    got = H.mirror_indices(m, stepper=False)
+    for k, g in zip(["neg_obs", "right_obs", "left_obs", "neg_act", "right_act", "left_act"], got):
+        np.testing.assert_array_equal(np.asarray(g), vg[f"laikago_mirror_{k}"], err_msg=k)
+
+
+@pytest.mark.parametrize("prec,tol", [("f64", 2e-6), ("f32", 2e-5)])
+def test_laikago_episodes(vg, prec, tol):
+    from oracle.oracle import PARAM_RANDOM_POSE
+    m = M.compile_laikago()
+    nj, sd = m.n_joints, 13 + 2 * m.n_joints
+    for ep in range(int(vg["laikago_n_episodes"])):
+        g = lambda k: vg[f"laikago_ep{ep}_{k}"]
+        orc = Oracle(m.to_bytes(), M.TASK_WALKER3D_CUSTOM, 1, prec)
+        orc.set_param(PARAM_RANDOM_POSE, 0)                              # robot_random_start = False
+        orc.set_tape(g("tape"))
+        obs0 = orc.reset(seed=0)
+        st = orc.get_state()[0]
+        np.testing.assert_allclose(st[13:13 + nj], g("reset_q"), atol=tol)
+        np.testing.assert_allclose(st[0:3], g("reset_base_pos"), atol=tol)
+        np.testing.assert_allclose(st[3:7], g("reset_base_quat"), atol=tol)
+        tk = orc.get_task()[0]
+        assert int(tk[11]) == int(g("reset_mirrored"))
+        np.testing.assert_allclose(tk[0:3], g("reset_walk_target"), atol=tol)
+        np.testing.assert_allclose(obs0[0, 1:], g("reset_obs")[1:], atol=10 * tol)   # [0] = height: the fake reports the feet at the origin at reset
+        states, touch, body, actions = g("states"), g("touch"), g("body"), g("actions")
+        for t in range(len(states)):
+            full = np.zeros((1, orc.state_dim))
+            full[0, :sd] = states[t]
+            orc.set_state(full)
+            o, r, d, _ = orc.task_step(actions[t][None], touch[t][None], None, body[t:t + 1])
+            np.testing.assert_allclose(o[0], g("obs")[t], atol=20 * tol, err_msg=f"ep{ep} t{t} obs")
+            assert (d[0] & 1) == int(g("done")[t]), f"ep{ep} t{t} done"
+            np.testing.assert_allclose(r[0], g("rew")[t], atol=2e3 * tol, err_msg=f"ep{ep} t{t} reward")
+        # tall_bonus is 0 while only feet touch, -1 + done on the frame where the chassis / a lower leg touches
+        # (done may also latch earlier through the inherited height <= 0 test: a foot above the base)
+        assert (g("terms")[:-1, 3] == 0).all() and g("terms")[-1, 3] == -1 and g("done")[-1] == 1

@@ -148,7 +148,7 @@ def test_argument_checking_and_action_handling():
     with pytest.raises(ValueError):
         env.step(torch.zeros(4, 20, device="cuda"))
     with pytest.raises(KeyError):
-        VecEnv("LaikagoCustomEnv-v0", 4)   # a reference id without a GPU stepper
+        VecEnv("Monkey3DCustomEnv-v0", 4)   # a reference id without a GPU stepper
     # out-of-range actions are clipped for the torque (robots.py:33), a float64 / CPU / strided tensor is accepted
     st0 = env.get_state().clone()
     big = torch.full((4, NJ), 7.0, dtype=torch.float64)

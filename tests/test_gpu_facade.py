@@ -124,7 +124,8 @@ def test_shard_offset_reproduces_the_owned_envs():
 
 
 @pytest.mark.parametrize("env_id,obs_dim,z0", [("Child3DCustomEnv-v0", 52, 0.38), ("MikeStepperEnv-v0", 65, 1.0),
-                                               ("Walker2DCustomEnv-v0", 24, 1.05), ("Crab2DCustomEnv-v0", 22, 1.06)])
+                                               ("Walker2DCustomEnv-v0", 24, 1.05), ("Crab2DCustomEnv-v0", 22, 1.06),
+                                               ("LaikagoCustomEnv-v0", 36, 0.56)])
 def test_same_tree_variants(env_id, obs_dim, z0):
     """Child3D / Mike run on the Walker3D kernels with their own model blobs (env_locomotion.py:317-327, :843-851);
     Walker2D / Crab2D on their own topologies (:285-314: reset tail zero, never done)."""

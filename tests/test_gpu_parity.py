@@ -10,7 +10,9 @@ TASKS = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM), ("Walker3DStepperEnv-
          # same tree, other model blobs (child3d.xml from the crawl pose, mike.xml): same kernels
          ("Child3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM), ("MikeStepperEnv-v0", M.TASK_WALKER3D_STEPPER),
          # planar robots: own topologies (7 / 6 hinges), Custom task
-         ("Walker2DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM), ("Crab2DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM)]
+         ("Walker2DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM), ("Crab2DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM),
+         # quadruped: four feet, 8 substeps, body contact ends the episode
+         ("LaikagoCustomEnv-v0", M.TASK_WALKER3D_CUSTOM)]
 
 # fp32 tolerance of one teacher-forced env.step() (4 substeps, up to 48 PGS rows).  Errors are measured in
 # units of (1e-3 + 1e-3 |x|): joint speeds reach 100 rad/s under random actions, hence the relative part.
@@ -31,8 +33,11 @@ def _mk(env_id, task, n, seed, auto_reset=False, curriculum=None):
     env = VecEnv(env_id, n, auto_reset=auto_reset, seed=seed)
     o32 = Oracle(env.model.to_bytes(), task, n, "f32")
     o64 = Oracle(env.model.to_bytes(), task, n, "f64")
+    from mocca_envs_amd.vec_env import _DEFAULT_PARAMS
     for o in (o32, o64):
         o.set_param(PARAM_AUTO_RESET, int(auto_reset))
+        for pid, val in _DEFAULT_PARAMS.get(env_id, {}).items():   # e.g. Laikago: no random start pose
+            o.set_param(pid, val)
     if curriculum is not None:
         env.set_param(2, curriculum)
         o32.set_param(PARAM_CURRICULUM, curriculum)

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 rev=$1; rounds=${2:-4}
 mkdir -p /tmp/abA && cd /tmp/abA
-for f in mocca_api.hip mocca_device.h topo_walker3d.h topo_cassie.h topo_walker2d.h topo_crab2d.h; do cp $R/.ab_src/$f . ; done
+for f in mocca_api.hip mocca_device.h topo_walker3d.h topo_cassie.h topo_walker2d.h topo_crab2d.h topo_laikago.h; do cp $R/.ab_src/$f . ; done
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -shared -fPIC -I$R/include -I. -o /tmp/libA.so mocca_api.hip || exit 1
 cd $R
 for i in $(seq $rounds); do
