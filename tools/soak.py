@@ -1,0 +1,19 @@
+import sys, torch
+import os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from mocca_envs_amd.vec_env import VecEnv, TASKS
+for env_id in TASKS:
+    n = 2048 if "Cassie" in env_id else 4096
+    env = VecEnv(env_id, n, auto_reset=True, seed=123)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    steps = 300 if "Cassie" in env_id else 3000
+    nd = 0; rsum = 0.0; bad = 0
+    for k in range(steps):
+        a = torch.rand(n, env.act_dim, device="cuda", generator=g) * 2 - 1
+        obs, r, d, info = env.step(a)
+        nd += int((d != 0).sum()); bad += int((~torch.isfinite(obs)).any(dim=1).sum())
+        rsum += float(r.mean())
+    st = env.get_state()
+    print(f"{env_id:26s} steps {steps} episodes ended {nd:7d} non-finite obs rows {bad} state finite {bool(torch.isfinite(st).all())} mean reward {rsum/steps:+.3f} |q|max {float(st[:,13:13+env.model.n_joints].abs().max()):.2f}")
+    env.close()
