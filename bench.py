@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--env-id", default=ENV_ID)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--curriculum", type=int, default=None, help="Stepper envs: curriculum 0..9 (SURVEY 8d config 3)")
     args = ap.parse_args()
 
     import torch
@@ -79,6 +80,8 @@ def main():
     lo, hi = sharding.env_range(rank, world, args.envs)
     # same seed on every rank, draws keyed by the GLOBAL env id: the job's result does not depend on how many GPUs share it
     env = VecEnv(args.env_id, args.envs, device=local_rank, auto_reset=True, seed=1000, env_offset=lo)
+    if args.curriculum is not None:
+        env.set_param(2, args.curriculum)  # MOCCA_PARAM_CURRICULUM: takes effect at reset
     env.reset()
     g = torch.Generator(device=dev)
     g.manual_seed(1 + rank)
