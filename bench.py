@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/sec of Walker3DCustomEnv-v0 at 4096 envs per MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
-For N > 1 the driver launches one process per GPU with torch.distributed.run; env batches are
-independent shards (no data-path collective; RCCL is only used for the barrier and the MAX of times).
+  python bench.py --gpus N --steps K --warmup W            (BASELINE.json configs[1]; N = 1, 2, 4, 8)
+  python bench.py --gpus 8 --envs 8192                     (configs[4]: 8 x 8192 envs, weak scaling)
+  python bench.py --env-id Walker3DStepperEnv-v0 [--curriculum 9]     (configs[2])
+  python bench.py --env-id CassieEnv-v0 --envs 2048                   (configs[3])
 
-One "step" = one env.step() of all envs of a rank = one launch of the step kernel (4 physics substeps,
-observation, reward, termination, in-kernel auto-reset), inputs resident in HBM.
+One "step" = one env.step() of all envs of a rank = ONE launch of the step kernel (4 physics substeps, observation,
+reward, termination, in-kernel auto-reset), inputs resident in HBM.
+
+Multi-GPU: env batches are independent shards (each env is its own world in the reference, env_base.py:55): one
+process per GPU, env_offset = rank x envs, NO data-path collective and no RCCL -- the start/stop barrier and the MAX of
+the per-rank times go over a gloo (CPU) group.  Two ways in:
+  * under torchrun / torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE set): this process is one rank;
+  * plain `python bench.py --gpus N` with N > 1: this process touches no GPU, spawns N child ranks (subprocess, fresh
+    interpreters) with the same environment variables torchrun would set, and relays rank 0's JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,117 +32,200 @@ sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
 ENV_ID = "Walker3DCustomEnv-v0"
-# algorithmic HBM bytes of one env-step (state + task + action in, state + task +
-# obs + reward + done out) for Walker3DCustomEnv, contact warm-start impulses persisted (34 slots)
+# algorithmic HBM bytes of one env-step (state + task + action in, state + task + obs + reward +
+# done out) for Walker3DCustomEnv, contact warm-start impulses persisted (34 slots)
 ALGO_BYTES_PER_ENV_STEP = 836 + 2 * 34 * 4
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3   # same guide: peak FP32 vector rate
+KERNEL_SOURCES = ["mocca_envs_amd/csrc/mocca_device.h", "mocca_envs_amd/csrc/mocca_kernels.h", "mocca_envs_amd/csrc/mocca_api.hip",
+                  "mocca_envs_amd/csrc/topo_walker3d.h", "include/mocca_model.h"]
 
 
-def cpu_baseline(env_id: str = ENV_ID, seconds_target: float = 12.0):
-    """The CPU oracle (a scalar C port of the same algorithm; PyBullet is not installable here) on one host core."""
+def kernel_source_hash() -> str:
+    """Identifies the step kernel the PMC numbers in profiles/traffic.json were measured on."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def _oracle_rate(env_id, n_envs, seconds_target, max_steps=None):
     import numpy as np
     from oracle.oracle import Oracle, PARAM_AUTO_RESET
     from mocca_envs_amd.vec_env import TASKS, compile_model_for
-    task = TASKS[env_id]
-    m = compile_model_for(env_id)
-    n = 16
-    orc = Oracle(m.to_bytes(), task, n, "f32")
+    orc = Oracle(compile_model_for(env_id).to_bytes(), TASKS[env_id], n_envs, "f32")
     orc.set_param(PARAM_AUTO_RESET, 1)
     orc.reset(seed=0)
-    rng = np.random.default_rng(0)
-    tape = rng.uniform(-1, 1, (64, n, orc.act_dim)).astype(np.float32)
+    tape = np.random.default_rng(0).uniform(-1, 1, (64, n_envs, orc.act_dim)).astype(np.float32)
     t0 = time.perf_counter()
     steps = 0
-    while time.perf_counter() - t0 < seconds_target:
-        for k in range(64):
-            orc.step(tape[k])
-        steps += 64
-    dt = time.perf_counter() - t0
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{env_id}: {n} envs x {steps} steps, auto-reset, U(-1,1) actions, f32 C oracle (oracle/mocca_oracle.c)"}
+    while time.perf_counter() - t0 < seconds_target and (max_steps is None or steps < max_steps):
+        orc.step(tape[steps % 64])
+        steps += 1
+    return n_envs * steps / (time.perf_counter() - t0), steps
 
 
-def main():
+def cpu_baseline(env_id: str = ENV_ID, seconds_target: float = 10.0):
+    """The CPU oracle (a scalar C port of the same algorithm; PyBullet is not installable here) on the host cores:
+    one core (the headline `value`), BASELINE.json configs[0] (1 env x 1000 steps, 1 thread) and all cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = 16
+    rate1, steps1 = _oracle_rate(env_id, n, seconds_target)
+    out = {"value": rate1, "unit": "env-steps/s", "cores": 1, "kind": "port",
+           "sample": f"{env_id}: {n} envs x {steps1} steps, auto-reset, U(-1,1) actions, f32 C oracle (oracle/mocca_oracle.c)"}
+    # configs[0]: "1 env, 1000 random-action steps" on one thread (the reference's own CPU-runnable case)
+    r0, s0 = _oracle_rate(env_id, 1, 30.0, max_steps=1000)
+    out["config0_1env_1000steps"] = {"value": r0, "unit": "env-steps/s", "cores": 1, "steps": s0}
+    # every host core: one independent oracle instance per thread (ctypes releases the GIL inside orc_step)
+    cores = os.cpu_count() or 1
+    with ThreadPoolExecutor(cores) as ex:
+        t0 = time.perf_counter()
+        res = list(ex.map(lambda _: _oracle_rate(env_id, n, 0.6 * seconds_target), range(cores)))
+        wall = time.perf_counter() - t0
+    out["all_cores"] = {"value": sum(n * s for _, s in res) / wall, "unit": "env-steps/s", "cores": cores,
+                        "sample": f"{cores} threads x {n} envs, {sum(s for _, s in res)} steps in total"}
+    return out
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--envs", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU (4096 = the metric's config; 8192 = configs[4])")
     ap.add_argument("--env-id", default=ENV_ID)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--curriculum", type=int, default=None, help="Stepper envs: curriculum 0..9 (SURVEY 8d config 3)")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise launch / rendezvous / reporting only (CPU tests)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="TEST ONLY: let ranks share GPUs (device = rank %% visible GPUs) so the N-rank path can be exercised on a 1-GPU box; "
+                         "the line is marked and is not a scaling measurement")
+    return ap.parse_args(argv)
 
-    import torch
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without torchrun: spawn the N ranks.  Nothing here may touch the GPU (a process that has
+    initialised HIP must not be replaced or forked on this pool); device_count() does not."""
+    if not args.dry_run:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus and not args.oversubscribe:
+            print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return max(rcs)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: note: WORLD_SIZE={world} overrides --gpus {args.gpus}", file=sys.stderr)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group("gloo")   # barrier + MAX of times only: no RCCL on this path (independent shards)
 
-    from mocca_envs_amd.vec_env import VecEnv
     from mocca_envs_amd import sharding
     lo, hi = sharding.env_range(rank, world, args.envs)
-    # same seed on every rank, draws keyed by the GLOBAL env id: the job's result does not depend on how many GPUs share it
-    env = VecEnv(args.env_id, args.envs, device=local_rank, auto_reset=True, seed=1000, env_offset=lo)
-    if args.curriculum is not None:
-        env.set_param(2, args.curriculum)  # MOCCA_PARAM_CURRICULUM: takes effect at reset
-    env.reset()
-    g = torch.Generator(device=dev)
-    g.manual_seed(1 + rank)
-    tape = torch.rand(64, args.envs, env.act_dim, device=dev, generator=g) * 2 - 1  # U(-1,1) action tape, looped
+    reset_frac, kern_ms, kinfo, env = 0.0, 0.0, {}, None
+    if args.dry_run:
+        if dist is not None:
+            dist.barrier()
+        elapsed = sharding.max_over_ranks(1e-3 * args.steps * (1 + rank), dist)
+        kern_ms = 1.0
+    else:
+        import torch
+        if args.oversubscribe:
+            local_rank %= max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        from mocca_envs_amd.vec_env import VecEnv
+        # same seed on every rank, draws keyed by the GLOBAL env id: the job's result does not depend on how many GPUs share it
+        env = VecEnv(args.env_id, args.envs, device=local_rank, auto_reset=True, seed=1000, env_offset=lo)
+        if args.curriculum is not None:
+            env.set_param(2, args.curriculum)  # MOCCA_PARAM_CURRICULUM: takes effect at reset
+        env.reset()
+        g = torch.Generator(device=dev)
+        g.manual_seed(1 + rank)
+        tape = torch.rand(64, args.envs, env.act_dim, device=dev, generator=g) * 2 - 1  # U(-1,1) action tape, looped
 
-    n_done = torch.zeros((), device=dev)
-    for i in range(args.warmup):
-        _, _, done, _ = env.step(tape[i % 64])
-        n_done += (done != 0).sum()  # reset fraction is sampled during warm-up, outside the timed region
-    reset_frac = float(n_done.item()) / max(1, args.envs * args.warmup)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # HIP events on the stream the kernel is launched on (torch's current stream is the one handed to mocca_step)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        env.step(tape[i % 64])
-    ev1.record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, dist, dev)
-    kern_ms = ev0.elapsed_time(ev1) / args.steps  # back-to-back launches: average launch duration incl. launch gaps
+        n_done = torch.zeros((), device=dev)
+        for i in range(args.warmup):
+            _, _, done, _ = env.step(tape[i % 64])
+            n_done += (done != 0).sum()  # reset fraction is sampled during warm-up, outside the timed region
+        reset_frac = float(n_done.item()) / max(1, args.envs * args.warmup)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        # HIP events on the stream the kernel is launched on (torch's current stream is the one handed to mocca_step)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for i in range(args.steps):
+            env.step(tape[i % 64])
+        ev1.record()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        elapsed = sharding.max_over_ranks(elapsed, dist)
+        kern_ms = ev0.elapsed_time(ev1) / args.steps  # back-to-back launches: average launch duration incl. launch gaps
+        kinfo = env.kernel_info()
 
     if rank == 0:
-        traffic = None
+        traffic, valu, pmc_note = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and args.envs == ENVS_PER_GPU and args.env_id == ENV_ID:
-            # HBM bytes per launch measured offline with rocprofv3 PMC passes (see the file's "method")
-            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
-        total_envs = args.envs * world
+            # HBM bytes / VALU work per launch measured offline with rocprofv3 PMC passes at steady state (tools/profile_round.sh).
+            # The file names the kernel sources it was measured on; numbers of another kernel are not reported.
+            tj = json.load(open(tpath))
+            if tj.get("kernel_source_sha256") == kernel_source_hash():
+                traffic = tj["traffic_bytes_per_launch"]
+                valu = tj.get("valu")
+            else:
+                pmc_note = "profiles/traffic.json was measured on other kernel sources (stale): traffic not reported"
         value = sharding.aggregate_throughput(args.envs, world, args.steps, elapsed)
-        # per env-step: state + task + action read, state + task + obs + reward + done written (SURVEY.md 8d)
-        sd, td = env.state_dim * 4, 40 * 4
-        algo = (sd + td + env.act_dim * 4) + (sd + td + env.obs_dim * 4 + 5)
         if args.env_id == ENV_ID:
             algo = ALGO_BYTES_PER_ENV_STEP  # the figure quoted in DESIGN.md (24-word task record of the metric env)
+        elif env is not None:
+            # per env-step: state + task + action read, state + task + obs + reward + done written (SURVEY.md 8d)
+            sd, td = env.state_dim * 4, 40 * 4
+            algo = (sd + td + env.act_dim * 4) + (sd + td + env.obs_dim * 4 + 5)
+        else:
+            algo = 0
         achieved = algo * args.envs / (kern_ms * 1e-3) / 1e9
+        terrain = "20 stepping planks" if "Stepper" in args.env_id else "flat ground"
         out = {
             "metric": "env-steps/sec, Walker3DCustomEnv-v0 @ 4096 envs, 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.env_id}, {args.envs} envs/GPU, "
-                                   f"{'20 stepping planks' if 'Stepper' in args.env_id else 'flat ground'}, U(-1,1) action tape, auto-reset",
+            "config": {"workload": f"{args.env_id}, {args.envs} envs/GPU, {terrain}, U(-1,1) action tape, auto-reset",
                        "envs_per_gpu": args.envs, "parallelism": f"independent env shards x{world}, no collective",
                        "reset_fraction_per_step": reset_frac},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -139,12 +233,28 @@ def main():
                          "kernel": "mocca_step_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": algo * args.envs,
                          "note": "path is latency/VALU-bound by construction (SURVEY.md 8d); HBM fraction reported per contract"},
-            "kernel_info": env.kernel_info(),
+            "kernel_info": kinfo,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if pmc_note:
+            out["roofline"]["traffic_note"] = pmc_note
+        if valu:
+            # secondary roofline: counted fp32 VALU lane-operations of one launch (SQ_THREAD_CYCLES_VALU, offline
+            # PMC pass) over THIS run's launch time, against the 157.3 TFLOP/s vector peak (an FMA lane-op counted as 2 flop)
+            lane_ops = valu["active_lane_ops_per_launch"]
+            tf = 2.0 * lane_ops / (kern_ms * 1e-3) / 1e12
+            out["roofline_valu"] = {"bound": "valu", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": tf / VALU_PEAK_TFLOPS, "valu_insts_per_env_step": valu["valu_insts_per_env_step"],
+                                    "active_lanes_per_valu_inst": valu["active_lanes_per_valu_inst"],
+                                    "note": "upper bound on useful flop: every active VALU lane-op counted as one FMA"}
+        if args.dry_run:
+            out["dry_run"] = True
+        if args.oversubscribe:
+            out["oversubscribed"] = True
+        if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(args.env_id)
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MOCCA_ABI_VERSION 1
+#define MOCCA_ABI_VERSION 2
 
 typedef struct mocca_ctx *mocca_handle;
 
@@ -56,6 +56,21 @@ enum {
   MOCCA_PARAM_SEED = 5,        /* Philox key used by step() for in-kernel draws (also set by mocca_reset) */
   MOCCA_PARAM_ENV_OFFSET = 6,  /* global index of this handle's env 0: draws are keyed by (seed, offset + env, episode),
                                   so a shard of a larger batch reproduces exactly the envs it owns */
+  MOCCA_PARAM_APPLIED_GAIN = 7, /* set_robot_params({"applied_gain": g}), env_base.py:108-115 / robots.py:16,33: acts on the
+                                   next apply_action; the Stepper overwrites it at reset from its curriculum (:489) */
+};
+
+/* words of the per-env debug record (mocca_set_debug_buffer): the active set of the LAST physics substep */
+#define MOCCA_DEBUG_WORDS 8
+enum {
+  MOCCA_DBG_ROWS = 0,        /* constraint rows solved                                  */
+  MOCCA_DBG_LIMIT_ROWS = 1,  /* of which joint-limit rows                               */
+  MOCCA_DBG_CONTACTS = 2,    /* contacts kept (each gives 1 normal + 2 friction rows)   */
+  MOCCA_DBG_SLOTS_LO = 3,    /* bit s: terrain contact slot s is within the margin      */
+  MOCCA_DBG_SLOTS_HI = 4,
+  MOCCA_DBG_LIMITS_LO = 5,   /* bit 2j + side: limit candidate of joint j (0 lower, 1 upper) */
+  MOCCA_DBG_LIMITS_HI = 6,
+  MOCCA_DBG_SELF = 7,        /* self-collision pairs within the margin                  */
 };
 
 int mocca_abi_version(void);
@@ -86,6 +101,21 @@ int mocca_reset(mocca_handle h, const uint8_t *mask_dev, uint64_t seed, float *o
 int mocca_step(mocca_handle h, const float *act_dev, float *obs_dev, float *rew_dev, uint8_t *done_dev,
                int32_t *info_dev, void *stream);
 
+/* The task layer of env.step(a) alone -- everything of env_locomotion.py:111-141 / :515-568 EXCEPT stepSimulation:
+ * the stored dynamic state is taken as the post-physics state, and the contact queries the reference makes after
+ * stepping (robots.py:74-86 feet_contact; calc_feet_state's target-plank test, env_locomotion.py:634-650;
+ * LaikagoCustomEnv's body contacts, :880-890) are supplied by the caller.  Same kernel source as mocca_step with zero
+ * substeps.  Used to replay the reference's own scripted episodes (tests/golden) through the HIP path.
+ *   touch_dev  [N][n_feet] i32, target_dev [N][n_feet] i32 or NULL, body_dev [N] i32 or NULL; rest as mocca_step. */
+int mocca_task_step(mocca_handle h, const float *act_dev, const int32_t *touch_dev, const int32_t *target_dev,
+                    const int32_t *body_dev, float *obs_dev, float *rew_dev, uint8_t *done_dev, int32_t *info_dev,
+                    void *stream);
+
+/* Replace the Philox draws of mocca_reset / mocca_task_step by uniforms read from tape_dev [N][n_per_env] f32, indexed
+ * by the episode's draw counter (task word 10) -- the numbers `np_random` gave the reference in the recorded episode.
+ * NULL detaches.  mocca_step (the physics path) never reads the tape.  The buffer must outlive its use. */
+int mocca_set_draw_tape(mocca_handle h, const float *tape_dev, int n_per_env);
+
 /* robot.calc_state() + the task's observation tail on the CURRENT state, without stepping
  * (robots.py:42-95 with env_locomotion.py:102-109 / :712-759).  Used after set_state/set_task, e.g. by the
  * single-env facade whose reset draws come from a host numpy RandomState like the reference's.
@@ -104,6 +134,17 @@ int mocca_set_terrain(mocca_handle h, const float *terrain_dev, void *stream);
 
 /* set_env_params / evaluation_mode / auto-reset switch (see MOCCA_PARAM_*) */
 int mocca_set_param(mocca_handle h, int param_id, double value);
+/* Per-env form for MOCCA_PARAM_CURRICULUM / _EVAL_MODE / _APPLIED_GAIN (each env of the reference owns its own
+ * attributes, env_base.py:103-115): values_dev [N] f32 is COPIED into the handle; broadcast != 0 reads values_dev[0]
+ * for every env.  A later scalar mocca_set_param of the same id drops the vector. */
+int mocca_set_param_v(mocca_handle h, int param_id, const float *values_dev, int broadcast, void *stream);
+/* full 64-bit Philox key (MOCCA_PARAM_SEED travels through a double: exact below 2^53 only) */
+int mocca_set_seed(mocca_handle h, uint64_t seed);
+/* dbg_dev [N][MOCCA_DEBUG_WORDS] i32 receives the active set of each env's last substep on every mocca_step; NULL stops it */
+int mocca_set_debug_buffer(mocca_handle h, int32_t *dbg_dev);
+/* 1 if the library was compiled with a profiling switch that makes results wrong or slow by construction
+ * (MOCCA_SKIP_*, MOCCA_DUMMY_VALU, MOCCA_STAMPS); the Python binding refuses such a build unless told otherwise */
+int mocca_is_diagnostic_build(void);
 
 /* name, registers, LDS and scratch of the step kernel as built (for DESIGN.md / bench) */
 int mocca_kernel_info(mocca_handle h, int *vgprs, int *sgprs, int *lds_bytes, int *scratch_bytes, int *max_blocks_per_cu);

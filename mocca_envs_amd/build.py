@@ -10,8 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libmocca_hip.so")
-SOURCES = ["mocca_api.hip"]
-DEPS = ["mocca_api.hip", "mocca_device.h", "topo_walker3d.h", "topo_cassie.h", "topo_walker2d.h", "topo_crab2d.h", "topo_laikago.h"]
+SOURCES = ["mocca_api.hip", "mocca_task.hip"]   # physics kernels + C ABI; task-layer (INJECT) kernel instances
+DEPS = SOURCES + ["mocca_kernels.h", "mocca_device.h", "topo_walker3d.h", "topo_cassie.h", "topo_walker2d.h", "topo_crab2d.h", "topo_laikago.h"]
 
 
 def _stale() -> bool:
@@ -22,20 +22,31 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:
     """hipcc --offload-arch=gfx950 -O3 -shared -fPIC; cross-compiles without a GPU."""
-    if not force and not _stale():
+    if not force and out is None and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     # -fno-slp-vectorize: the SLP vectoriser pairs scalar fp32 ops into v_pk_* but pays ~2 v_mov per pair to line
     # up register pairs; measured on this kernel it ADDS 12 % VALU instructions (DESIGN.md section 6)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
-           "-o", LIB] + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES]
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-I" + INCLUDE, "-I" + CSRC] + list(extra_flags)
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
-    return LIB
+        base.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs, procs = [], []
+    for src in SOURCES:   # the translation units compile in parallel
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = base + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out or LIB] + objs)
+    return out or LIB
 
 
 if __name__ == "__main__":

@@ -112,7 +112,7 @@ enum : int {
   L_A = L_V,            // [MAXR][MAXR] Delassus matrix, row = updated row, column = lane
   L_J = L_V + 960,      // [MAXR][28] Jacobian rows (tail of the A region)
   L_XL = L_V,           // [MAXR][28] M^-1 J^T lambda, after the iterations
-  L_TOTAL = L_V + MAXR * MAXR + 28,  // + one dummy J row for lanes that own no row
+  L_TOTAL = L_V + MAXR * MAXR + MAXR,  // + one dummy row: J row of lanes that own no row (28) / A-row prefetch past the last row (MAXR)
 };
 static_assert(L_ABA_END <= L_TOTAL, "ABA view must fit");
 static_assert(L_JR1 + 16 * MOCCA_MAX_BODIES <= L_TOTAL && (L_JR0 % 4) == 0 && (L_JR1 % 4) == 0, "joint records must fit, 16-byte aligned");
@@ -148,6 +148,21 @@ struct StepArgs {
   int host_retarget; // Custom: the host re-randomises the walk target
   int env_offset;    // global id of env 0 (RNG key)
   uint32_t seed_lo, seed_hi;
+  // per-env parameter vectors (mocca_set_param_v); null = the handle-wide scalar above
+  const float* curriculum_v;   // [N]
+  const float* eval_mode_v;    // [N]
+  const float* gain_v;         // [N] robot.applied_gain of the Custom envs (set_robot_params); the Stepper derives it from the curriculum
+  float gain;
+  // mocca_task_step (INJECT kernels): contact query results supplied by the caller instead of the physics
+  const int32_t* inj_touch;    // [N][NFEET] foot k touches the terrain
+  const int32_t* inj_target;   // [N][NFEET] foot k touches the cover of the target plank (or null)
+  const int32_t* inj_body;     // [N] a non-foot link touches the terrain (or null)
+  // INJECT kernels only: uniforms that replace the Philox draws, indexed by the episode's draw counter (the golden
+  // replays feed the very numbers the reference's numpy RandomState produced)
+  const float* tape;           // [N][tape_n] or null
+  int tape_n;
+  // optional per-env debug record of the LAST substep (mocca_set_debug_buffer): [N][MOCCA_DEBUG_WORDS] or null
+  int32_t* dbg;
 };
 
 // ------------------------------------------------------------------ helpers
@@ -285,6 +300,15 @@ DI float rng_uniform(uint32_t slo, uint32_t shi, uint32_t env, uint32_t episode,
   philox4x32(d >> 2, episode, env, 0u, slo, shi, o);
   uint32_t w = (d & 3) == 0 ? o[0] : (d & 3) == 1 ? o[1] : (d & 3) == 2 ? o[2] : o[3];
   return (float)(w >> 8) * (1.0f / 16777216.0f);
+}
+
+// d-th uniform of (env, episode): Philox, or -- in the INJECT kernels, when a tape is attached -- tape[d]
+template <bool INJECT>
+DI float draw_u(const StepArgs& a, int env, int episode, int d) {  // env = global id (env_offset + index in this handle)
+  if constexpr (INJECT) {
+    if (a.tape) return d < a.tape_n ? a.tape[(size_t)(env - a.env_offset) * a.tape_n + d] : 0.5f;
+  }
+  return rng_uniform(a.seed_lo, a.seed_hi, (uint32_t)env, (uint32_t)episode, (uint32_t)d);
 }
 
 // ------------------------------------------------------------------ kinematics
@@ -733,6 +757,10 @@ DI void seg_seg(const float* p1, const float* q1, const float* p2, const float* 
 // world (base-origin relative) end points of every geom: lane = geom end
 template <class T>
 DI void geom_points(ModelP M, float* L, int lane) {
+  // L_GP holds L_CT - L_GP floats; a topology with more geoms spills into the contact records, which is harmless only
+  // while nothing reads L_GP after the terrain contacts are written, i.e. without self-collision pairs
+  // (check_topology_t rejects blobs with pairs for such topologies)
+  static_assert(6 * T::NG <= L_CT - L_GP || T::NPAIR == 0, "geom points would overlap the contact records read by the self-collision pass");
   if (lane < 2 * T::NG) {
     const f4_t t = *(CF4P)(M->gp_tab[lane]);  // point (body frame) + body id, one load
     const int b = __float_as_int(t.w);
@@ -769,7 +797,7 @@ struct ContactFlags { int touch0, touch1, target0, target1, touch2, touch3, body
 // Contacts are compacted in slot order, then pair order (the oracle's priority), up to max_contacts.
 template <class T, int TASK>
 DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next_step_index,
-                        int* nc_out) {
+                        int* nc_out, int32_t* dbg) {
   STAMP_BEGIN;
   const float margin = unif(M->contact_margin);
   ContactFlags fl = {0, 0, 0, 0, 0, 0, 0};
@@ -842,6 +870,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
     fl.target1 = __ballot(active && gfoot == 1 && is_target) != 0ull;
   }
   int nc = __popcll(am);
+  int n_self = 0;
   {
     const int idx = lane_rank(am);
     if (active && idx < maxc) {
@@ -935,9 +964,13 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
       ct[C_MA] = __uint_as_float(M->anc_mask[ba]); ct[C_MB] = __uint_as_float(M->anc_mask[bb]);  // rare path
     }
     nc += __popcll(hm);
+    n_self += __popcll(hm);
     if (nc > maxc) nc = maxc;
   }
   STAMP(14);
+  if (dbg && lane == 0) {  // active set of this substep (MOCCA_DEBUG_WORDS, include/mocca.h)
+    dbg[3] = (int32_t)(unsigned)am; dbg[4] = (int32_t)(unsigned)(am >> 32); dbg[7] = n_self;
+  }
   *nc_out = nc;
   return fl;
 }
@@ -1013,7 +1046,7 @@ DI void pgs_fixed_rows(const float* Acol, float a, float a1, int r_fr, float& y,
 //      a visit is clamp, subtract, readlane, one-lane commit, fma (pgs_fixed_rows + the friction loop)
 //   6. nu += sum_r X_r lambda_r, summed in row order through LDS
 template <class T>
-DI void solve_constraints(ModelP M, float* L, int lane, int nc_found) {
+DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int32_t* dbg) {
   STAMP_BEGIN;
   // wave-uniform scalars live in SGPRs: loop control becomes s_cmp/s_cbranch instead of exec-mask bookkeeping
   const float dt = unif(M->dt), idt = rcp(dt);
@@ -1033,12 +1066,14 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found) {
     if (act && rk < maxr) reinterpret_cast<int*>(L)[L_ROWD + rk] = lane;
     nl = uni(__popcll(lm));
     if (nl > maxr) nl = maxr;
+    if (dbg && lane == 0) { dbg[5] = (int32_t)(unsigned)lm; dbg[6] = (int32_t)(unsigned)(lm >> 32); }
   }
   constexpr int NCL = 3 * T::NCLOS;  // point-to-point closure rows sit between the limit and the contact rows
   int nc = uni(nc_found);
   if (nc > (maxr - nl - NCL) / 3) nc = (maxr - nl - NCL) / 3;
   if (nc < 0) nc = 0;
   const int nr = nl + NCL + 3 * nc;
+  if (dbg && lane == 0) { dbg[0] = nr; dbg[1] = nl; dbg[2] = nc; }
   // Load balancing across the waves of a SIMD: the launch lasts as long as its slowest wave, and a wave's cost grows with
   // its row count (an env lying on the ground has 48 rows, a standing one ~20).  Issue priority follows the row count,
   // so heavy waves run at nearly their stand-alone speed while light ones -- which have slack -- yield.  nr is in an
@@ -1283,12 +1318,12 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found) {
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
     pgs_fixed_rows<0>(Acol, Acol[0], Acol[MAXR], r_fr, y, lam, invdiag, lo0);
-    float a = Acol[MAXR * r_fr];
+    float a = Acol[MAXR * (r_fr < MAXR ? r_fr : MAXR)];
 #pragma unroll 1
     for (int i = 0; i < nc; ++i) {  // the two friction rows of contact i share the bound mu * lam[normal row of i]
       const float lm = mu * readlane(lam, nl + NCL + i);
       const int rr = r_fr + 2 * i;
-      const float a1 = Acol[MAXR * (rr + 1)], a2 = Acol[MAXR * (rr + 2)];
+      const float a1 = Acol[MAXR * (rr + 1)], a2 = Acol[MAXR * (rr + 2 < MAXR ? rr + 2 : MAXR)];  // row MAXR: the dummy row
       const float as = a * invdiag, as1 = a1 * invdiag;
       float nl_ = __builtin_amdgcn_fmed3f(y, -lm, lm);
       float dl = readlane(nl_ - lam, rr);
@@ -1388,7 +1423,7 @@ DI void stage_joints(ModelP M, float* L, int lane) {
 // one physics substep (what stepSimulation does numSubSteps times, bullet_utils.py:346-353)
 template <class T, int TASK>
 DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next_step_index,
-                        unsigned long long ppk) {
+                        unsigned long long ppk, int32_t* dbg) {
   STAMP(30);
   stage_joints<T>(M, L, lane);
   STAMP(29);
@@ -1402,7 +1437,7 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
 #ifdef MOCCA_SKIP_COLLIDE  // profiling builds only (tools/ablate.sh): results are wrong by construction
   ContactFlags fl = {0, 0, 0, 0, 0, 0, 0};
 #else
-  ContactFlags fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc);
+  ContactFlags fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc, dbg);
 #endif
   STAMP(1);
 #ifndef MOCCA_SKIP_ABA
@@ -1410,7 +1445,7 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
 #endif
   STAMP(2);
 #ifndef MOCCA_SKIP_SOLVE
-  solve_constraints<T>(M, L, lane, nc);
+  solve_constraints<T>(M, L, lane, nc, dbg);
 #endif
   STAMP(3);
 #ifdef MOCCA_DUMMY_VALU  // experiment: is the kernel VALU-issue-bound?  (tools/ab.sh variants)
@@ -1518,16 +1553,17 @@ DI void calc_potential(ModelP M, const float* L, TaskRegs& t, float yaw, float* 
   t.linpot = -(*dist) / M->control_dt;
   t.angpot = cosf(*ang);
 }
-DI void randomize_target(const StepArgs& a, int env, TaskRegs& t) {  // env_locomotion.py:67-74
-  if (a.eval_mode) { t.dist = 4; t.angle = 0; }
+template <bool INJECT>
+DI void randomize_target(const StepArgs& a, int env, TaskRegs& t, bool eval_mode) {  // env_locomotion.py:67-74
+  if (eval_mode) { t.dist = 4; t.angle = 0; }
   else {
-    const float u0 = rng_uniform(a.seed_lo, a.seed_hi, env, t.episode, t.draw);
-    const float u1 = rng_uniform(a.seed_lo, a.seed_hi, env, t.episode, t.draw + 1);
+    const float u0 = draw_u<INJECT>(a, env, t.episode, t.draw);
+    const float u1 = draw_u<INJECT>(a, env, t.episode, t.draw + 1);
     t.draw += 2;
     t.dist = 3 + 2 * u0;
     t.angle = -1.5707963267948966f + 3.141592653589793f * u1;
   }
-  const float u2 = rng_uniform(a.seed_lo, a.seed_hi, env, t.episode, t.draw);
+  const float u2 = draw_u<INJECT>(a, env, t.episode, t.draw);
   t.draw += 1;
   t.stopf = u2 < 0.5f ? 30.0f : 60.0f;
 }
@@ -1565,13 +1601,14 @@ DI void delta_to_k_targets(const float* L, const float* ter, TaskRegs& t, float 
 
 // generate_step_placements, env_locomotion.py:395-441: 100 uniforms (5 x 20) -> 20 x 6 table in `ter`.
 // Lanes draw in parallel (counter-based RNG), lane 0 runs the cumulative sums.
+template <bool INJECT>
 DI void generate_terrain(const StepArgs& a, int env, TaskRegs& t, float* L, float* ter, int lane) {
   const float DEG = 3.14159265358979323846f / 180.0f, HP = 1.5707963267948966f;
   const int N = MOCCA_MAX_TERRAIN_STEPS;
   const int cur = t.cur > 9 ? 9 : t.cur;
   const float ratio = (float)cur / 9.0f;
   float* u = L + L_J;  // scratch (solver view is idle during a reset)
-  for (int k = lane; k < 5 * N; k += 64) u[k] = rng_uniform(a.seed_lo, a.seed_hi, env, t.episode, t.draw + k);
+  for (int k = lane; k < 5 * N; k += 64) u[k] = draw_u<INJECT>(a, env, t.episode, t.draw + k);
   t.draw += 5 * N;
   wsync();
   if (lane == 0) {
@@ -1607,23 +1644,29 @@ DI void generate_terrain(const StepArgs& a, int env, TaskRegs& t, float* L, floa
 }
 
 // env.reset() for one env (lane-parallel); leaves the new state in LDS and writes obs.
-template <class T, int TASK>
+DI int live_curriculum(const StepArgs& a, int env) {  // env = index in this handle
+  if (a.curriculum_v) { const int c = (int)a.curriculum_v[env]; return c < 0 ? 0 : (c > 9 ? 9 : c); }
+  return a.curriculum;
+}
+DI bool live_eval_mode(const StepArgs& a, int env) { return a.eval_mode_v ? a.eval_mode_v[env] != 0.0f : a.eval_mode != 0; }
+
+template <class T, int TASK, bool INJECT = false>
 DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, int lane, TaskRegs& t,
                   float* obs) {
   const int ep = t.episode + 1, cur = t.cur;
   t = TaskRegs{};
   t.episode = ep;
-  t.cur = TASK == MOCCA_TASK_WALKER3D_STEPPER ? a.curriculum : cur;
-  t.gain = 1.0f;
+  t.cur = TASK == MOCCA_TASK_WALKER3D_STEPPER ? live_curriculum(a, env - a.env_offset) : cur;
+  t.gain = a.gain_v ? a.gain_v[env - a.env_offset] : a.gain;  // robot.applied_gain persists across resets (robots.py:16,33)
   if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
-    randomize_target(a, env, t);
+    randomize_target<INJECT>(a, env, t, live_eval_mode(a, env - a.env_offset));
     t.wt[0] = t.dist * cosf(t.angle);
     t.wt[1] = t.dist * sinf(t.angle);
     t.wt[2] = 1.0f;
   } else {
     t.gain = 1.0f + 0.2f * t.cur / 9;
   }
-  t.mirrored = rng_uniform(a.seed_lo, a.seed_hi, env, t.episode, t.draw) < 0.5f;
+  t.mirrored = draw_u<INJECT>(a, env, t.episode, t.draw) < 0.5f;
   t.draw += 1;
   if (lane >= 1 && lane < T::NB) {
     const int b = lane;
@@ -1640,12 +1683,15 @@ DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, in
       for (int k = 0; k < M->n_mirror_neg; ++k) if (M->mirror_neg[k] == j) sgn = -1.0f;
     }
     const float base = sgn * M->init_q[src];
-    float ds = -0.1f + 0.2f * rng_uniform(a.seed_lo, a.seed_hi, env, t.episode, t.draw + (b - 1));
-    if (!a.random_pose) ds = 0.0f;
-    const float wt = M->jhi[b] - M->jlo[b], bs = M->jlo[b];
-    float ps = 2 * (base + ds - bs) / wt - 1;
-    ps = ps < -0.95f ? -0.95f : (ps > 0.95f ? 0.95f : ps);
-    L[L_Q + b] = wt * (ps + 1) / 2 + bs;
+    const float ds = -0.1f + 0.2f * draw_u<INJECT>(a, env, t.episode, t.draw + (b - 1));
+    float qn = base;
+    if (a.random_pose) {  // robots.py:190-194: deviation, normalise, clip to +-0.95, back to radians -- only when random_pose
+      const float wt = M->jhi[b] - M->jlo[b], bs = M->jlo[b];
+      float ps = 2 * (base + ds - bs) / wt - 1;
+      ps = ps < -0.95f ? -0.95f : (ps > 0.95f ? 0.95f : ps);
+      qn = wt * (ps + 1) / 2 + bs;
+    }
+    L[L_Q + b] = qn;
     L[L_QD + b] = 0.0f;
   }
   t.draw += T::NJ;
@@ -1670,7 +1716,7 @@ DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, in
       if (M->task_flags & MOCCA_TASKF_RESET_TAIL_ZERO) { obs[nbo] = 0.0f; obs[nbo + 1] = 0.0f; }  // Walker2DCustomEnv.reset, :299-300
     }
   } else {
-    generate_terrain(a, env, t, L, ter, lane);
+    generate_terrain<INJECT>(a, env, t, L, ter, lane);
     t.nsi = 1;
     delta_to_k_targets(L, ter, t, ro.rpy[2], lane, obs + nbo);
     calc_potential(M, L, t, ro.rpy[2], &dist, &ang);

@@ -1,0 +1,360 @@
+// mocca_kernels.h -- the __global__ entry points (templates over topology, task and the INJECT switch).
+// Instantiated by mocca_api.hip (physics kernels: INJECT = false) and mocca_task.hip (task-layer kernels behind
+// mocca_task_step / taped resets: INJECT = true), two translation units so they compile in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mocca.h"
+#include "mocca_device.h"
+
+namespace mocca {
+
+#ifndef MOCCA_WAVES_PER_EU
+#define MOCCA_WAVES_PER_EU 4
+#endif
+
+// --------------------------------------------------------------------------------------------
+// kernels: one 64-lane workgroup (= one wavefront) per environment
+// --------------------------------------------------------------------------------------------
+// INJECT = true is the task-layer entry (mocca_task_step): the same code with ZERO physics substeps, the contact query
+// results taken from the caller (a.inj_*) and, when a tape is attached, its uniforms in place of the Philox draws.
+template <class T, int TASK, bool INJECT = false>
+__global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(StepArgs a) {
+  __shared__ float L[L_TOTAL];
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= a.n_envs) return;
+  ModelP M = (ModelP)a.model;
+  float* st = a.dyn + (size_t)env * DYN_STRIDE;
+  uint32_t* tk = a.task + (size_t)env * MOCCA_TASK_WORDS;
+  float* ter = TASK == MOCCA_TASK_WALKER3D_STEPPER ? a.terrain + (size_t)env * TERRAIN_STRIDE : nullptr;
+  float* obs = a.obs + (size_t)env * a.obs_dim;
+  int32_t* dbg = a.dbg ? a.dbg + (size_t)env * MOCCA_DEBUG_WORDS : nullptr;
+
+  load_dyn(st, L, lane, T::NJ, T::NSLOT);
+  // the lane's root->body path, packed 5 bits per step; the only lane-derived value kept across the substeps
+  const unsigned long long ppk = T::path_packed(lane < T::NB ? lane : 0);
+  if constexpr (TASK == MOCCA_TASK_CASSIE) {
+    // ---- CassieEnv.step (env_cassie.py:433-479): 50 x { filter joint speeds, PD torques, one physics step }
+    const int no = M->n_ordered, nctl = M->n_ctrl;
+    float target = 0.0f;  // env_cassie.py:434-443: base angle (residual control) + action, 0 for the springs
+    if (lane < nctl) target = M->ctrl_base[lane] + (lane < nctl - 2 ? a.act[(size_t)env * (nctl - 2) + lane] : 0.0f);
+    if (lane < no) {
+      L[L_JVEL + lane] = __uint_as_float(tk[T_JVEL + lane]);
+      L[L_Q0 + lane] = L[L_Q + M->ordered_body[lane]];
+    }
+    if (lane < MOCCA_MAX_BODIES) L[L_TAU + lane] = 0.0f;
+    if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
+    wsync();
+    const int nllc = INJECT ? 0 : M->n_llc;
+#pragma unroll 1
+    for (int it = 0; it < nllc; ++it) {
+      ModelP Ms = M;
+      int ln = lane;
+      unsigned long long pk = ppk;
+      asm volatile("" : "+s"(Ms), "+v"(ln), "+v"(pk));
+      if (ln < no) {  // :451-453
+        const float al = Ms->jvel_alpha;
+        L[L_JVEL + ln] = (1.0f - al) * L[L_JVEL + ln] + al * L[L_QD + Ms->ordered_body[ln]];
+      }
+      wsync();
+      if (ln < nctl) {  // pd_control :380-393 + torque clip :225-230
+        const int b = Ms->ctrl_body[ln];
+        const float perr = target - L[L_Q + b];
+        float verr = -L[L_JVEL + Ms->ctrl_oidx[ln]];
+        verr = verr < -5.0f ? -5.0f : (verr > 5.0f ? 5.0f : verr);
+        const float tq = Ms->ctrl_kp[ln] * perr + Ms->ctrl_kd[ln] * verr, lim = Ms->torque_limit[b];
+        L[L_TAU + b] = tq < -lim ? -lim : (tq > lim ? lim : tq);
+      }
+      wsync();
+      substep<T, TASK>(Ms, L, ln, nullptr, 0, pk, dbg);
+    }
+    TaskRegs t;
+    load_task(tk, t);
+    t.istep += nllc;
+    if (lane < no) {  // :467-468 finite-difference joint velocity over the control step
+      const float jv = (L[L_Q + M->ordered_body[lane]] - L[L_Q0 + lane]) / M->control_dt;
+      tk[T_JVEL + lane] = __float_as_uint(jv);
+    }
+    stage_joints<T>(M, L, lane);
+    walk_kinematics<T, false>(M, L, lane, T::path_packed(lane < T::NB ? lane : 0));
+    wsync();
+    t.t += 1;
+    bool fin;
+    const float height = cassie_obs<T>(M, L, lane, t.initz, obs, &fin);
+    const float old = t.linpot;
+    t.linpot = cassie_potential(M, L);
+    const float alive = height > M->alive_height ? 2.0f : -1.0f;  // compute_rewards :401-414
+    if (!fin || alive < 0.0f) t.done = 1;
+    const int timeout = t.t >= M->max_episode_steps;
+    const int dflag = (t.done ? 1 : 0) | (timeout ? 2 : 0);
+    if (lane == 0) {
+      a.rew[env] = alive + (t.linpot - old);
+      a.done[env] = (uint8_t)dflag;
+      if (a.info) a.info[env] = 0;
+    }
+    if (a.auto_reset && dflag) {
+      wsync();
+      cassie_reset_env<T>(M, L, lane, t, obs);
+      if (lane < MOCCA_MAX_CTRL) tk[T_JVEL + lane] = 0u;
+    }
+    wsync();
+    store_dyn(st, L, lane, T::NJ, T::NSLOT);
+    if (lane == 0) store_task(tk, t);
+    return;
+  }
+  // apply_action, robots.py:31-40.  Only the two task words the physics needs are read before the substeps;
+  // the rest of the task record is loaded after them so it does not occupy registers across the loop.
+  {
+    const float applied_gain = __uint_as_float(tk[T_GAIN]);
+    if (lane < T::NJ) {
+      const float act_raw = a.act[(size_t)env * T::NJ + lane];
+      const float c = act_raw < -1.0f ? -1.0f : (act_raw > 1.0f ? 1.0f : act_raw);
+      L[L_TAU + 1 + lane] = M->gain[lane + 1] * applied_gain * c;
+    }
+  }
+  if (lane == 0) { L[L_TAU] = 0.0f; L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
+  wsync();
+
+  STAMP(28);  // kernel prologue done
+  if constexpr (TASK == MOCCA_TASK_WALKER3D_STEPPER) stage_planks(M, L, lane, ter);
+  ContactFlags fl = {0, 0, 0, 0, 0, 0, 0};
+  const int nsub = INJECT ? 0 : M->n_substeps;
+  const int nsi0 = TASK == MOCCA_TASK_WALKER3D_STEPPER ? (int)tk[T_NSI] : 0;
+#pragma unroll 1
+  for (int s = 0; s < nsub; ++s) {
+    // launder the model pointer: keeps LICM from hoisting dozens of loop-invariant model loads out of the
+    // substep loop, where they would sit in registers (and spill to scratch) for the whole kernel
+    ModelP Ms = M;
+    int ln = lane;  // same for lane-derived offsets and predicates (recomputing them costs a few instructions)
+    unsigned long long pk = ppk;  // laundered too: otherwise every (ppk >> 5k) & 31 and the addresses derived from it
+    asm volatile("" : "+s"(Ms), "+v"(ln), "+v"(pk));  // are hoisted out of the loop and spilled
+    fl = substep<T, TASK>(Ms, L, ln, ter, nsi0, pk, dbg);
+  }
+  if constexpr (INJECT) {  // getContactPoints results handed in by the caller (robots.py:74-86, env_locomotion.py:634-650, :880-890)
+    const int32_t* tc = a.inj_touch + (size_t)env * T::NFEET;
+    fl.touch0 = tc[0] != 0; fl.touch1 = tc[1] != 0;
+    if constexpr (T::NFEET > 2) { fl.touch2 = tc[2] != 0; fl.touch3 = tc[3] != 0; }
+    if (a.inj_target) { fl.target0 = a.inj_target[(size_t)env * T::NFEET] != 0; fl.target1 = a.inj_target[(size_t)env * T::NFEET + 1] != 0; }
+    if (a.inj_body) fl.body_touch = a.inj_body[env] != 0;
+  }
+  STAMP(27);  // substeps done
+  TaskRegs t;
+  load_task(tk, t, T::NFEET > 2);
+  // the raw (unclipped) action enters the energy penalty (env_locomotion.py:185-188); re-read it rather than
+  // hold a register across the substeps
+  const float act_raw = lane < T::NJ ? a.act[(size_t)env * T::NJ + lane] : 0.0f;
+
+  // ---- calc_state + task logic on the post-step state
+  {
+    int lo = lane;  // laundered: the walk's lane-derived body index would otherwise be kept (spilled) from kernel entry
+    asm volatile("" : "+v"(lo));
+    stage_joints<T>(M, L, lo);
+    walk_kinematics<T, false>(M, L, lo, ppk);
+  }
+  wsync();
+  t.t += 1;
+  constexpr int NBO = 6 + 2 * T::NJ + T::NFEET;
+  float rew = 0.0f;
+  int info = 0;
+  if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
+    const bool evalm = live_eval_mode(a, env);
+    if (evalm) { t.wt[0] = t.prevx + 4.0f; t.wt[1] = 0.0f; t.wt[2] = 1.0f; }  // env_locomotion.py:115-116
+    t.fc0 = (float)fl.touch0; t.fc1 = (float)fl.touch1;                                // robots.py:74-86
+    t.fc2 = (float)fl.touch2; t.fc3 = (float)fl.touch3;
+    RobotObs ro = robot_obs<T>(M, L, lane, t.fc0, t.fc1, obs, t.fc2, t.fc3);
+    if (!ro.finite) t.done = 1;                                                        // :205-207
+    const float old = t.linpot;
+    float dist, ang;
+    calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+    const float progress = t.linpot - old;
+    float posture = 0.0f;
+    const float pitch = ro.rpy[1], roll = ro.rpy[0];
+    if (!(-0.2f < pitch && pitch < 0.4f)) posture = fabsf(pitch);                      // :178-183
+    if (!(-0.4f < roll && roll < 0.4f)) posture += fabsf(roll);
+    const float e1 = wave_sum(lane < T::NJ ? fabsf(act_raw * ro.spd) : 0.0f);
+    const float e2 = wave_sum(lane < T::NJ ? act_raw * act_raw : 0.0f);
+    const float energy = M->electricity_cost * (e1 / T::NJ) + M->stall_torque_cost * (e2 / T::NJ);
+    const float joints = M->joints_at_limit_cost * (float)ro.jal;
+    float tall = ro.height > M->termination_height ? 2.0f : -1.0f;
+    if (tall < 0) t.done = 1;
+    if (M->task_flags & MOCCA_TASKF_BODY_CONTACT) {                                    // LaikagoCustomEnv, :877-890
+      tall = 0.0f;
+      if (fl.body_touch) { tall = -1.0f; t.done = 1; }
+    }
+    float bonus = 0.0f;
+    if (dist < 0.15f) { t.close += 1; bonus = 2.0f; }                                  // :198-202
+    if ((float)t.close >= t.stopf && !a.host_retarget) {                               // :214-222
+      t.close = 0;
+      randomize_target<INJECT>(a, env + a.env_offset, t, evalm);
+      t.wt[0] += t.dist * cosf(t.angle);
+      t.wt[1] += t.dist * sinf(t.angle);
+      calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+    }
+    rew = progress + bonus - energy + tall - posture - joints;                         // :121-122
+    if (lane == 0) softsign_tail(dist, ang, obs + NBO);
+    if (M->task_flags & MOCCA_TASKF_NEVER_DONE) t.done = 0;                            // Walker2DCustomEnv.step, :302-309
+  } else {
+    // env_locomotion.py:515-568
+    t.setstop = (t.nsi == 6 || t.nsi == 7 || t.nsi == 13 || t.nsi == 14);             // :522
+    RobotObs ro = robot_obs<T>(M, L, lane, t.fc0, t.fc1, obs);                         // previous step's contacts, :525
+    if (!ro.finite) t.done = 1;
+    const int cur_idx = t.nsi;
+    // calc_feet_state :632-674
+    float fd[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float dx = L[L_FEET + 3 * k] - ter[6 * t.nsi], dy = L[L_FEET + 3 * k + 1] - ter[6 * t.nsi + 1];
+      fd[k] = sqrtf(dx * dx + dy * dy);
+    }
+    t.fc0 = (float)fl.touch0; t.fc1 = (float)fl.touch1;
+    const bool reached = fl.target0 || fl.target1;
+    if (reached) {
+      t.trc += 1;
+      if (t.trc > 120) { t.stop = 0; t.setstop = 0; }
+      if (t.trc >= 2) {
+        if (!t.stop) {
+          t.nsi += 1;
+          t.trc = 0;
+          if (t.nsi >= MOCCA_MAX_PLANKS) {                                              // update_steps :472-479
+            const int oldest = t.nsi % MOCCA_MAX_PLANKS;
+            const int nx = t.nsi < MOCCA_MAX_TERRAIN_STEPS - 1 ? t.nsi : MOCCA_MAX_TERRAIN_STEPS - 1;
+            if (lane == 0) ter[120 + oldest] = (float)nx;
+          }
+        }
+        t.stop = t.setstop;
+      }
+      if (t.nsi >= MOCCA_MAX_TERRAIN_STEPS) t.nsi -= 1;
+    }
+    // calc_base_reward :598-630
+    const float old = t.linpot;
+    float dist, ang;
+    calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+    const float progress = t.linpot - old;
+    float posture = 0.0f;
+    const float pitch = ro.rpy[1], roll = ro.rpy[0];
+    if (!(-0.2f < pitch && pitch < 0.4f)) posture = fabsf(pitch);
+    if (!(-0.4f < roll && roll < 0.4f)) posture += fabsf(roll);
+    const float e1 = wave_sum(lane < T::NJ ? fabsf(act_raw * ro.spd) : 0.0f);
+    const float e2 = wave_sum(lane < T::NJ ? act_raw * act_raw : 0.0f);
+    const float energy = M->electricity_cost * (e1 / T::NJ) + M->stall_torque_cost * (e2 / T::NJ);
+    const float joints = M->joints_at_limit_cost * (float)ro.jal;
+    // terminal_height_curriculum[self.curriculum], :368,628: the env's CURRENT curriculum (set_env_params acts at once
+    // on this line, at the next reset on terrain and gain)
+    const float term_h = 0.75f + (0.45f - 0.75f) * live_curriculum(a, env) / 9;
+    const float tall = ro.height > term_h ? 2.0f : -1.0f;
+    if (tall < 0) t.done = 1;
+    // calc_step_reward :676-693
+    const int last = MOCCA_MAX_TERRAIN_STEPS - 1;
+    float step_bonus = 0.0f, bonus = 0.0f;
+    if (reached && t.trc == 1 && t.nsi != last) step_bonus = 50.0f * powf(2.718f, -fminf(fd[0], fd[1]) / 0.25f);
+    if ((t.nsi == last || t.stop) && dist < 0.15f) bonus = 2.0f;
+    __threadfence_block();
+    delta_to_k_targets(L, ter, t, ro.rpy[2], lane, obs + NBO);
+    if (cur_idx != t.nsi) calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+    rew = progress - energy + step_bonus + bonus + tall - posture - joints;            // :528-531
+    info = t.nsi;
+  }
+  t.prevx = L[L_BASE];
+  const int timeout = t.t >= M->max_episode_steps;
+  const int dflag = (t.done ? 1 : 0) | (timeout ? 2 : 0);
+  if (lane == 0) {
+    a.rew[env] = rew;
+    a.done[env] = (uint8_t)dflag;
+    if (a.info) a.info[env] = info;
+  }
+  STAMP(26);  // observation + reward done
+  if (a.auto_reset && dflag) {
+    wsync();
+    reset_env<T, TASK, INJECT>(a, M, L, ter, env + a.env_offset, lane, t, obs);
+  }
+  wsync();
+  store_dyn(st, L, lane, T::NJ, T::NSLOT);
+  if (lane == 0) store_task(tk, t, T::NFEET > 2);
+  STAMP(25);  // reset (if any) + write-back done
+#ifdef MOCCA_STAMPS
+  if (lane == 0 && blockIdx.x < STAMP_WAVES) g_stamps[blockIdx.x * STAMP_SLOTS + 24] = (unsigned long long)(a.auto_reset && dflag);
+#endif
+}
+
+template <class T, int TASK, bool INJECT = false>
+__global__ __launch_bounds__(64) void mocca_reset_kernel(StepArgs a) {
+  __shared__ float L[L_TOTAL];
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= a.n_envs) return;
+  if (a.mask && !a.mask[env]) return;
+  ModelP M = (ModelP)a.model;
+  float* st = a.dyn + (size_t)env * DYN_STRIDE;
+  uint32_t* tk = a.task + (size_t)env * MOCCA_TASK_WORDS;
+  float* ter = TASK == MOCCA_TASK_WALKER3D_STEPPER ? a.terrain + (size_t)env * TERRAIN_STRIDE : nullptr;
+  TaskRegs t;
+  load_task(tk, t, T::NFEET > 2);
+  if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
+  if constexpr (TASK == MOCCA_TASK_CASSIE) {
+    cassie_reset_env<T>(M, L, lane, t, a.obs + (size_t)env * a.obs_dim);
+    if (lane < MOCCA_MAX_CTRL) tk[T_JVEL + lane] = 0u;
+  } else {
+    reset_env<T, TASK, INJECT>(a, M, L, ter, env + a.env_offset, lane, t, a.obs + (size_t)env * a.obs_dim);
+  }
+  wsync();
+  store_dyn(st, L, lane, T::NJ, T::NSLOT);
+  if (lane == 0) store_task(tk, t, T::NFEET > 2);
+}
+
+// calc_state + observation tail on the stored state (no physics, no randomness)
+template <class T, int TASK>
+__global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
+  __shared__ float L[L_TOTAL];
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= a.n_envs) return;
+  ModelP M = (ModelP)a.model;
+  const float* st = a.dyn + (size_t)env * DYN_STRIDE;
+  uint32_t* tk = a.task + (size_t)env * MOCCA_TASK_WORDS;
+  const float* ter = TASK == MOCCA_TASK_WALKER3D_STEPPER ? a.terrain + (size_t)env * TERRAIN_STRIDE : nullptr;
+  float* obs = a.obs + (size_t)env * a.obs_dim;
+  load_dyn(st, L, lane, T::NJ, T::NSLOT);
+  TaskRegs t;
+  load_task(tk, t, T::NFEET > 2);
+  if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
+  wsync();
+  stage_joints<T>(M, L, lane);
+  walk_kinematics<T, false>(M, L, lane, T::path_packed(lane < T::NB ? lane : 0));
+  wsync();
+  constexpr int NBO = 6 + 2 * T::NJ + T::NFEET;
+  if constexpr (TASK == MOCCA_TASK_CASSIE) {
+    bool fin;
+    cassie_obs<T>(M, L, lane, t.initz, obs, &fin);
+    t.linpot = cassie_potential(M, L);
+  } else {
+    RobotObs ro = robot_obs<T>(M, L, lane, t.fc0, t.fc1, obs, t.fc2, t.fc3);
+    float dist, ang;
+    if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
+      calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+      if (lane == 0) softsign_tail(dist, ang, obs + NBO);
+    } else {
+      delta_to_k_targets(L, ter, t, ro.rpy[2], lane, obs + NBO);
+      calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+    }
+    t.prevx = L[L_BASE];
+  }
+  if (lane == 0) store_task(tk, t, T::NFEET > 2);
+}
+
+
+// compiled topologies: the tree of the blob selects the kernel instance
+enum { TOPO_WALKER3D = 0, TOPO_CASSIE = 1, TOPO_WALKER2D = 2, TOPO_CRAB2D = 3, TOPO_LAIKAGO = 4 };
+// kernel selection by (topology, task id)
+template <template <class, int> class Launcher, class... Args>
+static void dispatch(int topo, int task_id, Args... args) {
+  if (topo == TOPO_CASSIE) Launcher<TopoCassie, MOCCA_TASK_CASSIE>::run(args...);
+  else if (topo == TOPO_WALKER2D) Launcher<TopoWalker2D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
+  else if (topo == TOPO_CRAB2D) Launcher<TopoCrab2D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
+  else if (topo == TOPO_LAIKAGO) Launcher<TopoLaikago, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
+  else if (task_id == MOCCA_TASK_WALKER3D_CUSTOM) Launcher<TopoWalker3D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
+  else Launcher<TopoWalker3D, MOCCA_TASK_WALKER3D_STEPPER>::run(args...);
+}
+
+// defined in mocca_task.hip (INJECT = true instances)
+void launch_task_step(int topo, int task_id, int n, hipStream_t s, StepArgs a);
+void launch_taped_reset(int topo, int task_id, int n, hipStream_t s, StepArgs a);
+
+}  // namespace mocca

@@ -12,8 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # MOCCA_LIB_PATH selects another build of the same HIP library (A/B kernel experiments); never a CPU fallback
 LIB_PATH = os.environ.get("MOCCA_LIB_PATH") or os.path.join(HERE, "libmocca_hip.so")
 
-ABI_VERSION = 1
-PARAM_AUTO_RESET, PARAM_EVAL_MODE, PARAM_CURRICULUM, PARAM_RANDOM_POSE, PARAM_HOST_RETARGET, PARAM_SEED, PARAM_ENV_OFFSET = 0, 1, 2, 3, 4, 5, 6
+ABI_VERSION = 2
+PARAM_AUTO_RESET, PARAM_EVAL_MODE, PARAM_CURRICULUM, PARAM_RANDOM_POSE, PARAM_HOST_RETARGET, PARAM_SEED, PARAM_ENV_OFFSET, PARAM_APPLIED_GAIN = 0, 1, 2, 3, 4, 5, 6, 7
+DEBUG_WORDS = 8
 
 # every symbol include/mocca.h declares: (name, restype, argtypes)
 _vp, _i, _u64, _sz, _d = C.c_void_p, C.c_int, C.c_uint64, C.c_size_t, C.c_double
@@ -28,6 +29,8 @@ SYMBOLS = {
     "mocca_state_dim": (_i, [_vp]),
     "mocca_reset": (_i, [_vp, _vp, _u64, _vp, _vp]),
     "mocca_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocca_task_step": (_i, [_vp] * 10),
+    "mocca_set_draw_tape": (_i, [_vp, _vp, _i]),
     "mocca_observe": (_i, [_vp, _vp, _vp]),
     "mocca_get_state": (_i, [_vp, _vp, _vp]),
     "mocca_set_state": (_i, [_vp, _vp, _vp]),
@@ -36,6 +39,10 @@ SYMBOLS = {
     "mocca_get_terrain": (_i, [_vp, _vp, _vp]),
     "mocca_set_terrain": (_i, [_vp, _vp, _vp]),
     "mocca_set_param": (_i, [_vp, _i, _d]),
+    "mocca_set_param_v": (_i, [_vp, _i, _vp, _i, _vp]),
+    "mocca_set_seed": (_i, [_vp, _u64]),
+    "mocca_set_debug_buffer": (_i, [_vp, _vp]),
+    "mocca_is_diagnostic_build": (_i, []),
     "mocca_kernel_info": (_i, [_vp] + [C.POINTER(_i)] * 5),
     "mocca_last_error": (C.c_char_p, [_vp]),
 }
@@ -62,6 +69,11 @@ def load() -> C.CDLL:
         fn.restype, fn.argtypes = res, args
     if lib.mocca_abi_version() != ABI_VERSION:
         raise MoccaError("libmocca_hip.so ABI version mismatch; rebuild")
+    if lib.mocca_is_diagnostic_build() and not os.environ.get("MOCCA_ALLOW_DIAGNOSTIC_BUILD"):
+        # -DMOCCA_SKIP_* / MOCCA_DUMMY_VALU / MOCCA_STAMPS builds (tools/ablate*.sh, tools/stamps.py) skip phases of the
+        # physics or add timing stores: never the product
+        raise MoccaError(f"{LIB_PATH} is a diagnostic build (results wrong or slow by construction); "
+                         "set MOCCA_ALLOW_DIAGNOSTIC_BUILD=1 to load it for profiling")
     _lib = lib
     return lib
 

@@ -116,10 +116,47 @@ class VecEnv:
     def set_param(self, pid: int, value: float):
         _lib.check(self.lib.mocca_set_param(self.h, pid, float(value)), self.h)
 
+    def set_param_v(self, pid: int, values, broadcast: bool = False):
+        """Per-env curriculum / eval_mode / applied_gain (include/mocca.h mocca_set_param_v); values: [N] (or [1] with broadcast)."""
+        v = torch.as_tensor(values, dtype=torch.float32).to(self.device).contiguous().reshape(-1)
+        if v.numel() != (1 if broadcast else self.n_envs):
+            raise ValueError("values must hold one float per env (or one float with broadcast=True)")
+        _lib.check(self.lib.mocca_set_param_v(self.h, pid, C.c_void_p(v.data_ptr()), int(broadcast), self._stream()), self.h)
+
     def seed(self, seed: int):
-        self.seed_value = int(seed)
-        self.set_param(_lib.PARAM_SEED, self.seed_value)
+        """Philox key of the in-kernel draws.  The (episode, draw) counters of the envs are NOT rewound: a re-seeded
+        VecEnv continues with new random numbers, it does not replay a fresh env's stream (create a new VecEnv for that)."""
+        self.seed_value = int(seed) & 0xFFFFFFFFFFFFFFFF
+        _lib.check(self.lib.mocca_set_seed(self.h, self.seed_value), self.h)
         return [seed]
+
+    def set_draw_tape(self, tape) -> None:
+        """Uniforms that replace the Philox draws of reset() / task_step(), [N][n] (None detaches); golden replays only."""
+        if tape is None:
+            self._tape = None
+            _lib.check(self.lib.mocca_set_draw_tape(self.h, None, 0), self.h)
+            return
+        self._tape = torch.as_tensor(tape, dtype=torch.float32).to(self.device).contiguous().reshape(self.n_envs, -1)
+        _lib.check(self.lib.mocca_set_draw_tape(self.h, C.c_void_p(self._tape.data_ptr()), self._tape.shape[1]), self.h)
+
+    def set_debug(self, on: bool = True) -> Optional[torch.Tensor]:
+        """Attach (or detach) the per-env active-set record of the last substep: [N][8] int32, words MOCCA_DBG_*."""
+        self.debug = torch.zeros(self.n_envs, _lib.DEBUG_WORDS, dtype=torch.int32, device=self.device) if on else None
+        _lib.check(self.lib.mocca_set_debug_buffer(self.h, C.c_void_p(self.debug.data_ptr()) if on else None), self.h)
+        return self.debug
+
+    def task_step(self, actions: torch.Tensor, touch, target=None, body=None):
+        """env.step()'s task layer on the stored (post-physics) state with caller-supplied contact flags
+        (include/mocca.h mocca_task_step): the golden replays of the reference's scripted episodes."""
+        actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        i32 = lambda x: None if x is None else torch.as_tensor(x, dtype=torch.int32).to(self.device).contiguous()
+        touch, target, body = i32(touch), i32(target), i32(body)
+        ptr = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+        _lib.check(self.lib.mocca_task_step(self.h, C.c_void_p(actions.data_ptr()), ptr(touch), ptr(target), ptr(body),
+                                            C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.rew.data_ptr()),
+                                            C.c_void_p(self.done.data_ptr()), C.c_void_p(self.info.data_ptr()), self._stream()), self.h)
+        torch.cuda.current_stream(self.device).synchronize()   # the int32 temporaries above must outlive the launch
+        return self.obs, self.rew, self.done, self.info
 
     def reset(self, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         mp = None

@@ -211,6 +211,8 @@ typedef struct {
   int row_normal[MAX_ROWS]; /* friction: index of its normal row */
   real row_mu[MAX_ROWS];
   int row_slot[MAX_ROWS];
+  /* active set of the last substep, same words as the HIP path's debug record (include/mocca.h MOCCA_DBG_*) */
+  int32_t dbg[8];
 } Work;
 
 typedef struct {
@@ -222,6 +224,7 @@ typedef struct {
   Task *task;
   Terrain *ter;
   Work wk;
+  int32_t *dbg; /* [n_envs][8]: copy of wk.dbg after each env's last substep */
   real feet_xyz[MOCCA_MAX_FEET][3];
   real body_rpy[3], body_vel[3];
   /* optional uniform tape: when set, every random draw pops from it instead of Philox, so the golden
@@ -507,6 +510,8 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
   w->nc = 0;
   for (int k = 0; k < m->n_feet; ++k) w->foot_touch[k] = w->foot_target[k] = 0;
   w->body_touch = 0;
+  uint64_t slot_mask = 0;
+  int n_self = 0;
   real margin = m->contact_margin;
   /* terrain */
   for (int g = 0; g < m->n_geoms; ++g) {
@@ -545,6 +550,7 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
         cfm = 1 / (dt * kk + cc) / dt;
       }
       if (gap < margin) {
+        slot_mask |= (uint64_t)1 << (m->g_slot[g] + e);
         if (m->g_foot[g] >= 0) { w->foot_touch[m->g_foot[g]] = 1; if (is_target) w->foot_target[m->g_foot[g]] = 1; }
         else w->body_touch = 1; /* a non-foot link on the terrain (LaikagoCustomEnv, env_locomotion.py:880-890) */
         if (w->nc < m->max_contacts) {
@@ -577,11 +583,13 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
       w->c_depth[i] = -gap; w->c_mu[i] = (real)m->g_friction[ga] * (real)m->g_friction[gb];
       w->c_erp[i] = m->erp; w->c_cfm[i] = 0;
     }
+    if (gap < margin && dist > (real)1e-9) ++n_self;
     /* Walker3DStepperEnv.calc_feet_state counts ANY contact of a foot link (env_locomotion.py:645-647) */
     if (gap < margin && dist > (real)1e-9 && o->task_id == MOCCA_TASK_WALKER3D_STEPPER)
       for (int f = 0; f < m->n_feet; ++f)
         if (m->g_body[ga] == m->foot_body[f] || m->g_body[gb] == m->foot_body[f]) w->foot_touch[f] = 1;
   }
+  w->dbg[3] = (int32_t)(uint32_t)slot_mask; w->dbg[4] = (int32_t)(uint32_t)(slot_mask >> 32); w->dbg[7] = n_self;
 }
 
 /* ------------------------------------------------------------------ */
@@ -615,12 +623,15 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
   int nd = 6 + m->n_joints, nr = 0;
   real dt = m->dt, idt = 1 / dt;
   /* --- joint limit rows first (Bullet solves non-contact rows first) --- */
+  uint64_t limit_mask = 0;
   for (int b = 1; b < m->n_bodies; ++b) {
     for (int side = 0; side < 2; ++side) {
       real sgn = side == 0 ? 1 : -1;
       real gap = side == 0 ? s->q[b] - (real)m->jlo[b] : (real)m->jhi[b] - s->q[b];
       real vel = sgn * nu[5 + b];
-      if (gap + dt * vel >= (real)m->limit_slack || nr >= m->max_rows) continue;
+      if (gap + dt * vel >= (real)m->limit_slack) continue;
+      limit_mask |= (uint64_t)1 << (2 * (b - 1) + side);
+      if (nr >= m->max_rows) continue;
       int r = nr++;
       for (int k = 0; k < nd; ++k) w->J[r][k] = 0;
       w->J[r][5 + b] = sgn;
@@ -669,6 +680,8 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
     }
   }
   w->nr = nr;
+  w->dbg[0] = nr; w->dbg[1] = first_normal - 3 * m->n_closures; w->dbg[2] = nc;
+  w->dbg[5] = (int32_t)(uint32_t)limit_mask; w->dbg[6] = (int32_t)(uint32_t)(limit_mask >> 32);
   /* --- responses, Delassus matrix, initial velocities --- */
   for (int r = 0; r < nr; ++r) minv_apply(m, w, w->J[r], w->Mi[r]);
   for (int r = 0; r < nr; ++r)
@@ -980,6 +993,7 @@ static void cassie_step(Oracle *o, int env, const float *act, float *obs, float 
     tk->istep += 1;
     substep(o, s, tk, &o->ter[env], tau, w);
   }
+  memcpy(o->dbg + 8 * env, w->dbg, sizeof(w->dbg));
   for (int k = 0; k < no; ++k) tk->jvel[k] = ((real)(float)s->q[m->ordered_body[k]] - q0[k]) / (real)m->control_dt; /* :467-468 */
   tk->t += 1;
   kinematics(m, s, w);
@@ -1035,11 +1049,13 @@ static void reset_env(Oracle *o, int env, float *obs) {
     dsv[b] = (real)-0.1 + (real)0.2 * draw_uniform(o, env, tk);
   }
   for (int b = 1; b <= nj; ++b) {
-    real ds = o->random_pose ? dsv[b] : 0;
-    real wt = (real)(float)(m->jhi[b] - m->jlo[b]), bs = m->jlo[b];
-    real ps = 2 * (base[b] + ds - bs) / wt - 1;
-    ps = ps < (real)-0.95 ? (real)-0.95 : (ps > (real)0.95 ? (real)0.95 : ps);
-    s->q[b] = wt * (ps + 1) / 2 + bs;
+    s->q[b] = base[b];
+    if (o->random_pose) { /* robots.py:190-194: deviation + normalise + clip(+-0.95) only inside `if random_pose` */
+      real wt = (real)(float)(m->jhi[b] - m->jlo[b]), bs = m->jlo[b];
+      real ps = 2 * (base[b] + dsv[b] - bs) / wt - 1;
+      ps = ps < (real)-0.95 ? (real)-0.95 : (ps > (real)0.95 ? (real)0.95 : ps);
+      s->q[b] = wt * (ps + 1) / 2 + bs;
+    }
     s->qd[b] = 0;
   }
   for (int k = 0; k < 3; ++k) { s->pos[k] = m->init_pos[k]; s->vel[k] = 0; s->omg[k] = 0; }
@@ -1086,6 +1102,7 @@ static void step_env(Oracle *o, int env, const float *act, float *obs, float *re
   int touch[MOCCA_MAX_FEET] = {0}, target[MOCCA_MAX_FEET] = {0}, body_touch = 0;
   if (!ext_touch) {
     for (int k = 0; k < m->n_substeps; ++k) substep(o, s, tk, tr, tau, w);
+    memcpy(o->dbg + 8 * env, w->dbg, sizeof(w->dbg));
     /* contact queries after stepSimulation see the manifolds of the LAST substep's collision pass */
     for (int k = 0; k < m->n_feet; ++k) { touch[k] = w->foot_touch[k]; target[k] = w->foot_target[k]; }
     body_touch = w->body_touch;
@@ -1216,13 +1233,14 @@ API void *orc_create(const void *blob, int nbytes, int task_id, int n_envs) {
   o->dyn = (Dyn *)calloc(n_envs, sizeof(Dyn));
   o->task = (Task *)calloc(n_envs, sizeof(Task));
   o->ter = (Terrain *)calloc(n_envs, sizeof(Terrain));
+  o->dbg = (int32_t *)calloc((size_t)n_envs * 8, sizeof(int32_t));
   for (int e = 0; e < n_envs; ++e) { o->dyn[e].quat[3] = 1; o->task[e].applied_gain = 1; o->task[e].episode = -1; }
   return o;
 }
 API void orc_destroy(void *h) {
   Oracle *o = (Oracle *)h;
   if (!o) return;
-  free(o->dyn); free(o->task); free(o->ter); free(o);
+  free(o->dyn); free(o->task); free(o->ter); free(o->dbg); free(o);
 }
 API int orc_obs_dim(void *h) { return obs_dim((Oracle *)h); }
 API int orc_act_dim(void *h) { Oracle *o = (Oracle *)h; return o->task_id == MOCCA_TASK_CASSIE ? o->m.n_ctrl - 2 : o->m.n_joints; }
@@ -1420,3 +1438,8 @@ API int orc_last_contacts(void *h, double *out) { /* per contact: a, b, slot, P(
   return o->wk.nc;
 }
 API int orc_last_rows(void *h) { return ((Oracle *)h)->wk.nr; }
+/* active set of every env's last substep: [n_envs][8] int32, words as MOCCA_DBG_* (include/mocca.h) */
+API void orc_get_debug(void *h, int32_t *out) {
+  Oracle *o = (Oracle *)h;
+  memcpy(out, o->dbg, (size_t)o->n_envs * 8 * sizeof(int32_t));
+}

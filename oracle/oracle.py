@@ -58,6 +58,7 @@ def _load(precision: str) -> C.CDLL:
     lib.orc_link_velocities.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.orc_last_contacts.argtypes = [C.c_void_p, C.c_void_p]
     lib.orc_last_contacts.restype = C.c_int
+    lib.orc_get_debug.argtypes = [C.c_void_p, C.c_void_p]
     return lib
 
 
@@ -202,3 +203,9 @@ class Oracle:
 
     def last_rows(self) -> int:
         return self.lib.orc_last_rows(self.h)
+
+    def get_debug(self) -> np.ndarray:
+        """Active set of every env's last substep, [N][8] int32 (words: include/mocca.h MOCCA_DBG_*)."""
+        out = np.zeros((self.n_envs, 8), np.int32)
+        self.lib.orc_get_debug(self.h, _p(out))
+        return out

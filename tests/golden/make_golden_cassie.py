@@ -189,8 +189,12 @@ def main():
         phys.reset(seed=0)
         obs0 = env.reset()
         acts, obs_l, rew_l, done_l = [], [obs0], [], []
+        pre_state, pre_jvel, pre_pot = [], [], []   # what a teacher-forced replay (tests/test_gpu_golden.py) restarts every step from
         for t in range(8 if ep == 0 else 30):
             a = (0.25 if ep == 0 else 0.6) * rng.uniform(-1, 1, 10)
+            pre_state.append(phys.get_state()[0].copy())
+            pre_jvel.append(np.array(env.jvel, dtype=np.float64) * np.ones(14))
+            pre_pot.append(float(env.potential))
             o, r, d, info = env.step(a)
             acts.append(a); obs_l.append(o); rew_l.append(r); done_l.append(d)
             if d:
@@ -200,6 +204,9 @@ def main():
         out[f"ep{ep}_rew"] = np.array(rew_l)
         out[f"ep{ep}_done"] = np.array(done_l).astype(np.int32)
         out[f"ep{ep}_final_state"] = phys.get_state()[0].copy()
+        out[f"ep{ep}_pre_state"] = np.array(pre_state)
+        out[f"ep{ep}_pre_jvel"] = np.array(pre_jvel)
+        out[f"ep{ep}_pre_potential"] = np.array(pre_pot)
     np.savez_compressed(os.path.join(HERE, "cassie_reference.npz"), **out)
     print("wrote cassie_reference.npz", {k: v.shape for k, v in out.items() if k.startswith("ep")})
 

@@ -1,0 +1,252 @@
+"""The reference's own scripted episodes replayed through the HIP task layer (mocca_task_step, mocca_set_draw_tape).
+
+tests/golden/*.npz hold what the reference's real classes computed (tests/golden/make_golden*.py import them from
+/root/reference): states handed to `calc_state`, contact query results, actions, and the observations / rewards / done
+flags / targets / plank moves that came out.  tests/test_golden_*.py check the CPU oracle against them; here the very same
+numbers go through libmocca_hip.so on the GPU: the dynamic state of frame t is written with mocca_set_state, the foot /
+target / body contact flags are injected, np_random's uniforms are fed through the draw tape, and the kernel's task
+layer (same source as mocca_step, zero substeps) must reproduce the reference within fp32 rounding.
+
+Covers on the GPU what random flailing never reaches: Stepper steps up to index 19, both stop windows, the > 120-frame
+release, plank recycling, last-step bonus (env_locomotion.py:632-693, 472-479), the in-kernel re-target (:214-222),
+eval mode, the planar envs' forced done = False, Laikago's body-contact termination, Child3D's 0.1 m line.
+Needs a real MI355X: -m gpu.  f32 tolerances = those of the f32 oracle in tests/test_golden_task.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from mocca_envs_amd import model as M
+
+pytestmark = pytest.mark.gpu
+
+TOL = 3e-5          # fp32 task arithmetic (the oracle's f32 build is held to 2e-5 .. 3e-5)
+OBS_TOL = 20 * TOL
+# reward = progress + ...: progress is the difference of two potentials of O(300) (distance * 60 Hz) in fp32
+REW_TOL = 4e-2
+REPL = 3            # replicas of the episode in the batch: every wave must produce the same bits
+
+
+@pytest.fixture(scope="module")
+def vg():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "variants_reference.npz"), allow_pickle=False)
+
+
+def _env(env_id, tape, params=()):
+    import torch
+    from mocca_envs_amd.vec_env import VecEnv
+    env = VecEnv(env_id, REPL, auto_reset=False, seed=0)
+    for pid, val in params:
+        env.set_param(pid, val)
+    env.set_draw_tape(np.tile(np.asarray(tape, np.float32)[None], (REPL, 1)))
+    return env
+
+
+def _set_state(env, st):
+    full = np.zeros((REPL, env.state_dim), np.float32)
+    full[:, :len(st)] = st
+    env.set_state(full)
+
+
+def _same_in_every_replica(*tensors):
+    for x in tensors:
+        x = x.cpu().numpy()
+        assert all(np.array_equal(x[0], x[k], equal_nan=True) for k in range(1, REPL)), "replicas differ"
+
+
+def _replay_custom(env, g, sd, n_feet=2, body=None, check_done=True):
+    """Teacher-forced replay of one scripted Custom-task episode; returns the per-step task records."""
+    import torch
+    from mocca_envs_amd.vec_env import task_to_float64
+    states, touch, actions = g("states"), g("touch"), g("actions")
+    recs = []
+    for t in range(len(states)):
+        _set_state(env, states[t][:sd])
+        a = torch.from_numpy(np.tile(actions[t][None].astype(np.float32), (REPL, 1)))
+        tc = np.tile(np.asarray(touch[t], np.int32).reshape(1, n_feet), (REPL, 1))
+        bd = None if body is None else np.full(REPL, int(body[t]), np.int32)
+        o, r, d, _ = env.task_step(a, tc, None, bd)
+        _same_in_every_replica(o, r, d)
+        o, r, d = o.cpu().numpy()[0], float(r[0]), int(d[0])
+        want_o = g("obs")[t]
+        fin = np.isfinite(want_o)
+        np.testing.assert_allclose(o[fin], want_o[fin], atol=OBS_TOL, err_msg=f"t{t} obs")
+        if check_done:
+            assert (d & 1) == int(g("done")[t]), f"t{t} done"
+        if np.isfinite(g("rew")[t]):
+            np.testing.assert_allclose(r, g("rew")[t], atol=REW_TOL, err_msg=f"t{t} reward")
+        recs.append(task_to_float64(env.get_task())[0])
+    return recs
+
+
+def test_custom_env_episodes_on_the_gpu(golden):
+    """4 scripted Walker3DCustomEnv episodes (incl. evaluation mode and target re-randomisation) -- env_locomotion.py:79-222."""
+    from mocca_envs_amd import lib as L
+    from mocca_envs_amd.vec_env import task_to_float64
+    retargets = 0
+    for ep in range(int(golden["custom_n_episodes"])):
+        g = lambda k: golden[f"custom_ep{ep}_{k}"]
+        env = _env("Walker3DCustomEnv-v0", g("tape"), [(L.PARAM_EVAL_MODE, int(g("eval_mode")))])
+        obs0 = env.reset().cpu().numpy()
+        st = env.get_state().cpu().numpy()
+        tk = task_to_float64(env.get_task())
+        np.testing.assert_allclose(st[0, 13:34], g("reset_q"), atol=TOL, err_msg=f"ep{ep} reset pose")
+        assert int(tk[0, 11]) == int(g("reset_mirrored"))
+        np.testing.assert_allclose(tk[0, 0:3], g("reset_walk_target"), atol=TOL)
+        assert tk[0, 6] == float(g("reset_stop_frames"))
+        np.testing.assert_allclose(obs0[0, 1:], g("reset_obs")[1:], atol=10 * TOL, err_msg=f"ep{ep} reset obs")
+        recs = _replay_custom(env, g, 55)
+        for t, tk in enumerate(recs):
+            np.testing.assert_allclose(tk[0:3], g("walk_target")[t], atol=10 * TOL, err_msg=f"ep{ep} t{t} target")
+            assert int(tk[5]) == int(g("close_count")[t]), f"ep{ep} t{t} close_count"
+        wt = g("walk_target")
+        if not int(g("eval_mode")):
+            retargets += int((np.abs(np.diff(wt[:, :2], axis=0)).max(axis=1) > 1e-9).sum())
+        env.close()
+    assert retargets >= 1, "the scripts must drive the in-kernel re-target (env_locomotion.py:214-222) at least once"
+
+
+def test_stepper_env_episodes_on_the_gpu(golden):
+    """3 scripted Walker3DStepperEnv episodes: the foot / target state machine up to the last step, stop windows,
+    >120-frame release, plank recycling, step and target bonuses -- env_locomotion.py:472-479, 515-568, 632-693."""
+    import torch
+    from mocca_envs_amd import lib as L
+    from mocca_envs_amd.vec_env import task_to_float64
+    m = M.compile_walker3d(M.TASK_WALKER3D_STEPPER)
+    seen = dict(max_nsi=0, stops=set(), released=False, recycled=False, step_bonus=0, last_bonus=0)
+    for ep in range(int(golden["stepper_n_episodes"])):
+        g = lambda k: golden[f"stepper_ep{ep}_{k}"]
+        env = _env("Walker3DStepperEnv-v0", g("tape"), [(L.PARAM_CURRICULUM, int(g("curriculum")))])
+        obs0 = env.reset().cpu().numpy()
+        st = env.get_state().cpu().numpy()
+        np.testing.assert_allclose(st[0, 13:34], g("reset_q"), atol=TOL)
+        np.testing.assert_allclose(st[0, 0:3], g("reset_base"), atol=TOL)
+        table = env.get_terrain().cpu().numpy()[0, :120].reshape(20, 6)
+        np.testing.assert_allclose(table, g("terrain"), atol=10 * TOL)      # generate_step_placements, :395-441
+        tk = task_to_float64(env.get_task())[0]
+        assert abs(tk[21] - float(g("applied_gain"))) < 1e-6
+        np.testing.assert_allclose(obs0[0, 1:], g("reset_obs")[1:], atol=OBS_TOL)
+        states, touch, target, actions = g("states"), g("touch"), g("target"), g("actions")
+        prev_trc = 0
+        for t in range(len(states)):
+            _set_state(env, states[t])
+            a = torch.from_numpy(np.tile(actions[t][None].astype(np.float32), (REPL, 1)))
+            o, r, d, info = env.task_step(a, np.tile(touch[t].astype(np.int32)[None], (REPL, 1)),
+                                          np.tile(target[t].astype(np.int32)[None], (REPL, 1)))
+            _same_in_every_replica(o, r, d, info)
+            np.testing.assert_allclose(o.cpu().numpy()[0], g("obs")[t], atol=OBS_TOL, err_msg=f"ep{ep} t{t} obs")
+            assert (int(d[0]) & 1) == int(g("done")[t]), f"ep{ep} t{t} done"
+            np.testing.assert_allclose(float(r[0]), g("rew")[t], atol=REW_TOL, err_msg=f"ep{ep} t{t} reward")
+            nsi = int(info[0])
+            assert nsi == int(g("next_step_index")[t]), f"ep{ep} t{t} next_step_index"
+            ter = env.get_terrain().cpu().numpy()[0]
+            pinfo = ter[120:123].astype(int)
+            want = g("plank_pos")[t] - np.array([0, 0, m.plank_com_z])
+            np.testing.assert_allclose(table[pinfo, 0:3], want, atol=10 * TOL, err_msg=f"ep{ep} t{t} planks")
+            # bookkeeping of what the replay exercised on the GPU
+            tk = task_to_float64(env.get_task())[0]
+            seen["max_nsi"] = max(seen["max_nsi"], nsi)
+            if int(tk[18]):
+                seen["stops"].add(nsi)
+            if prev_trc > 120:
+                seen["released"] = True
+            prev_trc = int(tk[17])
+            if sorted(pinfo) != [0, 1, 2]:
+                seen["recycled"] = True
+        terms = g("terms") if f"stepper_ep{ep}_terms" in golden.files else None
+        env.close()
+    assert seen["max_nsi"] == 19, seen                       # walked the whole staircase
+    assert {6, 7} & seen["stops"] and {13, 14} & seen["stops"], seen   # both stop windows (:522)
+    assert seen["released"] and seen["recycled"], seen       # > 120 frames on a stop step (:655-657); update_steps (:472-479)
+
+
+def test_child3d_episodes_on_the_gpu(vg):
+    for ep in range(int(vg["child_n_episodes"])):
+        g = lambda k: vg[f"child_ep{ep}_{k}"]
+        env = _env("Child3DCustomEnv-v0", g("tape"))
+        env.reset()
+        st = env.get_state().cpu().numpy()
+        np.testing.assert_allclose(st[0, 13:34], g("reset_q"), atol=TOL, err_msg="crawl pose")
+        np.testing.assert_allclose(st[0, 3:7], g("reset_base_quat"), atol=TOL)
+        _replay_custom(env, g, 55)
+        env.close()
+
+
+@pytest.mark.parametrize("tag,env_id", [("walker2d", "Walker2DCustomEnv-v0"), ("crab2d", "Crab2DCustomEnv-v0")])
+def test_planar_episode_on_the_gpu(vg, tag, env_id):
+    g = lambda k: vg[f"{tag}_ep0_{k}"]
+    env = _env(env_id, g("tape"))
+    obs0 = env.reset().cpu().numpy()
+    np.testing.assert_array_equal(obs0[0, -2:], [0.0, 0.0])          # env_locomotion.py:299-300
+    nj = env.act_dim
+    np.testing.assert_allclose(env.get_state().cpu().numpy()[0, 13:13 + nj], g("reset_q"), atol=TOL)
+    recs = _replay_custom(env, g, 13 + 2 * nj, check_done=False)
+    assert all(int(tk[7]) == 0 for tk in recs) and (g("done") == 0).all()    # :302-309: never done
+    env.close()
+
+
+def test_laikago_episodes_on_the_gpu(vg):
+    from mocca_envs_amd import lib as L
+    for ep in range(int(vg["laikago_n_episodes"])):
+        g = lambda k: vg[f"laikago_ep{ep}_{k}"]
+        env = _env("LaikagoCustomEnv-v0", g("tape"), [(L.PARAM_RANDOM_POSE, 0)])
+        env.reset()
+        st = env.get_state().cpu().numpy()
+        np.testing.assert_allclose(st[0, 13:25], g("reset_q"), atol=TOL)
+        np.testing.assert_allclose(st[0, 0:3], g("reset_base_pos"), atol=TOL)
+        _replay_custom(env, g, 13 + 24, n_feet=4, body=g("body"))
+        assert g("done")[-1] == 1 and g("terms")[-1, 3] == -1      # the script ends on the body contact (:880-890)
+        env.close()
+
+
+def test_mike_reset_on_the_gpu(vg):
+    from mocca_envs_amd import lib as L
+    from mocca_envs_amd.vec_env import task_to_float64
+    for ep in range(int(vg["mike_n_episodes"])):
+        g = lambda k: vg[f"mike_ep{ep}_{k}"]
+        env = _env("MikeStepperEnv-v0", g("tape"), [(L.PARAM_CURRICULUM, int(g("curriculum")))])
+        obs0 = env.reset().cpu().numpy()
+        st = env.get_state().cpu().numpy()
+        np.testing.assert_allclose(st[0, 13:34], g("reset_q"), atol=TOL)
+        np.testing.assert_allclose(st[0, 0:3], g("reset_base_pos"), atol=TOL)
+        np.testing.assert_allclose(env.get_terrain().cpu().numpy()[0, :120].reshape(20, 6), g("terrain"), atol=10 * TOL)
+        tk = task_to_float64(env.get_task())[0]
+        assert abs(tk[21] - float(g("applied_gain"))) < 1e-6 and int(tk[11]) == int(g("reset_mirrored"))
+        np.testing.assert_allclose(obs0[0, 1:], g("reset_obs")[1:], atol=OBS_TOL)
+        env.close()
+
+
+def test_cassie_steps_against_the_reference_code_on_the_gpu():
+    """tests/golden/make_golden_cassie.py ran the reference's real Cassie / CassieEnv methods over the f64 oracle's physics
+    and recorded the state before every env.step.  The GPU restarts each step from that state (teacher forcing) and
+    runs its own 50-iteration PD + physics loop in fp32: observation, reward and done must match the reference's."""
+    import torch
+    from mocca_envs_amd.vec_env import VecEnv, task_to_float64, task_from_float64
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cassie_reference.npz"))
+    env = VecEnv("CassieEnv-v0", REPL, auto_reset=False, seed=0)
+    obs0 = env.reset().cpu().numpy()
+    np.testing.assert_allclose(obs0[0], g["ep0_obs"][0], atol=1e-5)
+    errs = []
+    for ep in range(2):
+        env.reset()
+        for t, a in enumerate(g[f"ep{ep}_actions"]):
+            _set_state(env, g[f"ep{ep}_pre_state"][t])
+            tk = task_to_float64(env.get_task())
+            tk[:, 24:38] = g[f"ep{ep}_pre_jvel"][t]
+            tk[:, 3] = g[f"ep{ep}_pre_potential"][t]
+            tk[:, 7] = 0
+            env.set_task(task_from_float64(tk))
+            o, r, d, _ = env.step(torch.from_numpy(np.tile(a[None].astype(np.float32), (REPL, 1))).cuda())
+            _same_in_every_replica(o, r, d)
+            o = o.cpu().numpy()[0]
+            want = g[f"ep{ep}_obs"][t + 1]
+            errs.append(np.abs(o - want) / (1e-3 + 1e-3 * np.abs(want)))
+            # 50 stiff fp32 iterations from an f64 state: joint speeds (entries 20..33) carry the largest rounding error
+            np.testing.assert_allclose(o, want, atol=2e-2, rtol=2e-2, err_msg=f"ep{ep} t{t}")
+            assert abs(float(r[0]) - g[f"ep{ep}_rew"][t]) < 0.15, (ep, t, float(r[0]), g[f"ep{ep}_rew"][t])
+            assert bool(int(d[0]) & 1) == bool(g[f"ep{ep}_done"][t]), (ep, t)
+    e = np.concatenate(errs)
+    print(f"\nCassie GPU vs reference-code-over-f64-oracle, one env.step: median {np.median(e):.3g} p99 {np.percentile(e, 99):.3g} max {e.max():.3g} units")
+    assert np.median(e) < 0.5
+    env.close()

@@ -1,0 +1,56 @@
+"""The sharded HIP path with real processes: two ranks, each its own process and its own libmocca_hip handle with
+env_offset = rank x envs, reproduce bit for bit the envs they own of the unsharded batch (draws are keyed by the global
+env id) -- the property that makes `bench.py --gpus N` a weak-scaling run of ONE job rather than N unrelated ones.
+On a 1-GPU box both ranks share the device.  Needs a real MI355X: -m gpu."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from mocca_envs_amd.vec_env import VecEnv
+rank, world, n, out = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+dev = rank % torch.cuda.device_count()
+torch.cuda.set_device(dev)
+env = VecEnv("Walker3DCustomEnv-v0", n, device=dev, auto_reset=True, seed=77, env_offset=rank * n)
+obs = [env.reset().cpu().numpy().copy()]
+acts = np.random.default_rng(5).uniform(-1, 1, (60, world * n, 21)).astype(np.float32)[:, rank * n:(rank + 1) * n]
+rew, done = [], []
+for k in range(60):
+    o, r, d, _ = env.step(torch.from_numpy(acts[k]).to(env.device))
+    obs.append(o.cpu().numpy().copy()); rew.append(r.cpu().numpy().copy()); done.append(d.cpu().numpy().copy())
+np.savez(out, obs=np.array(obs), rew=np.array(rew), done=np.array(done), state=env.get_state().cpu().numpy())
+"""
+
+
+def test_two_process_shards_reproduce_the_unsharded_batch(tmp_path):
+    n = 96
+    outs = [str(tmp_path / f"r{r}.npz") for r in range(2)] + [str(tmp_path / "full.npz")]
+    jobs = [(0, 2, n, outs[0]), (1, 2, n, outs[1]), (0, 1, 2 * n, outs[2])]
+    procs = [subprocess.Popen([sys.executable, "-c", WORKER, ROOT, str(r), str(w), str(k), o]) for r, w, k, o in jobs]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    a, b, full = (np.load(o) for o in outs)
+    for key in ("obs", "rew", "done"):
+        np.testing.assert_array_equal(np.concatenate([a[key], b[key]], axis=1), full[key], err_msg=key)
+    np.testing.assert_array_equal(np.concatenate([a["state"], b["state"]], axis=0), full["state"])
+    assert int((full["done"] != 0).sum()) > 0          # the run crossed in-kernel auto-resets (global-id keyed draws)
+
+
+def test_bench_two_ranks_on_this_box():
+    """bench.py's own N-rank launch on real hardware (ranks share the GPU when the box has one): one JSON line, n_gpus = 2."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--envs", "512", "--oversubscribe", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["envs_per_gpu"] == 512

@@ -1,0 +1,195 @@
+"""HIP path vs f32 oracle at the granularity of ONE physics substep, with the active sets of both sides compared.
+
+An env.step() is 4 substeps (Cassie: 50); every substep takes discrete decisions -- which contact slots are within the
+margin, which joint-limit rows are built, which rows are clamped -- and a 1-ulp difference that flips one of them is
+amplified by the following substeps.  Here every model is compiled with n_substeps = 1 (Cassie: n_llc = 1), every
+step is teacher-forced from the oracle's state, and both sides export the active set of the substep (row count, limit
+rows, contacts, contact-slot bitmask, limit-candidate bitmask, self-contact count: include/mocca.h MOCCA_DBG_*).
+  * where the active sets agree the new state must agree to 1e-5 relative (units of 1e-5 (1 + |x|)), SURVEY 7.2;
+  * the fraction of (env, substep) samples whose active sets differ must stay below 1 %.
+Needs a real MI355X: -m gpu.
+"""
+import numpy as np
+import pytest
+
+from mocca_envs_amd import model as M
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {}),
+         ("Child3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("MikeStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {}),
+         ("Walker2DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("Crab2DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}),
+         ("LaikagoCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("CassieEnv-v0", M.TASK_CASSIE, {})]
+
+
+def _one_substep_blob(env_id):
+    from mocca_envs_amd.vec_env import compile_model_for
+    m = compile_model_for(env_id)
+    m.n_substeps = 1
+    if env_id.startswith("Cassie"):
+        m.n_llc = 1
+    return m
+
+
+@pytest.mark.parametrize("env_id,task,kw", CASES)
+def test_single_substep_parity_with_matching_active_sets(env_id, task, kw):
+    import torch
+    from mocca_envs_amd.vec_env import VecEnv, task_from_float64, _DEFAULT_PARAMS
+    from oracle.oracle import Oracle, PARAM_CURRICULUM
+    n, steps = 256, 160
+    m = _one_substep_blob(env_id)
+    blob = m.to_bytes()
+    env = VecEnv(env_id, n, auto_reset=False, seed=4, model_blob=blob)
+    dbg = env.set_debug(True)
+    orc = Oracle(blob, task, n, "f32")
+    for pid, val in _DEFAULT_PARAMS.get(env_id, {}).items():
+        env.set_param(pid, val); orc.set_param(pid, val)
+    if task == M.TASK_WALKER3D_STEPPER:
+        env.set_param(2, 9); orc.set_param(PARAM_CURRICULUM, 9)
+    env.reset(); orc.reset(seed=4)
+    rng = np.random.default_rng(2)
+    nd = 13 + 2 * m.n_joints
+    n_same = n_diff = 0
+    worst = []
+    rows_seen = []
+    for t in range(steps):
+        env.set_state(orc.get_state().astype(np.float32))
+        env.set_task(task_from_float64(orc.get_task()))
+        if task == M.TASK_WALKER3D_STEPPER:
+            ter = np.zeros((n, 128), np.float32); ter[:, :123] = orc.get_terrain(); env.set_terrain(ter)
+        scale = 1.0 if t % 3 else 0.3
+        a = (scale * rng.uniform(-1, 1, (n, env.act_dim))).astype(np.float32)
+        env.step(torch.from_numpy(a).cuda())
+        _, _, dc, _ = orc.step(a)
+        sg, sc = env.get_state().cpu().numpy(), orc.get_state()
+        dg_, dc_ = dbg.cpu().numpy(), orc.get_debug()
+        ok = np.isfinite(sc).all(axis=1)
+        same = (dg_ == dc_).all(axis=1) & ok
+        n_same += int(same.sum()); n_diff += int((~same & ok).sum())
+        rows_seen.append(dc_[ok, 0])
+        err = np.abs(sg[same][:, :nd] - sc[same][:, :nd]) / (1e-5 * (1.0 + np.abs(sc[same][:, :nd])))
+        if err.size:
+            worst.append(err.max(axis=1))
+        # restart fallen envs so the sample keeps standing / stepping / falling robots
+        if t % 8 == 7:
+            fallen = (dc != 0).astype(np.uint8)
+            if fallen.any():
+                orc.reset(seed=4, mask=fallen)
+    worst = np.concatenate(worst)
+    rows = np.concatenate(rows_seen)
+    frac = n_diff / max(1, n_same + n_diff)
+    print(f"\n{env_id}: {n_same + n_diff} substeps, rows/substep median {np.median(rows):.0f} max {rows.max()}, active sets differ in "
+          f"{100 * frac:.3f} %; where they agree: state error [units of 1e-5 (1+|x|)] median {np.median(worst):.3g} "
+          f"p99 {np.percentile(worst, 99):.3g} max {worst.max():.3g}")
+    assert rows.max() >= (6 if task == M.TASK_CASSIE else 12), "the sample must contain contact-rich substeps"
+    assert frac < 0.01, f"active sets differ in {100 * frac:.2f} % of the substeps"
+    # same rows, same arithmetic in another association order: 1e-5 relative per substep.  PGS clamps (friction bounds,
+    # unilateral normals) are discrete too but not part of the exported set: a flipped clamp shows as an outlier,
+    # so the bound is on the 99th percentile with a hard cap two orders above it.
+    assert np.median(worst) < 1.0 and np.percentile(worst, 99) < 10.0, (np.median(worst), np.percentile(worst, 99))
+    assert worst.max() < 1000.0, worst.max()
+    env.close()
+
+
+def test_per_env_parameters_through_the_abi():
+    """mocca_set_param_v: two halves of one batch run different curricula (terrain spread, applied gain, terminal height)
+    and each env matches the oracle run with ITS curriculum -- env_base.py:103-106, env_locomotion.py:368-369,489,628."""
+    import torch
+    from mocca_envs_amd import lib as L
+    from mocca_envs_amd.vec_env import VecEnv, task_to_float64
+    from oracle.oracle import Oracle, PARAM_CURRICULUM
+    n = 64
+    env = VecEnv("Walker3DStepperEnv-v0", n, auto_reset=True, seed=6)
+    cur = np.where(np.arange(n) % 2 == 0, 2, 9).astype(np.float32)
+    env.set_param_v(L.PARAM_CURRICULUM, cur)
+    og = env.reset().cpu().numpy()
+    tk = task_to_float64(env.get_task())
+    np.testing.assert_array_equal(tk[:, 20], cur)                                      # task word 20 = curriculum
+    np.testing.assert_allclose(tk[:, 21], 1.0 + 0.2 * cur / 9, atol=1e-6)              # applied gain, :369,489
+    ter_g = env.get_terrain().cpu().numpy()
+    for c in (2, 9):
+        orc = Oracle(env.model.to_bytes(), M.TASK_WALKER3D_STEPPER, n, "f32")
+        orc.set_param(PARAM_CURRICULUM, c)
+        oc = orc.reset(seed=6)
+        sel = cur == c
+        np.testing.assert_allclose(og[sel], oc[sel], atol=2e-6)
+        np.testing.assert_allclose(ter_g[sel][:, :123], orc.get_terrain()[sel], atol=5e-6)
+    spread = np.abs(ter_g[:, 1:120:6]).max(axis=1)                                     # lateral spread grows with the curriculum
+    assert spread[cur == 9].mean() > 2 * spread[cur == 2].mean()
+    # terminal height follows the env's own curriculum (:368,628): a robot pitched 1.3 rad stands ~0.58 m above its lower
+    # foot -- alive at curriculum 9 (0.45 m), dead at curriculum 2 (0.683 m)
+    st = env.get_state().cpu().numpy()
+    st[:, 3:7] = [0, np.sin(0.65), 0, np.cos(0.65)]
+    st[:, 13 + 21:13 + 42] = 0
+    env.set_param(L.PARAM_AUTO_RESET, 0)
+    env.set_state(st)
+    z = np.zeros((n, 2), np.int32)
+    o, _, d, _ = env.task_step(torch.zeros(n, 21), z, z)
+    h = o[:, 0].cpu().numpy()
+    assert ((h > 0.46) & (h < 0.68)).all(), (h.min(), h.max())
+    d = d.cpu().numpy() & 1
+    assert (d[cur == 2] == 1).all() and (d[cur == 9] == 0).all(), d
+    # broadcast form + scalar form drop back to one value for all
+    env.set_param_v(L.PARAM_CURRICULUM, np.array([5.0], np.float32), broadcast=True)
+    env.reset()
+    assert (task_to_float64(env.get_task())[:, 20] == 5).all()
+    env.set_param(L.PARAM_CURRICULUM, 1)
+    env.reset()
+    assert (task_to_float64(env.get_task())[:, 20] == 1).all()
+    # applied_gain acts on the next apply_action (robots.py:33) and persists across a Custom env's resets
+    cenv = VecEnv("Walker3DCustomEnv-v0", 8, auto_reset=False, seed=1)
+    cenv.reset()
+    g = np.linspace(0.5, 1.2, 8).astype(np.float32)
+    cenv.set_param_v(L.PARAM_APPLIED_GAIN, g)
+    np.testing.assert_allclose(task_to_float64(cenv.get_task())[:, 21], g, atol=1e-7)
+    cenv.reset()
+    np.testing.assert_allclose(task_to_float64(cenv.get_task())[:, 21], g, atol=1e-7)
+    cenv.set_param(L.PARAM_APPLIED_GAIN, 1.1)
+    np.testing.assert_allclose(task_to_float64(cenv.get_task())[:, 21], 1.1, atol=1e-7)
+    # eval mode per env: walk target = (x + 4, 0, 1) for the flagged envs only (env_locomotion.py:115-116)
+    cenv.set_param_v(L.PARAM_EVAL_MODE, (np.arange(8) < 4).astype(np.float32))
+    cenv.reset()
+    tk = task_to_float64(cenv.get_task())
+    np.testing.assert_allclose(tk[:4, 14], 4.0); np.testing.assert_allclose(tk[:4, 15], 0.0)
+    assert (tk[4:, 14] != 4.0).all()
+    env.close(); cenv.close()
+
+
+@pytest.mark.parametrize("env_id,n,steps", [("Walker3DStepperEnv-v0", 4096, 120), ("CassieEnv-v0", 2048, 12),
+                                            ("Walker3DCustomEnv-v0", 8192, 120)])
+def test_properties_at_the_benchmark_sizes(env_id, n, steps):
+    """BASELINE.json configs 2, 3 and 4's per-GPU shard at full size: bitwise determinism run to run, finite state, unit
+    quaternions, joint limits honoured up to the solver's slack, speed clamp, done envs really restart."""
+    import torch
+    from mocca_envs_amd.vec_env import VecEnv, compile_model_for
+    m = compile_model_for(env_id)
+    nj = m.n_joints
+
+    def run():
+        env = VecEnv(env_id, n, auto_reset=True, seed=31)
+        if "Stepper" in env_id:
+            env.set_param(2, 9)
+        env.reset()
+        g = torch.Generator(device="cuda").manual_seed(17)
+        n_done = 0
+        for k in range(steps):
+            a = torch.rand(n, env.act_dim, device="cuda", generator=g) * 2 - 1
+            o, r, d, info = env.step(a)
+            n_done += int((d != 0).sum())
+        out = (o.clone(), r.clone(), d.clone(), env.get_state().clone(), env.get_task().clone())
+        env.close()
+        return out, n_done
+
+    (o1, r1, d1, s1, t1), nd1 = run()
+    (o2, r2, d2, s2, t2), nd2 = run()
+    assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(s1, s2) and torch.equal(t1, t2)
+    assert nd1 == nd2 and (nd1 > 0 or "Cassie" in env_id)
+    assert torch.isfinite(s1).all() and torch.isfinite(o1).all() and torch.isfinite(r1).all()
+    assert torch.allclose(s1[:, 3:7].norm(dim=1), torch.ones(n, device="cuda"), atol=1e-5)
+    lo, hi = M.joint_limits(m)
+    q = s1[:, 13:13 + nj].cpu().numpy()
+    fin = (hi > lo) & (hi - lo < 1e20)          # Cassie's continuous rod joints carry +-1e30
+    assert (q[:, fin] > lo[fin] - 0.35).all() and (q[:, fin] < hi[fin] + 0.35).all()
+    assert (s1[:, 13 + nj:13 + 2 * nj].abs() <= m.max_qd + 1e-3).all()
+    ep = t1[:, 9].cpu().numpy()
+    assert (ep >= 0).all() and (nd1 == 0 or ep.max() >= 1)          # episode counters advanced where envs finished

@@ -59,3 +59,35 @@ def test_two_ranks_gloo():
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x, y)       # both ranks see the same gathered shards
     assert not np.array_equal(a[0], a[1])          # different shards, different episodes
+
+
+def _bench(*argv, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` (no torchrun) spawns N ranks, rendezvous over gloo on 127.0.0.1, reports n_gpus = N and the
+    whole-job rate over the SLOWEST rank's time (the dry run makes rank r take (r + 1) ms per step)."""
+    out = _bench("--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run")
+    assert out["n_gpus"] == 2 and out["dry_run"] and out["scaling"] == "weak"
+    assert abs(out["ms_per_step"] - 2.0) < 1e-6                          # rank 1's time, not rank 0's
+    assert abs(out["value"] - 2 * 4096 * 4 / (4 * 2e-3)) < 1e-3
+    assert "x2" in out["config"]["parallelism"]
+    out = _bench("--gpus", "1", "--steps", "2", "--dry-run", "--envs", "8192")
+    assert out["n_gpus"] == 1 and out["config"]["envs_per_gpu"] == 8192
+
+
+def test_bench_as_a_torchrun_rank():
+    """Under torch.distributed.run the process is one rank: WORLD_SIZE from the environment decides, a lone rank 0 of world 1."""
+    out = _bench("--gpus", "1", "--steps", "2", "--dry-run", env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"))
+    assert out["n_gpus"] == 1
