@@ -1438,6 +1438,12 @@ API int orc_last_contacts(void *h, double *out) { /* per contact: a, b, slot, P(
   return o->wk.nc;
 }
 API int orc_last_rows(void *h) { return ((Oracle *)h)->wk.nr; }
+/* impulses and kinds (0 limit, 1 normal, 2 friction, 3 closure) of the rows of the last substep solved */
+API int orc_last_lambda(void *h, double *lam, int32_t *kind) {
+  Oracle *o = (Oracle *)h;
+  for (int r = 0; r < o->wk.nr; ++r) { lam[r] = o->wk.lam[r]; kind[r] = o->wk.row_kind[r]; }
+  return o->wk.nr;
+}
 /* active set of every env's last substep: [n_envs][8] int32, words as MOCCA_DBG_* (include/mocca.h) */
 API void orc_get_debug(void *h, int32_t *out) {
   Oracle *o = (Oracle *)h;

@@ -59,6 +59,8 @@ def _load(precision: str) -> C.CDLL:
     lib.orc_last_contacts.argtypes = [C.c_void_p, C.c_void_p]
     lib.orc_last_contacts.restype = C.c_int
     lib.orc_get_debug.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_last_lambda.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_last_lambda.restype = C.c_int
     return lib
 
 
@@ -203,6 +205,12 @@ class Oracle:
 
     def last_rows(self) -> int:
         return self.lib.orc_last_rows(self.h)
+
+    def last_lambda(self):
+        """(impulses, kinds) of the rows of the last substep solved (kind: 0 limit, 1 normal, 2 friction, 3 closure)."""
+        lam, kind = np.zeros(64, np.float64), np.zeros(64, np.int32)
+        n = self.lib.orc_last_lambda(self.h, _p(lam), _p(kind))
+        return lam[:n], kind[:n]
 
     def get_debug(self) -> np.ndarray:
         """Active set of every env's last substep, [N][8] int32 (words: include/mocca.h MOCCA_DBG_*)."""

@@ -9,6 +9,9 @@ from mocca_envs_amd import model as M
 from oracle.oracle import Oracle, PARAM_CURRICULUM
 
 NJ = 21
+# reward = d(potential) + ...: the potential is -distance * 60 Hz, O(300): a difference of two such numbers costs ~4e-2 in fp32
+# arithmetic, nothing in f64 (what is left there is the float32 rounding calc_state applies to the joint speeds, robots.py:55,95)
+REW_TOL = {"f64": 5e-6, "f32": 4e-2}   # f64: the reward leaves the oracle as a float32 (up to 52 with a step bonus)
 
 
 @pytest.fixture(scope="module")
@@ -89,7 +92,7 @@ def test_child3d_episodes(vg, prec, tol):
             o, r, d, _ = orc.task_step(actions[t][None], touch[t][None])
             np.testing.assert_allclose(o[0], g("obs")[t], atol=20 * tol, err_msg=f"ep{ep} t{t} obs")
             assert (d[0] & 1) == int(g("done")[t]), f"ep{ep} t{t} done (height {o[0][0]})"
-            np.testing.assert_allclose(r[0], g("rew")[t], atol=2e3 * tol, err_msg=f"ep{ep} t{t} reward")
+            np.testing.assert_allclose(r[0], g("rew")[t], atol=REW_TOL[prec], err_msg=f"ep{ep} t{t} reward")
         # the script must exercise the 0.1 m line itself: heights in (0.1, 0.7) stay alive, heights below 0.1 fall
         h, tall = g("obs")[:, 0], g("terms")[:, 3]
         assert ((h > 0.1) & (h < 0.7) & (tall == 2)).sum() > 10 and ((h < 0.1) & (tall == -1)).sum() > 3
@@ -165,7 +168,7 @@ def test_planar_episode(vg, tag, compile_fn, xml, prec, tol):
         o, r, d, _ = orc.task_step(actions[t][None], touch[t][None])
         np.testing.assert_allclose(o[0], g("obs")[t], atol=20 * tol, err_msg=f"t{t} obs")
         assert (d[0] & 1) == 0 and int(g("done")[t]) == 0, f"t{t}: Walker2DCustomEnv.step never reports done"
-        np.testing.assert_allclose(r[0], g("rew")[t], atol=2e3 * tol, err_msg=f"t{t} reward")
+        np.testing.assert_allclose(r[0], g("rew")[t], atol=REW_TOL[prec], err_msg=f"t{t} reward")
     tall = g("terms")[:, 3]
     assert (tall == -1).sum() > 3 and (tall == 2).sum() > 3      # the script does cross the 0.7 m line; done stays 0
 
@@ -220,7 +223,7 @@ def test_laikago_episodes(vg, prec, tol):
             o, r, d, _ = orc.task_step(actions[t][None], touch[t][None], None, body[t:t + 1])
             np.testing.assert_allclose(o[0], g("obs")[t], atol=20 * tol, err_msg=f"ep{ep} t{t} obs")
             assert (d[0] & 1) == int(g("done")[t]), f"ep{ep} t{t} done"
-            np.testing.assert_allclose(r[0], g("rew")[t], atol=2e3 * tol, err_msg=f"ep{ep} t{t} reward")
+            np.testing.assert_allclose(r[0], g("rew")[t], atol=REW_TOL[prec], err_msg=f"ep{ep} t{t} reward")
         # tall_bonus is 0 while only feet touch, -1 + done on the frame where the chassis / a lower leg touches
         # (done may also latch earlier through the inherited height <= 0 test: a foot above the base)
         assert (g("terms")[:-1, 3] == 0).all() and g("terms")[-1, 3] == -1 and g("done")[-1] == 1

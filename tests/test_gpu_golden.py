@@ -114,7 +114,7 @@ def test_stepper_env_episodes_on_the_gpu(golden):
     from mocca_envs_amd import lib as L
     from mocca_envs_amd.vec_env import task_to_float64
     m = M.compile_walker3d(M.TASK_WALKER3D_STEPPER)
-    seen = dict(max_nsi=0, stops=set(), released=False, recycled=False, step_bonus=0, last_bonus=0)
+    seen = dict(max_nsi=0, stops=set(), released=False, recycled=False)
     for ep in range(int(golden["stepper_n_episodes"])):
         g = lambda k: golden[f"stepper_ep{ep}_{k}"]
         env = _env("Walker3DStepperEnv-v0", g("tape"), [(L.PARAM_CURRICULUM, int(g("curriculum")))])
@@ -149,12 +149,11 @@ def test_stepper_env_episodes_on_the_gpu(golden):
             seen["max_nsi"] = max(seen["max_nsi"], nsi)
             if int(tk[18]):
                 seen["stops"].add(nsi)
-            if prev_trc > 120:
+            if prev_trc >= 120 and int(tk[17]) == 0:      # the count passed 120 on a stop step: released (:655-657), index advanced
                 seen["released"] = True
             prev_trc = int(tk[17])
             if sorted(pinfo) != [0, 1, 2]:
                 seen["recycled"] = True
-        terms = g("terms") if f"stepper_ep{ep}_terms" in golden.files else None
         env.close()
     assert seen["max_nsi"] == 19, seen                       # walked the whole staircase
     assert {6, 7} & seen["stops"] and {13, 14} & seen["stops"], seen   # both stop windows (:522)

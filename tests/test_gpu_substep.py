@@ -42,52 +42,63 @@ def test_single_substep_parity_with_matching_active_sets(env_id, task, kw):
     env = VecEnv(env_id, n, auto_reset=False, seed=4, model_blob=blob)
     dbg = env.set_debug(True)
     orc = Oracle(blob, task, n, "f32")
+    o64 = Oracle(blob, task, n, "f64")          # the yardstick: how far fp32 arithmetic itself is from the exact substep
     for pid, val in _DEFAULT_PARAMS.get(env_id, {}).items():
-        env.set_param(pid, val); orc.set_param(pid, val)
+        env.set_param(pid, val); orc.set_param(pid, val); o64.set_param(pid, val)
     if task == M.TASK_WALKER3D_STEPPER:
-        env.set_param(2, 9); orc.set_param(PARAM_CURRICULUM, 9)
-    env.reset(); orc.reset(seed=4)
+        env.set_param(2, 9); orc.set_param(PARAM_CURRICULUM, 9); o64.set_param(PARAM_CURRICULUM, 9)
+    env.reset(); orc.reset(seed=4); o64.reset(seed=4)
     rng = np.random.default_rng(2)
     nd = 13 + 2 * m.n_joints
     n_same = n_diff = 0
-    worst = []
-    rows_seen = []
+    e_gpu, e_f32, rows_seen = [], [], []
+    units = lambda a, b: np.abs(a - b) / (1e-5 * (1.0 + np.abs(b)))
     for t in range(steps):
         env.set_state(orc.get_state().astype(np.float32))
         env.set_task(task_from_float64(orc.get_task()))
+        o64.set_state(orc.get_state()); o64.set_task(orc.get_task())
         if task == M.TASK_WALKER3D_STEPPER:
             ter = np.zeros((n, 128), np.float32); ter[:, :123] = orc.get_terrain(); env.set_terrain(ter)
+            o64.set_terrain(orc.get_terrain())
         scale = 1.0 if t % 3 else 0.3
         a = (scale * rng.uniform(-1, 1, (n, env.act_dim))).astype(np.float32)
         env.step(torch.from_numpy(a).cuda())
         _, _, dc, _ = orc.step(a)
-        sg, sc = env.get_state().cpu().numpy(), orc.get_state()
-        dg_, dc_ = dbg.cpu().numpy(), orc.get_debug()
-        ok = np.isfinite(sc).all(axis=1)
+        o64.step(a)
+        sg, sc, s6 = env.get_state().cpu().numpy(), orc.get_state(), o64.get_state()
+        dg_, dc_, d6_ = dbg.cpu().numpy(), orc.get_debug(), o64.get_debug()
+        ok = np.isfinite(sc).all(axis=1) & np.isfinite(s6).all(axis=1)
         same = (dg_ == dc_).all(axis=1) & ok
         n_same += int(same.sum()); n_diff += int((~same & ok).sum())
         rows_seen.append(dc_[ok, 0])
-        err = np.abs(sg[same][:, :nd] - sc[same][:, :nd]) / (1e-5 * (1.0 + np.abs(sc[same][:, :nd])))
-        if err.size:
-            worst.append(err.max(axis=1))
+        if same.any():
+            e_gpu.append(units(sg[same][:, :nd], sc[same][:, :nd]).max(axis=1))
+        same64 = (d6_ == dc_).all(axis=1) & ok
+        if same64.any():
+            e_f32.append(units(sc[same64][:, :nd], s6[same64][:, :nd]).max(axis=1))
         # restart fallen envs so the sample keeps standing / stepping / falling robots
         if t % 8 == 7:
             fallen = (dc != 0).astype(np.uint8)
             if fallen.any():
                 orc.reset(seed=4, mask=fallen)
-    worst = np.concatenate(worst)
+    e_gpu, e_f32 = np.concatenate(e_gpu), np.concatenate(e_f32)
     rows = np.concatenate(rows_seen)
     frac = n_diff / max(1, n_same + n_diff)
+    q = lambda x, p: float(np.percentile(x, p))
     print(f"\n{env_id}: {n_same + n_diff} substeps, rows/substep median {np.median(rows):.0f} max {rows.max()}, active sets differ in "
-          f"{100 * frac:.3f} %; where they agree: state error [units of 1e-5 (1+|x|)] median {np.median(worst):.3g} "
-          f"p99 {np.percentile(worst, 99):.3g} max {worst.max():.3g}")
+          f"{100 * frac:.3f} %; same active set, state error in units of 1e-5 (1+|x|): GPU vs f32 oracle median {q(e_gpu, 50):.3g} "
+          f"p90 {q(e_gpu, 90):.3g} p99 {q(e_gpu, 99):.3g} max {e_gpu.max():.3g} | f32 oracle vs f64 oracle median {q(e_f32, 50):.3g} "
+          f"p90 {q(e_f32, 90):.3g} p99 {q(e_f32, 99):.3g} max {e_f32.max():.3g}")
     assert rows.max() >= (6 if task == M.TASK_CASSIE else 12), "the sample must contain contact-rich substeps"
     assert frac < 0.01, f"active sets differ in {100 * frac:.2f} % of the substeps"
-    # same rows, same arithmetic in another association order: 1e-5 relative per substep.  PGS clamps (friction bounds,
-    # unilateral normals) are discrete too but not part of the exported set: a flipped clamp shows as an outlier,
-    # so the bound is on the 99th percentile with a hard cap two orders above it.
-    assert np.median(worst) < 1.0 and np.percentile(worst, 99) < 10.0, (np.median(worst), np.percentile(worst, 99))
-    assert worst.max() < 1000.0, worst.max()
+    # Same rows, same arithmetic, another association order.  The fp32 tolerance of ONE substep is what fp32 arithmetic itself
+    # costs on this substep: the f32 oracle's distance from the f64 oracle (stiff rows divide position errors of 1e-7 by dt:
+    # Cassie's closure rows at dt = 0.6 ms turn them into 1e-4 of velocity).  The kernel may be no further from the f32 oracle
+    # than 3x that, with 1e-5 relative as the floor.  PGS clamps (friction bounds, unilateral normals) are
+    # discrete too but not part of the exported set: a flipped clamp shows in the tail, hence percentile bounds + a hard cap.
+    assert q(e_gpu, 50) < max(1.0, 3 * q(e_f32, 50)), (q(e_gpu, 50), q(e_f32, 50))
+    assert q(e_gpu, 99) < max(10.0, 3 * q(e_f32, 99)), (q(e_gpu, 99), q(e_f32, 99))
+    assert e_gpu.max() < max(1000.0, 3 * e_f32.max()), (e_gpu.max(), e_f32.max())
     env.close()
 
 
@@ -125,10 +136,13 @@ def test_per_env_parameters_through_the_abi():
     env.set_state(st)
     z = np.zeros((n, 2), np.int32)
     o, _, d, _ = env.task_step(torch.zeros(n, 21), z, z)
-    h = o[:, 0].cpu().numpy()
-    assert ((h > 0.46) & (h < 0.68)).all(), (h.min(), h.max())
+    h = o[:, 0].cpu().numpy()                                  # differs a little from env to env (random start poses)
     d = d.cpu().numpy() & 1
-    assert (d[cur == 2] == 1).all() and (d[cur == 9] == 0).all(), d
+    term_h = 0.75 + (0.45 - 0.75) * cur / 9
+    margin = np.abs(h - term_h) > 1e-4
+    np.testing.assert_array_equal(d[margin], (h <= term_h)[margin].astype(d.dtype))
+    both = (h > 0.46) & (h < 0.68)
+    assert both.sum() > n // 2 and (d[both & (cur == 2)] == 1).all() and (d[both & (cur == 9)] == 0).all()
     # broadcast form + scalar form drop back to one value for all
     env.set_param_v(L.PARAM_CURRICULUM, np.array([5.0], np.float32), broadcast=True)
     env.reset()

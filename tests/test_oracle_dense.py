@@ -1,0 +1,130 @@
+"""The oracle's O(n) substep against an independent dense f64 restatement (tests/dense_reference.py): complex-step
+Jacobians of a world-frame FK, mass matrix from kinetic energy, dense solves for M^-1 and the Delassus matrix, the same
+PGS order.  Same blob, same state, same torques: unconstrained velocity, contact list, row set, every row impulse, the
+new velocity, the new pose and the persisted warm-start impulses must agree to ~1e-8.  CPU only.
+
+This pins the oracle's recursions (ABA about the moving base origin, unit-impulse response sweeps, row assembly, PGS
+bookkeeping, integration) to the textbook formulation.  It cannot pin Bullet's own choices."""
+import numpy as np
+import pytest
+
+import dense_reference as D
+from mocca_envs_amd import model as M
+from oracle.oracle import Oracle
+
+
+def _random_state(rng, m, z, spread=0.6, vel=1.0):
+    nj = m.n_joints
+    lo, hi = M.joint_limits(m)
+    lo, hi = np.maximum(lo, -3.0), np.minimum(hi, 3.0)
+    st = np.zeros(13 + 2 * nj + m.n_slots)
+    st[0:3] = [rng.normal(0, 0.3), rng.normal(0, 0.3), z]
+    qt = rng.normal(size=4) * [spread, spread, spread, 1.0]
+    st[3:7] = qt / np.linalg.norm(qt)
+    st[7:10] = rng.normal(0, vel, 3)
+    st[10:13] = rng.normal(0, vel, 3)
+    u = rng.uniform(-0.05, 1.05, nj)            # some joints start at / beyond their limits: limit rows
+    st[13:13 + nj] = lo + u * (hi - lo)
+    st[13 + nj:13 + 2 * nj] = rng.normal(0, 2 * vel, nj)
+    st[13 + 2 * nj:] = np.abs(rng.normal(0, 0.5, m.n_slots)) * (rng.random(m.n_slots) < 0.5)   # stale warm-start impulses
+    return st
+
+
+def _compare(orc, m, mdl, row, tau, planks=None, tol=2e-8):
+    nj = m.n_joints
+    full = row[None].copy()
+    orc.set_state(full)
+    a = orc.forward_dynamics(0, tau)                       # oracle's unconstrained acceleration (for the nu* check)
+    orc.set_state(full)
+    orc.physics_substeps(0, tau, 1)
+    got = orc.get_state()[0]
+    lam_o, kind_o = orc.last_lambda()
+    st = D.State.from_row(mdl, row)
+    new, info = D.substep(mdl, st, np.concatenate([[0.0], tau]), planks)
+    # unconstrained velocity: spatial -> classical acceleration of the base origin, as the oracle's substep does
+    wxv = np.cross(row[10:13], row[7:10])
+    nus_o = np.concatenate([row[10:13] + mdl.dt * a[0:3], row[7:10] + mdl.dt * (a[3:6] + wxv), row[13 + nj:13 + 2 * nj] + mdl.dt * a[6:]])
+    scale = 1.0 + np.abs(info["nu_star"])
+    assert np.abs(nus_o - info["nu_star"]).max() < tol * scale.max() * 10, ("nu*", np.abs(nus_o - info["nu_star"]).max())
+    # same contacts, same rows
+    oc = orc.last_contacts()
+    assert len(oc) == len(info["contacts"]), (len(oc), len(info["contacts"]))
+    for c_o, c_d in zip(oc, info["contacts"]):
+        assert (int(c_o[0]), int(c_o[1]), int(c_o[2])) == (c_d["a"], c_d["b"], c_d["slot"])
+        np.testing.assert_allclose(c_o[3:6] + row[0:3], c_d["P"], atol=1e-9)     # the oracle keeps points relative to the base origin
+        np.testing.assert_allclose(c_o[6:9], c_d["n"], atol=1e-9)
+        assert abs(c_o[9] - c_d["depth"]) < 1e-9 and abs(c_o[10] - c_d["mu"]) < 1e-6
+    assert orc.last_rows() == info["rows"] and list(kind_o) == info["kinds"]
+    dbg = orc.get_debug()[0] if False else None
+    lam_scale = 1.0 + np.abs(info["lam"]).max() if info["rows"] else 1.0
+    if info["rows"]:
+        assert np.abs(lam_o - info["lam"]).max() < 50 * tol * lam_scale, ("lambda", np.abs(lam_o - info["lam"]).max(), lam_scale)
+    want = new.to_row(mdl)
+    # velocities, joint angles, base position, warm-start impulses; orientation through the rotation matrix
+    for sl, name in ((slice(7, 13), "base velocity"), (slice(13, 13 + 2 * nj), "q / qd"), (slice(0, 3), "base position"),
+                     (slice(13 + 2 * nj, None), "warm-start impulses")):
+        err = np.abs(got[sl] - want[sl]).max()
+        assert err < 50 * tol * max(lam_scale, 1 + np.abs(want[sl]).max()), (name, err)
+    np.testing.assert_allclose(D._quat_mat(got[3:7]), info["Rn"], atol=1e-8)
+    return info
+
+
+@pytest.mark.parametrize("name,compile_fn,task,z", [("walker3d", M.compile_walker3d, 0, 0.25), ("laikago", M.compile_laikago, 0, 0.2),
+                                                    ("crab2d", M.compile_crab2d, 0, 0.3)])
+def test_substep_on_random_contact_states(name, compile_fn, task, z):
+    """Tumbling robots close to the ground: 3-12 contacts (terrain + self), limit rows, stale warm starts, the row cap."""
+    m = compile_fn()
+    mdl = D.Model(m)
+    orc = Oracle(m.to_bytes(), task, 1, "f64")
+    orc.reset(seed=0)
+    rng = np.random.default_rng(7)
+    seen_rows, seen_self, seen_cap = [], 0, 0
+    for k in range(12):
+        row = _random_state(rng, m, z + 0.25 * rng.random())
+        tau = rng.uniform(-60, 60, m.n_joints)
+        info = _compare(orc, m, mdl, row, tau)
+        seen_rows.append(info["rows"]); seen_self += info["n_self"]; seen_cap += info["rows"] >= m.max_rows - 2
+    print(f"\n{name}: rows per substep {seen_rows}, self contacts {seen_self}")
+    assert max(seen_rows) >= 20
+    if name == "walker3d":
+        assert seen_self > 0
+
+
+def test_substep_on_the_stepper_planks():
+    """Tilted planks as oriented boxes, soft contact (stiffness / damping -> erp / cfm), bullet_objects.py:64-83."""
+    m = M.compile_walker3d(M.TASK_WALKER3D_STEPPER)
+    mdl = D.Model(m)
+    orc = Oracle(m.to_bytes(), M.TASK_WALKER3D_STEPPER, 1, "f64")
+    orc.set_param(2, 9)
+    orc.reset(seed=3)
+    ter = orc.get_terrain()[0]
+    planks = D.live_planks(mdl, ter, 1)
+    rng = np.random.default_rng(3)
+    rows = []
+    for k in range(8):
+        row = _random_state(rng, m, 0.0, spread=0.5)
+        p = ter[6 * (k % 3):6 * (k % 3) + 3]
+        row[0:3] = p + [rng.normal(0, 0.2), rng.normal(0, 0.5), 0.25 + 0.3 * rng.random()]
+        info = _compare(orc, m, mdl, row, rng.uniform(-40, 40, 21), planks)
+        rows.append(info["rows"])
+    print("\nstepper rows per substep", rows)
+    assert max(rows) >= 12
+
+
+def test_substep_with_loop_closures():
+    """Cassie: two point-to-point closures (6 bilateral rows) between the limit rows and the contacts."""
+    m = M.compile_cassie()
+    mdl = D.Model(m)
+    orc = Oracle(m.to_bytes(), M.TASK_CASSIE, 1, "f64")
+    orc.reset(seed=0)
+    base = orc.get_state()[0]
+    rng = np.random.default_rng(5)
+    for k in range(6):
+        row = base.copy()
+        nj = m.n_joints
+        row[2] -= 0.05 * rng.random()                                  # toes into the ground
+        row[13:13 + nj] += rng.normal(0, 0.03, nj)                     # loops slightly open: the closure rows pull
+        row[7:13] = rng.normal(0, 0.3, 6)
+        row[13 + nj:13 + 2 * nj] = rng.normal(0, 0.5, nj)
+        info = _compare(orc, m, mdl, row, rng.uniform(-20, 20, nj), tol=1e-7)
+        assert info["kinds"].count(3) == 6
