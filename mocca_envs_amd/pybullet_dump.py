@@ -1,0 +1,250 @@
+"""Model blob from a REAL PyBullet session: `tools/dump_pybullet_trace.py`, run on any machine
+that has pybullet, records the multibody Bullet actually built from the robot file -- per link `getJointInfo`
+(names, types, axes, limits, damping, parent frames, parent indices) and `getDynamicsInfo` (mass, local inertia
+diagonal, inertial frame).  `from_pybullet_dump` turns that record into a `MoccaModel`: every number this project's
+model compiler had to *assume* about Bullet's importer (link masses, inertial frames and principal inertias, the
+joint frames, damping; DESIGN.md "Model assumptions") is replaced by what Bullet reported, link by link.
+
+What stays from the compiled template (`model.compile_*`): the tree (checked against the dump), the collision geoms
+(re-expressed in the dump's link frames: the geometry is the robot file's, the frames are Bullet's), the
+self-collision pair list, feet, physics and task constants.
+
+PyBullet conventions used (pybullet quick-start guide, getJointInfo / getDynamicsInfo):
+  * a link's frame in the API is its centre-of-mass (inertial) frame C; the URDF/MJCF link frame L satisfies
+    C = L o (localInertialPos, localInertialOrn);
+  * parentFramePos / parentFrameOrn: the joint (= child link) frame expressed in the PARENT's inertial frame, so at
+    q = 0   L_child = C_parent o (parentFramePos, parentFrameOrn);
+  * jointAxis is given in the child link frame L; the base pose/velocity the API reports is that of the base's C frame;
+  * localInertiaDiagonal is expressed in C's axes.
+Quaternions are (x, y, z, w).
+"""
+from __future__ import annotations
+
+from typing import Dict, Mapping, Optional, Sequence
+
+import numpy as np
+
+from . import model as M
+
+JOINT_REVOLUTE, JOINT_FIXED = 0, 4
+
+
+def _qmat(q) -> np.ndarray:
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+class _T:
+    """Rigid transform x -> R x + t."""
+
+    def __init__(self, R=None, t=None):
+        self.R = np.eye(3) if R is None else np.asarray(R, float)
+        self.t = np.zeros(3) if t is None else np.asarray(t, float)
+
+    def __matmul__(self, o: "_T") -> "_T":
+        return _T(self.R @ o.R, self.R @ o.t + self.t)
+
+    def inv(self) -> "_T":
+        return _T(self.R.T, -self.R.T @ self.t)
+
+    def apply(self, p) -> np.ndarray:
+        return self.R @ np.asarray(p, float) + self.t
+
+
+def _template_frames(m: M.MoccaModel):
+    """Body frames of the template at q = 0, relative to its base frame."""
+    fr = [_T()]
+    for b in range(1, m.n_bodies):
+        p = m.parent[b]
+        fr.append(fr[p] @ _T(np.array(list(m.jrot[b])).reshape(3, 3), list(m.jpos[b])))
+    return fr
+
+
+def from_pybullet_dump(dump: Mapping[str, np.ndarray], template: M.MoccaModel, joint_names: Sequence[str],
+                       armature: Optional[float] = None) -> M.MoccaModel:
+    """`dump`: the arrays written by tools/dump_pybullet_trace.py (an open .npz works).  `template`: the compiled blob of
+    the same robot.  `joint_names[b - 1]`: Bullet joint name of template body b (e.g. model.WALKER3D_JOINT_NAMES).
+    `armature`: None keeps the template's joint armature (Bullet's API does not expose what its importer did with it)."""
+    names = [str(n) for n in dump["joint_names"]]
+    jtype = np.asarray(dump["joint_type"]).astype(int)
+    parent = np.asarray(dump["parent_index"]).astype(int)          # -1 = base
+    n_links = len(names)
+    mass = np.asarray(dump["mass"], float)                         # index 0 = base, 1 + j = link j
+    inertia_diag = np.asarray(dump["local_inertia_diag"], float)
+    ipos, iorn = np.asarray(dump["inertial_pos"], float), np.asarray(dump["inertial_orn"], float)
+    pf_pos, pf_orn = np.asarray(dump["parent_frame_pos"], float), np.asarray(dump["parent_frame_orn"], float)
+    axis = np.asarray(dump["joint_axis"], float)
+    if not (len(mass) == n_links + 1 and len(parent) == n_links):
+        raise ValueError("dump arrays are inconsistent")
+
+    # link frames L_j and inertial frames C_j at q = 0, relative to the base's inertial frame (= our base frame)
+    I_of = lambda k: _T(_qmat(iorn[k]), ipos[k])                   # noqa: E731  (k = 0 base, 1 + j link j)
+    C = {-1: _T()}
+    L = {}
+    for j in range(n_links):                                       # Bullet lists links parents-first
+        if parent[j] >= j:
+            raise ValueError("links are not in parents-first order")
+        L[j] = C[parent[j]] @ _T(_qmat(pf_orn[j]), pf_pos[j])
+        C[j] = L[j] @ I_of(1 + j)
+
+    # template body b <-> Bullet link carrying the joint of that name; every other link must be rigidly attached (fixed)
+    link_of = {}
+    for b in range(1, template.n_bodies):
+        nm = joint_names[b - 1]
+        if nm not in names:
+            raise ValueError(f"joint {nm!r} is not in the dump")
+        j = names.index(nm)
+        if jtype[j] != JOINT_REVOLUTE:
+            raise ValueError(f"joint {nm!r} is not a hinge in the dump")
+        link_of[b] = j
+    body_of_link = {j: b for b, j in link_of.items()}
+
+    def owner(j: int) -> int:
+        """Template body a link moves with: itself if it carries an actuated hinge, else its nearest such ancestor (0 = base)."""
+        while j >= 0 and j not in body_of_link:
+            if jtype[j] != JOINT_FIXED:
+                raise ValueError(f"link {names[j]!r} moves on a joint the template does not have")
+            j = parent[j]
+        return body_of_link[j] if j >= 0 else 0
+
+    for b, j in link_of.items():
+        if owner(parent[j]) != template.parent[b]:
+            raise ValueError(f"tree mismatch at {names[j]!r}: dump parent body {owner(parent[j])}, template {template.parent[b]}")
+
+    out = M.MoccaModel.from_bytes(template.to_bytes())
+    frame = {0: _T()}
+    frame.update({b: L[j] for b, j in link_of.items()})
+    # the template's base frame is the robot file's root BODY frame (DESIGN.md "Model assumptions"); Bullet's base frame is the
+    # root link's inertial frame C_base = L_base o I_base, so in the dump's coordinates the template's frames sit at inv(I_base) o .
+    base_link = I_of(0).inv()
+    tf = [base_link @ t for t in _template_frames(template)]
+    for b in range(1, out.n_bodies):
+        j = link_of[b]
+        rel = frame[out.parent[b]].inv() @ frame[b]
+        for k in range(3):
+            out.jpos[b][k] = rel.t[k]
+            out.jaxis[b][k] = axis[j][k]
+        for k in range(9):
+            out.jrot[b][k] = rel.R.reshape(-1)[k]
+        out.jlo[b], out.jhi[b] = float(dump["joint_limits"][j][0]), float(dump["joint_limits"][j][1])
+        out.jdamp[b] = float(dump["joint_damping"][j])
+        if armature is not None:
+            out.jarm[b] = armature
+        # the hinge axis must be the template's, seen from the new frame (same robot file): a sign flip would silently
+        # reverse the joint coordinate
+        ax_new = frame[b].R @ axis[j]
+        ax_old = tf[b].R @ np.array(list(template.jaxis[b]))
+        if ax_new @ ax_old < 0.99:
+            raise ValueError(f"hinge axis of {names[j]!r} differs from the template's")
+
+    # inertial parameters: every Bullet link contributes to the template body it moves with
+    acc = {b: [0.0, np.zeros(3), []] for b in range(out.n_bodies)}
+    for k in range(n_links + 1):
+        j = k - 1
+        b = 0 if j < 0 else owner(j)
+        Cw = C[j]
+        rel = frame[b].inv() @ Cw                                   # inertial frame of the link in the body's frame
+        Ic = rel.R @ np.diag(inertia_diag[k]) @ rel.R.T
+        acc[b][0] += mass[k]
+        acc[b][1] += mass[k] * rel.t
+        acc[b][2].append((mass[k], rel.t, Ic))
+    for b in range(out.n_bodies):
+        mb = acc[b][0]
+        com = acc[b][1] / mb if mb > 0 else np.zeros(3)
+        I = np.zeros((3, 3))
+        for mk, ck, Ik in acc[b][2]:
+            d = ck - com
+            I += Ik + mk * ((d @ d) * np.eye(3) - np.outer(d, d))
+        out.mass[b] = mb
+        for k in range(3):
+            out.com[b][k] = com[k]
+        for k, (r, c) in enumerate([(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)]):
+            out.inertia[b][k] = I[r, c]
+
+    # geometry: the template's geoms (the robot file's shapes) re-expressed in the dump's link frames
+    for g in range(out.n_geoms):
+        b = out.g_body[g]
+        re = frame[b].inv() @ tf[b]
+        for src, dst in ((template.g_p1[g], out.g_p1[g]), (template.g_p2[g], out.g_p2[g])):
+            p = re.apply(list(src))
+            for k in range(3):
+                dst[k] = p[k]
+    for f in range(out.n_feet):
+        fb = out.foot_body[f]
+        if all(abs(template.foot_point[f][k] - template.com[fb][k]) < 1e-9 for k in range(3)):
+            for k in range(3):
+                out.foot_point[f][k] = out.com[fb][k]            # getLinkState()[0] = the foot link's centre of mass
+        else:
+            p = (frame[fb].inv() @ tf[fb]).apply(list(template.foot_point[f]))
+            for k in range(3):
+                out.foot_point[f][k] = p[k]
+    # init_pos / init_quat are kept: the reference resets with resetBasePositionAndOrientation (bullet_utils.py:97-102), which
+    # places Bullet's base frame -- now this blob's base frame -- at those values
+    return out.finalize_tables()
+
+
+def synthetic_dump(m: M.MoccaModel, joint_names: Sequence[str], fixed_children: Dict[int, float] = None) -> Dict[str, np.ndarray]:
+    """The record tools/dump_pybullet_trace.py WOULD write for a Bullet multibody equal to blob `m` (tests: loader round trip).
+    Inertial frames are the principal-axes frames at the COM, as Bullet reports them.  `fixed_children`: {body: fraction}
+    splits that fraction of the body's mass off into an extra FIXED link (exercises the merge of fixed links)."""
+    nb = m.n_bodies
+    fr = _template_frames(m)
+
+    def principal(b, mass_scale=1.0):
+        xx, yy, zz, xy, xz, yz = m.inertia[b]
+        Im = np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]]) * mass_scale
+        w, V = np.linalg.eigh(Im)
+        if np.linalg.det(V) < 0:
+            V[:, 0] = -V[:, 0]
+        return w, V
+
+    def mat_quat(R):
+        w = np.sqrt(max(0.0, 1 + np.trace(R))) / 2
+        if w > 1e-8:
+            return np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+        x = np.sqrt(max(0.0, 1 + R[0, 0] - R[1, 1] - R[2, 2])) / 2
+        if x > 1e-8:
+            return np.array([x, (R[0, 1] + R[1, 0]) / (4 * x), (R[0, 2] + R[2, 0]) / (4 * x), (R[2, 1] - R[1, 2]) / (4 * x)])
+        y = np.sqrt(max(0.0, 1 - R[0, 0] + R[1, 1] - R[2, 2])) / 2
+        if y > 1e-8:
+            return np.array([(R[0, 1] + R[1, 0]) / (4 * y), y, (R[1, 2] + R[2, 1]) / (4 * y), (R[0, 2] - R[2, 0]) / (4 * y)])
+        return np.array([0.0, 0.0, 1.0, 0.0])
+
+    fixed_children = fixed_children or {}
+    # base: Bullet's base frame is its inertial frame; our blob's base frame may have com != 0 -- shift everything
+    w0, V0 = principal(0)
+    C0 = _T(V0, list(m.com[0]))                                    # base inertial frame in OUR base frame
+    rows = []                                                      # (name, type, parent link, L frame (our base coords), body, mass frac)
+    link_index = {0: -1}
+    for b in range(1, nb):
+        rows.append(dict(name=joint_names[b - 1], type=JOINT_REVOLUTE, parent=link_index[m.parent[b]], L=fr[b], body=b, frac=1.0 - fixed_children.get(b, 0.0)))
+        link_index[b] = len(rows) - 1
+        if b in fixed_children:
+            rows.append(dict(name=f"jointfix_{b}", type=JOINT_FIXED, parent=link_index[b], L=fr[b], body=b, frac=fixed_children[b]))
+    n = len(rows)
+    out = dict(joint_names=np.array([r["name"] for r in rows]), link_names=np.array([r["name"] + "_link" for r in rows]),
+               joint_type=np.array([r["type"] for r in rows]), parent_index=np.array([r["parent"] for r in rows]),
+               joint_damping=np.zeros(n), joint_limits=np.zeros((n, 2)), joint_axis=np.zeros((n, 3)),
+               parent_frame_pos=np.zeros((n, 3)), parent_frame_orn=np.zeros((n, 4)),
+               mass=np.zeros(n + 1), local_inertia_diag=np.zeros((n + 1, 3)), inertial_pos=np.zeros((n + 1, 3)), inertial_orn=np.zeros((n + 1, 4)),
+               n_links=np.array(n))
+    out["mass"][0], out["local_inertia_diag"][0] = m.mass[0], w0
+    out["inertial_pos"][0], out["inertial_orn"][0] = C0.t, mat_quat(C0.R)        # base inertial frame in the root body (link) frame
+    Cw = {-1: C0}
+    for j, r in enumerate(rows):
+        b = r["body"]
+        w, V = principal(b, r["frac"])
+        Ij = _T(V, list(m.com[b]))                                  # inertial frame in the link frame (a split-off fixed part shares COM and axes)
+        Cw[j] = r["L"] @ Ij
+        F = Cw[r["parent"]].inv() @ r["L"]                          # (all frames in the template's base coordinates; only relatives are stored)
+        out["parent_frame_pos"][j], out["parent_frame_orn"][j] = F.t, mat_quat(F.R)
+        out["mass"][1 + j], out["local_inertia_diag"][1 + j] = m.mass[b] * r["frac"], w
+        out["inertial_pos"][1 + j], out["inertial_orn"][1 + j] = Ij.t, mat_quat(Ij.R)
+        if r["type"] == JOINT_REVOLUTE:
+            out["joint_axis"][j] = list(m.jaxis[b])
+            out["joint_limits"][j] = [m.jlo[b], m.jhi[b]]
+            out["joint_damping"][j] = m.jdamp[b]
+    out["_base_inertial_in_template_base"] = np.concatenate([C0.t, C0.R.reshape(-1)])
+    return out

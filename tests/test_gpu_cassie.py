@@ -62,7 +62,11 @@ def test_cassie_teacher_forced_steps():
     eg, ec = np.concatenate(eg), np.concatenate(ec)
     print(f"vs f64 oracle: GPU median {np.median(eg):.3g} p99 {np.percentile(eg, 99):.3g} | f32 oracle median {np.median(ec):.3g} "
           f"p99 {np.percentile(ec, 99):.3g}")
-    assert np.median(errs) < 3.0 and np.percentile(errs, 90) < 20.0
+    # Tolerance of one env.step = 50 PD + physics iterations with stiff closure rows at dt = 0.6 ms: what fp32 arithmetic itself
+    # costs over those 50 iterations (f32 oracle vs f64 oracle, same start state), times 3.  The strict per-substep statement
+    # (same active set -> 1e-5-relative, f64 yardstick) is tests/test_gpu_substep.py.
+    assert np.median(errs) < 3 * np.median(ec) + 0.05 and np.percentile(errs, 90) < 3 * np.percentile(ec, 90) + 0.5, \
+        (np.median(errs), np.median(ec), np.percentile(errs, 90), np.percentile(ec, 90))
     # the GPU is as close to the f64 oracle as the scalar f32 oracle is
     assert np.median(eg) <= 3 * np.median(ec) + 0.05 and np.percentile(eg, 99) <= 3 * np.percentile(ec, 99) + 0.5
 

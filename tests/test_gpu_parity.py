@@ -110,7 +110,12 @@ def test_teacher_forced_steps(env_id, task):
         e_state = _err_units(sg[ok][:, :nd_], sc[ok][:, :nd_]).max(axis=1)
         e_state = np.maximum(e_state, _err_units(sg[ok][:, nd_:].sum(axis=1), sc[ok][:, nd_:].sum(axis=1)))
         e_obs = _err_units(og[ok], oc[ok]).max(axis=1)
-        assert e_state.max() < 50 and e_obs.max() < 50, f"t={t}: gross mismatch {e_state.max()} {e_obs.max()}"
+        # hard cap on a single env.step (4 substeps, each with discrete row decisions): 3x the worst that fp32 arithmetic itself
+        # does on this very step (f32 oracle vs f64 oracle), never more than 2 % -- the strict per-substep statement with
+        # matching active sets is tests/test_gpu_substep.py
+        e_ref = _err_units(sc[ok][:, :nd_], s6[ok][:, :nd_]).max()
+        assert e_state.max() < min(20.0, 3 * e_ref + 1.0) and e_obs.max() < min(20.0, 3 * e_ref + 1.0), \
+            f"t={t}: gross mismatch {e_state.max()} {e_obs.max()} (fp32 itself: {e_ref})"
         errs["state"].append(e_state); errs["obs"].append(e_obs)
         errs["rew"].append(np.abs(rg[ok] - rc[ok]))
         # termination flags may only differ where the height sits on the threshold

@@ -1,0 +1,106 @@
+"""mocca_envs_amd.pybullet_dump: a model blob built from what a real PyBullet session reports.
+
+PyBullet is not installable here, so the record is synthesised from a compiled blob in PyBullet's own conventions
+(inertial = principal-axes frames, parent frames relative to the parent's inertial frame, the base frame = the root
+link's inertial frame, a fixed link split off one body) and loaded back.  The loaded blob describes the SAME mechanism
+in OTHER frames; the test is physical equivalence: same link COMs and geom points in the world, same kinetic energy,
+and the same joint trajectory through the oracle's physics.  CPU only."""
+import numpy as np
+
+from mocca_envs_amd import model as M
+from mocca_envs_amd import pybullet_dump as PD
+from oracle.oracle import Oracle
+
+
+def _map_state(st, C0t, C0R, nj):
+    """Template-frame state row -> the same physical state for the dump-frame blob (base point moved to the base COM,
+    base axes = principal axes)."""
+    import dense_reference as D
+    out = st.copy()
+    R = D._quat_mat(st[3:7])
+    out[0:3] = st[0:3] + R @ C0t
+    out[3:7] = D._mat_quat(R @ C0R)
+    out[7:10] = st[7:10] + np.cross(st[10:13], R @ C0t)
+    return out
+
+
+def test_loader_reproduces_the_mechanism_in_bullets_frames():
+    import dense_reference as D
+    tmpl = M.compile_walker3d()
+    dump = PD.synthetic_dump(tmpl, M.WALKER3D_JOINT_NAMES, fixed_children={4: 0.3, 17: 0.5})
+    assert int(dump["n_links"]) == 23 and (dump["joint_type"] == PD.JOINT_FIXED).sum() == 2
+    m = PD.from_pybullet_dump(dump, tmpl, M.WALKER3D_JOINT_NAMES)
+    base = dump["_base_inertial_in_template_base"]
+    C0t, C0R = base[:3], base[3:].reshape(3, 3)
+    np.testing.assert_allclose([m.mass[b] for b in range(22)], [tmpl.mass[b] for b in range(22)], rtol=1e-6)
+    np.testing.assert_allclose(list(m.com[0]), 0.0, atol=1e-7)              # Bullet's base frame sits at the base COM
+    assert abs(sum(m.mass[b] for b in range(22)) - 60.0) < 0.01
+    nj = 21
+    rng = np.random.default_rng(0)
+    ma, mb = D.Model(tmpl), D.Model(m)
+    for trial in range(3):
+        st = np.zeros(13 + 2 * nj + tmpl.n_slots)
+        st[0:3] = [0.1, -0.2, 1.5]
+        q = rng.normal(size=4); st[3:7] = q / np.linalg.norm(q)
+        st[7:13] = rng.normal(0, 1, 6)
+        st[13:13 + nj] = rng.uniform(-0.5, 0.5, nj)
+        st[13 + nj:13 + 2 * nj] = rng.normal(0, 2, nj)
+        st2 = _map_state(st, C0t, C0R, nj)
+        sa, sb = D.State.from_row(ma, st), D.State.from_row(mb, st2)
+        # same link COMs, same geom end points in the world
+        Ra, oa = D.fk(ma, sa.pos, D._quat_mat(sa.quat), sa.q)
+        Rb, ob = D.fk(mb, sb.pos, D._quat_mat(sb.quat), sb.q)
+        for b in range(22):
+            np.testing.assert_allclose(oa[b] + Ra[b] @ ma.com[b], ob[b] + Rb[b] @ mb.com[b], atol=2e-6)
+        for ga, gb in zip(ma.geoms, mb.geoms):
+            for e in range(2):
+                np.testing.assert_allclose(oa[ga["body"]] + Ra[ga["body"]] @ ga["p"][e], ob[gb["body"]] + Rb[gb["body"]] @ gb["p"][e], atol=2e-6)
+        # same kinetic energy
+        Ma, *_ = D.mass_matrix(ma, sa)
+        Mb, *_ = D.mass_matrix(mb, sb)
+        Ta, Tb = 0.5 * sa.nu() @ Ma @ sa.nu(), 0.5 * sb.nu() @ Mb @ sb.nu()
+        assert abs(Ta - Tb) < 1e-5 * Ta
+    # and the same dynamics through the oracle: ONE substep from contact-rich states (tumbling close to the ground: terrain and
+    # self contacts, limit rows), and a free-flight trajectory.  Base damping off: it acts at the base point, which moved.
+    for mm in (tmpl, m):
+        mm.lin_damp = mm.ang_damp = 0.0
+    oa_, ob_ = Oracle(tmpl.to_bytes(), 0, 1, "f64"), Oracle(m.to_bytes(), 0, 1, "f64")
+    oa_.reset(seed=1); ob_.reset(seed=1)
+    from test_oracle_dense import _random_state
+    rows = []
+    for trial in range(8):
+        s0 = _random_state(rng, tmpl, 0.3 + 0.2 * rng.random())
+        s0[13 + 2 * nj:] = 0.0
+        tau = rng.uniform(-40, 40, nj)
+        oa_.set_state(s0[None].copy()); ob_.set_state(_map_state(s0, C0t, C0R, nj)[None].copy())
+        oa_.physics_substeps(0, tau, 1); ob_.physics_substeps(0, tau, 1)
+        assert oa_.last_rows() == ob_.last_rows()
+        rows.append(oa_.last_rows())
+        qa, qb = oa_.get_state()[0], ob_.get_state()[0]
+        # blob numbers are fp32 (1e-7 relative) and Baumgarte rows divide positions by dt: 1e-5-level agreement of the new speeds
+        np.testing.assert_allclose(qa[13:13 + 2 * nj], qb[13:13 + 2 * nj], atol=5e-5 * (1 + np.abs(qa[13:13 + 2 * nj]).max()))
+        mapped = _map_state(qa, C0t, C0R, nj)
+        np.testing.assert_allclose(D._quat_mat(mapped[3:7]), D._quat_mat(qb[3:7]), atol=2e-5)
+        np.testing.assert_allclose(mapped[10:13], qb[10:13], atol=5e-5 * (1 + np.abs(qb[10:13]).max()))
+        # the base POINT differs between the two blobs (body origin vs base COM, 6.8 cm apart) and the integrator is first order
+        # in dt for the velocity of whichever point it carries: the two agree to O(dt |omega|^2 r), not to rounding
+        w2 = qb[10:13] @ qb[10:13]
+        np.testing.assert_allclose(mapped[7:10], qb[7:10], atol=1e-3 + 2.0 * tmpl.dt * w2 * np.linalg.norm(C0t))
+    assert max(rows) >= 20
+    s0 = _random_state(rng, tmpl, 3.0)
+    oa_.set_state(s0[None].copy()); ob_.set_state(_map_state(s0, C0t, C0R, nj)[None].copy())
+    for k in range(60):
+        oa_.physics_substeps(0, tau, 1); ob_.physics_substeps(0, tau, 1)
+    np.testing.assert_allclose(oa_.get_state()[0][13:13 + 2 * nj], ob_.get_state()[0][13:13 + 2 * nj], atol=2e-5)
+
+
+def test_loader_rejects_a_different_tree():
+    import pytest
+    tmpl = M.compile_walker3d()
+    dump = PD.synthetic_dump(tmpl, M.WALKER3D_JOINT_NAMES)
+    bad = dict(dump); bad["parent_index"] = dump["parent_index"].copy(); bad["parent_index"][5] = 0
+    with pytest.raises(ValueError):
+        PD.from_pybullet_dump(bad, tmpl, M.WALKER3D_JOINT_NAMES)
+    bad = dict(dump); bad["joint_axis"] = -dump["joint_axis"]
+    with pytest.raises(ValueError):
+        PD.from_pybullet_dump(bad, tmpl, M.WALKER3D_JOINT_NAMES)

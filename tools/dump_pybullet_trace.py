@@ -7,9 +7,11 @@ Writes pybullet_walker3d.npz with
   * a teacher-forcing trace of N steps: state before (base pose/velocity, q, qd), the 21 torques applied, state after
     one stepSimulation with the reference's parameters (fixedTimeStep 1/60, 4 substeps, 5 iterations, contact ERP 0.9),
     foot contact flags.
-The loader side is tests/test_pybullet_trace.py (skipped while the file is absent): it feeds every "before" state
-through the HIP stepper / the oracle and reports the one-step error against Bullet's "after" -- the number the north
-star asks for ("joint state within 1e-4 of PyBullet"), which cannot be produced in the build image.
+The loader side is mocca_envs_amd/pybullet_dump.py (from_pybullet_dump: model blob from this record, no importer
+assumptions left) and tests/test_pybullet_trace.py (skipped while the file is absent): it feeds every "before" state
+through the f64 oracle and through the HIP stepper and bounds the one-step error against Bullet's "after" by the north
+star's 1e-4 -- the number that cannot be produced in the build image.  Copy the file to
+tests/golden/pybullet_walker3d.npz.
 Usage: python tools/dump_pybullet_trace.py /path/to/mocca_envs/data 1000
 """
 import sys
