@@ -56,6 +56,9 @@ enum {
   MOCCA_PARAM_SEED = 5,        /* Philox key used by step() for in-kernel draws (also set by mocca_reset) */
   MOCCA_PARAM_ENV_OFFSET = 6,  /* global index of this handle's env 0: draws are keyed by (seed, offset + env, episode),
                                   so a shard of a larger batch reproduces exactly the envs it owns */
+  MOCCA_PARAM_RANDOM_REWARD = 8, /* Walker3DStepperEnv(random_reward=True), env_locomotion.py:533-547: the 8 reward terms are weighted by
+                                    U(0.8, 1.2) numbers drawn every step.  1: drawn in the kernel (8 draws per step); 2: supplied by
+                                    the host in task words 30..37 before each step (the single-env classes: np_random stays on the host) */
   MOCCA_PARAM_APPLIED_GAIN = 7, /* set_robot_params({"applied_gain": g}), env_base.py:108-115 / robots.py:16,33: acts on the
                                    next apply_action; the Stepper overwrites it at reset from its curriculum (:489) */
 };
@@ -124,7 +127,7 @@ int mocca_observe(mocca_handle h, float *obs_dev, void *stream);
 
 /* In-memory snapshot of the simulation (the role of saveState/restoreState, env_base.py:101): dynamic
  * state [N][state_dim] f32, task record [N][MOCCA_TASK_WORDS] 32-bit words, terrain [N][128] f32
- * (Stepper: 20 rows x 6 then the 3 live plank rows as floats). Device pointers. */
+ * (Stepper: 20 rows x 6 then the n_planks (3 or 4) live plank rows as floats). Device pointers. */
 int mocca_get_state(mocca_handle h, float *state_dev, void *stream);
 int mocca_set_state(mocca_handle h, const float *state_dev, void *stream);
 int mocca_get_task(mocca_handle h, uint32_t *task_dev, void *stream);

@@ -31,14 +31,14 @@ extern "C" {
 #endif
 
 #define MOCCA_MODEL_MAGIC 0x41434F4Du /* "MOCA" */
-#define MOCCA_MODEL_VERSION 8u
+#define MOCCA_MODEL_VERSION 9u
 
 #define MOCCA_MAX_BODIES 24
 #define MOCCA_MAX_GEOMS 32
 #define MOCCA_MAX_PAIRS 192
 #define MOCCA_MAX_FEET 4
 #define MOCCA_MAX_SLOTS 40   /* terrain contact slots (warm-start impulses) */
-#define MOCCA_MAX_PLANKS 3
+#define MOCCA_MAX_PLANKS 4   /* rendered_step_count: 3 (Walker3DStepperEnv, env_locomotion.py:345) / 4 (LaikagoStepperEnv, :904) */
 #define MOCCA_MAX_TERRAIN_STEPS 20
 #define MOCCA_MAX_CLOSURES 2
 #define MOCCA_MAX_CTRL 16
@@ -51,7 +51,13 @@ enum {
   MOCCA_TASKF_RESET_TAIL_ZERO = 2, /* Walker2DCustomEnv.reset returns [robot_state, 0, 0] (env_locomotion.py:299-300)            */
   MOCCA_TASKF_BODY_CONTACT = 4,    /* LaikagoCustomEnv.calc_base_reward: tall_bonus = 0, and -1 + done as soon as a non-foot link
                                       touches the ground (env_locomotion.py:877-890)                                              */
+  MOCCA_TASKF_QUADRUPED_STEPPER = 8, /* LaikagoStepperEnv.calc_base_reward (env_locomotion.py:928-979): posture penalty from the hip /
+                                      knee angles, progress x 2, posture x 0.2, tall_bonus 2, done = (t > 240 and next step <= 4),
+                                      -1 + done when a non-foot link touches a plank                                              */
 };
+
+/* MoccaModel.plank_shape */
+enum { MOCCA_PLANK_BOX = 0 /* Plank, LargePlank (bullet_objects.py:92-103) */, MOCCA_PLANK_CYLINDER = 1 /* Pillar (:86-89), axis = plank z */ };
 
 /* task ids accepted by mocca_create() */
 enum {
@@ -169,6 +175,24 @@ typedef struct MoccaModel {
   float init_quat[4];                  /* base orientation at reset, xyzw (robots.py:199-200; "crawl" pose :316-318) */
   int32_t task_flags;                 /* MOCCA_TASKF_*: quirks of the planar Custom envs (env_locomotion.py:285-314) */
 
+  /* ---- Stepper terrain and task parameters: class attributes of Walker3DStepperEnv (env_locomotion.py:338-351,367-385)
+   *      and their LaikagoStepperEnv overrides (:894-926); lookahead is 2 in both ---- */
+  int32_t n_planks;             /* rendered_step_count            3    / 4    */
+  int32_t lookbehind;           /*                                1    / 2    (also the first next_step_index, :499) */
+  int32_t plank_shape;          /* MOCCA_PLANK_*: plank_half = half extents (box) or (radius, radius, half height) (cylinder) */
+  float step_radius;            /*                                0.25 / 0.16 */
+  float init_step_separation;   /*                                0.75 / 0.45 */
+  float dist_range[2];          /*                           0.65 1.25 / 0.45 0.75 */
+  float pitch_range_deg;        /* +-                             30   / 20   */
+  float yaw_range_deg;          /* +-                             20   / 20   */
+  float tilt_range_deg;         /* +-                             15   / 10   */
+  float step_bonus_smoothness;  /*                                1    / 6    (:686) */
+  float term_height_cur[2];     /* terminal_height_curriculum = linspace(a, b, 10):   0.75 0.45 / 0.20 0.0 */
+  float gain_cur[2];            /* applied_gain_curriculum    = linspace(a, b, 10):   1.0  1.2  / 1.0  1.0 */
+  float init_vel[3];            /* robot_init_velocity            None / (0.5, 0, 0.25)  (:340,901) */
+  int32_t planar;               /* CassieEnv(planar=True) (env_cassie.py:326-341): base held in the x-z plane by three bilateral
+                                   rows (v_y, omega_x, omega_z) -- stands in for the missing cassie_collide_2d.urdf (:279-282) */
+
   /* ---- derived lookup tables (model.py finalize_tables): one 16-byte load instead of chains of dependent loads ---- */
   float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | terrain<<24), bits(anc_mask[body]) */
   float gp_tab[2 * MOCCA_MAX_GEOMS][4];     /* geom end point in its body frame (x, y, z), bits(body) */
@@ -195,6 +219,7 @@ typedef struct MoccaModel {
  *  16 i next_step_index 17 i target_reached_count 18 i stop_on_next_step
  *  19 i set_stop_on_next_step 20 i curriculum 21 f applied_gain
  *  22 f prev_body_x  23 reserved
+ *  30..37 f reward weights of this step (Stepper with MOCCA_PARAM_RANDOM_REWARD, env_locomotion.py:533-547)
  *  --- quadrupeds only (n_feet == 4) ---
  *  24 f feet_contact[2]  25 f feet_contact[3]
  *  --- Cassie only ---

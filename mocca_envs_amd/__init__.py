@@ -19,6 +19,8 @@ REGISTERED = {
     "Walker2DCustomEnv-v0": ("mocca_envs_amd.envs:Walker2DCustomEnv", {}),
     "Crab2DCustomEnv-v0": ("mocca_envs_amd.envs:Crab2DCustomEnv", {}),
     "LaikagoCustomEnv-v0": ("mocca_envs_amd.envs:LaikagoCustomEnv", {}),
+    "LaikagoStepperEnv-v0": ("mocca_envs_amd.envs:LaikagoStepperEnv", {}),
+    "Cassie2DEnv-v0": ("mocca_envs_amd.envs:CassieEnv", {"planar": True}),   # reference __init__.py:24-29
 }
 
 

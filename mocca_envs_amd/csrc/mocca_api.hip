@@ -32,7 +32,7 @@ struct mocca_ctx {
   float* d_dyn = nullptr;
   uint32_t* d_task = nullptr;
   float* d_terrain = nullptr;
-  int auto_reset = 0, eval_mode = 0, random_pose = 1, curriculum = 0, host_retarget = 0, env_offset = 0;
+  int auto_reset = 0, eval_mode = 0, random_pose = 1, curriculum = 0, host_retarget = 0, env_offset = 0, random_reward = 0;
   float gain = 1.0f;
   float* d_pvec[3] = {nullptr, nullptr, nullptr};  // per-env curriculum / eval_mode / applied_gain (mocca_set_param_v), lazily allocated
   bool pvec_on[3] = {false, false, false};
@@ -84,8 +84,8 @@ static int check_topology(const MoccaModel& m, int task_id, int* topo, std::stri
   if (task_id == MOCCA_TASK_WALKER3D_CUSTOM && m.n_bodies == TopoCrab2D::NB) {
     *topo = TOPO_CRAB2D; return check_topology_t<TopoCrab2D>(m, "TopoCrab2D", err);
   }
-  if (task_id == MOCCA_TASK_WALKER3D_CUSTOM && m.n_bodies == TopoLaikago::NB) {
-    *topo = TOPO_LAIKAGO; return check_topology_t<TopoLaikago>(m, "TopoLaikago", err);
+  if ((task_id == MOCCA_TASK_WALKER3D_CUSTOM || task_id == MOCCA_TASK_WALKER3D_STEPPER) && m.n_bodies == TopoLaikago::NB) {
+    *topo = TOPO_LAIKAGO; return check_topology_t<TopoLaikago>(m, "TopoLaikago", err);   // LaikagoCustomEnv / LaikagoStepperEnv
   }
   *topo = TOPO_WALKER3D;
   return check_topology_t<TopoWalker3D>(m, "TopoWalker3D", err);
@@ -149,7 +149,11 @@ int mocca_create(const void* model_blob, size_t nbytes, int task_id, int n_envs,
   h->task_id = task_id; h->n_envs = n_envs; h->device = device;
   h->obs_dim = task_id == MOCCA_TASK_CASSIE
                    ? 6 + 2 * h->model.n_ordered + 2
-                   : 6 + 2 * h->model.n_joints + h->model.n_feet + (task_id == MOCCA_TASK_WALKER3D_CUSTOM ? 2 : 15);
+                   : 6 + 2 * h->model.n_joints + h->model.n_feet + (task_id == MOCCA_TASK_WALKER3D_CUSTOM ? 2 : 5 * (h->model.lookbehind + 2));
+  if (task_id == MOCCA_TASK_WALKER3D_STEPPER &&
+      (h->model.n_planks < 1 || h->model.n_planks > MOCCA_MAX_PLANKS || h->model.lookbehind < 1 || h->model.lookbehind > 2)) {
+    g_err = "Stepper blob: n_planks must be 1..4 and lookbehind 1 or 2"; delete h; return MOCCA_E_ARG;
+  }
   auto fail = [&](const char* what, hipError_t e) {
     g_err = std::string(what) + ": " + hipGetErrorString(e);
     mocca_destroy(h);
@@ -216,7 +220,7 @@ static StepArgs make_args(mocca_handle h) {
   a.model = h->d_model; a.dyn = h->d_dyn; a.task = h->d_task; a.terrain = h->d_terrain;
   a.n_envs = h->n_envs; a.obs_dim = h->obs_dim;
   a.auto_reset = h->auto_reset; a.eval_mode = h->eval_mode; a.random_pose = h->random_pose; a.curriculum = h->curriculum;
-  a.host_retarget = h->host_retarget; a.env_offset = h->env_offset;
+  a.host_retarget = h->host_retarget; a.env_offset = h->env_offset; a.random_reward = h->random_reward;
   a.seed_lo = (uint32_t)h->seed; a.seed_hi = (uint32_t)(h->seed >> 32);
   a.curriculum_v = h->pvec_on[0] ? h->d_pvec[0] : nullptr;
   a.eval_mode_v = h->pvec_on[1] ? h->d_pvec[1] : nullptr;
@@ -367,6 +371,9 @@ int mocca_set_param(mocca_handle h, int param_id, double value) {
     case MOCCA_PARAM_HOST_RETARGET: h->host_retarget = value != 0; break;
     case MOCCA_PARAM_SEED: h->seed = (uint64_t)value; break;
     case MOCCA_PARAM_ENV_OFFSET: h->env_offset = (int)value; break;
+    case MOCCA_PARAM_RANDOM_REWARD:
+      if (value != 0 && value != 1 && value != 2) { h->err = "MOCCA_PARAM_RANDOM_REWARD is 0, 1 or 2"; return MOCCA_E_ARG; }
+      h->random_reward = (int)value; break;
     default: h->err = "unknown parameter id"; return MOCCA_E_ARG;
   }
   return MOCCA_OK;

@@ -79,13 +79,12 @@ enum : int {
   L_NU = 72,      // [28] omega(3) v(3) qd(at 5+body)
   L_BASE = 100,   // [16] pos3 quat4 vel3 omg3
   L_WARM = 116,   // [40] warm-start impulses per terrain slot
-  L_FEET = 156,   // [12] feet COM xyz (NFEET x 3; a quadruped's last two reach into L_MISC, which only the Stepper uses)
-  L_MISC = 164,   // [12]
-  L_PLANK = 164,  // [3][12] Stepper: frames of the three live planks (rotation 9, box centre 3), built once per env.step;
-                  //         overlays L_MISC / L_JVEL / L_Q0 (the last two are Cassie-only)
-  L_JVEL = 176,   // [16] Cassie: filtered joint speeds of the low-level PD loop (env_cassie.py:451-453)
-  L_Q0 = 192,     // [16] Cassie: joint angles at the start of the env.step (finite-difference jvel, :467-468)
-  L_V = 208,
+  L_FEET = 156,   // [12] feet COM xyz (NFEET x 3)
+  L_PLANK = 168,  // [4][12] Stepper: frames of the live planks (rotation 9, centre 3), built once per env.step;
+                  //         overlays L_JVEL / L_Q0 (Cassie-only)
+  L_JVEL = 168,   // [16] Cassie: filtered joint speeds of the low-level PD loop (env_cassie.py:451-453)
+  L_Q0 = 184,     // [16] Cassie: joint angles at the start of the env.step (finite-difference jvel, :467-468)
+  L_V = 216,
   // ---- ABA view
   L_SQ = L_V + 0,       // [24] (free)
   L_CQ = L_V + 24,      // [24] (free)
@@ -112,12 +111,14 @@ enum : int {
   L_A = L_V,            // [MAXR][MAXR] Delassus matrix, row = updated row, column = lane
   L_J = L_V + 960,      // [MAXR][28] Jacobian rows (tail of the A region)
   L_XL = L_V,           // [MAXR][28] M^-1 J^T lambda, after the iterations
-  L_TOTAL = L_V + MAXR * MAXR + MAXR,  // + one dummy row: J row of lanes that own no row (28) / A-row prefetch past the last row (MAXR)
+  L_TOTAL = L_V + MAXR * MAXR + 28,  // + one dummy J row for lanes that own no row (A-row prefetches clamp to row MAXR - 1)
 };
 static_assert(L_ABA_END <= L_TOTAL, "ABA view must fit");
 static_assert(L_JR1 + 16 * MOCCA_MAX_BODIES <= L_TOTAL && (L_JR0 % 4) == 0 && (L_JR1 % 4) == 0, "joint records must fit, 16-byte aligned");
 static_assert(L_J + (MAXR + 1) * 28 <= L_TOTAL, "Jacobian rows (+ dummy) must fit the tail of the A region");
 static_assert(L_J % 4 == 0 && L_V % 4 == 0, "16-byte alignment of broadcast rows");
+static_assert(L_PLANK + 12 * MOCCA_MAX_PLANKS <= L_V && L_Q0 + 16 <= L_V, "persistent region overflows into the two-view region");
+static_assert(L_TOTAL * 4 <= 10240, "more than 10 KB of LDS per wave: fewer than 16 waves per CU, the 4096-env batch no longer fits one round");
 static_assert(L_J >= L_R, "J rows may be written while S, U, 1/D, the factor of IA0 and the contacts are still being read");
 
 // contact record fields
@@ -126,7 +127,8 @@ enum : int { C_BA = 0, C_BB = 1, C_SLOT = 2, C_P = 3, C_N = 6, C_DEPTH = 9, C_MU
 // task record words (include/mocca_model.h)
 enum : int { T_WTX = 0, T_WTY, T_WTZ, T_LINPOT, T_ANGPOT, T_CLOSE, T_STOPF, T_DONE, T_T, T_EPISODE, T_DRAW, T_MIRROR,
              T_FC0, T_FC1, T_DIST, T_ANGLE, T_NSI, T_TRC, T_STOP, T_SETSTOP, T_CUR, T_GAIN, T_PREVX, T_RES23,
-             T_JVEL = 24, T_FC2 = 24, T_FC3 = 25 /* quadrupeds; Cassie's jvel otherwise */, T_INITZ = 38, T_ISTEP = 39 };
+             T_JVEL = 24, T_FC2 = 24, T_FC3 = 25 /* quadrupeds; Cassie's jvel otherwise */, T_RW = 30 /* Stepper: 8 reward weights */,
+             T_INITZ = 38, T_ISTEP = 39 };
 
 struct StepArgs {
   const MoccaModel* model;
@@ -151,6 +153,7 @@ struct StepArgs {
   // per-env parameter vectors (mocca_set_param_v); null = the handle-wide scalar above
   const float* curriculum_v;   // [N]
   const float* eval_mode_v;    // [N]
+  int random_reward;           // Stepper, env_locomotion.py:533-547: 0 off, 1 weights drawn in the kernel, 2 weights supplied in the task record
   const float* gain_v;         // [N] robot.applied_gain of the Custom envs (set_robot_params); the Stepper derives it from the curriculum
   float gain;
   // mocca_task_step (INJECT kernels): contact query results supplied by the caller instead of the physics
@@ -730,6 +733,25 @@ DI float sphere_box(const float* l, float rad, const float* Rb, const float* h, 
   matvec3(Rb, nl, n);
   return dist - rad;
 }
+// the same against an upright cylinder (Pillar, bullet_objects.py:86-89): axis = local z, h = (radius, radius, half height)
+DI float sphere_cylinder(const float* l, float rad, const float* Rb, const float* h, float* n) {
+  const float rho = sqrtf(l[0] * l[0] + l[1] * l[1]), R = h[0], hz = h[2];
+  const float ux = rho > 1e-12f ? l[0] / rho : 1.0f, uy = rho > 1e-12f ? l[1] / rho : 0.0f;
+  float nl[3] = {0, 0, 0}, dist;
+  if (rho <= R && fabsf(l[2]) <= hz) {
+    const float dcap = hz - fabsf(l[2]), dside = R - rho;
+    if (dcap < dside) { nl[2] = l[2] >= 0 ? 1.0f : -1.0f; dist = -dcap; }
+    else { nl[0] = ux; nl[1] = uy; dist = -dside; }
+  } else {
+    const float qr = rho < R ? rho : R, qz = l[2] > hz ? hz : (l[2] < -hz ? -hz : l[2]);
+    const float e[3] = {l[0] - qr * ux, l[1] - qr * uy, l[2] - qz};
+    dist = sqrtf(dot3(e, e));
+    const float id = 1.0f / dist;
+    nl[0] = e[0] * id; nl[1] = e[1] * id; nl[2] = e[2] * id;
+  }
+  matvec3(Rb, nl, n);
+  return dist - rad;
+}
 DI float clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
 DI void seg_seg(const float* p1, const float* q1, const float* p2, const float* q2, float* c1, float* c2) {
   float d1[3], d2[3], r[3];
@@ -776,7 +798,7 @@ DI void geom_points(ModelP M, float* L, int lane) {
 // Stepper: rotation and box centre of the three live planks (bullet_objects.py:77-83 offset included), once per env.step.
 // They were rebuilt from the terrain table -- six sin/cos and seven global reads -- per (lane, plank, substep).
 DI void stage_planks(ModelP M, float* L, int lane, const float* ter) {
-  if (lane < MOCCA_MAX_PLANKS) {
+  if (lane < M->n_planks) {
     const int row = (int)ter[120 + lane];
     const float* ti = ter + 6 * row;
     float Rb[9];
@@ -791,7 +813,7 @@ DI void stage_planks(ModelP M, float* L, int lane, const float* ter) {
   wsync();
 }
 
-struct ContactFlags { int touch0, touch1, target0, target1, touch2, touch3, body_touch; };  // feet 2, 3: quadrupeds; body_touch: a non-foot link on the terrain
+struct ContactFlags { int touch0, touch1, target0, target1, touch2, touch3, body_touch, target2, target3; };  // feet 2, 3: quadrupeds; body_touch: a non-foot link on the terrain
 
 // lane = terrain contact slot, then self-collision pairs strided over the wave.
 // Contacts are compacted in slot order, then pair order (the oracle's priority), up to max_contacts.
@@ -800,7 +822,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
                         int* nc_out, int32_t* dbg) {
   STAMP_BEGIN;
   const float margin = unif(M->contact_margin);
-  ContactFlags fl = {0, 0, 0, 0, 0, 0, 0};
+  ContactFlags fl = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int maxc = uni(M->max_contacts);
   // ---- terrain: lane -> (geom, end)
   bool active = false;
@@ -824,8 +846,10 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
         mu = M->ground_friction * gfric;
       } else {
         const float h[3] = {M->plank_half[0], M->plank_half[1], M->plank_half[2]};
+        const int n_planks = M->n_planks;
+        const bool cyl = M->plank_shape == MOCCA_PLANK_CYLINDER;
 #pragma unroll 1
-        for (int k = 0; k < MOCCA_MAX_PLANKS; ++k) {
+        for (int k = 0; k < n_planks; ++k) {
           float Rb[9], bc[3], nn[3];  // staged by stage_planks(): the planks do not move during the substeps
 #pragma unroll
           for (int i = 0; i < 9; ++i) Rb[i] = L[L_PLANK + 12 * k + i];
@@ -837,13 +861,13 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
           // activate a slot nor win the minimum against one that does)
           const float reach = rad + margin;
           if (__ballot(fabsf(lb[0]) < h[0] + reach && fabsf(lb[1]) < h[1] + reach && fabsf(lb[2]) < h[2] + reach) == 0ull) continue;
-          const float gk = sphere_box(lb, rad, Rb, h, nn);
+          const float gk = cyl ? sphere_cylinder(lb, rad, Rb, h, nn) : sphere_box(lb, rad, Rb, h, nn);  // uniform branch
           if (gk < gap) {
             gap = gk;
             n[0] = nn[0]; n[1] = nn[1]; n[2] = nn[2];
             float d[3] = {Cw[0] - rad * nn[0] - bc[0], Cw[1] - rad * nn[1] - bc[1], Cw[2] - rad * nn[2] - bc[2]};
             const float lz = Rb[2] * d[0] + Rb[5] * d[1] + Rb[8] * d[2];
-            is_target = (lz >= h[2] * 0.8f) && (k == next_step_index % MOCCA_MAX_PLANKS);
+            is_target = (lz >= h[2] * 0.8f) && (k == next_step_index % n_planks);
           }
         }
         mu = M->plank_friction * gfric;
@@ -865,6 +889,8 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
       fl.touch3 = __ballot(active && gfoot == 3) != 0ull;
       // LaikagoCustomEnv ends the episode when anything but a foot link meets the ground (env_locomotion.py:880-890)
       fl.body_touch = __ballot(active && gfoot < 0) != 0ull;
+      fl.target2 = __ballot(active && gfoot == 2 && is_target) != 0ull;
+      fl.target3 = __ballot(active && gfoot == 3 && is_target) != 0ull;
     }
     fl.target0 = __ballot(active && gfoot == 0 && is_target) != 0ull;
     fl.target1 = __ballot(active && gfoot == 1 && is_target) != 0ull;
@@ -953,6 +979,11 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
       const int f0 = M->foot_body[0], f1 = M->foot_body[1];
       if (__ballot(hit && (ba == f0 || bb == f0)) != 0ull) fl.touch0 = 1;
       if (__ballot(hit && (ba == f1 || bb == f1)) != 0ull) fl.touch1 = 1;
+      if constexpr (T::NFEET > 2) {
+        const int f2 = M->foot_body[2], f3 = M->foot_body[3];
+        if (__ballot(hit && (ba == f2 || bb == f2)) != 0ull) fl.touch2 = 1;
+        if (__ballot(hit && (ba == f3 || bb == f3)) != 0ull) fl.touch3 = 1;
+      }
     }
     const int idx = nc + lane_rank(hm);
     if (hit && idx < maxc) {
@@ -1022,7 +1053,7 @@ DI void pgs_fixed_rows(const float* Acol, float a, float a1, int r_fr, float& y,
     // A entries travel two visits ahead: a (this visit) was pinned at the end of the previous one, a1 (next visit) is
     // pinned at the end of this one, a2 is issued now.  Without the pins the optimiser sinks each read into the visit
     // that uses it (the early exit does not need it), and every visit then waits a full LDS round trip.
-    const float a2 = Acol[MAXR * (RR + 2 < MAXR ? RR + 2 : MAXR)];  // row MAXR is the dummy J row: readable, unused
+    const float a2 = Acol[MAXR * (RR + 2 < MAXR ? RR + 2 : MAXR - 1)];  // past the last row: any readable row, the value is never used
     const float as = a * invdiag;
     const float nl_ = __builtin_amdgcn_fmed3f(y, lo0, 1e30f);
     const float dl = readlane(nl_ - lam, RR);
@@ -1069,10 +1100,13 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int32_t* d
     if (dbg && lane == 0) { dbg[5] = (int32_t)(unsigned)lm; dbg[6] = (int32_t)(unsigned)(lm >> 32); }
   }
   constexpr int NCL = 3 * T::NCLOS;  // point-to-point closure rows sit between the limit and the contact rows
+  // CassieEnv(planar=True): three more bilateral rows hold the base in the x-z plane (omega_x, omega_z, v_y); only the Cassie
+  // topology carries them, every other kernel instance sees a compile-time zero
+  const int NFIX = NCL + ((T::NCLOS > 0 && uni(M->planar)) ? 3 : 0);
   int nc = uni(nc_found);
-  if (nc > (maxr - nl - NCL) / 3) nc = (maxr - nl - NCL) / 3;
+  if (nc > (maxr - nl - NFIX) / 3) nc = (maxr - nl - NFIX) / 3;
   if (nc < 0) nc = 0;
-  const int nr = nl + NCL + 3 * nc;
+  const int nr = nl + NFIX + 3 * nc;
   if (dbg && lane == 0) { dbg[0] = nr; dbg[1] = nl; dbg[2] = nc; }
   // Load balancing across the waves of a SIMD: the launch lasts as long as its slowest wave, and a wave's cost grows with
   // its row count (an env lying on the ground has 48 rows, a standing one ~20).  Issue priority follows the row count,
@@ -1123,8 +1157,18 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int32_t* d
     for (int x = 0; x < 3; ++x) { F2[x] = pn[x]; F2[3 + x] = dir[x]; }
     const float e = ax == 0 ? Pb[0] - Pa[0] : (ax == 1 ? Pb[1] - Pa[1] : Pb[2] - Pa[2]);
     bias = M->erp * e * idt;
-  } else if (r < nr) {
+  } else if (T::NCLOS > 0 && r < nl + NFIX) {
+    // planar base: the base's y axis stays the world's (R e_y = e_y <=> omega_x = omega_z = 0) and y stays where it started;
+    // small-angle error of R e_y = (u_x, u_y, u_z): delta_x = u_z, delta_z = -u_x
     const int k = r - nl - NCL;
+    const int comp = k == 0 ? 0 : (k == 1 ? 2 : 4);   // entry of nu = [omega; v] the row acts on
+    kind = 3; ba = 0; bb = -1;
+#pragma unroll
+    for (int x = 0; x < 6; ++x) F[x] = x == comp ? 1.0f : 0.0f;
+    const float err = k == 0 ? L[L_R + 7] : (k == 1 ? -L[L_R + 1] : L[L_BASE + 1] - M->init_pos[1]);
+    bias = -M->erp * err * idt;
+  } else if (r < nr) {
+    const int k = r - nl - NFIX;
     const int i = k < nc ? k : (k - nc) >> 1;
     const float* ct = L + L_CT + 16 * i;
     float n[3] = {ct[C_N], ct[C_N + 1], ct[C_N + 2]}, P[3] = {ct[C_P], ct[C_P + 1], ct[C_P + 2]}, dir[3];
@@ -1155,11 +1199,11 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int32_t* d
   // ancestor masks travel with the contact records; limit / closure rows use the compile-time table (few distinct bodies)
   unsigned ma = 0u, mb = 0u;
   if (kind == 1 || kind == 2) {
-    const float* ct = L + L_CT + 16 * ((r - nl - NCL) < nc ? (r - nl - NCL) : ((r - nl - NCL - nc) >> 1));
+    const float* ct = L + L_CT + 16 * ((r - nl - NFIX) < nc ? (r - nl - NFIX) : ((r - nl - NFIX - nc) >> 1));
     ma = __float_as_uint(ct[C_MA]); mb = __float_as_uint(ct[C_MB]);
   } else if (kind >= 0) {
     ma = M->anc_mask[ba];
-    mb = (kind == 3) ? M->anc_mask[bb] : 0u;
+    mb = (kind == 3 && bb >= 0) ? M->anc_mask[bb] : 0u;
   }
   const float sa = kind >= 1 ? 1.0f : 0.0f, sb = (kind >= 1 && bb >= 0) ? 1.0f : 0.0f;  // base part: F on a, -F2 on b
 
@@ -1300,7 +1344,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int32_t* d
   STAMP(7);
   // warm-start impulses act before the first iteration (normal rows only)
 #pragma unroll 1
-  for (int rr = nl + NCL; rr < nl + NCL + nc; ++rr) {
+  for (int rr = nl + NFIX; rr < nl + NFIX + nc; ++rr) {
     const float l0 = readlane(lam, rr);
     if (l0 != 0.0f) w += L[L_A + MAXR * rr + lc] * l0;
   }
@@ -1312,18 +1356,18 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int32_t* d
   // a fixed-bound row (ds_read, mul, med3, sub, 2 readlane, writelane, fma, wait, 2 for the uniform exit test).
   const int iters = uni(M->n_iters);
   const float lo0 = kind == 3 ? -1e30f : 0.0f;
-  const int r_fr = nl + NCL + nc;  // first friction row
+  const int r_fr = nl + NFIX + nc;  // first friction row
   const float* Acol = L + L_A + lc;
   float y = (bias - w) * invdiag;
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
     pgs_fixed_rows<0>(Acol, Acol[0], Acol[MAXR], r_fr, y, lam, invdiag, lo0);
-    float a = Acol[MAXR * (r_fr < MAXR ? r_fr : MAXR)];
+    float a = Acol[MAXR * (r_fr < MAXR ? r_fr : MAXR - 1)];
 #pragma unroll 1
     for (int i = 0; i < nc; ++i) {  // the two friction rows of contact i share the bound mu * lam[normal row of i]
-      const float lm = mu * readlane(lam, nl + NCL + i);
+      const float lm = mu * readlane(lam, nl + NFIX + i);
       const int rr = r_fr + 2 * i;
-      const float a1 = Acol[MAXR * (rr + 1)], a2 = Acol[MAXR * (rr + 2 < MAXR ? rr + 2 : MAXR)];  // row MAXR: the dummy row
+      const float a1 = Acol[MAXR * (rr + 1)], a2 = Acol[MAXR * (rr + 2 < MAXR ? rr + 2 : MAXR - 1)];  // clamp: in-bounds, unused
       const float as = a * invdiag, as1 = a1 * invdiag;
       float nl_ = __builtin_amdgcn_fmed3f(y, -lm, lm);
       float dl = readlane(nl_ - lam, rr);
@@ -1573,28 +1617,25 @@ DI void softsign_tail(float dist, float ang, float* o2) {
   o2[1] = c / (1 + fabsf(c));
 }
 
-// delta_to_k_targets, env_locomotion.py:712-759 (lane 0 writes the 15 floats; sets walk_target)
-DI void delta_to_k_targets(const float* L, const float* ter, TaskRegs& t, float yaw, int lane, float* out15) {
-  const int N = t.nsi, TT = MOCCA_MAX_TERRAIN_STEPS;
-  int idx[3];
-  if (!t.stop) {
-    idx[0] = N - 1 >= 0 ? N - 1 : 0; idx[1] = N; idx[2] = N + 1;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) if (idx[i] > TT - 1) idx[i] = TT - 1;
-  } else { idx[0] = N - 1; idx[1] = N; idx[2] = N; }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) t.wt[i] = ter[6 * idx[2] + i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const float* tt = ter + 6 * idx[i];
+// delta_to_k_targets, env_locomotion.py:712-759: lookbehind j rows before the next step, then lookahead 2 rows from it, indices
+// clamped at both ends; a stop repeats the next step.  Lane 0 writes the 5 (j + 2) floats; sets walk_target (index -1).
+DI void delta_to_k_targets(ModelP M, const float* L, const float* ter, TaskRegs& t, float yaw, int lane, float* out) {
+  const int N = t.nsi, TT = MOCCA_MAX_TERRAIN_STEPS, j = M->lookbehind, nt = j + 2;
+#pragma unroll 1
+  for (int i = 0; i < nt; ++i) {
+    int v = N - j + i;
+    if (t.stop && i >= j) v = N;
+    v = v < 0 ? 0 : (v > TT - 1 ? TT - 1 : v);
+    const float* tt = ter + 6 * v;
+    if (i == nt - 1) { t.wt[0] = tt[0]; t.wt[1] = tt[1]; t.wt[2] = tt[2]; }
     const float dx = tt[0] - L[L_BASE], dy = tt[1] - L[L_BASE + 1], dz = tt[2] - L[L_BASE + 2];
     const float ang = atan2f(dy, dx) - yaw, dist = sqrtf(dx * dx + dy * dy);
     if (lane == 0) {
-      out15[5 * i + 0] = sinf(ang) * dist;
-      out15[5 * i + 1] = cosf(ang) * dist;
-      out15[5 * i + 2] = dz;
-      out15[5 * i + 3] = tt[4];
-      out15[5 * i + 4] = tt[5];
+      out[5 * i + 0] = sinf(ang) * dist;
+      out[5 * i + 1] = cosf(ang) * dist;
+      out[5 * i + 2] = dz;
+      out[5 * i + 3] = tt[4];
+      out[5 * i + 4] = tt[5];
     }
   }
 }
@@ -1602,7 +1643,7 @@ DI void delta_to_k_targets(const float* L, const float* ter, TaskRegs& t, float 
 // generate_step_placements, env_locomotion.py:395-441: 100 uniforms (5 x 20) -> 20 x 6 table in `ter`.
 // Lanes draw in parallel (counter-based RNG), lane 0 runs the cumulative sums.
 template <bool INJECT>
-DI void generate_terrain(const StepArgs& a, int env, TaskRegs& t, float* L, float* ter, int lane) {
+DI void generate_terrain(const StepArgs& a, ModelP M, int env, TaskRegs& t, float* L, float* ter, int lane) {
   const float DEG = 3.14159265358979323846f / 180.0f, HP = 1.5707963267948966f;
   const int N = MOCCA_MAX_TERRAIN_STEPS;
   const int cur = t.cur > 9 ? 9 : t.cur;
@@ -1612,10 +1653,11 @@ DI void generate_terrain(const StepArgs& a, int env, TaskRegs& t, float* L, floa
   t.draw += 5 * N;
   wsync();
   if (lane == 0) {
-    const float dist_lo = 0.65f, dist_hi = 0.65f + (1.25f - 0.65f) * cur / 9;
-    const float yaw_lo = -20 * ratio * DEG, yaw_hi = 20 * ratio * DEG;
-    const float pit_lo = -30 * ratio * DEG + HP, pit_hi = 30 * ratio * DEG + HP;
-    const float tl_lo = -15 * ratio * DEG, tl_hi = 15 * ratio * DEG;
+    const float d0 = M->dist_range[0], d1 = M->dist_range[1], sep = M->init_step_separation, dx_min = M->step_radius * 2.5f;
+    const float dist_lo = d0, dist_hi = d0 + (d1 - d0) * cur / 9;
+    const float yaw_lo = -M->yaw_range_deg * ratio * DEG, yaw_hi = M->yaw_range_deg * ratio * DEG;
+    const float pit_lo = -M->pitch_range_deg * ratio * DEG + HP, pit_hi = M->pitch_range_deg * ratio * DEG + HP;
+    const float tl_lo = -M->tilt_range_deg * ratio * DEG, tl_hi = M->tilt_range_deg * ratio * DEG;
     float x = 0, y = 0, z = 0, phi = 0;
 #pragma unroll 1
     for (int i = 0; i < N; ++i) {
@@ -1625,20 +1667,20 @@ DI void generate_terrain(const StepArgs& a, int env, TaskRegs& t, float* L, floa
       float xt = tl_lo + (tl_hi - tl_lo) * u[3 * N + i];
       float yt = tl_lo + (tl_hi - tl_lo) * u[4 * N + i];
       if (i == 0) { dr = 0; dphi = 0; dth = HP; }
-      if (i == 1 || i == 2) { dr = 0.75f; dphi = 0; dth = HP; }
+      if (i == 1 || i == 2) { dr = sep; dphi = 0; dth = HP; }
       if (i < 3) { xt = 0; yt = 0; }
       phi += dphi;
       float dx = dr * sinf(dth) * cosf(phi);
       const float dy = dr * sinf(dth) * sinf(phi), dz = dr * cosf(dth);
       if (i >= 2) {
-        const float ax = fabsf(dx), mx = ax > 0.625f ? ax : 0.625f;
+        const float ax = fabsf(dx), mx = ax > dx_min ? ax : dx_min;
         const float sg = dx > 0 ? 1.0f : (dx < 0 ? -1.0f : 0.0f);
-        dx = sg * (mx < 1.25f ? mx : 1.25f);
+        dx = sg * (mx < d1 ? mx : d1);
       }
       x += dx; y += dy; z += dz;
       ter[6 * i] = x; ter[6 * i + 1] = y; ter[6 * i + 2] = z; ter[6 * i + 3] = phi; ter[6 * i + 4] = xt; ter[6 * i + 5] = yt;
     }
-    ter[120] = 0.0f; ter[121] = 1.0f; ter[122] = 2.0f;
+    ter[120] = 0.0f; ter[121] = 1.0f; ter[122] = 2.0f; ter[123] = 3.0f;
   }
   wsync();
 }
@@ -1664,7 +1706,7 @@ DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, in
     t.wt[1] = t.dist * sinf(t.angle);
     t.wt[2] = 1.0f;
   } else {
-    t.gain = 1.0f + 0.2f * t.cur / 9;
+    t.gain = M->gain_cur[0] + (M->gain_cur[1] - M->gain_cur[0]) * t.cur / 9;           // applied_gain_curriculum[curriculum], :369,489
   }
   t.mirrored = draw_u<INJECT>(a, env, t.episode, t.draw) < 0.5f;
   t.draw += 1;
@@ -1683,9 +1725,9 @@ DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, in
       for (int k = 0; k < M->n_mirror_neg; ++k) if (M->mirror_neg[k] == j) sgn = -1.0f;
     }
     const float base = sgn * M->init_q[src];
-    const float ds = -0.1f + 0.2f * draw_u<INJECT>(a, env, t.episode, t.draw + (b - 1));
     float qn = base;
-    if (a.random_pose) {  // robots.py:190-194: deviation, normalise, clip to +-0.95, back to radians -- only when random_pose
+    if (a.random_pose) {  // robots.py:190-194: deviation (drawn here only), normalise, clip to +-0.95, back to radians
+      const float ds = -0.1f + 0.2f * draw_u<INJECT>(a, env, t.episode, t.draw + (b - 1));
       const float wt = M->jhi[b] - M->jlo[b], bs = M->jlo[b];
       float ps = 2 * (base + ds - bs) / wt - 1;
       ps = ps < -0.95f ? -0.95f : (ps > 0.95f ? 0.95f : ps);
@@ -1694,10 +1736,10 @@ DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, in
     L[L_Q + b] = qn;
     L[L_QD + b] = 0.0f;
   }
-  t.draw += T::NJ;
+  if (a.random_pose) t.draw += T::NJ;
   if (lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { L[L_BASE + i] = M->init_pos[i]; L[L_BASE + 7 + i] = 0; L[L_BASE + 10 + i] = 0; }
+    for (int i = 0; i < 3; ++i) { L[L_BASE + i] = M->init_pos[i]; L[L_BASE + 7 + i] = M->init_vel[i]; L[L_BASE + 10 + i] = 0; }  // robot_init_velocity, :92,493
 #pragma unroll
     for (int i = 0; i < 4; ++i) L[L_BASE + 3 + i] = M->init_quat[i];
   }
@@ -1716,9 +1758,9 @@ DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, in
       if (M->task_flags & MOCCA_TASKF_RESET_TAIL_ZERO) { obs[nbo] = 0.0f; obs[nbo + 1] = 0.0f; }  // Walker2DCustomEnv.reset, :299-300
     }
   } else {
-    generate_terrain<INJECT>(a, env, t, L, ter, lane);
-    t.nsi = 1;
-    delta_to_k_targets(L, ter, t, ro.rpy[2], lane, obs + nbo);
+    generate_terrain<INJECT>(a, M, env, t, L, ter, lane);
+    t.nsi = M->lookbehind;                                                             // :499
+    delta_to_k_targets(M, L, ter, t, ro.rpy[2], lane, obs + nbo);
     calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
   }
   t.prevx = L[L_BASE];

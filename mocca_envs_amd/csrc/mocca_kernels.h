@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
 
   STAMP(28);  // kernel prologue done
   if constexpr (TASK == MOCCA_TASK_WALKER3D_STEPPER) stage_planks(M, L, lane, ter);
-  ContactFlags fl = {0, 0, 0, 0, 0, 0, 0};
+  ContactFlags fl = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int nsub = INJECT ? 0 : M->n_substeps;
   const int nsi0 = TASK == MOCCA_TASK_WALKER3D_STEPPER ? (int)tk[T_NSI] : 0;
 #pragma unroll 1
@@ -134,7 +134,11 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     const int32_t* tc = a.inj_touch + (size_t)env * T::NFEET;
     fl.touch0 = tc[0] != 0; fl.touch1 = tc[1] != 0;
     if constexpr (T::NFEET > 2) { fl.touch2 = tc[2] != 0; fl.touch3 = tc[3] != 0; }
-    if (a.inj_target) { fl.target0 = a.inj_target[(size_t)env * T::NFEET] != 0; fl.target1 = a.inj_target[(size_t)env * T::NFEET + 1] != 0; }
+    if (a.inj_target) {
+      const int32_t* tg = a.inj_target + (size_t)env * T::NFEET;
+      fl.target0 = tg[0] != 0; fl.target1 = tg[1] != 0;
+      if constexpr (T::NFEET > 2) { fl.target2 = tg[2] != 0; fl.target3 = tg[3] != 0; }
+    }
     if (a.inj_body) fl.body_touch = a.inj_body[env] != 0;
   }
   STAMP(27);  // substeps done
@@ -196,18 +200,20 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   } else {
     // env_locomotion.py:515-568
     t.setstop = (t.nsi == 6 || t.nsi == 7 || t.nsi == 13 || t.nsi == 14);             // :522
-    RobotObs ro = robot_obs<T>(M, L, lane, t.fc0, t.fc1, obs);                         // previous step's contacts, :525
+    RobotObs ro = robot_obs<T>(M, L, lane, t.fc0, t.fc1, obs, t.fc2, t.fc3);           // previous step's contacts, :525
     if (!ro.finite) t.done = 1;
     const int cur_idx = t.nsi;
+    const int n_planks = M->n_planks;
     // calc_feet_state :632-674
-    float fd[2];
+    float fdmin = 1e30f;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < T::NFEET; ++k) {
       const float dx = L[L_FEET + 3 * k] - ter[6 * t.nsi], dy = L[L_FEET + 3 * k + 1] - ter[6 * t.nsi + 1];
-      fd[k] = sqrtf(dx * dx + dy * dy);
+      fdmin = fminf(fdmin, sqrtf(dx * dx + dy * dy));
     }
     t.fc0 = (float)fl.touch0; t.fc1 = (float)fl.touch1;
-    const bool reached = fl.target0 || fl.target1;
+    t.fc2 = (float)fl.touch2; t.fc3 = (float)fl.touch3;
+    const bool reached = fl.target0 || fl.target1 || fl.target2 || fl.target3;
     if (reached) {
       t.trc += 1;
       if (t.trc > 120) { t.stop = 0; t.setstop = 0; }
@@ -215,8 +221,8 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
         if (!t.stop) {
           t.nsi += 1;
           t.trc = 0;
-          if (t.nsi >= MOCCA_MAX_PLANKS) {                                              // update_steps :472-479
-            const int oldest = t.nsi % MOCCA_MAX_PLANKS;
+          if (t.nsi >= n_planks) {                                                      // update_steps :472-479
+            const int oldest = t.nsi % n_planks;
             const int nx = t.nsi < MOCCA_MAX_TERRAIN_STEPS - 1 ? t.nsi : MOCCA_MAX_TERRAIN_STEPS - 1;
             if (lane == 0) ter[120 + oldest] = (float)nx;
           }
@@ -229,29 +235,66 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     const float old = t.linpot;
     float dist, ang;
     calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
-    const float progress = t.linpot - old;
-    float posture = 0.0f;
+    float progress = t.linpot - old;
+    float posture = 0.0f, tall;
     const float pitch = ro.rpy[1], roll = ro.rpy[0];
-    if (!(-0.2f < pitch && pitch < 0.4f)) posture = fabsf(pitch);
-    if (!(-0.4f < roll && roll < 0.4f)) posture += fabsf(roll);
     const float e1 = wave_sum(lane < T::NJ ? fabsf(act_raw * ro.spd) : 0.0f);
     const float e2 = wave_sum(lane < T::NJ ? act_raw * act_raw : 0.0f);
     const float energy = M->electricity_cost * (e1 / T::NJ) + M->stall_torque_cost * (e2 / T::NJ);
     const float joints = M->joints_at_limit_cost * (float)ro.jal;
-    // terminal_height_curriculum[self.curriculum], :368,628: the env's CURRENT curriculum (set_env_params acts at once
-    // on this line, at the next reset on terrain and gain)
-    const float term_h = 0.75f + (0.45f - 0.75f) * live_curriculum(a, env) / 9;
-    const float tall = ro.height > term_h ? 2.0f : -1.0f;
-    if (tall < 0) t.done = 1;
+    if (!(M->task_flags & MOCCA_TASKF_QUADRUPED_STEPPER)) {
+      if (!(-0.2f < pitch && pitch < 0.4f)) posture = fabsf(pitch);
+      if (!(-0.4f < roll && roll < 0.4f)) posture += fabsf(roll);
+      // terminal_height_curriculum[self.curriculum], :368,628: the env's CURRENT curriculum (set_env_params acts at once
+      // on this line, at the next reset on terrain and gain)
+      const float term_h = M->term_height_cur[0] + (M->term_height_cur[1] - M->term_height_cur[0]) * live_curriculum(a, env) / 9;
+      tall = ro.height > term_h ? 2.0f : -1.0f;
+      if (tall < 0) t.done = 1;
+    } else {
+      // LaikagoStepperEnv.calc_base_reward, :928-979: posture from the hip_x / hip_y / knee angles in degrees, progress x 2,
+      // posture x 0.2, tall_bonus 2, the time-based early termination REPLACES done, a non-foot link on a plank ends it
+      const float R2D = 57.29577951308232f, D2R = 0.017453292519943295f;
+      float pj = 0.0f;
+      if (lane < T::NJ) {
+        const float adeg = L[L_Q + 1 + lane] * R2D;
+        const int kind = lane % 3;
+        const float lo_ = kind == 0 ? -25.0f : (kind == 1 ? -35.0f : -75.0f), hi_ = kind == 0 ? 25.0f : (kind == 1 ? 35.0f : -15.0f);
+        if (!(lo_ < adeg && adeg < hi_)) pj = fabsf(adeg * D2R);
+      }
+      posture = wave_sum(pj);
+      if (!(-25.0f < pitch * R2D && pitch * R2D < 25.0f)) posture += fabsf(pitch);
+      progress *= 2.0f;
+      posture *= 0.2f;
+      tall = 2.0f;
+      t.done = (t.t > 240 && t.nsi <= 4);
+      if (fl.body_touch) { tall = -1.0f; t.done = 1; }
+    }
     // calc_step_reward :676-693
     const int last = MOCCA_MAX_TERRAIN_STEPS - 1;
     float step_bonus = 0.0f, bonus = 0.0f;
-    if (reached && t.trc == 1 && t.nsi != last) step_bonus = 50.0f * powf(2.718f, -fminf(fd[0], fd[1]) / 0.25f);
+    if (reached && t.trc == 1 && t.nsi != last) step_bonus = 50.0f * powf(2.718f, -powf(fdmin, M->step_bonus_smoothness) / 0.25f);
     if ((t.nsi == last || t.stop) && dist < 0.15f) bonus = 2.0f;
     __threadfence_block();
-    delta_to_k_targets(L, ter, t, ro.rpy[2], lane, obs + NBO);
+    delta_to_k_targets(M, L, ter, t, ro.rpy[2], lane, obs + NBO);
     if (cur_idx != t.nsi) calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
-    rew = progress - energy + step_bonus + bonus + tall - posture - joints;            // :528-531
+    if (!a.random_reward) {
+      rew = progress - energy + step_bonus + bonus + tall - posture - joints;          // :528-531
+    } else {                                                                           // :533-547
+      const float terms[8] = {progress, -energy, step_bonus, bonus, 0.0f, tall, -posture, -joints};
+      rew = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float w;
+        if (a.random_reward == 1) {  // np_random.uniform(0.8, 1.2, 8): eight draws of this episode's stream
+          w = 0.8f + 0.4f * draw_u<INJECT>(a, env + a.env_offset, t.episode, t.draw + k);
+          if (lane == 0) tk[T_RW + k] = __float_as_uint(w);
+        } else {
+          w = __uint_as_float(tk[T_RW + k]);   // the host drew them (MOCCA_PARAM_RANDOM_REWARD = 2)
+        }
+        rew += w * terms[k];
+      }
+      if (a.random_reward == 1) t.draw += 8;
+    }
     info = t.nsi;
   }
   t.prevx = L[L_BASE];
@@ -331,7 +374,7 @@ __global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
       calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
       if (lane == 0) softsign_tail(dist, ang, obs + NBO);
     } else {
-      delta_to_k_targets(L, ter, t, ro.rpy[2], lane, obs + NBO);
+      delta_to_k_targets(M, L, ter, t, ro.rpy[2], lane, obs + NBO);
       calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
     }
     t.prevx = L[L_BASE];
@@ -348,6 +391,7 @@ static void dispatch(int topo, int task_id, Args... args) {
   if (topo == TOPO_CASSIE) Launcher<TopoCassie, MOCCA_TASK_CASSIE>::run(args...);
   else if (topo == TOPO_WALKER2D) Launcher<TopoWalker2D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
   else if (topo == TOPO_CRAB2D) Launcher<TopoCrab2D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
+  else if (topo == TOPO_LAIKAGO && task_id == MOCCA_TASK_WALKER3D_STEPPER) Launcher<TopoLaikago, MOCCA_TASK_WALKER3D_STEPPER>::run(args...);
   else if (topo == TOPO_LAIKAGO) Launcher<TopoLaikago, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
   else if (task_id == MOCCA_TASK_WALKER3D_CUSTOM) Launcher<TopoWalker3D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
   else Launcher<TopoWalker3D, MOCCA_TASK_WALKER3D_STEPPER>::run(args...);

@@ -76,7 +76,7 @@ class EnvBase(gym.Env):
     env_id = None
     task_id = None
 
-    def __init__(self, render=False, remove_ground=False, use_egl=False, use_ffmpeg=False, device=None, **kwargs):
+    def __init__(self, render=False, remove_ground=False, use_egl=False, use_ffmpeg=False, device=None, model_kw=None, **kwargs):
         if render or use_egl or use_ffmpeg:
             raise NotImplementedError("rendering is outside the GPU stepper's scope (SURVEY.md section 2.1 #6)")
         if kwargs:
@@ -85,7 +85,7 @@ class EnvBase(gym.Env):
         self.metadata = dict(self.metadata)
         self.metadata["video.frames_per_second"] = int(1 / self.control_step)
         from .vec_env import VecEnv  # imports torch; needs the HIP library and a GPU (no CPU fallback)
-        self._vec = VecEnv(self.env_id, 1, device=device, auto_reset=False)
+        self._vec = VecEnv(self.env_id, 1, device=device, auto_reset=False, **(model_kw or {}))
         self.model = self._vec.model
         self.robot = _CassieRobot(self.model) if self.task_id == M.TASK_CASSIE else _Robot(self.model)
         self.seed()
@@ -116,6 +116,9 @@ class EnvBase(gym.Env):
         for k, v in params_dict.items():
             if hasattr(self.robot, k):
                 setattr(self.robot, k, v)
+        if "applied_gain" in params_dict and hasattr(self.robot, "applied_gain"):   # used by the next apply_action, robots.py:33
+            from . import lib as _lib
+            self._vec.set_param(_lib.PARAM_APPLIED_GAIN, float(self.robot.applied_gain))
 
     # ---- helpers --------------------------------------------------------------------------------
     def _push(self, state, task, terrain=None):
@@ -268,37 +271,41 @@ class Walker3DStepperEnv(EnvBase):
     robot_random_start = True
     n_steps, step_radius, rendered_step_count = 20, 0.25, 3
     lookahead, lookbehind, step_param_dim = 2, 1, 5
+    plank_class = "LargePlank"          # Pillar, Plank, LargePlank (env_locomotion.py:342, bullet_objects.py:86-103)
 
     def __init__(self, **kwargs):
         self.random_reward = kwargs.pop("random_reward", False)
         plank = kwargs.pop("plank_class", None)
-        if self.random_reward:
-            raise NotImplementedError("random_reward (env_locomotion.py:533-547) is not in the GPU stepper yet")
-        if plank not in (None, "LargePlank"):
-            raise NotImplementedError("only plank_class=LargePlank (the reference default) is modelled")
+        if plank is not None:
+            if plank not in M.PLANK_CLASSES:    # the reference falls back to the default for unknown names (:356-357)
+                plank = self.plank_class
+            self.plank_class = plank
         kwargs.pop("remove_ground", None)
-        super().__init__(**kwargs)
+        super().__init__(model_kw={"plank_class": self.plank_class}, **kwargs)
+        from . import lib as _lib
+        # random_reward (:533-547): the eight weights come from THIS env's np_random, like every other draw of the facade
+        self._vec.set_param(_lib.PARAM_RANDOM_REWARD, 2 if self.random_reward else 0)
         self.curriculum, self.max_curriculum = 0, 9
-        self.terminal_height_curriculum = np.linspace(0.75, 0.45, 10)
-        self.applied_gain_curriculum = np.linspace(1.0, 1.2, 10)
+        self.terminal_height_curriculum = np.linspace(H._dec(self.model.term_height_cur[0]), H._dec(self.model.term_height_cur[1]), 10)
+        self.applied_gain_curriculum = np.linspace(H._dec(self.model.gain_cur[0]), H._dec(self.model.gain_cur[1]), 10)
         self.next_step_index = self.lookbehind
         self.terrain_info = np.zeros((self.n_steps, 6))
         self.robot_obs_dim = self.robot.observation_space.shape[0]
-        high = np.inf * np.ones(self.robot_obs_dim + 3 * self.step_param_dim)
+        high = np.inf * np.ones(self.robot_obs_dim + (self.lookahead + self.lookbehind) * self.step_param_dim)
         self.observation_space = gym.spaces.Box(-high, high, dtype=np.float32)
         self.action_space = self.robot.action_space
 
     def reset(self):
         self.timestep, self.done = 0, False
         cur = min(int(self.curriculum), self.max_curriculum)
-        self.robot.applied_gain = H.applied_gain(cur)
+        self.robot.applied_gain = H.applied_gain(cur, self.model)
         q, self.robot.mirrored = H.reset_pose(self.robot.np_random, self.model, self.robot_random_start)
-        self.terrain_info = H.generate_step_placements(self.np_random, cur)
+        self.terrain_info = H.generate_step_placements(self.np_random, cur, self.model)
         self.next_step_index = self.lookbehind
         self._episode = getattr(self, "_episode", -1) + 1
         terrain = np.zeros(128, np.float32)
         terrain[:120] = self.terrain_info.reshape(-1)
-        terrain[120:123] = [0, 1, 2]
+        terrain[120:124] = [0, 1, 2, 3]
         task = H.task_record(next_step_index=self.next_step_index, curriculum=cur, applied_gain=self.robot.applied_gain,
                              mirrored=int(self.robot.mirrored), episode=self._episode, draw=122)
         self._vec.set_param(2, cur)
@@ -309,6 +316,15 @@ class Walker3DStepperEnv(EnvBase):
 
     def step(self, action):
         self.timestep += 1
+        if self.random_reward:   # np_random.uniform(0.8, 1.2, 8), :533-535: drawn here, handed to the kernel in task words 30..37
+            from .vec_env import task_to_float64, task_from_float64
+            tk = task_to_float64(self._vec.get_task())
+            tk[0, 30:38] = self.np_random.uniform(0.8, 1.2, 8)
+            self._vec.set_task(task_from_float64(tk))
+        cur = min(int(self.curriculum), self.max_curriculum)
+        if cur != getattr(self, "_pushed_curriculum", None):   # terminal height follows self.curriculum at once (:628)
+            self._vec.set_param(2, cur)
+            self._pushed_curriculum = cur
         obs, rew, done, nsi = self._step_device(action)
         self._pull_robot()
         self.done, self.next_step_index = done, nsi
@@ -330,6 +346,20 @@ class MikeStepperEnv(Walker3DStepperEnv):
     env_id = "MikeStepperEnv-v0"
 
 
+class LaikagoStepperEnv(Walker3DStepperEnv):
+    """env_locomotion.py:893-979: the quadruped on four live planks of radius 0.16, two planks of look-behind, started at
+    (0.25, 0, 0.53) with velocity (0.5, 0, 0.25); its own posture penalty, doubled progress, time-based early termination and
+    body-contact termination (calc_base_reward :928-979) are in the kernel (MOCCA_TASKF_QUADRUPED_STEPPER)."""
+
+    env_id = "LaikagoStepperEnv-v0"
+    robot_random_start = False
+    robot_init_position = [0.25, 0, 0.53]
+    robot_init_velocity = [0.5, 0, 0.25]
+    step_radius, rendered_step_count, init_step_separation = 0.16, 4, 0.45
+    lookahead, lookbehind = 2, 2
+    step_bonus_smoothness = 6
+
+
 class CassieEnv(EnvBase):
     """env_cassie.py:284-479 (3-D, residual control).  The reference class is not importable in the reference
     snapshot; this follows its text.  `planar=True` (the 2-D ids) is not modelled."""
@@ -341,10 +371,14 @@ class CassieEnv(EnvBase):
     sim_frame_skip = 1
 
     def __init__(self, render=False, planar=False, power_coef=1.0, residual_control=True, rsi=True, **kwargs):
-        if planar:
-            raise NotImplementedError("Cassie2D points at a missing URDF directory in the reference (env_cassie.py:280-282)")
         if power_coef != 1.0 or not residual_control:
             raise NotImplementedError("only power_coef=1.0, residual_control=True are compiled into the model blob")
+        # planar (Cassie2DEnv-v0, reference __init__.py:24-29): "constrains the robot movement to a 2D plane" (env_cassie.py:333).
+        # The reference points at a URDF that is not in its tree (:279-282); here the 3-D robot's base is held in the x-z plane
+        # by three bilateral solver rows (Cassie)
+        self.planar = bool(planar)
+        if self.planar:
+            self.env_id = "Cassie2DEnv-v0"
         super().__init__(render=render, **kwargs)
         self.rsi = rsi
         high = np.inf * np.ones(self.robot.observation_space.shape[0] + 2)

@@ -56,39 +56,52 @@ def reset_pose(np_random, mdl: M.MoccaModel, random_pose: bool = True) -> Tuple[
     return base, mirrored
 
 
-def generate_step_placements(np_random, curriculum: int) -> np.ndarray:
+def _dec(x) -> float:
+    """The short decimal an fp32 blob constant renders (0.65, 0.45, 1.2 ...): the reference computes with the decimal."""
+    return round(float(x), 6)
+
+
+def generate_step_placements(np_random, curriculum: int, mdl: M.MoccaModel = None) -> np.ndarray:
     """Stepping-stone table [20, 6] = (x, y, z, heading, x_tilt, y_tilt), the distribution of
     env_locomotion.py:395-441: per step a radial distance, a heading increment, a polar angle and two tilts,
-    each uniform in a range that widens with the curriculum; draw order = five blocks of 20."""
+    each uniform in a range that widens with the curriculum; draw order = five blocks of 20.  The ranges are the
+    env class's attributes (Walker3DStepperEnv :380-385 / LaikagoStepperEnv :919-922), carried by the model blob."""
+    if mdl is None:
+        mdl = M.set_stepper_params(M.MoccaModel())
+    d0, d1 = _dec(mdl.dist_range[0]), _dec(mdl.dist_range[1])
+    yaw, pitch, tilt = _dec(mdl.yaw_range_deg), _dec(mdl.pitch_range_deg), _dec(mdl.tilt_range_deg)
     level = min(int(curriculum), MAX_CURRICULUM)
     frac = level / MAX_CURRICULUM
     half_pi = np.pi / 2
     ranges = (
-        (0.65, np.linspace(0.65, 1.25, MAX_CURRICULUM + 1)[level]),      # radial distance [m]
-        (-20 * frac * DEG2RAD, 20 * frac * DEG2RAD),                      # heading increment
-        (-30 * frac * DEG2RAD + half_pi, 30 * frac * DEG2RAD + half_pi),  # polar angle (pi/2 = level ground)
-        (-15 * frac * DEG2RAD, 15 * frac * DEG2RAD),                      # tilt about x
-        (-15 * frac * DEG2RAD, 15 * frac * DEG2RAD),                      # tilt about y
+        (d0, np.linspace(d0, d1, MAX_CURRICULUM + 1)[level]),                   # radial distance [m]
+        (-yaw * frac * DEG2RAD, yaw * frac * DEG2RAD),                          # heading increment
+        (-pitch * frac * DEG2RAD + half_pi, pitch * frac * DEG2RAD + half_pi),  # polar angle (pi/2 = level ground)
+        (-tilt * frac * DEG2RAD, tilt * frac * DEG2RAD),                        # tilt about x
+        (-tilt * frac * DEG2RAD, tilt * frac * DEG2RAD),                        # tilt about y
     )
     radial, turn, polar, tilt_x, tilt_y = (np_random.uniform(lo, hi, size=N_STEPS) for lo, hi in ranges)
-    # the robot starts on step 0; steps 1 and 2 lie flat, straight ahead, INIT_STEP_SEPARATION apart
-    radial[:3] = (0.0, INIT_STEP_SEPARATION, INIT_STEP_SEPARATION)
+    # the robot starts on step 0; steps 1 and 2 lie flat, straight ahead, init_step_separation apart
+    sep = _dec(mdl.init_step_separation)
+    radial[:3] = (0.0, sep, sep)
     turn[:3], polar[:3], tilt_x[:3], tilt_y[:3] = 0.0, half_pi, 0.0, 0.0
     heading = np.cumsum(turn)
     ground = radial * np.sin(polar)
     hop = np.stack((ground * np.cos(heading), ground * np.sin(heading), radial * np.cos(polar)), axis=1)
     # from the third step on keep consecutive planks from overlapping or drifting apart along x
     fwd = hop[2:, 0]
-    hop[2:, 0] = np.sign(fwd) * np.clip(np.abs(fwd), 2.5 * STEP_RADIUS, 1.25)
+    hop[2:, 0] = np.sign(fwd) * np.clip(np.abs(fwd), 2.5 * _dec(mdl.step_radius), d1)
     return np.column_stack((np.cumsum(hop, axis=0), heading, tilt_x, tilt_y))
 
 
-def applied_gain(curriculum: int) -> float:
-    return float(np.linspace(1.0, 1.2, MAX_CURRICULUM + 1)[min(curriculum, MAX_CURRICULUM)])  # :369
+def applied_gain(curriculum: int, mdl: M.MoccaModel = None) -> float:
+    a, b = (1.0, 1.2) if mdl is None else (_dec(mdl.gain_cur[0]), _dec(mdl.gain_cur[1]))
+    return float(np.linspace(a, b, MAX_CURRICULUM + 1)[min(curriculum, MAX_CURRICULUM)])  # :369 / :918
 
 
-def terminal_height(curriculum: int) -> float:
-    return float(np.linspace(0.75, 0.45, MAX_CURRICULUM + 1)[min(curriculum, MAX_CURRICULUM)])  # :368
+def terminal_height(curriculum: int, mdl: M.MoccaModel = None) -> float:
+    a, b = (0.75, 0.45) if mdl is None else (_dec(mdl.term_height_cur[0]), _dec(mdl.term_height_cur[1]))
+    return float(np.linspace(a, b, MAX_CURRICULUM + 1)[min(curriculum, MAX_CURRICULUM)])  # :368 / :917
 
 
 def yaw_from_quat(x: float, y: float, z: float, w: float) -> float:
@@ -107,6 +120,7 @@ def initial_state(mdl: M.MoccaModel, q: np.ndarray) -> np.ndarray:
     st = np.zeros(mdl.state_dim, dtype=np.float32)
     st[0:3] = list(mdl.init_pos)
     st[3:7] = list(mdl.init_quat)
+    st[7:10] = list(mdl.init_vel)     # robot_init_velocity (env_locomotion.py:92,493; LaikagoStepperEnv :901)
     st[13:13 + mdl.n_joints] = q
     return st
 
@@ -140,6 +154,7 @@ def mirror_indices(mdl: M.MoccaModel, stepper: bool):
         neg_obs = np.concatenate((robot_neg, [6 + 2 * nj + nf]))
     else:
         robot_obs_dim = 6 + 2 * nj + nf
-        steps_neg = np.array([(i * 5 + 0, i * 5 + 3) for i in range(3)], dtype=np.int64).flatten()
+        n_targets = 2 + (mdl.lookbehind or 1)      # lookahead + lookbehind rows of 5 (:806-812)
+        steps_neg = np.array([(i * 5 + 0, i * 5 + 3) for i in range(n_targets)], dtype=np.int64).flatten()
         neg_obs = np.concatenate((robot_neg, steps_neg + robot_obs_dim))
     return (neg_obs.astype(np.int64), right_obs.astype(np.int64), left_obs.astype(np.int64), neg.copy(), right.copy(), left.copy())

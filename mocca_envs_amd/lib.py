@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOCCA_LIB_PATH") or os.path.join(HERE, "libmocca_hip.so")
 
 ABI_VERSION = 2
-PARAM_AUTO_RESET, PARAM_EVAL_MODE, PARAM_CURRICULUM, PARAM_RANDOM_POSE, PARAM_HOST_RETARGET, PARAM_SEED, PARAM_ENV_OFFSET, PARAM_APPLIED_GAIN = 0, 1, 2, 3, 4, 5, 6, 7
+PARAM_AUTO_RESET, PARAM_EVAL_MODE, PARAM_CURRICULUM, PARAM_RANDOM_POSE, PARAM_HOST_RETARGET, PARAM_SEED, PARAM_ENV_OFFSET, PARAM_APPLIED_GAIN, PARAM_RANDOM_REWARD = 0, 1, 2, 3, 4, 5, 6, 7, 8
 DEBUG_WORDS = 8
 
 # every symbol include/mocca.h declares: (name, restype, argtypes)

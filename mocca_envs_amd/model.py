@@ -29,12 +29,14 @@ MAX_PAIRS = 192
 MAX_FEET = 4
 MAX_SLOTS = 40
 MAGIC = 0x41434F4D
-VERSION = 8
+VERSION = 9
 
 GEOM_SPHERE, GEOM_CAPSULE = 0, 1
 TASK_WALKER3D_CUSTOM, TASK_WALKER3D_STEPPER, TASK_CASSIE = 0, 1, 2
 TASK_WORDS = 40
-TASKF_NEVER_DONE, TASKF_RESET_TAIL_ZERO, TASKF_BODY_CONTACT = 1, 2, 4  # MoccaModel.task_flags (include/mocca_model.h)
+TASKF_NEVER_DONE, TASKF_RESET_TAIL_ZERO, TASKF_BODY_CONTACT, TASKF_QUADRUPED_STEPPER = 1, 2, 4, 8  # MoccaModel.task_flags (include/mocca_model.h)
+PLANK_BOX, PLANK_CYLINDER = 0, 1
+MAX_PLANKS = 4
 MAX_CLOSURES = 2
 MAX_CTRL = 16
 STATE_BASE = 13
@@ -132,6 +134,20 @@ class MoccaModel(C.Structure):
         ("cassie_target", C.c_float * 3),
         ("init_quat", C.c_float * 4),
         ("task_flags", C.c_int32),
+        ("n_planks", C.c_int32),
+        ("lookbehind", C.c_int32),
+        ("plank_shape", C.c_int32),
+        ("step_radius", C.c_float),
+        ("init_step_separation", C.c_float),
+        ("dist_range", C.c_float * 2),
+        ("pitch_range_deg", C.c_float),
+        ("yaw_range_deg", C.c_float),
+        ("tilt_range_deg", C.c_float),
+        ("step_bonus_smoothness", C.c_float),
+        ("term_height_cur", C.c_float * 2),
+        ("gain_cur", C.c_float * 2),
+        ("init_vel", C.c_float * 3),
+        ("planar", C.c_int32),
         ("slot_tab", (C.c_float * 4) * MAX_SLOTS),
         ("gp_tab", (C.c_float * 4) * (2 * MAX_GEOMS)),
         ("pair_tab", (C.c_float * 4) * MAX_PAIRS),
@@ -451,6 +467,37 @@ def filters_collide(group_a: int, mask_a: int, group_b: int, mask_b: int) -> boo
     return bool(group_a & mask_b) or bool(group_b & mask_a)
 
 
+# step objects of the Stepper envs (bullet_objects.py:86-103, data/objects/steps/*.urdf): (shape, unscaled half extents of base + cover
+# -- box: x y z; cylinder: radius radius half-height --, unscaled z of the base link's inertial frame, scale per unit step_radius)
+PLANK_CLASSES = {
+    "LargePlank": (PLANK_BOX, (0.5, 10.0, 0.25), -0.275, 2.0),      # plank_large.urdf: boxes 1 x 20 x (0.45 + 0.05), scale 2 * width
+    "Plank": (PLANK_BOX, (0.5, 0.75, 0.25), -0.275, 2.0),           # plank.urdf: boxes 1 x 1.5 x (0.45 + 0.05), scale 2 * width
+    "Pillar": (PLANK_CYLINDER, (1.0, 1.0, 0.5), -0.55, 1.0),        # pillar.urdf: cylinders r 1, length 0.9 + 0.1, scale = radius
+}
+
+
+def set_stepper_params(m: "MoccaModel", *, quadruped: bool = False, plank_class: str = "LargePlank") -> "MoccaModel":
+    """Class attributes of Walker3DStepperEnv (env_locomotion.py:338-351,367-385) or LaikagoStepperEnv (:894-926) into the blob."""
+    if plank_class not in PLANK_CLASSES:
+        raise ValueError(f"unknown plank_class {plank_class!r}; the reference has {sorted(PLANK_CLASSES)}")
+    m.n_planks, m.lookbehind = (4, 2) if quadruped else (3, 1)
+    m.step_radius = 0.16 if quadruped else 0.25
+    m.init_step_separation = 0.45 if quadruped else 0.75
+    m.dist_range[0], m.dist_range[1] = (0.45, 0.75) if quadruped else (0.65, 1.25)
+    m.pitch_range_deg, m.yaw_range_deg, m.tilt_range_deg = (20.0, 20.0, 10.0) if quadruped else (30.0, 20.0, 15.0)
+    m.step_bonus_smoothness = 6.0 if quadruped else 1.0
+    m.term_height_cur[0], m.term_height_cur[1] = (0.20, 0.0) if quadruped else (0.75, 0.45)
+    m.gain_cur[0], m.gain_cur[1] = (1.0, 1.0) if quadruped else (1.0, 1.2)
+    shape, half, com_z, per_radius = PLANK_CLASSES[plank_class]
+    scale = per_radius * m.step_radius
+    m.plank_shape = shape
+    for k in range(3):
+        m.plank_half[k] = half[k] * scale
+    m.plank_com_z = com_z * scale                  # BaseStep._pos_offset (bullet_objects.py:62)
+    m.plank_friction, m.plank_stiffness, m.plank_damping = 1.0, 30000.0, 1000.0      # bullet_objects.py:64-72
+    return m
+
+
 def compile_model(
     root: Body,
     foot_names: Sequence[str],
@@ -466,6 +513,7 @@ def compile_model(
     self_collision: bool = True,
     init_quat_xyzw: Sequence[float] = (0.0, 0.0, 0.0, 1.0),
     link_mass: Optional[Dict[str, float]] = None,
+    plank_class: str = "LargePlank",
 ) -> MoccaModel:
     flat, bl_parent, _ = _flatten(root, base_ref)
     nb = len(flat)
@@ -580,15 +628,10 @@ def compile_model(
     m.max_qd = 100.0                # [UNVERIFIED-BULLET] maxCoordinateVelocity
     m.warmstart = 0.85              # [UNVERIFIED-BULLET] m_warmstartingFactor
     m.ground_friction = 0.8         # bullet_utils.py:371
-    m.plank_friction = 1.0          # bullet_objects.py:68
-    m.plank_stiffness = 30000.0     # bullet_objects.py:70
-    m.plank_damping = 1000.0        # bullet_objects.py:71
-    # plank_large.urdf boxes 1 x 20 x (0.45 + 0.05) scaled by 2*step_radius = 0.5
-    m.plank_half[0], m.plank_half[1], m.plank_half[2] = 0.25, 5.0, 0.125
+    set_stepper_params(m, plank_class=plank_class)   # plank geometry, terrain ranges, curricula (LargePlank: 0.5 x 10 x 0.25 m slab)
     m.limit_slack = 0.05
     m.max_contacts = 12
     m.max_rows = 48
-    m.plank_com_z = -0.275 * 0.5    # plank_large.urdf:8 scaled by 2*step_radius (bullet_objects.py:62,98-103)
 
     for k in range(3):
         m.init_pos[k] = init_pos[k]
@@ -756,7 +799,7 @@ CASSIE_SPRINGS = [4, 11]                                                        
 CASSIE_KP = np.array([100, 100, 88, 96, 50, 100, 100, 88, 96, 50, 400, 400]) / 1.9  # env_cassie.py:292-317
 
 
-def compile_cassie() -> MoccaModel:
+def compile_cassie(planar: bool = False) -> MoccaModel:
     """Cassie blob: URDF tree with inertia from file (env_cassie.py:81-99), two point-to-point loop closures
     (:114-137), per-joint damping (:57,197-201), torque limits (:41-56), the PD gains of CassieEnv (:292-319).
     Ground contact: 12 support points of each toe's convex hull (radius-0 spheres); other meshes and mesh-mesh
@@ -880,6 +923,7 @@ def compile_cassie() -> MoccaModel:
     m.jvel_alpha = min(10 / 50, 1)                                           # env_cassie.py:319
     m.alive_height = 0.6                                                     # env_cassie.py:406-412
     m.cassie_target[0], m.cassie_target[1], m.cassie_target[2] = 1000.0, 0.0, 0.0  # env_cassie.py:366
+    m.planar = int(planar)                                                   # env_cassie.py:326-341 (Cassie2DEnv-v0, __init__.py:24-29)
     return m.finalize_tables()
 
 
@@ -889,7 +933,7 @@ LAIKAGO_FEET = ["toeFR", "toeFL", "toeRR", "toeRL"]                             
 LAIKAGO_SHAPE_MARGIN = 0.001  # collision margin PyBullet gives URDF mesh shapes; enters the box inertia  [UNVERIFIED-BULLET]
 
 
-def compile_laikago() -> MoccaModel:
+def compile_laikago(stepper: bool = False, plank_class: str = "LargePlank") -> MoccaModel:
     """Laikago for LaikagoCustomEnv (robots.py:554-656, env_locomotion.py:854-890) from mocca_envs_amd/laikago_table.py.
 
     * The URDF is y-up; its chassis INERTIAL frame (rpy -1.57 -1.57 0) is what stands the robot up: PyBullet's base pose is
@@ -995,6 +1039,14 @@ def compile_laikago() -> MoccaModel:
     for k, v in enumerate(left):
         m.mirror_left[k] = v
     m.task_flags = TASKF_BODY_CONTACT
+    if stepper:
+        # LaikagoStepperEnv (env_locomotion.py:893-979): sim_frame_skip 4 -> 4 substeps of 1/240 s, start at (0.25, 0, 0.53) moving
+        # at (0.5, 0, 0.25), four live planks of step_radius 0.16, its own reward / termination (MOCCA_TASKF_QUADRUPED_STEPPER)
+        m.dt, m.n_substeps = 1.0 / 240.0, 4
+        m.init_pos[0], m.init_pos[1], m.init_pos[2] = 0.25, 0.0, 0.53
+        m.init_vel[0], m.init_vel[1], m.init_vel[2] = 0.5, 0.0, 0.25
+        set_stepper_params(m, quadruped=True, plank_class=plank_class)
+        m.task_flags = TASKF_QUADRUPED_STEPPER
     return m.finalize_tables()
 
 

@@ -27,14 +27,21 @@ TASKS = {
     "Crab2DCustomEnv-v0": M.TASK_WALKER3D_CUSTOM,
     # quadruped (laikago_toes_limits.urdf): own topology, four feet, Custom task ending on body contact
     "LaikagoCustomEnv-v0": M.TASK_WALKER3D_CUSTOM,
+    # the quadruped on four live planks (env_locomotion.py:893-979): Laikago topology x Stepper task
+    "LaikagoStepperEnv-v0": M.TASK_WALKER3D_STEPPER,
+    # CassieEnv(planar=True), __init__.py:24-29: the base held in the x-z plane by three bilateral rows
+    "Cassie2DEnv-v0": M.TASK_CASSIE,
 }
 # class attributes of the reference envs that are device parameters here
-_DEFAULT_PARAMS = {"LaikagoCustomEnv-v0": {_lib.PARAM_RANDOM_POSE: 0}}   # robot_random_start = False, env_locomotion.py:863
+_DEFAULT_PARAMS = {"LaikagoCustomEnv-v0": {_lib.PARAM_RANDOM_POSE: 0},    # robot_random_start = False, env_locomotion.py:863
+                   "LaikagoStepperEnv-v0": {_lib.PARAM_RANDOM_POSE: 0}}   # :899
 
 _MODELS = {
     "Walker3DCustomEnv-v0": lambda **kw: M.compile_walker3d(M.TASK_WALKER3D_CUSTOM, **kw),
-    "Walker3DStepperEnv-v0": lambda **kw: M.compile_walker3d(M.TASK_WALKER3D_STEPPER, **kw),
+    "Walker3DStepperEnv-v0": lambda **kw: M.compile_walker3d(M.TASK_WALKER3D_STEPPER, **kw),   # kw: plank_class = LargePlank | Plank | Pillar
     "CassieEnv-v0": lambda **kw: M.compile_cassie(**kw),
+    "Cassie2DEnv-v0": lambda **kw: M.compile_cassie(planar=True, **kw),
+    "LaikagoStepperEnv-v0": lambda **kw: M.compile_laikago(stepper=True, **kw),
     "Child3DCustomEnv-v0": M.compile_child3d,
     "MikeStepperEnv-v0": M.compile_mike,
     "Walker2DCustomEnv-v0": M.compile_walker2d,

@@ -181,6 +181,8 @@ typedef struct {
   real jvel[MOCCA_MAX_CTRL];
   real initial_z;
   int32_t istep;
+  /* Stepper with random_reward (env_locomotion.py:533-547): this step's eight U(0.8, 1.2) weights */
+  real rw[8];
 } Task;
 
 typedef struct {
@@ -219,7 +221,7 @@ typedef struct {
   MoccaModel m;
   int task_id, n_envs;
   uint64_t seed;
-  int auto_reset, eval_mode, random_pose;
+  int auto_reset, eval_mode, random_pose, random_reward;
   Dyn *dyn;
   Task *task;
   Terrain *ter;
@@ -459,6 +461,27 @@ static real sphere_box(const real *C, real rad, const real *bc, const real *Rb, 
   return dist - rad;
 }
 
+/* the same against an upright cylinder (Pillar, bullet_objects.py:86-89): axis = local z, h = (radius, radius, half height) */
+static real sphere_cylinder(const real *C, real rad, const real *bc, const real *Rb, const real *h, real *n) {
+  real d[3] = {C[0] - bc[0], C[1] - bc[1], C[2] - bc[2]}, l[3];
+  for (int i = 0; i < 3; ++i) l[i] = Rb[i] * d[0] + Rb[3 + i] * d[1] + Rb[6 + i] * d[2];
+  real rho = sqrt(l[0] * l[0] + l[1] * l[1]), R = h[0], hz = h[2];
+  real ux = rho > (real)1e-12 ? l[0] / rho : 1, uy = rho > (real)1e-12 ? l[1] / rho : 0; /* radial direction */
+  real nl[3] = {0, 0, 0}, dist;
+  if (rho <= R && fabs(l[2]) <= hz) { /* centre inside: leave through the nearer of cap / side */
+    real dcap = hz - fabs(l[2]), dside = R - rho;
+    if (dcap < dside) { nl[2] = l[2] >= 0 ? 1 : -1; dist = -dcap; }
+    else { nl[0] = ux; nl[1] = uy; dist = -dside; }
+  } else {
+    real qr = rho < R ? rho : R, qz = l[2] > hz ? hz : (l[2] < -hz ? -hz : l[2]);
+    real e[3] = {l[0] - qr * ux, l[1] - qr * uy, l[2] - qz};
+    dist = sqrt(dot3(e, e));
+    for (int i = 0; i < 3; ++i) nl[i] = e[i] / dist;
+  }
+  matvec3(Rb, nl, n);
+  return dist - rad;
+}
+
 static void geom_point(const MoccaModel *m, const Work *w, int g, int e, real *C) {
   int b = m->g_body[g];
   real pl[3], pw[3];
@@ -529,10 +552,10 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
       } else {
         gap = 1e30;
         real h[3] = {m->plank_half[0], m->plank_half[1], m->plank_half[2]};
-        for (int k = 0; k < MOCCA_MAX_PLANKS; ++k) {
+        for (int k = 0; k < m->n_planks; ++k) {
           real bc[3], Rb[9], nn[3];
           plank_frame(o, tr, k, bc, Rb);
-          real gk = sphere_box(Cw, rad, bc, Rb, h, nn);
+          real gk = m->plank_shape == MOCCA_PLANK_CYLINDER ? sphere_cylinder(Cw, rad, bc, Rb, h, nn) : sphere_box(Cw, rad, bc, Rb, h, nn);
           if (gk < gap) {
             gap = gk;
             n[0] = nn[0]; n[1] = nn[1]; n[2] = nn[2];
@@ -541,7 +564,7 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
             real d[3] = {Cw[0] - rad * nn[0] - bc[0], Cw[1] - rad * nn[1] - bc[1], Cw[2] - rad * nn[2] - bc[2]};
             real lz = Rb[2] * d[0] + Rb[5] * d[1] + Rb[8] * d[2];
             int cover = lz >= (real)m->plank_half[2] * (real)0.8;
-            is_target = cover && (k == tk->next_step_index % MOCCA_MAX_PLANKS);
+            is_target = cover && (k == tk->next_step_index % m->n_planks);
           }
         }
         mu = (real)m->plank_friction * (real)m->g_friction[g];
@@ -656,6 +679,23 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
       w->cfm[r] = 0; w->lam[r] = 0;
     }
   }
+  /* --- CassieEnv(planar=True), env_cassie.py:326-341: the base is held in the x-z plane by three bilateral rows on
+   *     nu = [omega; v]: omega_x, omega_z (the base's y axis stays the world's: small-angle error of R e_y) and v_y --- */
+  int n_planar = 0;
+  if (m->planar) {
+    const real *R0 = w->R[0];
+    real err[3] = {R0[7], -R0[1], s->pos[1] - (real)m->init_pos[1]};
+    int comp[3] = {0, 2, 4};
+    for (int k = 0; k < 3 && nr < m->max_rows; ++k) {
+      int r = nr++;
+      for (int c = 0; c < nd; ++c) w->J[r][c] = 0;
+      w->J[r][comp[k]] = 1;
+      w->row_kind[r] = 3; w->row_normal[r] = -1; w->row_mu[r] = 0; w->row_slot[r] = -1;
+      w->bias[r] = -(real)m->erp * err[k] * idt;
+      w->cfm[r] = 0; w->lam[r] = 0;
+      ++n_planar;
+    }
+  }
   /* --- contact normals, then friction pairs --- */
   int first_normal = nr;
   int nc = w->nc;
@@ -680,7 +720,7 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
     }
   }
   w->nr = nr;
-  w->dbg[0] = nr; w->dbg[1] = first_normal - 3 * m->n_closures; w->dbg[2] = nc;
+  w->dbg[0] = nr; w->dbg[1] = first_normal - 3 * m->n_closures - n_planar; w->dbg[2] = nc;
   w->dbg[5] = (int32_t)(uint32_t)limit_mask; w->dbg[6] = (int32_t)(uint32_t)(limit_mask >> 32);
   /* --- responses, Delassus matrix, initial velocities --- */
   for (int r = 0; r < nr; ++r) minv_apply(m, w, w->J[r], w->Mi[r]);
@@ -855,15 +895,22 @@ static void softsign_tail(real dist, real ang, float *o2) { /* env_locomotion.py
   o2[1] = (float)(c / (1 + fabs(c)));
 }
 
+/* The blob stores the Stepper's class attributes (0.65, 0.45, 1.2 ...) as fp32; the reference computes with the decimal
+ * itself.  DEC() recovers the 6-decimal number an fp32 constant renders, so the f64 build reproduces the reference to
+ * 1e-9 instead of 1e-7 x (a step bonus of 50 amplifies that to 1e-5); in the f32 build it is the identity. */
+#define DEC(x) ((real)(round((double)(x) * 1e6) / 1e6))
+
 /* ---- stepper terrain, env_locomotion.py:395-441 (device RNG version) ---- */
 static void generate_step_placements(Oracle *o, int env, Task *tk, Terrain *tr) {
+  const MoccaModel *m = &o->m;
   const real DEG2RAD = (real)(3.14159265358979323846 / 180.0);
   int N = MOCCA_MAX_TERRAIN_STEPS, cur = tk->curriculum > 9 ? 9 : tk->curriculum;
   real ratio = (real)cur / 9;
-  real dist_lo = 0.65, dist_hi = (real)0.65 + ((real)1.25 - (real)0.65) * cur / 9; /* np.linspace(0.65,1.25,10)[cur] */
-  real yaw_lo = -20 * ratio * DEG2RAD, yaw_hi = 20 * ratio * DEG2RAD;
-  real pit_lo = -30 * ratio * DEG2RAD + (real)1.5707963267948966, pit_hi = 30 * ratio * DEG2RAD + (real)1.5707963267948966;
-  real tl_lo = -15 * ratio * DEG2RAD, tl_hi = 15 * ratio * DEG2RAD;
+  real d0 = DEC(m->dist_range[0]), d1 = DEC(m->dist_range[1]);
+  real dist_lo = d0, dist_hi = d0 + (d1 - d0) * cur / 9; /* np.linspace(*dist_range, 10)[cur] */
+  real yaw_lo = -(real)m->yaw_range_deg * ratio * DEG2RAD, yaw_hi = (real)m->yaw_range_deg * ratio * DEG2RAD;
+  real pit_lo = -(real)m->pitch_range_deg * ratio * DEG2RAD + (real)1.5707963267948966, pit_hi = (real)m->pitch_range_deg * ratio * DEG2RAD + (real)1.5707963267948966;
+  real tl_lo = -(real)m->tilt_range_deg * ratio * DEG2RAD, tl_hi = (real)m->tilt_range_deg * ratio * DEG2RAD;
   real dr[MOCCA_MAX_TERRAIN_STEPS], dphi[MOCCA_MAX_TERRAIN_STEPS], dth[MOCCA_MAX_TERRAIN_STEPS];
   real xt[MOCCA_MAX_TERRAIN_STEPS], yt[MOCCA_MAX_TERRAIN_STEPS];
   /* draw order = the five np_random.uniform(size=N) calls of env_locomotion.py:408-412 */
@@ -873,16 +920,17 @@ static void generate_step_placements(Oracle *o, int env, Task *tk, Terrain *tr) 
   for (int i = 0; i < N; ++i) xt[i] = tl_lo + (tl_hi - tl_lo) * draw_uniform(o, env, tk);
   for (int i = 0; i < N; ++i) yt[i] = tl_lo + (tl_hi - tl_lo) * draw_uniform(o, env, tk);
   dr[0] = 0; dphi[0] = 0; dth[0] = (real)1.5707963267948966;
-  dr[1] = dr[2] = 0.75; dphi[1] = dphi[2] = 0; dth[1] = dth[2] = (real)1.5707963267948966;
+  dr[1] = dr[2] = DEC(m->init_step_separation); dphi[1] = dphi[2] = 0; dth[1] = dth[2] = (real)1.5707963267948966;
   xt[0] = xt[1] = xt[2] = 0; yt[0] = yt[1] = yt[2] = 0;
   real x = 0, y = 0, z = 0, phi = 0;
+  real dx_min = DEC(m->step_radius) * (real)2.5; /* :434-435 */
   for (int i = 0; i < N; ++i) {
     phi += dphi[i];
     real dx = dr[i] * sin(dth[i]) * cos(phi), dy = dr[i] * sin(dth[i]) * sin(phi), dz = dr[i] * cos(dth[i]);
     if (i >= 2) {
-      real ax = fabs(dx), mx = ax > (real)0.625 ? ax : (real)0.625;
+      real ax = fabs(dx), mx = ax > dx_min ? ax : dx_min;
       real sg = dx > 0 ? 1 : (dx < 0 ? -1 : 0);
-      dx = sg * (mx < (real)1.25 ? mx : (real)1.25);
+      dx = sg * (mx < d1 ? mx : d1);
     }
     x += dx; y += dy; z += dz;
     tr->terrain[i][0] = x; tr->terrain[i][1] = y; tr->terrain[i][2] = z;
@@ -891,30 +939,32 @@ static void generate_step_placements(Oracle *o, int env, Task *tk, Terrain *tr) 
 }
 
 /* delta_to_k_targets, env_locomotion.py:712-759 : 3 rows x (x,y,z,x_tilt,y_tilt), sets walk_target */
-static void delta_to_k_targets(const Oracle *o, const Dyn *s, Task *tk, const Terrain *tr, float *out15) {
-  int N = tk->next_step_index, T = MOCCA_MAX_TERRAIN_STEPS, idx[3];
-  if (!tk->stop_on_next_step) {
-    idx[0] = N - 1 >= 0 ? N - 1 : 0;
-    idx[1] = N; idx[2] = N + 1;
-    for (int i = 0; i < 3; ++i) if (idx[i] > T - 1) idx[i] = T - 1; /* repeat last target */
-  } else { idx[0] = N - 1; idx[1] = N; idx[2] = N; }
-  for (int i = 0; i < 3; ++i) tk->walk_target[i] = tr->terrain[idx[2]][i]; /* walk_target_index = -1 */
-  for (int i = 0; i < 3; ++i) {
+static void delta_to_k_targets(const Oracle *o, const Dyn *s, Task *tk, const Terrain *tr, float *out) {
+  /* lookbehind j rows before the next step, then lookahead k = 2 rows from it; indices clamp at both ends ("repeat first /
+   * last target", :717-734); stopping repeats the next step */
+  int N = tk->next_step_index, T = MOCCA_MAX_TERRAIN_STEPS, j = o->m.lookbehind, nt = j + 2, idx[4];
+  for (int i = 0; i < nt; ++i) {
+    int v = N - j + i;
+    if (tk->stop_on_next_step && i >= j) v = N;
+    idx[i] = v < 0 ? 0 : (v > T - 1 ? T - 1 : v);
+  }
+  for (int i = 0; i < 3; ++i) tk->walk_target[i] = tr->terrain[idx[nt - 1]][i]; /* walk_target_index = -1 */
+  for (int i = 0; i < nt; ++i) {
     const real *t = tr->terrain[idx[i]];
     real dx = t[0] - s->pos[0], dy = t[1] - s->pos[1], dz = t[2] - s->pos[2];
     real ang = atan2(dy, dx) - o->body_rpy[2], dist = sqrt(dx * dx + dy * dy);
-    out15[5 * i + 0] = (float)(sin(ang) * dist);
-    out15[5 * i + 1] = (float)(cos(ang) * dist);
-    out15[5 * i + 2] = (float)dz;
-    out15[5 * i + 3] = (float)t[4];
-    out15[5 * i + 4] = (float)t[5];
+    out[5 * i + 0] = (float)(sin(ang) * dist);
+    out[5 * i + 1] = (float)(cos(ang) * dist);
+    out[5 * i + 2] = (float)dz;
+    out[5 * i + 3] = (float)t[4];
+    out[5 * i + 4] = (float)t[5];
   }
 }
 
 static int obs_dim(const Oracle *o) {
   if (o->task_id == MOCCA_TASK_CASSIE) return 6 + 2 * o->m.n_ordered + 2; /* env_cassie.py:76-79,344-346 */
   int base = 6 + 2 * o->m.n_joints + o->m.n_feet;
-  return o->task_id == MOCCA_TASK_WALKER3D_CUSTOM ? base + 2 : base + 15;
+  return o->task_id == MOCCA_TASK_WALKER3D_CUSTOM ? base + 2 : base + 5 * (o->m.lookbehind + 2);
 }
 
 /* ---------------- Cassie task layer, env_cassie.py:238-276,348-479 ---------------- */
@@ -1030,7 +1080,7 @@ static void reset_env(Oracle *o, int env, float *obs) {
     tk->walk_target[1] = tk->dist * sin(tk->angle);
     tk->walk_target[2] = 1;
   } else {
-    tk->applied_gain = 1 + (real)0.2 * tk->curriculum / 9; /* np.linspace(1.0,1.2,10), :369,489 */
+    tk->applied_gain = DEC(m->gain_cur[0]) + (DEC(m->gain_cur[1]) - DEC(m->gain_cur[0])) * tk->curriculum / 9; /* applied_gain_curriculum[curriculum], :369,489 */
   }
   /* robot.reset */
   real u = draw_uniform(o, env, tk);
@@ -1045,9 +1095,8 @@ static void reset_env(Oracle *o, int env, float *obs) {
     for (int k = 0; k < m->n_mirror_neg; ++k) base[m->mirror_neg[k] + 1] *= -1;
   }
   real dsv[MB];
-  for (int b = 1; b <= nj; ++b) {
-    dsv[b] = (real)-0.1 + (real)0.2 * draw_uniform(o, env, tk);
-  }
+  for (int b = 1; b <= nj; ++b) /* the deviations are drawn only inside `if random_pose` (robots.py:190-192) */
+    dsv[b] = o->random_pose ? (real)-0.1 + (real)0.2 * draw_uniform(o, env, tk) : 0;
   for (int b = 1; b <= nj; ++b) {
     s->q[b] = base[b];
     if (o->random_pose) { /* robots.py:190-194: deviation + normalise + clip(+-0.95) only inside `if random_pose` */
@@ -1058,7 +1107,7 @@ static void reset_env(Oracle *o, int env, float *obs) {
     }
     s->qd[b] = 0;
   }
-  for (int k = 0; k < 3; ++k) { s->pos[k] = m->init_pos[k]; s->vel[k] = 0; s->omg[k] = 0; }
+  for (int k = 0; k < 3; ++k) { s->pos[k] = m->init_pos[k]; s->vel[k] = m->init_vel[k]; s->omg[k] = 0; } /* robot_init_velocity, :92,493 */
   for (int k = 0; k < 4; ++k) s->quat[k] = m->init_quat[k];
   for (int k = 0; k < MOCCA_MAX_SLOTS; ++k) s->warm[k] = 0;
   kinematics(m, s, &o->wk);
@@ -1075,7 +1124,7 @@ static void reset_env(Oracle *o, int env, float *obs) {
      * not yet placed relative to a robot at rest above them): feet_contact = 0 */
     generate_step_placements(o, env, tk, tr);
     for (int k = 0; k < MOCCA_MAX_PLANKS; ++k) tr->plank_info[k] = k;
-    tk->next_step_index = 1; /* lookbehind */
+    tk->next_step_index = m->lookbehind; /* :499 */
     delta_to_k_targets(o, s, tk, tr, obs + nb);
     real dist, ang;
     calc_potential(o, s, tk, &dist, &ang);
@@ -1161,13 +1210,14 @@ static void step_env(Oracle *o, int env, const float *act, float *obs, float *re
     int cur_step_index = tk->next_step_index;
     /* calc_feet_state :632-674 */
     real fd[MOCCA_MAX_FEET];
+    int target_reached = 0;
     for (int k = 0; k < m->n_feet; ++k) {
       real dx = o->feet_xyz[k][0] - tr->terrain[tk->next_step_index][0];
       real dy = o->feet_xyz[k][1] - tr->terrain[tk->next_step_index][1];
       fd[k] = sqrt(dx * dx + dy * dy);
       tk->feet_contact[k] = touch[k];
+      if (target[k]) target_reached = 1;
     }
-    int target_reached = target[0] || target[1];
     if (target_reached) {
       tk->target_reached_count += 1;
       if (tk->target_reached_count > 120) { tk->stop_on_next_step = 0; tk->set_stop_on_next_step = 0; }
@@ -1175,8 +1225,8 @@ static void step_env(Oracle *o, int env, const float *act, float *obs, float *re
         if (!tk->stop_on_next_step) {
           tk->next_step_index += 1;
           tk->target_reached_count = 0;
-          if (tk->next_step_index >= MOCCA_MAX_PLANKS) { /* update_steps :472-479 */
-            int oldest = tk->next_step_index % MOCCA_MAX_PLANKS;
+          if (tk->next_step_index >= m->n_planks) { /* update_steps :472-479 */
+            int oldest = tk->next_step_index % m->n_planks;
             int nx = tk->next_step_index < MOCCA_MAX_TERRAIN_STEPS - 1 ? tk->next_step_index : MOCCA_MAX_TERRAIN_STEPS - 1;
             tr->plank_info[oldest] = nx;
           }
@@ -1190,25 +1240,51 @@ static void step_env(Oracle *o, int env, const float *act, float *obs, float *re
     calc_potential(o, s, tk, &dist, &ang);
     progress = tk->linear_potential - old;
     real pitch = o->body_rpy[1], roll = o->body_rpy[0];
-    if (!((real)-0.2 < pitch && pitch < (real)0.4)) posture = fabs(pitch);
-    if (!((real)-0.4 < roll && roll < (real)0.4)) posture += fabs(roll);
     real e1 = 0, e2 = 0;
     for (int j = 0; j < nj; ++j) { e1 += fabs((real)act[j] * (real)spd[j]); e2 += (real)act[j] * (real)act[j]; }
     energy = (real)m->electricity_cost * (e1 / nj) + (real)m->stall_torque_cost * (e2 / nj);
     joints = (real)m->joints_at_limit_cost * jal;
-    real term_h = (real)0.75 + ((real)0.45 - (real)0.75) * tk->curriculum / 9; /* np.linspace(0.75,0.45,10) :368 */
-    tall = obs[0] > term_h ? 2 : -1;
-    if (tall < 0) tk->done = 1;
+    if (!(m->task_flags & MOCCA_TASKF_QUADRUPED_STEPPER)) {
+      if (!((real)-0.2 < pitch && pitch < (real)0.4)) posture = fabs(pitch);
+      if (!((real)-0.4 < roll && roll < (real)0.4)) posture += fabs(roll);
+      real term_h = DEC(m->term_height_cur[0]) + (DEC(m->term_height_cur[1]) - DEC(m->term_height_cur[0])) * tk->curriculum / 9; /* :368,628 */
+      tall = obs[0] > term_h ? 2 : -1;
+      if (tall < 0) tk->done = 1;
+    } else {
+      /* LaikagoStepperEnv.calc_base_reward, :928-979: posture from the hip_x / hip_y / knee angles (degrees, float32 joint
+       * angles as robot.joint_angles holds them), progress x 2, posture x 0.2, time-based early termination REPLACES done */
+      const real R2D = (real)(180.0 / 3.14159265358979323846), D2R = (real)(3.14159265358979323846 / 180.0);
+      for (int j = 0; j < nj; ++j) {
+        real a = (real)(float)s->q[1 + j] * R2D, lo_ = j % 3 == 0 ? -25 : (j % 3 == 1 ? -35 : -75), hi_ = j % 3 == 0 ? 25 : (j % 3 == 1 ? 35 : -15);
+        if (!(lo_ < a && a < hi_)) posture += fabs(a * D2R);
+      }
+      if (!(-25 < pitch * R2D && pitch * R2D < 25)) posture += fabs(pitch);
+      progress *= 2;
+      posture *= (real)0.2;
+      tall = 2;
+      tk->done = (tk->t > 240 && tk->next_step_index <= 4);
+      if (body_touch) { tall = -1; tk->done = 1; }
+    }
     /* calc_step_reward :676-693 */
     int last = MOCCA_MAX_TERRAIN_STEPS - 1;
     if (target_reached && tk->target_reached_count == 1 && tk->next_step_index != last) {
-      real dmin = fd[0] < fd[1] ? fd[0] : fd[1];
-      step_bonus = 50 * pow((real)2.718, -dmin / (real)0.25);
+      real dmin = fd[0];
+      for (int k = 1; k < m->n_feet; ++k) if (fd[k] < dmin) dmin = fd[k];
+      step_bonus = 50 * pow((real)2.718, -pow(dmin, (real)m->step_bonus_smoothness) / (real)0.25);
     }
     if ((tk->next_step_index == last || tk->stop_on_next_step) && dist < (real)0.15) target_bonus = 2;
     delta_to_k_targets(o, s, tk, tr, obs + nb);
     if (cur_step_index != tk->next_step_index) calc_potential(o, s, tk, &dist, &ang);
-    *rew = (float)(progress - energy + step_bonus + target_bonus + tall - posture - joints); /* :528-531 */
+    if (!o->random_reward) {
+      *rew = (float)(progress - energy + step_bonus + target_bonus + tall - posture - joints); /* :528-531 */
+    } else { /* :533-547: np.dot(np_random.uniform(0.8, 1.2, 8), terms) */
+      if (o->random_reward == 1)
+        for (int k = 0; k < 8; ++k) tk->rw[k] = (real)0.8 + (real)0.4 * draw_uniform(o, env, tk);
+      const real terms[8] = {progress, -energy, step_bonus, target_bonus, 0, tall, -posture, -joints};
+      real acc = 0;
+      for (int k = 0; k < 8; ++k) acc += tk->rw[k] * terms[k];
+      *rew = (float)acc;
+    }
     *info = tk->next_step_index;
   }
   tk->prev_body_x = s->pos[0];
@@ -1246,13 +1322,14 @@ API int orc_obs_dim(void *h) { return obs_dim((Oracle *)h); }
 API int orc_act_dim(void *h) { Oracle *o = (Oracle *)h; return o->task_id == MOCCA_TASK_CASSIE ? o->m.n_ctrl - 2 : o->m.n_joints; }
 API int orc_state_dim(void *h) { Oracle *o = (Oracle *)h; return MOCCA_STATE_DIM(o->m.n_joints, o->m.n_slots); }
 
-enum { PARAM_AUTO_RESET = 0, PARAM_EVAL_MODE = 1, PARAM_CURRICULUM = 2, PARAM_RANDOM_POSE = 3 };
+enum { PARAM_AUTO_RESET = 0, PARAM_EVAL_MODE = 1, PARAM_CURRICULUM = 2, PARAM_RANDOM_POSE = 3, PARAM_RANDOM_REWARD = 8 /* ids of include/mocca.h */ };
 API void orc_set_param(void *h, int id, double v) {
   Oracle *o = (Oracle *)h;
   if (id == PARAM_AUTO_RESET) o->auto_reset = v != 0;
   else if (id == PARAM_EVAL_MODE) o->eval_mode = v != 0;
   else if (id == PARAM_CURRICULUM) for (int e = 0; e < o->n_envs; ++e) o->task[e].curriculum = (int)v;
   else if (id == PARAM_RANDOM_POSE) o->random_pose = v != 0;
+  else if (id == PARAM_RANDOM_REWARD) o->random_reward = (int)v;
 }
 
 API void orc_reset(void *h, const uint8_t *mask, uint64_t seed, float *obs) {
@@ -1340,6 +1417,7 @@ API void orc_get_task(void *h, double *t) {
     for (int j = 0; j < 14; ++j) p[24 + j] = k->jvel[j];
     if (o->m.n_feet > 2) { p[24] = k->feet_contact[2]; p[25] = k->feet_contact[3]; } /* quadrupeds: words shared with Cassie's jvel */
     p[38] = k->initial_z; p[39] = k->istep;
+    if (o->task_id == MOCCA_TASK_WALKER3D_STEPPER) for (int j = 0; j < 8; ++j) p[30 + j] = k->rw[j];
   }
 }
 API void orc_set_task(void *h, const double *t) {
@@ -1357,6 +1435,7 @@ API void orc_set_task(void *h, const double *t) {
     for (int j = 0; j < 14; ++j) k->jvel[j] = (real)p[24 + j];
     if (o->m.n_feet > 2) { k->feet_contact[2] = (real)p[24]; k->feet_contact[3] = (real)p[25]; }
     k->initial_z = (real)p[38]; k->istep = (int)p[39];
+    if (o->task_id == MOCCA_TASK_WALKER3D_STEPPER) for (int j = 0; j < 8; ++j) k->rw[j] = (real)p[30 + j];
   }
 }
 API void orc_get_terrain(void *h, double *t) { /* [N][20][6] + plank_info appended per env [3] */

@@ -15,7 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 TASK_WORDS = 40
-TERRAIN_WORDS = 20 * 6 + 3
+TERRAIN_WORDS = 20 * 6 + 4   # 20 x 6 step table + MOCCA_MAX_PLANKS live-plank rows
 
 
 def build(force: bool = False) -> None:
@@ -68,7 +68,7 @@ def _p(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
 
-PARAM_AUTO_RESET, PARAM_EVAL_MODE, PARAM_CURRICULUM, PARAM_RANDOM_POSE = 0, 1, 2, 3
+PARAM_AUTO_RESET, PARAM_EVAL_MODE, PARAM_CURRICULUM, PARAM_RANDOM_POSE, PARAM_RANDOM_REWARD = 0, 1, 2, 3, 8
 
 
 class Oracle:

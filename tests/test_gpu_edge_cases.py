@@ -23,7 +23,7 @@ def _sync(env, orc, task=0):
     env.set_state(orc.get_state().astype(np.float32))
     env.set_task(task_from_float64(orc.get_task()))
     if task:
-        ter = np.zeros((env.n_envs, 128), np.float32); ter[:, :123] = orc.get_terrain(); env.set_terrain(ter)
+        ter = np.zeros((env.n_envs, 128), np.float32); ter[:, :124] = orc.get_terrain(); env.set_terrain(ter)
 
 
 def _close(a, b, tol=5.0):

@@ -18,7 +18,7 @@ def _oracle_from(env, task):
     o.set_state(env._vec.get_state().cpu().numpy().astype(np.float64))
     o.set_task(task_to_float64(env._vec.get_task()))
     if task == M.TASK_WALKER3D_STEPPER:
-        o.set_terrain(env._vec.get_terrain().cpu().numpy()[:, :123].astype(np.float64))
+        o.set_terrain(env._vec.get_terrain().cpu().numpy()[:, :124].astype(np.float64))
     return o
 
 

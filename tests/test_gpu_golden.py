@@ -249,3 +249,87 @@ def test_cassie_steps_against_the_reference_code_on_the_gpu():
     print(f"\nCassie GPU vs reference-code-over-f64-oracle, one env.step: median {np.median(e):.3g} p99 {np.percentile(e, 99):.3g} max {e.max():.3g} units")
     assert np.median(e) < 0.5
     env.close()
+
+
+@pytest.fixture(scope="module")
+def sg():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "steppers_reference.npz"), allow_pickle=False)
+
+
+def test_laikago_stepper_episodes_on_the_gpu(sg):
+    """LaikagoStepperEnv (env_locomotion.py:893-979) through the HIP task layer: four feet on four live planks, two planks of
+    look-behind, joint-angle posture penalty, doubled progress, time-based early termination, body contact on a plank."""
+    import torch
+    from mocca_envs_amd import lib as L
+    from mocca_envs_amd.vec_env import task_to_float64
+    m = M.compile_laikago(stepper=True)
+    seen = dict(max_nsi=0, stops=set(), early=0, recycled=False)
+    for ep in range(int(sg["lstep_n_episodes"])):
+        g = lambda k: sg[f"lstep_ep{ep}_{k}"]
+        env = _env("LaikagoStepperEnv-v0", g("tape"), [(L.PARAM_CURRICULUM, int(g("curriculum"))), (L.PARAM_RANDOM_POSE, 0)])
+        assert env.obs_dim == 54
+        obs0 = env.reset().cpu().numpy()
+        st = env.get_state().cpu().numpy()
+        np.testing.assert_allclose(st[0, 13:25], g("reset_q"), atol=TOL)
+        np.testing.assert_allclose(st[0, 7:10], g("reset_base_vel"), atol=TOL)
+        table = env.get_terrain().cpu().numpy()[0, :120].reshape(20, 6)
+        np.testing.assert_allclose(table, g("terrain"), atol=10 * TOL)
+        np.testing.assert_allclose(obs0[0, 1:], g("reset_obs")[1:], atol=OBS_TOL)
+        states, touch, target, body, actions = g("states"), g("touch"), g("target"), g("body"), g("actions")
+        for t in range(len(states)):
+            _set_state(env, states[t])
+            a = torch.from_numpy(np.tile(actions[t][None].astype(np.float32), (REPL, 1)))
+            tile = lambda x: np.tile(np.asarray(x, np.int32).reshape(1, -1), (REPL, 1))
+            o, r, d, info = env.task_step(a, tile(touch[t]), tile(target[t]), np.full(REPL, int(body[t]), np.int32))
+            _same_in_every_replica(o, r, d, info)
+            np.testing.assert_allclose(o.cpu().numpy()[0], g("obs")[t], atol=OBS_TOL, err_msg=f"ep{ep} t{t} obs")
+            assert (int(d[0]) & 1) == int(g("done")[t]), f"ep{ep} t{t} done"
+            np.testing.assert_allclose(float(r[0]), g("rew")[t], atol=2 * REW_TOL, err_msg=f"ep{ep} t{t} reward")   # progress x 2
+            nsi = int(info[0])
+            assert nsi == int(g("next_step_index")[t]), f"ep{ep} t{t} next_step_index"
+            pinfo = env.get_terrain().cpu().numpy()[0, 120:124].astype(int)
+            want = g("plank_pos")[t] - np.array([0, 0, m.plank_com_z])
+            np.testing.assert_allclose(table[pinfo, 0:3], want, atol=10 * TOL, err_msg=f"ep{ep} t{t} planks")
+            seen["max_nsi"] = max(seen["max_nsi"], nsi)
+            if int(task_to_float64(env.get_task())[0][18]):
+                seen["stops"].add(nsi)
+            seen["recycled"] |= sorted(pinfo) != [0, 1, 2, 3]
+            seen["early"] += int(g("done")[t]) and t > 239 and not body[t]
+        env.close()
+    assert seen["max_nsi"] == 19 and {6, 7} & seen["stops"] and {13, 14} & seen["stops"] and seen["recycled"] and seen["early"] >= 5, seen
+
+
+def test_random_reward_episode_on_the_gpu(sg):
+    """Walker3DStepperEnv(random_reward=True), env_locomotion.py:533-547: the kernel draws eight weights per step; fed the
+    reference's np_random numbers through the tape it must reproduce the reference's rewards."""
+    import torch
+    from mocca_envs_amd import lib as L
+    from mocca_envs_amd.vec_env import task_to_float64
+    g = lambda k: sg[f"rr_ep0_{k}"]
+    env = _env("Walker3DStepperEnv-v0", g("tape"), [(L.PARAM_CURRICULUM, int(g("curriculum"))), (L.PARAM_RANDOM_REWARD, 1)])
+    env.reset()
+    states, touch, target, actions, terms = g("states"), g("touch"), g("target"), g("actions"), g("terms")
+    for t in range(len(states)):
+        _set_state(env, states[t])
+        a = torch.from_numpy(np.tile(actions[t][None].astype(np.float32), (REPL, 1)))
+        tile = lambda x: np.tile(np.asarray(x, np.int32).reshape(1, -1), (REPL, 1))
+        o, r, d, info = env.task_step(a, tile(touch[t]), tile(target[t]))
+        _same_in_every_replica(o, r, d, info)
+        np.testing.assert_allclose(float(r[0]), g("rew")[t], atol=REW_TOL, err_msg=f"t{t} reward")
+        w = task_to_float64(env.get_task())[0][30:38]
+        np.testing.assert_allclose(w @ terms[t], g("rew")[t], atol=2e-4)       # the weights in the task record are the reference's draws
+        assert int(info[0]) == int(g("next_step_index")[t])
+    assert int(task_to_float64(env.get_task())[0][10]) == 122 + 8 * len(states)
+    # mode 2: the host writes the weights (the single-env class keeps np_random on the host): all ones = the plain reward, all twos = twice it
+    from mocca_envs_amd.vec_env import task_from_float64
+    tk0 = task_to_float64(env.get_task())
+    rews = {}
+    for mode, w in ((0, 1.0), (2, 1.0), (2, 2.0)):
+        env.set_param(L.PARAM_RANDOM_REWARD, mode)
+        tk = tk0.copy(); tk[:, 30:38] = w
+        env.set_task(task_from_float64(tk))
+        _set_state(env, states[-1])
+        o, r, d, info = env.task_step(a, tile(touch[-1]), tile(target[-1]))
+        rews[(mode, w)] = float(r[0])
+    assert abs(rews[(2, 1.0)] - rews[(0, 1.0)]) < 1e-4 and abs(rews[(2, 2.0)] - 2 * rews[(0, 1.0)]) < 2e-4, rews
+    env.close()

@@ -12,7 +12,9 @@ TASKS = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM), ("Walker3DStepperEnv-
          # planar robots: own topologies (7 / 6 hinges), Custom task
          ("Walker2DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM), ("Crab2DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM),
          # quadruped: four feet, 8 substeps, body contact ends the episode
-         ("LaikagoCustomEnv-v0", M.TASK_WALKER3D_CUSTOM)]
+         ("LaikagoCustomEnv-v0", M.TASK_WALKER3D_CUSTOM),
+         # the quadruped on four live planks (Laikago topology x Stepper task)
+         ("LaikagoStepperEnv-v0", M.TASK_WALKER3D_STEPPER)]
 
 # fp32 tolerance of one teacher-forced env.step() (4 substeps, up to 48 PGS rows).  Errors are measured in
 # units of (1e-3 + 1e-3 |x|): joint speeds reach 100 rad/s under random actions, hence the relative part.
@@ -52,7 +54,7 @@ def _sync_from(env, orc, task):
     env.set_task(task_from_float64(orc.get_task()))
     if task == M.TASK_WALKER3D_STEPPER:
         ter = np.zeros((env.n_envs, 128), np.float32)
-        ter[:, :123] = orc.get_terrain()
+        ter[:, :124] = orc.get_terrain()
         env.set_terrain(ter)
 
 
@@ -69,7 +71,7 @@ def test_reset_matches_oracle(env_id, task):
     tg, tc = task_to_float64(env.get_task()), o32.get_task()
     np.testing.assert_allclose(tg, tc, atol=1e-4)
     if task == M.TASK_WALKER3D_STEPPER:
-        np.testing.assert_allclose(env.get_terrain().cpu().numpy()[:, :123], o32.get_terrain(), atol=5e-6)
+        np.testing.assert_allclose(env.get_terrain().cpu().numpy()[:, :124], o32.get_terrain(), atol=5e-6)
     # masked reset leaves the other envs alone
     mask = np.zeros(256, np.uint8); mask[::3] = 1
     before = env.get_state().cpu().numpy().copy()
@@ -121,7 +123,7 @@ def test_teacher_forced_steps(env_id, task):
         # termination flags may only differ where the height sits on the threshold
         mism = (dg != dc) & ok
         if mism.any():
-            thr = env.model.termination_height if task == 0 else 0.45
+            thr = env.model.termination_height if task == 0 else env.model.term_height_cur[1]
             assert (np.abs(oc[mism, 0] - thr) < 1e-3).all(), f"t={t} done flags differ away from the threshold"
         np.testing.assert_array_equal(ig[ok & ~mism], ic[ok & ~mism])
         nd = 13 + 2 * env.act_dim

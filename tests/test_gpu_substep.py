@@ -19,12 +19,16 @@ pytestmark = pytest.mark.gpu
 CASES = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {}),
          ("Child3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("MikeStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {}),
          ("Walker2DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("Crab2DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}),
-         ("LaikagoCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("CassieEnv-v0", M.TASK_CASSIE, {})]
+         ("LaikagoCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("CassieEnv-v0", M.TASK_CASSIE, {}),
+         ("LaikagoStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {}), ("Cassie2DEnv-v0", M.TASK_CASSIE, {}),
+         # the other step objects of Walker3DStepperEnv (plank_class, bullet_objects.py:86-97): short box, upright cylinder
+         ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"plank_class": "Plank"}),
+         ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"plank_class": "Pillar"})]
 
 
-def _one_substep_blob(env_id):
+def _one_substep_blob(env_id, **kw):
     from mocca_envs_amd.vec_env import compile_model_for
-    m = compile_model_for(env_id)
+    m = compile_model_for(env_id, **kw)
     m.n_substeps = 1
     if env_id.startswith("Cassie"):
         m.n_llc = 1
@@ -37,7 +41,7 @@ def test_single_substep_parity_with_matching_active_sets(env_id, task, kw):
     from mocca_envs_amd.vec_env import VecEnv, task_from_float64, _DEFAULT_PARAMS
     from oracle.oracle import Oracle, PARAM_CURRICULUM
     n, steps = 256, 160
-    m = _one_substep_blob(env_id)
+    m = _one_substep_blob(env_id, **kw)
     blob = m.to_bytes()
     env = VecEnv(env_id, n, auto_reset=False, seed=4, model_blob=blob)
     dbg = env.set_debug(True)
@@ -58,7 +62,7 @@ def test_single_substep_parity_with_matching_active_sets(env_id, task, kw):
         env.set_task(task_from_float64(orc.get_task()))
         o64.set_state(orc.get_state()); o64.set_task(orc.get_task())
         if task == M.TASK_WALKER3D_STEPPER:
-            ter = np.zeros((n, 128), np.float32); ter[:, :123] = orc.get_terrain(); env.set_terrain(ter)
+            ter = np.zeros((n, 128), np.float32); ter[:, :124] = orc.get_terrain(); env.set_terrain(ter)
             o64.set_terrain(orc.get_terrain())
         scale = 1.0 if t % 3 else 0.3
         a = (scale * rng.uniform(-1, 1, (n, env.act_dim))).astype(np.float32)
@@ -124,7 +128,7 @@ def test_per_env_parameters_through_the_abi():
         oc = orc.reset(seed=6)
         sel = cur == c
         np.testing.assert_allclose(og[sel], oc[sel], atol=2e-6)
-        np.testing.assert_allclose(ter_g[sel][:, :123], orc.get_terrain()[sel], atol=5e-6)
+        np.testing.assert_allclose(ter_g[sel][:, :124], orc.get_terrain()[sel], atol=5e-6)
     spread = np.abs(ter_g[:, 1:120:6]).max(axis=1)                                     # lateral spread grows with the curriculum
     assert spread[cur == 9].mean() > 2 * spread[cur == 2].mean()
     # terminal height follows the env's own curriculum (:368,628): a robot pitched 1.3 rad stands ~0.58 m above its lower

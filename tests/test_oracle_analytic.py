@@ -52,7 +52,7 @@ def test_resting_contact_carries_the_weight():
 def _plank_world(m, tilt):
     """Oracle on the Stepper task with plank 0 rolled by `tilt` about x (slope along y) under the origin."""
     o, st = _oracle(m, task=M.TASK_WALKER3D_STEPPER)
-    ter = np.zeros((1, 123))
+    ter = np.zeros((1, 124))
     ter[0, 0:6] = [0, 0, 0, 0, tilt, 0]                 # x y z phi x_tilt y_tilt (env_locomotion.py:441,461-465)
     ter[0, 6:12] = [50, 0, 0, 0, 0, 0]                  # the other two live planks far away
     ter[0, 12:18] = [60, 0, 0, 0, 0, 0]

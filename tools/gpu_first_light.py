@@ -22,7 +22,7 @@ print("reset state max diff", np.abs(st_g - st_c).max())
 tk_g = task_to_float64(env.get_task()); tk_c = orc.get_task()
 print("reset task max diff", np.abs(tk_g - tk_c).max())
 if task == 1:
-    print("terrain diff", np.abs(env.get_terrain().cpu().numpy()[:, :123] - orc.get_terrain()).max())
+    print("terrain diff", np.abs(env.get_terrain().cpu().numpy()[:, :124] - orc.get_terrain()).max())
 rng = np.random.default_rng(0)
 worst = {}
 for t in range(60):
@@ -30,7 +30,7 @@ for t in range(60):
     env.set_state(orc.get_state().astype(np.float32))
     env.set_task(task_from_float64(orc.get_task()))
     if task == 1:
-        ter = np.zeros((N, 128), np.float32); ter[:, :123] = orc.get_terrain(); env.set_terrain(ter)
+        ter = np.zeros((N, 128), np.float32); ter[:, :124] = orc.get_terrain(); env.set_terrain(ter)
     a = rng.uniform(-1, 1, (N, 21)).astype(np.float32)
     og, rg, dg, ig = env.step(torch.from_numpy(a).cuda())
     torch.cuda.synchronize()
