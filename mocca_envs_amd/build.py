@@ -32,7 +32,7 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: s
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-I" + INCLUDE, "-I" + CSRC] + list(extra_flags)
     if verbose:
         base.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build") if out is None else out + ".objs"
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []
     for src in SOURCES:   # the translation units compile in parallel
@@ -50,5 +50,9 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: s
 
 
 if __name__ == "__main__":
-    build_lib(force=True, verbose="-v" in sys.argv)
-    print(LIB)
+    # python -m mocca_envs_amd.build [-v] [--out /tmp/libX.so] [--src DIR] [-DFLAG ...]   (diagnostic / A-B builds pass -D flags and --out)
+    argv = sys.argv[1:]
+    out = argv[argv.index("--out") + 1] if "--out" in argv else None
+    if "--src" in argv:   # build another revision's kernel sources (tools/ab.sh)
+        CSRC = argv[argv.index("--src") + 1]
+    print(build_lib(force=True, verbose="-v" in argv, extra_flags=[a for a in argv if a.startswith("-D")], out=out))

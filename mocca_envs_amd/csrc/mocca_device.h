@@ -897,9 +897,21 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
   }
   int nc = __popcll(am);
   int n_self = 0;
+  unsigned long long kept = am;
+  if (nc > maxc) {
+    // More terrain contacts than the solver holds (a robot lying on the ground): keep the max_contacts DEEPEST ones (ties: lower
+    // slot first), still solved in slot order.  Rare and wave-uniform: one readlane per active slot.
+    int deeper = 0;
+    for (unsigned long long mm = am; mm; mm &= mm - 1) {
+      const int l = __builtin_ctzll(mm);
+      const float gl = readlane(gap, l);
+      deeper += (gl < gap || (gl == gap && l < lane)) ? 1 : 0;
+    }
+    kept = __ballot(active && deeper < maxc);
+  }
   {
-    const int idx = lane_rank(am);
-    if (active && idx < maxc) {
+    const int idx = lane_rank(kept);
+    if (active && ((kept >> lane) & 1ull)) {
       float* ct = L + L_CT + 16 * idx;
       ct[C_BA] = __int_as_float(body); ct[C_BB] = __int_as_float(-1); ct[C_SLOT] = __int_as_float(slot);
 #pragma unroll

@@ -7,7 +7,10 @@ and env_base.py:164-166 rely on.
 """
 from __future__ import annotations
 
+import hashlib
 import importlib
+import os
+import struct
 import types
 
 import numpy as np
@@ -130,9 +133,46 @@ def make(id, **kwargs):
     return env
 
 
+def _bigint_from_bytes(b: bytes) -> int:
+    pad = 4 - len(b) % 4           # gym pads a whole extra word when the length already is a multiple of 4: harmless zeros
+    b += b"\0" * pad
+    words = struct.unpack("{}I".format(len(b) // 4), b)
+    return sum(v << (32 * i) for i, v in enumerate(words))
+
+
+def hash_seed(seed=None, max_bytes=8) -> int:
+    """gym.utils.seeding.hash_seed (gym <= 0.21, the API generation the reference targets: 4-tuple step, `env.seed()`;
+    the dependency is un-pinned in /root/reference/setup.py:11): SHA-512 of the decimal string, first 8 bytes, little endian."""
+    if seed is None:
+        seed = create_seed(max_bytes=max_bytes)
+    return _bigint_from_bytes(hashlib.sha512(str(seed).encode("utf8")).digest()[:max_bytes])
+
+
+def create_seed(a=None, max_bytes=8) -> int:
+    if a is None:
+        return _bigint_from_bytes(os.urandom(max_bytes))
+    if isinstance(a, str):
+        a = a.encode("utf8") + hashlib.sha512(a.encode("utf8")).digest()
+        return _bigint_from_bytes(a[:max_bytes])
+    if isinstance(a, (int, np.integer)):
+        return int(a) % 2 ** (8 * max_bytes)
+    raise TypeError("Invalid type for seed: {} ({})".format(type(a), a))
+
+
 def _np_random(seed=None):
+    """gym.utils.seeding.np_random of gym <= 0.21: the seed is HASHED before it reaches numpy's Mersenne Twister
+    (RandomState.seed of the 32-bit words of hash_seed(seed)), so `env.seed(5)` here starts the stream the reference's
+    `env.seed(5)` starts under that gym.  Returns (RandomState, seed) like gym."""
+    if seed is not None and not (isinstance(seed, (int, np.integer)) and 0 <= seed):
+        raise ValueError("Seed must be a non-negative integer or omitted, not {}".format(seed))
+    seed = create_seed(seed)
+    big = hash_seed(seed)
+    words = []
+    while big > 0:
+        big, mod = divmod(big, 2 ** 32)
+        words.append(mod)
     rng = np.random.RandomState()
-    rng.seed(seed if seed is None else int(seed) % (2 ** 32))
+    rng.seed(words or [0])
     return rng, seed
 
 

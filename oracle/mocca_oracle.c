@@ -536,7 +536,11 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
   uint64_t slot_mask = 0;
   int n_self = 0;
   real margin = m->contact_margin;
-  /* terrain */
+  /* terrain: every slot within the margin is a candidate; when there are more than the solver holds (a robot lying on the
+   * ground) the max_contacts DEEPEST are kept (ties: lower slot first) and solved in slot order */
+  typedef struct { int body, slot; real n[3], P[3], depth, mu, erp, cfm; } TerrainCand;
+  TerrainCand cand[MOCCA_MAX_SLOTS];
+  int ncand = 0;
   for (int g = 0; g < m->n_geoms; ++g) {
     if (!m->g_terrain[g]) continue;
     int ne = m->g_type[g] == MOCCA_GEOM_CAPSULE ? 2 : 1;
@@ -576,14 +580,24 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
         slot_mask |= (uint64_t)1 << (m->g_slot[g] + e);
         if (m->g_foot[g] >= 0) { w->foot_touch[m->g_foot[g]] = 1; if (is_target) w->foot_target[m->g_foot[g]] = 1; }
         else w->body_touch = 1; /* a non-foot link on the terrain (LaikagoCustomEnv, env_locomotion.py:880-890) */
-        if (w->nc < m->max_contacts) {
-          int i = w->nc++;
-          w->c_a[i] = m->g_body[g]; w->c_b[i] = -1; w->c_slot[i] = m->g_slot[g] + e;
-          for (int k = 0; k < 3; ++k) { w->c_n[i][k] = n[k]; w->c_P[i][k] = C[k] - rad * n[k]; }
-          w->c_depth[i] = -gap; w->c_mu[i] = mu; w->c_erp[i] = erp; w->c_cfm[i] = cfm;
+        if (ncand < MOCCA_MAX_SLOTS) {
+          TerrainCand *q = &cand[ncand++];
+          q->body = m->g_body[g]; q->slot = m->g_slot[g] + e;
+          for (int k = 0; k < 3; ++k) { q->n[k] = n[k]; q->P[k] = C[k] - rad * n[k]; }
+          q->depth = -gap; q->mu = mu; q->erp = erp; q->cfm = cfm;
         }
       }
     }
+  }
+  for (int i = 0; i < ncand; ++i) {
+    int deeper = 0;
+    for (int j = 0; j < ncand; ++j)
+      if (cand[j].depth > cand[i].depth || (cand[j].depth == cand[i].depth && j < i)) ++deeper;
+    if (ncand > m->max_contacts && deeper >= m->max_contacts) continue;
+    int k = w->nc++;
+    w->c_a[k] = cand[i].body; w->c_b[k] = -1; w->c_slot[k] = cand[i].slot;
+    for (int x = 0; x < 3; ++x) { w->c_n[k][x] = cand[i].n[x]; w->c_P[k][x] = cand[i].P[x]; }
+    w->c_depth[k] = cand[i].depth; w->c_mu[k] = cand[i].mu; w->c_erp[k] = cand[i].erp; w->c_cfm[k] = cand[i].cfm;
   }
   /* self collisions */
   for (int k = 0; k < m->n_pairs; ++k) {

@@ -290,8 +290,10 @@ def detect_contacts(mdl: Model, st: State, planks=None):
                 mu, erp, cfm = mdl.plank_friction * g["friction"], dt * kk / (dt * kk + cc), 1 / (dt * kk + cc) / dt
             if gap < mdl.contact_margin:
                 slot_mask |= 1 << (g["slot"] + e)
-                if len(out) < mdl.max_contacts:
-                    out.append(dict(a=g["body"], b=-1, slot=g["slot"] + e, P=C - g["radius"] * n, n=n, depth=-gap, mu=mu, erp=erp, cfm=cfm))
+                out.append(dict(a=g["body"], b=-1, slot=g["slot"] + e, P=C - g["radius"] * n, n=n, depth=-gap, mu=mu, erp=erp, cfm=cfm))
+    if len(out) > mdl.max_contacts:      # more terrain contacts than the solver holds: the deepest stay (ties: lower slot), in slot order
+        order = sorted(range(len(out)), key=lambda i: (-out[i]["depth"], i))[:mdl.max_contacts]
+        out = [out[i] for i in sorted(order)]
     for ga, gb in mdl.pairs:
         A, B = mdl.geoms[ga], mdl.geoms[gb]
         a1, a2 = (o[A["body"]] + R[A["body"]] @ A["p"][k] for k in (0, 1))

@@ -99,3 +99,23 @@ def test_time_limit_shim():
     env = gym_shim.TimeLimit(Dummy(), 3)
     env.reset()
     assert [env.step(0)[2] for _ in range(3)] == [False, False, True]
+
+
+def test_shim_seeding_hashes_the_seed_like_classic_gym():
+    """gym.utils.seeding.np_random (gym <= 0.21) seeds numpy with the 32-bit words of SHA-512(str(seed))[:8], not with the seed:
+    the shim must do the same or `env.seed(s)` starts another stream than under the reference's gym."""
+    import hashlib
+    import struct
+    from mocca_envs_amd import gym_shim as g
+    rng, seed = g._np_random(5)
+    assert seed == 5
+    lo, hi = struct.unpack("<II", hashlib.sha512(b"5").digest()[:8])
+    want = np.random.RandomState(); want.seed([lo, hi])
+    assert rng.rand() == want.rand()
+    assert g._np_random(5)[0].rand() != np.random.RandomState(5).rand()
+    assert g._np_random(2 ** 64 + 5)[0].rand() == g._np_random(5)[0].rand()       # create_seed folds ints modulo 2^64
+    r0, s0 = g._np_random(None)
+    assert isinstance(s0, int) and 0 <= s0 < 2 ** 64
+    import pytest
+    with pytest.raises(ValueError):
+        g._np_random(-1)

@@ -5,9 +5,9 @@ import numpy as np
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, R)
 so = "/tmp/libmocca_stamps.so"
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-DMOCCA_STAMPS",
-                       "-I" + R + "/include", "-I" + R + "/mocca_envs_amd/csrc", "-o", so, R + "/mocca_envs_amd/csrc/mocca_api.hip"])
+subprocess.check_call([sys.executable, "-m", "mocca_envs_amd.build", "--out", so, "-DMOCCA_STAMPS"], cwd=R, stdout=subprocess.DEVNULL)
 os.environ["MOCCA_LIB_PATH"] = so
+os.environ["MOCCA_ALLOW_DIAGNOSTIC_BUILD"] = "1"   # lib.load() refuses diagnostic builds otherwise
 import torch
 from mocca_envs_amd.vec_env import VecEnv
 env_id = sys.argv[1] if len(sys.argv) > 1 else "Walker3DCustomEnv-v0"
