@@ -141,11 +141,12 @@ def test_teacher_forced_steps(env_id, task):
     # reward contains d(potential)/dt = (difference of O(100) numbers) * 60 in fp32
     assert np.median(cat["rew"]) < 1e-3 and np.percentile(cat["rew"], 99) < 5e-2
     # worst single sample of the run (80 steps x 128 envs, each step 4 substeps with discrete row decisions): within an order of
-    # magnitude of the worst fp32 itself produces over the same run (f32 oracle vs f64 oracle) and never 2 % -- the strict
+    # magnitude of the worst fp32 itself produces over the same run (f32 oracle vs f64 oracle) -- the strict
     # statement (per substep, matching active sets, 1e-5 relative) is tests/test_gpu_substep.py
     worst_ref = ec.max()
     for k in ("state", "obs"):
-        assert cat[k].max() < min(20.0, 10 * worst_ref + 2.0), (k, cat[k].max(), worst_ref)
+        assert cat[k].max() < 10 * worst_ref + 2.0, (k, cat[k].max(), worst_ref)
+        assert (cat[k] > 5.0).mean() < 2e-3, (k, (cat[k] > 5.0).mean())      # and such outliers (a flipped row decision) stay below 0.2 %
     # the GPU is as close to the f64 oracle as the f32 CPU oracle is
     assert np.median(eg) <= 3 * np.median(ec) + 0.01
     assert np.percentile(eg, 99) <= 3 * np.percentile(ec, 99) + 0.1

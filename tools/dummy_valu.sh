@@ -1,10 +1,11 @@
 #!/bin/bash
 # experiment: add N x 4 dependent FMAs per substep and watch the launch time
 R=${GRAFT_REPO_ROOT:-/root/repo}
-cd $R/mocca_envs_amd/csrc
+cd $R
+export MOCCA_ALLOW_DIAGNOSTIC_BUILD=1
 for n in 0 125 250 500; do
   flag=""; [ $n != 0 ] && flag="-DMOCCA_DUMMY_VALU=$n"
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -shared -fPIC -I../../include $flag -o /tmp/libdv_$n.so mocca_api.hip || exit 1
+  python -m mocca_envs_amd.build --out /tmp/libdv_$n.so $flag > /dev/null || exit 1
 done
 cd $R
 for r in 1 2; do for n in 0 125 250 500; do

@@ -1,16 +1,17 @@
 #!/bin/bash
 # Kernel time of builds with different -D flag sets, interleaved in one gpurun call.  usage: tools/flag_sweep.sh "<flags A>" "<flags B>" ...
 R=${GRAFT_REPO_ROOT:-/root/repo}
-cd $R/mocca_envs_amd/csrc
+cd $R
+export MOCCA_ALLOW_DIAGNOSTIC_BUILD=1
 i=0
 for f in "$@"; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -shared -fPIC -I../../include $f -o /tmp/libsweep_$i.so mocca_api.hip || exit 1
+  python -m mocca_envs_amd.build --out /tmp/libsweep_$i.so $f > /dev/null || exit 1
   i=$((i+1))
 done
 for round in 1 2; do
   i=0
   for f in "$@"; do
-    MOCCA_LIB_PATH=/tmp/libsweep_$i.so python $R/bench.py --steps 300 --warmup 30 --no-cpu-baseline 2>/dev/null | tail -1 | \
+    MOCCA_LIB_PATH=/tmp/libsweep_$i.so python bench.py --steps 300 --warmup 30 --no-cpu-baseline 2>/dev/null | tail -1 | \
       python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[$f]', round(d['roofline']['kernel_ms']*1000,1), 'us')"
     i=$((i+1))
   done
