@@ -1,0 +1,33 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, in one gpurun call: usage  tools/round_artifacts.sh <tag>
+tag=${1:-r02}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+cd $R
+# 1. the driver's own default invocation + a long steady-state line (with the CPU baselines)
+python bench.py --steps 1000 --warmup 200 > $O/${tag}_bench_full.json 2> $O/${tag}_bench_full.err
+# 2. batch-size sweep of the headline env (1 / 2 / 4 waves per SIMD resident, then 2 and 4 rounds of waves)
+for n in 512 1024 2048 4096 8192 16384; do
+  python bench.py --envs $n --steps 400 --warmup 200 --no-cpu-baseline 2>/dev/null | tail -1 | \
+    python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'envs': $n, 'kernel_us': round(1000*d['roofline']['kernel_ms'],1), 'env_steps_per_s': round(d['value'])}))"
+done > $O/${tag}_batch_sweep.jsonl
+# 3. the other configs / env ids (untraced bench lines)
+python bench.py --envs 8192 --steps 400 --warmup 200 --no-cpu-baseline > $O/${tag}_custom8192_bench.json 2>/dev/null
+python bench.py --env-id Walker3DStepperEnv-v0 --curriculum 0 --steps 400 --warmup 200 --no-cpu-baseline > $O/${tag}_stepper_c0_bench.json 2>/dev/null
+python bench.py --env-id Walker3DStepperEnv-v0 --curriculum 9 --steps 400 --warmup 200 --no-cpu-baseline > $O/${tag}_stepper_c9_bench.json 2>/dev/null
+python bench.py --env-id CassieEnv-v0 --envs 2048 --steps 100 --warmup 30 --no-cpu-baseline > $O/${tag}_cassie_bench.json 2>/dev/null
+for e in Child3DCustomEnv-v0 MikeStepperEnv-v0 Walker2DCustomEnv-v0 Crab2DCustomEnv-v0 LaikagoCustomEnv-v0 LaikagoStepperEnv-v0; do
+  python bench.py --env-id $e --steps 300 --warmup 100 --no-cpu-baseline > $O/${tag}_$(echo $e | tr 'A-Z' 'a-z' | sed 's/env-v0//')_bench.json 2>/dev/null
+done
+python bench.py --env-id Cassie2DEnv-v0 --envs 2048 --steps 100 --warmup 30 --no-cpu-baseline > $O/${tag}_cassie2d_bench.json 2>/dev/null
+# 4. per-phase timelines (diagnostic build)
+python tools/stamps.py Walker3DCustomEnv-v0 4096 > $O/${tag}_stamps_custom4096.txt 2>&1
+python tools/stamps.py Walker3DCustomEnv-v0 1024 > $O/${tag}_stamps_custom1024.txt 2>&1
+python tools/param_time.py 4096 > $O/${tag}_param_time_4096.txt 2>&1
+# 5. record layouts
+hipcc --offload-arch=gfx950 -O3 -o /tmp/layout_bench tools/layout_bench.hip && /tmp/layout_bench 4096 > $O/${tag}_layout_bench.json && /tmp/layout_bench 65536 >> $O/${tag}_layout_bench.json
+# 6. rocprofv3: kernel-trace stats + separate PMC passes at steady state, three configs
+tools/profile_round.sh ${tag} Walker3DCustomEnv-v0 4096 > /dev/null 2>&1
+tools/profile_round.sh ${tag}_stepper Walker3DStepperEnv-v0 4096 > /dev/null 2>&1
+tools/profile_round.sh ${tag}_cassie CassieEnv-v0 2048 > /dev/null 2>&1
+ls $O | grep "^${tag}" | head -80
