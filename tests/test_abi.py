@@ -73,3 +73,23 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 m = bad.search(txt)
                 assert m is None, f"{f}: {m.group(0)!r}"
+
+
+def test_diagnostic_builds_are_refused(tmp_path):
+    """A library compiled with a profiling switch (-DMOCCA_SKIP_* skips a physics phase, MOCCA_STAMPS adds timing stores) says so
+    through mocca_is_diagnostic_build(), and the binding refuses it unless MOCCA_ALLOW_DIAGNOSTIC_BUILD is set: a mis-set -D
+    cannot ship a kernel that is wrong by construction."""
+    import subprocess
+    import sys
+    from mocca_envs_amd.build import build_lib
+    so = build_lib(force=True, extra_flags=["-DMOCCA_SKIP_SOLVE"], out=str(tmp_path / "libdiag.so"))
+    assert C.CDLL(so).mocca_is_diagnostic_build() == 1
+    code = "from mocca_envs_amd import lib; lib.load()"
+    env = dict(os.environ, MOCCA_LIB_PATH=so, PYTHONPATH=ROOT)
+    env.pop("MOCCA_ALLOW_DIAGNOSTIC_BUILD", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "diagnostic build" in r.stderr
+    r = subprocess.run([sys.executable, "-c", code], env=dict(env, MOCCA_ALLOW_DIAGNOSTIC_BUILD="1"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    from mocca_envs_amd import lib
+    assert lib.load().mocca_is_diagnostic_build() == 0          # the product build is not one

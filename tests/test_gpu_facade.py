@@ -152,3 +152,81 @@ def test_same_tree_variants(env_id, obs_dim, z0):
         np.testing.assert_allclose(o, oc[0], atol=5e-3)
         assert abs(r - rc[0]) < 5e-2 and d == bool(dc[0] & 1)
     env.close()
+
+
+def test_laikago_stepper_class():
+    """LaikagoStepperEnv-v0 (env_locomotion.py:893-979) through the gym surface: 54-float observation, the reference's draw
+    order (mirror coin, no pose noise, then 100 terrain draws with ITS ranges), start velocity, steps agree with the oracle."""
+    import mocca_envs_amd
+    env = mocca_envs_amd.make("LaikagoStepperEnv-v0")
+    base = env.unwrapped
+    assert base.observation_space.shape == (54,) and base.action_space.shape == (12,)
+    assert (base.lookbehind, base.rendered_step_count, base.step_radius) == (2, 4, 0.16)
+    base.set_env_params({"curriculum": 6})
+    env.seed(4)
+    rng = copy.deepcopy(base.np_random)
+    obs = env.reset()
+    q, mirrored = H.reset_pose(rng, base.model, False)
+    table = H.generate_step_placements(rng, 6, base.model)
+    np.testing.assert_allclose(base.terrain_info, table)
+    assert np.abs(np.diff(table[:3, 0]) - 0.45).max() < 1e-12 and base.next_step_index == 2
+    st = base._vec.get_state()[0].cpu().numpy()
+    np.testing.assert_allclose(st[7:10], [0.5, 0.0, 0.25], atol=1e-7)       # robot_init_velocity
+    assert obs.shape == (54,) and abs(base.robot.applied_gain - 1.0) < 1e-12
+    orc = _oracle_from(base, M.TASK_WALKER3D_STEPPER)
+    from oracle.oracle import PARAM_CURRICULUM
+    orc.set_param(PARAM_CURRICULUM, 6)
+    arng = np.random.default_rng(2)
+    for t in range(5):
+        a = arng.uniform(-1, 1, 12)
+        o, r, d, info = env.step(a)
+        oc, rc, dc, _ = orc.step(a[None].astype(np.float32))
+        np.testing.assert_allclose(o, oc[0], atol=5e-3)
+        assert abs(r - rc[0]) < 5e-2 and d == bool(dc[0] & 1)
+    env.close()
+
+
+def test_stepper_kwargs_random_reward_and_plank_class():
+    """Walker3DStepperEnv(random_reward=True, plank_class=...) -- env_locomotion.py:342,356-357,533-547: the eight weights come from
+    the env's own np_random, eight per step, after the reset draws; unknown plank names fall back to LargePlank."""
+    import mocca_envs_amd
+    from mocca_envs_amd.vec_env import task_to_float64
+    env = mocca_envs_amd.make("Walker3DStepperEnv-v0", random_reward=True, plank_class="Pillar").unwrapped
+    assert env.model.plank_shape == M.PLANK_CYLINDER and abs(env.model.plank_half[0] - 0.25) < 1e-7
+    env.seed(8)
+    rng = copy.deepcopy(env.np_random)
+    env.reset()
+    H.reset_pose(rng, env.model, True); H.generate_step_placements(rng, 0, env.model)
+    plain = mocca_envs_amd.make("Walker3DStepperEnv-v0", plank_class="Pillar").unwrapped
+    plain.seed(8); plain.reset()
+    for t in range(4):
+        w = rng.uniform(0.8, 1.2, 8)
+        a = np.zeros(21)
+        _, r, _, _ = env.step(a)
+        _, r0, _, _ = plain.step(a)
+        tk = task_to_float64(env._vec.get_task())[0]
+        np.testing.assert_allclose(tk[30:38], w, atol=1e-6)               # the kernel used THIS step's host draws
+        assert abs(r - r0) < 0.25 * (abs(r0) + 1) and r != r0             # same physics, re-weighted terms
+    env.close(); plain.close()
+    other = mocca_envs_amd.make("Walker3DStepperEnv-v0", plank_class="NoSuchPlank").unwrapped
+    assert other.plank_class == "LargePlank" and other.model.plank_shape == M.PLANK_BOX
+    other.close()
+
+
+def test_cassie2d_id_and_robot_params():
+    import mocca_envs_amd
+    from mocca_envs_amd.vec_env import task_to_float64
+    env = mocca_envs_amd.make("Cassie2DEnv-v0")
+    base = env.unwrapped
+    assert base.planar and base.model.planar == 1 and base.observation_space.shape == (36,)
+    env.reset()
+    for t in range(3):
+        obs, rew, done, _ = env.step(0.3 * np.sin(np.arange(10) + t))
+    st = base._vec.get_state()[0].cpu().numpy()
+    assert abs(st[1]) < 1e-5 and abs(st[3]) < 1e-5 and abs(st[5]) < 1e-5      # y, quaternion x and z: still in the plane
+    env.close()
+    w = mocca_envs_amd.make("Walker3DCustomEnv-v0").unwrapped
+    w.reset()
+    w.set_robot_params({"applied_gain": 0.5})                                  # env_base.py:108-115, used by the next apply_action
+    assert abs(task_to_float64(w._vec.get_task())[0][21] - 0.5) < 1e-7
+    w.close()
