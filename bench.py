@@ -98,6 +98,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--curriculum", type=int, default=None, help="Stepper envs: curriculum 0..9 (SURVEY 8d config 3)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise launch / rendezvous / reporting only (CPU tests)")
+    ap.add_argument("--host-io", action="store_true",
+                    help="also time the loop with actions coming from pinned host memory and obs / reward / done copied back to the host "
+                         "every step (the PCIe-inclusive rate quoted in DESIGN.md; reported beside `value`, never as it)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST ONLY: let ranks share GPUs (device = rank %% visible GPUs) so the N-rank path can be exercised on a 1-GPU box; "
                          "the line is marked and is not a scaling measurement")
@@ -150,7 +153,7 @@ def main():
 
     from mocca_envs_amd import sharding
     lo, hi = sharding.env_range(rank, world, args.envs)
-    reset_frac, kern_ms, kinfo, env = 0.0, 0.0, {}, None
+    reset_frac, kern_ms, kinfo, env, host_io_ms = 0.0, 0.0, {}, None, None
     if args.dry_run:
         if dist is not None:
             dist.barrier()
@@ -196,6 +199,20 @@ def main():
         elapsed = sharding.max_over_ranks(elapsed, dist)
         kern_ms = ev0.elapsed_time(ev1) / args.steps  # back-to-back launches: average launch duration incl. launch gaps
         kinfo = env.kernel_info()
+        host_io_ms = None
+        if args.host_io:   # a trainer on the host: actions up, obs / reward / done down, every step, through PCIe
+            h_act = tape.cpu().pin_memory()
+            h_obs = torch.empty(args.envs, env.obs_dim).pin_memory()
+            h_rew, h_done = torch.empty(args.envs).pin_memory(), torch.empty(args.envs, dtype=torch.uint8).pin_memory()
+            d_act = torch.empty(args.envs, env.act_dim, device=dev)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                d_act.copy_(h_act[i % 64], non_blocking=True)
+                o, r, d, _ = env.step(d_act)
+                h_obs.copy_(o, non_blocking=True); h_rew.copy_(r, non_blocking=True); h_done.copy_(d, non_blocking=True)
+                torch.cuda.synchronize()          # the host policy needs this step's observation before it can act
+            host_io_ms = 1e3 * (time.perf_counter() - t1) / args.steps
 
     if rank == 0:
         traffic, valu, pmc_note = None, None, None
@@ -246,6 +263,9 @@ def main():
                                     "frac": tf / VALU_PEAK_TFLOPS, "valu_insts_per_env_step": valu["valu_insts_per_env_step"],
                                     "active_lanes_per_valu_inst": valu["active_lanes_per_valu_inst"],
                                     "note": "upper bound on useful flop: every active VALU lane-op counted as one FMA"}
+        if not args.dry_run and host_io_ms is not None:
+            out["host_io"] = {"ms_per_step": host_io_ms, "value": args.envs * world / (host_io_ms * 1e-3), "unit": "env-steps/s",
+                              "note": "actions from pinned host memory, obs + reward + done copied to the host and waited for every step"}
         if args.dry_run:
             out["dry_run"] = True
         if args.oversubscribe:
