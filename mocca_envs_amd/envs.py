@@ -361,8 +361,8 @@ class LaikagoStepperEnv(Walker3DStepperEnv):
 
 
 class CassieEnv(EnvBase):
-    """env_cassie.py:284-479 (3-D, residual control).  The reference class is not importable in the reference
-    snapshot; this follows its text.  `planar=True` (the 2-D ids) is not modelled."""
+    """env_cassie.py:284-479: CassieEnv-v0 and, with planar=True, Cassie2DEnv-v0.  The reference class is not importable in the
+    reference snapshot; this follows its text, pinned by tests/golden/make_golden_cassie.py."""
 
     env_id = "CassieEnv-v0"
     task_id = M.TASK_CASSIE
@@ -371,14 +371,14 @@ class CassieEnv(EnvBase):
     sim_frame_skip = 1
 
     def __init__(self, render=False, planar=False, power_coef=1.0, residual_control=True, rsi=True, **kwargs):
-        if power_coef != 1.0 or not residual_control:
-            raise NotImplementedError("only power_coef=1.0, residual_control=True are compiled into the model blob")
         # planar (Cassie2DEnv-v0, reference __init__.py:24-29): "constrains the robot movement to a 2D plane" (env_cassie.py:333).
         # The reference points at a URDF that is not in its tree (:279-282); here the 3-D robot's base is held in the x-z plane
-        # by three bilateral solver rows (Cassie)
-        self.planar = bool(planar)
+        # by three bilateral solver rows (Cassie).  power_coef scales every torque limit (:192-195),
+        # residual_control=False adds the action to zero instead of the nominal angles (:434-443): both are blob numbers.
+        self.planar, self.residual_control = bool(planar), bool(residual_control)
         if self.planar:
             self.env_id = "Cassie2DEnv-v0"
+        kwargs["model_kw"] = dict(power_coef=float(power_coef), residual_control=self.residual_control)
         super().__init__(render=render, **kwargs)
         self.rsi = rsi
         high = np.inf * np.ones(self.robot.observation_space.shape[0] + 2)

@@ -799,7 +799,7 @@ CASSIE_SPRINGS = [4, 11]                                                        
 CASSIE_KP = np.array([100, 100, 88, 96, 50, 100, 100, 88, 96, 50, 400, 400]) / 1.9  # env_cassie.py:292-317
 
 
-def compile_cassie(planar: bool = False) -> MoccaModel:
+def compile_cassie(planar: bool = False, power_coef: float = 1.0, residual_control: bool = True) -> MoccaModel:
     """Cassie blob: URDF tree with inertia from file (env_cassie.py:81-99), two point-to-point loop closures
     (:114-137), per-joint damping (:57,197-201), torque limits (:41-56), the PD gains of CassieEnv (:292-319).
     Ground contact: 12 support points of each toe's convex hull (radius-0 spheres); other meshes and mesh-mesh
@@ -860,7 +860,7 @@ def compile_cassie(planar: bool = False) -> MoccaModel:
                 m.jrot[b][k] = bd["jrot"].reshape(-1)[k]
             m.jlo[b], m.jhi[b] = bd["lo"], bd["hi"]
             stem = bd["name"].rsplit("_", 1)[0]
-            m.torque_limit[b] = CASSIE_POWER.get(stem, 0.0)
+            m.torque_limit[b] = power_coef * CASSIE_POWER.get(stem, 0.0)      # base_power * power_coef[name], env_cassie.py:192-195
             m.init_q[b] = CASSIE_ROD_ANGLES.get(bd["name"], 0.0)
         mass, com, I = _compose_inertial(bd["parts"])
         m.mass[b] = mass
@@ -897,7 +897,8 @@ def compile_cassie(planar: bool = False) -> MoccaModel:
         m.ctrl_oidx[k] = oi
         m.ctrl_kp[k] = CASSIE_KP[k]
         m.ctrl_kd[k] = CASSIE_KP[k] / 10.0
-        m.ctrl_base[k] = CASSIE_BASE_ANGLES[oi] if k < len(CASSIE_POWERED) else 0.0  # residual_control=True, :434-443
+        # residual_control (:434-443): the action is added to the nominal angles of the powered joints, or to zero
+        m.ctrl_base[k] = CASSIE_BASE_ANGLES[oi] if (k < len(CASSIE_POWERED) and residual_control) else 0.0
     # loop closures tarsus <-> achilles rod (env_cassie.py:114-137)
     m.n_closures = 2
     for k, (side, z) in enumerate((("left", 0.00711836), ("right", -0.00711836))):

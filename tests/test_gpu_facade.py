@@ -225,6 +225,13 @@ def test_cassie2d_id_and_robot_params():
     st = base._vec.get_state()[0].cpu().numpy()
     assert abs(st[1]) < 1e-5 and abs(st[3]) < 1e-5 and abs(st[5]) < 1e-5      # y, quaternion x and z: still in the plane
     env.close()
+    # power_coef scales the torque limits (env_cassie.py:192-195); residual_control=False drops the nominal-angle offset (:434-443)
+    weak = mocca_envs_amd.make("CassieEnv-v0", power_coef=0.5, residual_control=False).unwrapped
+    assert abs(weak.model.torque_limit[1] - 0.5 * 112.5) < 1e-4 and weak.model.ctrl_base[0] == 0.0
+    weak.reset()
+    o, r, d, _ = weak.step(np.zeros(10))
+    assert np.isfinite(o).all()
+    weak.close()
     w = mocca_envs_amd.make("Walker3DCustomEnv-v0").unwrapped
     w.reset()
     w.set_robot_params({"applied_gain": 0.5})                                  # env_base.py:108-115, used by the next apply_action
