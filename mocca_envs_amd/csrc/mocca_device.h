@@ -1233,7 +1233,11 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int32_t* d
   const unsigned anymask = wave_or(ma | mb);
   // Rows that act on two bodies (self contacts, loop closures) carry two force paths that merge at the common
   // ancestor; when the wave has none (the usual case for the walker) a single-path sweep does half the work.
+#ifdef MOCCA_NO_TWO_PATHS  // diagnostic build (tools/icache_probe.py): code-size experiment, wrong with self contacts / closures
+  const bool two_paths = false;
+#else
   const bool two_paths = T::NCLOS > 0 || __ballot(kind >= 1 && bb >= 0) != 0ull;  // wave-uniform
+#endif
   STAMP(18);
   if (two_paths) {
 #pragma unroll
