@@ -152,23 +152,26 @@ def test_teacher_forced_steps(env_id, task):
     assert np.percentile(eg, 99) <= 3 * np.percentile(ec, 99) + 0.1
 
 
-def test_free_running_statistics():
-    """1000 free-running steps with auto-reset: no NaN leaks, episode statistics match the oracle's.
+@pytest.mark.parametrize("env_id,task,n,steps", [("Walker3DCustomEnv-v0", 0, 256, 300), ("Walker3DStepperEnv-v0", 1, 256, 200),
+                                                 ("LaikagoStepperEnv-v0", 1, 256, 200), ("Cassie2DEnv-v0", 2, 64, 30)])
+def test_free_running_statistics(env_id, task, n, steps):
+    """Free-running steps with auto-reset: no NaN leaks, episode statistics match the oracle's.
     (Trajectories of a contact-rich chaotic system diverge in fp32; statistics do not.)"""
     import torch
-    env, o32, _ = _mk("Walker3DCustomEnv-v0", 0, 256, seed=21, auto_reset=True)
+    env, o32, _ = _mk(env_id, task, n, seed=21, auto_reset=True, curriculum=5 if task == 1 else None)
     env.reset(); o32.reset(seed=21)
     rng = np.random.default_rng(5)
     ng = nc = 0
     rsum_g = rsum_c = 0.0
-    for t in range(300):
-        a = rng.uniform(-1, 1, (256, 21)).astype(np.float32)
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (n, env.act_dim)).astype(np.float32)
         og, rg, dg, _ = env.step(torch.from_numpy(a).cuda())
         oc, rc, dc, _ = o32.step(a)
         assert torch.isfinite(og).all()
         ng += int((dg != 0).sum()); nc += int((dc != 0).sum())
         rsum_g += float(rg.sum()); rsum_c += float(rc.sum())
-    assert abs(ng - nc) <= 0.1 * nc + 10, (ng, nc)
+    print(f"\n{env_id}: episodes ended GPU {ng} / oracle {nc}; reward sum GPU {rsum_g:.1f} / oracle {rsum_c:.1f}")
+    assert nc > 0 and abs(ng - nc) <= 0.1 * nc + 10, (ng, nc)
     assert abs(rsum_g - rsum_c) <= 0.1 * abs(rsum_c) + 50, (rsum_g, rsum_c)
 
 
