@@ -196,7 +196,8 @@ typedef struct MoccaModel {
   /* ---- derived lookup tables (model.py finalize_tables): one 16-byte load instead of chains of dependent loads ---- */
   float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | terrain<<24), bits(anc_mask[body]) */
   float gp_tab[2 * MOCCA_MAX_GEOMS][4];     /* geom end point in its body frame (x, y, z), bits(body) */
-  float pair_tab[MOCCA_MAX_PAIRS][4];       /* bits(geom_a | geom_b<<8 | body_a<<16 | body_b<<24), radius_a, radius_b, friction_a*friction_b */
+  float pair_tab[MOCCA_MAX_PAIRS][4];       /* bits(geom_a | geom_b<<8 | body_a<<16 | body_b<<24), radius_a, radius_b,
+                                               broad-phase reach = half_len_a + half_len_b + radius_a + radius_b (padded; + contact_margin at run time) */
 } MoccaModel;
 
 /* ------------------------------------------------------------------------

@@ -682,11 +682,11 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
 // ------------------------------------------------------------------ collision
 DI void plane_space(const float* n, float* t1, float* t2) {  // btPlaneSpace1
   if (fabsf(n[2]) > 0.70710678f) {
-    const float a = n[1] * n[1] + n[2] * n[2], k = 1.0f / sqrtf(a);
+    const float a = n[1] * n[1] + n[2] * n[2], k = rsq(a);  // v_rsq_f32 (1 ulp; a >= 0.5)
     t1[0] = 0; t1[1] = -n[2] * k; t1[2] = n[1] * k;
     t2[0] = a * k; t2[1] = -n[0] * t1[2]; t2[2] = n[0] * t1[1];
   } else {
-    const float a = n[0] * n[0] + n[1] * n[1], k = 1.0f / sqrtf(a);
+    const float a = n[0] * n[0] + n[1] * n[1], k = rsq(a);
     t1[0] = -n[1] * k; t1[1] = n[0] * k; t1[2] = 0;
     t2[0] = -n[2] * t1[1]; t2[1] = n[2] * t1[0]; t2[2] = a * k;
   }
@@ -716,8 +716,8 @@ DI float sphere_box(const float* l, float rad, const float* Rb, const float* h, 
   float nl[3] = {0, 0, 0}, dist;
   if (!inside) {
     float e[3] = {l[0] - q[0], l[1] - q[1], l[2] - q[2]};
-    dist = sqrtf(dot3(e, e));
-    const float id = 1.0f / dist;
+    const float e2 = dot3(e, e), id = rsq(e2);  // v_rsq_f32: distance and unit normal without IEEE sqrt / division
+    dist = e2 * id;
 #pragma unroll
     for (int i = 0; i < 3; ++i) nl[i] = e[i] * id;
   } else {
@@ -745,8 +745,8 @@ DI float sphere_cylinder(const float* l, float rad, const float* Rb, const float
   } else {
     const float qr = rho < R ? rho : R, qz = l[2] > hz ? hz : (l[2] < -hz ? -hz : l[2]);
     const float e[3] = {l[0] - qr * ux, l[1] - qr * uy, l[2] - qz};
-    dist = sqrtf(dot3(e, e));
-    const float id = 1.0f / dist;
+    const float e2 = dot3(e, e), id = rsq(e2);
+    dist = e2 * id;
     nl[0] = e[0] * id; nl[1] = e[1] * id; nl[2] = e[2] * id;
   }
   matvec3(Rb, nl, n);
@@ -754,22 +754,23 @@ DI float sphere_cylinder(const float* l, float rad, const float* Rb, const float
 }
 DI float clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
 DI void seg_seg(const float* p1, const float* q1, const float* p2, const float* q2, float* c1, float* c2) {
+  // closest points of two segments (Ericson 5.1.9); quotients through v_rcp_f32 (1 ulp) instead of IEEE division
   float d1[3], d2[3], r[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) { d1[k] = q1[k] - p1[k]; d2[k] = q2[k] - p2[k]; r[k] = p1[k] - p2[k]; }
   const float a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r), EPS = 1e-12f;
   float s, t;
   if (a <= EPS && e <= EPS) { s = t = 0; }
-  else if (a <= EPS) { s = 0; t = clamp01(f / e); }
+  else if (a <= EPS) { s = 0; t = clamp01(f * rcp(e)); }
   else {
-    const float c = dot3(d1, r);
-    if (e <= EPS) { t = 0; s = clamp01(-c / a); }
+    const float c = dot3(d1, r), ia = rcp(a);
+    if (e <= EPS) { t = 0; s = clamp01(-c * ia); }
     else {
       const float b = dot3(d1, d2), den = a * e - b * b;
-      s = den > EPS ? clamp01((b * f - c * e) / den) : 0.0f;
-      t = (b * s + f) / e;
-      if (t < 0) { t = 0; s = clamp01(-c / a); }
-      else if (t > 1) { t = 1; s = clamp01((b - c) / a); }
+      s = den > EPS ? clamp01((b * f - c * e) * rcp(den)) : 0.0f;
+      t = (b * s + f) * rcp(e);
+      if (t < 0) { t = 0; s = clamp01(-c * ia); }
+      else if (t > 1) { t = 1; s = clamp01((b - c) * ia); }
     }
   }
 #pragma unroll
@@ -935,16 +936,14 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
     const int k = base + lane;
     bool near = false;
     if (k < npairs) {
-      const f4_t pt = *(CF4P)(M->pair_tab[k]);  // geoms, bodies, radii, friction: one load
+      const f4_t pt = *(CF4P)(M->pair_tab[k]);  // geoms, bodies, radii, reach: one load
       const int ids = __float_as_int(pt.x);
       const int ga = ids & 0xFF, gb = (ids >> 8) & 0xFF;
-      float dm[3], ha[3], hb[3];
+      float dm[3];  // distance of the two segment midpoints (x2); the segments' half lengths and radii are constants of the pair (pt.w)
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const float a1 = L[L_GP + 6 * ga + i], a2 = L[L_GP + 6 * ga + 3 + i], b1 = L[L_GP + 6 * gb + i], b2 = L[L_GP + 6 * gb + 3 + i];
-        dm[i] = 0.5f * ((a1 + a2) - (b1 + b2)); ha[i] = 0.5f * (a2 - a1); hb[i] = 0.5f * (b2 - b1);
-      }
-      const float reach = sqrtf(dot3(ha, ha)) + sqrtf(dot3(hb, hb)) + pt.y + pt.z + margin;
+      for (int i = 0; i < 3; ++i)
+        dm[i] = (L[L_GP + 6 * ga + i] + L[L_GP + 6 * ga + 3 + i]) - (L[L_GP + 6 * gb + i] + L[L_GP + 6 * gb + 3 + i]);
+      const float reach = 2.0f * (pt.w + margin);
       near = dot3(dm, dm) < reach * reach;
     }
     const unsigned long long nm = __ballot(near);
@@ -972,18 +971,17 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
       float ca[3], cb[3];
       seg_seg(a1, a2, b1, b2, ca, cb);
       float d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
-      const float dist = sqrtf(dot3(d, d)), ra = pt.y, rb = pt.z;
+      const float d2 = dot3(d, d), id = rsq(d2), dist = d2 * id, ra = pt.y, rb = pt.z;  // v_rsq_f32 (1 ulp)
       g2 = dist - ra - rb;
-      hit = g2 < margin && dist > 1e-9f;
+      hit = g2 < margin && d2 > 1e-18f;
       if (hit) {
-        const float id = 1.0f / dist;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           nn[i] = d[i] * id;
           PP[i] = 0.5f * ((ca[i] - ra * d[i] * id) + (cb[i] + rb * d[i] * id));
         }
         ba = (ids >> 16) & 0xFF; bb = (ids >> 24) & 0xFF;
-        mu2 = pt.w;
+        mu2 = M->g_friction[ga] * M->g_friction[gb];  // rare path (a self contact): two cached loads
       }
     }
     const unsigned long long hm = __ballot(hit);
@@ -1431,13 +1429,20 @@ DI void integrate(ModelP M, float* L, int lane) {
     float om[3] = {L[L_NU], L[L_NU + 1], L[L_NU + 2]}, vl[3] = {L[L_NU + 3], L[L_NU + 4], L[L_NU + 5]};
 #pragma unroll
     for (int i = 0; i < 3; ++i) { L[L_BASE + 10 + i] = om[i]; L[L_BASE + 7 + i] = vl[i]; L[L_BASE + i] += dt * vl[i]; }
-    const float wn = sqrtf(dot3(om, om)), th = wn * dt;
+    // quaternion exponential map dq = (om sin(th/2)/|om|, cos(th/2)), th = |om| dt.  x = th/2 is below 0.5 rad unless the base spins
+    // faster than 240 rad/s: there sin(x)/x and cos(x) are short even series in x^2 (truncation < 1e-13, i.e. correctly rounded
+    // fp32 up to the last bit), with no square root, no division and no small-angle branch; libm's sinf / cosf -- 400
+    // instructions of argument reduction on one busy lane per substep -- stay as the fallback.
+    const float hdt = 0.5f * dt, x2 = dot3(om, om) * hdt * hdt;
     float dq[4];
-    if (th > 1e-8f) {
-      const float sn = sinf(0.5f * th) / wn;
-      dq[0] = om[0] * sn; dq[1] = om[1] * sn; dq[2] = om[2] * sn; dq[3] = cosf(0.5f * th);
+    if (x2 < 0.25f) {
+      const float sinc = 1.0f + x2 * (-1.0f / 6 + x2 * (1.0f / 120 + x2 * (-1.0f / 5040 + x2 * (1.0f / 362880 + x2 * (-1.0f / 39916800)))));
+      dq[3] = 1.0f + x2 * (-0.5f + x2 * (1.0f / 24 + x2 * (-1.0f / 720 + x2 * (1.0f / 40320 + x2 * (-1.0f / 3628800 + x2 * (1.0f / 479001600))))));
+      const float k = hdt * sinc;
+      dq[0] = om[0] * k; dq[1] = om[1] * k; dq[2] = om[2] * k;
     } else {
-      dq[0] = 0.5f * dt * om[0]; dq[1] = 0.5f * dt * om[1]; dq[2] = 0.5f * dt * om[2]; dq[3] = 1.0f;
+      const float wn = sqrtf(dot3(om, om)), sn = sinf(wn * hdt) / wn;
+      dq[0] = om[0] * sn; dq[1] = om[1] * sn; dq[2] = om[2] * sn; dq[3] = cosf(wn * hdt);
     }
     const float q0 = L[L_BASE + 3], q1 = L[L_BASE + 4], q2 = L[L_BASE + 5], q3 = L[L_BASE + 6];
     float nq[4];
@@ -1445,11 +1450,28 @@ DI void integrate(ModelP M, float* L, int lane) {
     nq[1] = dq[3] * q1 - dq[0] * q2 + dq[1] * q3 + dq[2] * q0;
     nq[2] = dq[3] * q2 + dq[0] * q1 - dq[1] * q0 + dq[2] * q3;
     nq[3] = dq[3] * q3 - dq[0] * q0 - dq[1] * q1 - dq[2] * q2;
-    const float nn = 1.0f / sqrtf(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+    const float nn = rsq(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);  // v_rsq_f32, 1 ulp (the norm is 1 +- 1e-6)
 #pragma unroll
     for (int i = 0; i < 4; ++i) L[L_BASE + 3 + i] = nq[i] * nn;
   }
   wsync();
+}
+
+// sin and cos of a joint angle: quadrant reduction (Cody-Waite, two constants: exact for the |q| < 200 rad a hinge can reach) +
+// odd / even series on |r| <= pi/4, < 1 ulp at these magnitudes; libm's sincosf carries a large-argument path (Payne-Hanek)
+// that costs instruction-cache and issue slots on every call.
+DI void fast_sincos(float q, float* s, float* c) {
+  const float k = rintf(q * 0.636619772f);
+  float r = fmaf(-k, 1.57079601e+00f, q);
+  r = fmaf(-k, 3.13916473e-07f, r);
+  r = fmaf(-k, 5.39030253e-15f, r);
+  const float r2 = r * r;
+  const float sr = r + r * r2 * (-1.0f / 6 + r2 * (1.0f / 120 + r2 * (-1.0f / 5040 + r2 * (1.0f / 362880))));
+  const float cr = 1.0f + r2 * (-0.5f + r2 * (1.0f / 24 + r2 * (-1.0f / 720 + r2 * (1.0f / 40320 + r2 * (-1.0f / 3628800)))));
+  const int qd = (int)k & 3;
+  const float ss = (qd & 1) ? cr : sr, cc = (qd & 1) ? sr : cr;
+  *s = (qd & 2) ? -ss : ss;
+  *c = ((qd + 1) & 2) ? -cc : cc;
 }
 
 // lane = joint: sin/cos of the joint angle and everything a path walk needs about the joint, as one 16-float LDS
@@ -1460,7 +1482,7 @@ DI void stage_joints(ModelP M, float* L, int lane) {
   if (lane >= 1 && lane < T::NB) {
     const int j = lane;
     float s, cq;
-    sincosf(L[L_Q + j], &s, &cq);
+    fast_sincos(L[L_Q + j], &s, &cq);
     const float t = 1.0f - cq;
     float ax[3], jr[9], Rq[9], Tl[9];
 #pragma unroll

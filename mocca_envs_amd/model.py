@@ -188,7 +188,10 @@ class MoccaModel(C.Structure):
             self.pair_tab[k][0] = bits(ga | (gb << 8) | (self.g_body[ga] << 16) | (self.g_body[gb] << 24))
             self.pair_tab[k][1] = self.g_radius[ga]
             self.pair_tab[k][2] = self.g_radius[gb]
-            self.pair_tab[k][3] = self.g_friction[ga] * self.g_friction[gb]
+            # broad-phase reach of the pair: half lengths + radii (constants of the two geoms; the contact margin is added at run
+            # time), padded by 1e-6 relative + 1e-6 m so that fp32 rounding can only widen the conservative test
+            half = lambda g: 0.5 * math.sqrt(sum((float(self.g_p2[g][i]) - float(self.g_p1[g][i])) ** 2 for i in range(3)))
+            self.pair_tab[k][3] = (half(ga) + half(gb) + self.g_radius[ga] + self.g_radius[gb]) * (1.0 + 1e-6) + 1e-6
         return self
 
     @property

@@ -91,7 +91,7 @@ def test_teacher_forced_steps(env_id, task):
     env.reset(); o32.reset(seed=9); o64.reset(seed=9)
     rng = np.random.default_rng(1)
     err_gpu, err_f32 = [], []
-    errs = {"state": [], "obs": [], "rew": []}
+    errs = {"state": [], "obs": [], "rew": [], "obs_ref": []}
     for t in range(80):
         o64.set_state(o32.get_state()); o64.set_task(o32.get_task())
         if task:
@@ -111,8 +111,14 @@ def test_teacher_forced_steps(env_id, task):
         nd_ = 13 + 2 * env.act_dim
         e_state = _err_units(sg[ok][:, :nd_], sc[ok][:, :nd_]).max(axis=1)
         e_state = np.maximum(e_state, _err_units(sg[ok][:, nd_:].sum(axis=1), sc[ok][:, nd_:].sum(axis=1)))
-        e_obs = _err_units(og[ok], oc[ok]).max(axis=1)
+        # the observation's Euler angles have a discrete decision of their own: Bullet's clamp at pitch = +-90 deg (|sarg| >= 0.99999,
+        # getEulerFromQuaternion) switches roll / yaw formulas -- Child3D's crawl pose starts ON it; a state within rounding of the
+        # switch is compared through the state only
+        qx, qy, qz, qw = (sc[ok][:, 3 + i] for i in range(4))
+        on_switch = np.abs(np.abs(-2 * (qx * qz - qw * qy)) - 0.99999) < 2e-5
+        e_obs = np.where(on_switch, 0.0, _err_units(og[ok], oc[ok]).max(axis=1))
         errs["state"].append(e_state); errs["obs"].append(e_obs)
+        errs["obs_ref"].append(np.where(on_switch, 0.0, _err_units(oc[ok], o6[ok]).max(axis=1)))   # fp32's own error on the observation
         errs["rew"].append(np.abs(rg[ok] - rc[ok]))
         # termination flags may only differ where the height sits on the threshold
         mism = (dg != dc) & ok
@@ -143,8 +149,9 @@ def test_teacher_forced_steps(env_id, task):
     # worst single sample of the run (80 steps x 128 envs, each step 4 substeps with discrete row decisions): within an order of
     # magnitude of the worst fp32 itself produces over the same run (f32 oracle vs f64 oracle) -- the strict
     # statement (per substep, matching active sets, 1e-5 relative) is tests/test_gpu_substep.py
-    worst_ref = ec.max()
-    for k in ("state", "obs"):
+    # (the observation has its own yardstick: Euler angles of a robot pitched near +-90 deg amplify a 1e-6 state difference by
+    # 1 / cos(pitch), for the f32 oracle exactly as for the kernel)
+    for k, worst_ref in (("state", ec.max()), ("obs", cat["obs_ref"].max())):
         assert cat[k].max() < 10 * worst_ref + 2.0, (k, cat[k].max(), worst_ref)
         assert (cat[k] > 5.0).mean() < 2e-3, (k, (cat[k] > 5.0).mean())      # and such outliers (a flipped row decision) stay below 0.2 %
     # the GPU is as close to the f64 oracle as the f32 CPU oracle is
