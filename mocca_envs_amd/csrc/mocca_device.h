@@ -1057,21 +1057,43 @@ DI void delassus_store(float* L, int c, int nr, int tmax, const float* v) {
 // readlane / writelane index and the LDS offset are constants and the A entry of the next visit is fetched one visit
 // ahead with no register shuffling.  See solve_constraints for the y formulation.
 template <int RR>
-DI void pgs_fixed_rows(const float* Acol, float a, float a1, int r_fr, float& y, float& lam, float invdiag, float lo0) {
-  if constexpr (RR < MAXR) {
+DI void pgs_visit(const float* Acol, float& a, float& a1, float& y, float& lam, float invdiag, float lo0) {
+  // A entries travel two visits ahead: a (this visit) was pinned at the end of the previous one, a1 (next visit) is
+  // pinned at the end of this one, a2 is issued now.  Without the pins the optimiser sinks each read into the visit
+  // that uses it (the early exit does not need it), and every visit then waits a full LDS round trip.
+  const float a2 = Acol[MAXR * (RR + 2 < MAXR ? RR + 2 : MAXR - 1)];  // past the last row: any readable row, the value is never used
+  const float as = a * invdiag;
+  const float nl_ = __builtin_amdgcn_fmed3f(y, lo0, 1e30f);
+  const float dl = readlane(nl_ - lam, RR);
+  lam = writelane_c<RR>(readlane(nl_, RR), lam);
+  y = fmaf(-as, dl, y);
+  pin1(a1);
+  a = a1; a1 = a2;
+}
+// fewer than four fixed-bound rows left: one uniform exit test per visit
+template <int RR, int LEFT>
+DI void pgs_fixed_tail(const float* Acol, float& a, float& a1, int r_fr, float& y, float& lam, float invdiag, float lo0) {
+  if constexpr (RR < MAXR && LEFT > 0) {
     if (RR >= r_fr) return;
-    // A entries travel two visits ahead: a (this visit) was pinned at the end of the previous one, a1 (next visit) is
-    // pinned at the end of this one, a2 is issued now.  Without the pins the optimiser sinks each read into the visit
-    // that uses it (the early exit does not need it), and every visit then waits a full LDS round trip.
-    const float a2 = Acol[MAXR * (RR + 2 < MAXR ? RR + 2 : MAXR - 1)];  // past the last row: any readable row, the value is never used
-    const float as = a * invdiag;
-    const float nl_ = __builtin_amdgcn_fmed3f(y, lo0, 1e30f);
-    const float dl = readlane(nl_ - lam, RR);
-    lam = writelane_c<RR>(readlane(nl_, RR), lam);
-    y = fmaf(-as, dl, y);
-    pin1(a1);
-    pgs_fixed_rows<RR + 1>(Acol, a1, a2, r_fr, y, lam, invdiag, lo0);
+    pgs_visit<RR>(Acol, a, a1, y, lam, invdiag, lo0);
+    pgs_fixed_tail<RR + 1, LEFT - 1>(Acol, a, a1, r_fr, y, lam, invdiag, lo0);
   }
+}
+template <int RR>
+DI void pgs_fixed_rows(const float* Acol, float a, float a1, int r_fr, float& y, float& lam, float invdiag, float lo0) {
+  // Rows are visited in GROUPS OF FOUR with one uniform exit test per group (s_cmp + s_cbranch per visit were two of a visit's
+  // eleven instructions, and a wave cannot issue past an unresolved branch); the last one to three rows take the per-visit path.
+  if constexpr (RR + 4 <= MAXR) {
+    if (RR + 4 <= r_fr) {
+      pgs_visit<RR>(Acol, a, a1, y, lam, invdiag, lo0);
+      pgs_visit<RR + 1>(Acol, a, a1, y, lam, invdiag, lo0);
+      pgs_visit<RR + 2>(Acol, a, a1, y, lam, invdiag, lo0);
+      pgs_visit<RR + 3>(Acol, a, a1, y, lam, invdiag, lo0);
+      pgs_fixed_rows<RR + 4>(Acol, a, a1, r_fr, y, lam, invdiag, lo0);
+      return;
+    }
+  }
+  pgs_fixed_tail<RR, 3>(Acol, a, a1, r_fr, y, lam, invdiag, lo0);
 }
 
 // ------------------------------------------------------------------ constraint rows + PGS
