@@ -63,6 +63,13 @@ def load() -> C.CDLL:
         raise MoccaError(
             f"{LIB_PATH} not found: build it with `python -m mocca_envs_amd.build` "
             "(or __graft_entry__.build()); there is no CPU fallback")
+    # PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64; libmocca_hip.so names the same sonames.  Whichever is loaded
+    # first serves both, so torch goes first: one HIP runtime per process, and torch's device pointers / streams are valid in it.
+    # (Loading this library first and torch afterwards left mocca_create without a visible device.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
