@@ -163,6 +163,7 @@ def test_substep_on_random_mechanisms():
         orc = Oracle(m.to_bytes(), 0, 1, "f64")
         for k in range(3):
             row = _random_state(rng, m, 0.15 + 0.2 * rng.random(), spread=1.0)
-            info = _compare(orc, m, mdl, row, rng.uniform(-5, 5, n))
+            # random hinge axes are unit vectors only to fp32 rounding (|a|^2 = 1 +- 6e-8) and the two Rodrigues forms differ at that order
+            info = _compare(orc, m, mdl, row, rng.uniform(-5, 5, n), tol=5e-7)
             total_rows += info["rows"]
     assert total_rows > 100
