@@ -158,3 +158,32 @@ def test_argument_checking_and_action_handling():
     # same physics (clipped torque); the energy penalty differs but not the observation
     assert torch.allclose(o1, o2, atol=1e-6)
     env.close()
+
+
+def test_seed_is_a_full_64_bit_key():
+    """mocca_set_seed / mocca_reset take the Philox key as uint64: seeds that differ only above bit 53 (where a double cannot tell
+    them apart, the weakness of MOCCA_PARAM_SEED) give different episodes, equal seeds give equal ones; VecEnv.seed() re-keys the
+    in-kernel draws of step() without touching the state."""
+    import torch
+    from mocca_envs_amd.vec_env import VecEnv
+    big = (1 << 62) + 12345
+    obs = {}
+    for s in (big, big + 1, big):
+        env = VecEnv("Walker3DCustomEnv-v0", 64, auto_reset=True, seed=s)
+        obs.setdefault(s, []).append(env.reset().clone())
+        env.close()
+    assert torch.equal(obs[big][0], obs[big][1]) and not torch.equal(obs[big][0], obs[big + 1][0])
+    a = VecEnv("Walker3DCustomEnv-v0", 64, auto_reset=True, seed=7)
+    b = VecEnv("Walker3DCustomEnv-v0", 64, auto_reset=True, seed=7)
+    a.reset(); b.reset()
+    st = a.get_state().clone()
+    b.seed(big)                                   # same states, other key from now on
+    assert torch.equal(b.get_state(), st)
+    act = torch.zeros(64, 21, device="cuda")
+    differ = False
+    for k in range(60):                           # passive ragdolls fall and auto-reset within 60 steps: the reset draws differ
+        oa, _, da, _ = a.step(act)
+        ob, _, db, _ = b.step(act)
+        differ |= not torch.equal(oa, ob)
+    assert differ
+    a.close(); b.close()
