@@ -873,8 +873,9 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
         }
         mu = M->plank_friction * gfric;
         const float kk = M->plank_stiffness, cc = M->plank_damping, dt = M->dt;
-        erp = dt * kk / (dt * kk + cc);
-        cfm = 1.0f / (dt * kk + cc) / dt;
+        const float ikc = rcp(dt * kk + cc);  // soft contact (bullet_objects.py:70-71): erp = dt k / (dt k + c), cfm = 1 / ((dt k + c) dt)
+        erp = dt * kk * ikc;
+        cfm = ikc * rcp(dt);
       }
       active = gap < margin;
 #pragma unroll
@@ -1056,44 +1057,44 @@ DI void delassus_store(float* L, int c, int nr, int tmax, const float* v) {
 // wave-uniform early exit; the optimiser keeps a `#pragma unroll` loop with a break rolled).  With RR an immediate, the
 // readlane / writelane index and the LDS offset are constants and the A entry of the next visit is fetched one visit
 // ahead with no register shuffling.  See solve_constraints for the y formulation.
+// One PGS visit of fixed-bound row RR (see solve_constraints for the y formulation): `as` = A[RR][lane] / (A_ll + cfm).
 template <int RR>
-DI void pgs_visit(const float* Acol, float& a, float& a1, float& y, float& lam, float invdiag, float lo0) {
-  // A entries travel two visits ahead: a (this visit) was pinned at the end of the previous one, a1 (next visit) is
-  // pinned at the end of this one, a2 is issued now.  Without the pins the optimiser sinks each read into the visit
-  // that uses it (the early exit does not need it), and every visit then waits a full LDS round trip.
-  const float a2 = Acol[MAXR * (RR + 2 < MAXR ? RR + 2 : MAXR - 1)];  // past the last row: any readable row, the value is never used
-  const float as = a * invdiag;
+DI void pgs_visit(float as, float& y, float& lam, float lo0) {
   const float nl_ = __builtin_amdgcn_fmed3f(y, lo0, 1e30f);
   const float dl = readlane(nl_ - lam, RR);
   lam = writelane_c<RR>(readlane(nl_, RR), lam);
   y = fmaf(-as, dl, y);
-  pin1(a1);
-  a = a1; a1 = a2;
 }
 // fewer than four fixed-bound rows left: one uniform exit test per visit
 template <int RR, int LEFT>
-DI void pgs_fixed_tail(const float* Acol, float& a, float& a1, int r_fr, float& y, float& lam, float invdiag, float lo0) {
+DI void pgs_fixed_tail(float a0, float a1, float a2, int r_fr, float& y, float& lam, float invdiag, float lo0) {
   if constexpr (RR < MAXR && LEFT > 0) {
     if (RR >= r_fr) return;
-    pgs_visit<RR>(Acol, a, a1, y, lam, invdiag, lo0);
-    pgs_fixed_tail<RR + 1, LEFT - 1>(Acol, a, a1, r_fr, y, lam, invdiag, lo0);
+    pgs_visit<RR>(a0 * invdiag, y, lam, lo0);
+    pgs_fixed_tail<RR + 1, LEFT - 1>(a1, a2, 0.0f, r_fr, y, lam, invdiag, lo0);
   }
 }
+// Fixed-bound rows are visited in GROUPS OF FOUR (compile-time recursion = guaranteed unrolling; readlane / writelane indices and
+// LDS offsets are immediates): one uniform exit test per group instead of per visit, and the four A entries of the NEXT group are
+// requested from LDS before this group's visits start -- a visit is ~30 cycles of dependent issue, an LDS round trip is more than
+// two of them, so the former two-visits-ahead prefetch left every visit waiting.  The last one to three rows take pgs_fixed_tail.
 template <int RR>
-DI void pgs_fixed_rows(const float* Acol, float a, float a1, int r_fr, float& y, float& lam, float invdiag, float lo0) {
-  // Rows are visited in GROUPS OF FOUR with one uniform exit test per group (s_cmp + s_cbranch per visit were two of a visit's
-  // eleven instructions, and a wave cannot issue past an unresolved branch); the last one to three rows take the per-visit path.
+DI void pgs_fixed_rows(const float* Acol, float a0, float a1, float a2, float a3, int r_fr, float& y, float& lam, float invdiag, float lo0) {
   if constexpr (RR + 4 <= MAXR) {
     if (RR + 4 <= r_fr) {
-      pgs_visit<RR>(Acol, a, a1, y, lam, invdiag, lo0);
-      pgs_visit<RR + 1>(Acol, a, a1, y, lam, invdiag, lo0);
-      pgs_visit<RR + 2>(Acol, a, a1, y, lam, invdiag, lo0);
-      pgs_visit<RR + 3>(Acol, a, a1, y, lam, invdiag, lo0);
-      pgs_fixed_rows<RR + 4>(Acol, a, a1, r_fr, y, lam, invdiag, lo0);
+      constexpr int R4 = RR + 4 < MAXR ? RR + 4 : MAXR - 1, R5 = RR + 5 < MAXR ? RR + 5 : MAXR - 1;   // past the last row: any
+      constexpr int R6 = RR + 6 < MAXR ? RR + 6 : MAXR - 1, R7 = RR + 7 < MAXR ? RR + 7 : MAXR - 1;   // readable row, never used
+      float n0 = Acol[MAXR * R4], n1 = Acol[MAXR * R5], n2 = Acol[MAXR * R6], n3 = Acol[MAXR * R7];
+      pgs_visit<RR>(a0 * invdiag, y, lam, lo0);
+      pgs_visit<RR + 1>(a1 * invdiag, y, lam, lo0);
+      pgs_visit<RR + 2>(a2 * invdiag, y, lam, lo0);
+      pgs_visit<RR + 3>(a3 * invdiag, y, lam, lo0);
+      pin1(n0); pin1(n1); pin1(n2); pin1(n3);   // keeps the optimiser from sinking the reads into the group that uses them
+      pgs_fixed_rows<RR + 4>(Acol, n0, n1, n2, n3, r_fr, y, lam, invdiag, lo0);
       return;
     }
   }
-  pgs_fixed_tail<RR, 3>(Acol, a, a1, r_fr, y, lam, invdiag, lo0);
+  pgs_fixed_tail<RR, 3>(a0, a1, a2, r_fr, y, lam, invdiag, lo0);
 }
 
 // ------------------------------------------------------------------ constraint rows + PGS
@@ -1397,7 +1398,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int32_t* d
   float y = (bias - w) * invdiag;
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
-    pgs_fixed_rows<0>(Acol, Acol[0], Acol[MAXR], r_fr, y, lam, invdiag, lo0);
+    pgs_fixed_rows<0>(Acol, Acol[0], Acol[MAXR], Acol[2 * MAXR], Acol[3 * MAXR], r_fr, y, lam, invdiag, lo0);
     float a = Acol[MAXR * (r_fr < MAXR ? r_fr : MAXR - 1)];
 #pragma unroll 1
     for (int i = 0; i < nc; ++i) {  // the two friction rows of contact i share the bound mu * lam[normal row of i]
