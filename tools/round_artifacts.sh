@@ -4,6 +4,9 @@ tag=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd $R
+# 0. rocprofv3 on the headline config first: its PMC passes refresh profiles/traffic.json, which the bench lines below quote
+tools/profile_round.sh ${tag} Walker3DCustomEnv-v0 4096 > /dev/null 2>&1
+[ -s $O/${tag}_traffic.json ] && cp $O/${tag}_traffic.json profiles/traffic.json
 # 1. the driver's own default invocation + a long steady-state line (with the CPU baselines)
 python bench.py --steps 1000 --warmup 200 > $O/${tag}_bench_full.json 2> $O/${tag}_bench_full.err
 # 2. batch-size sweep of the headline env (1 / 2 / 4 waves per SIMD resident, then 2 and 4 rounds of waves)
@@ -26,8 +29,7 @@ python tools/stamps.py Walker3DCustomEnv-v0 1024 > $O/${tag}_stamps_custom1024.t
 python tools/param_time.py 4096 > $O/${tag}_param_time_4096.txt 2>&1
 # 5. record layouts
 hipcc --offload-arch=gfx950 -O3 -o /tmp/layout_bench tools/layout_bench.hip && /tmp/layout_bench 4096 > $O/${tag}_layout_bench.json && /tmp/layout_bench 65536 >> $O/${tag}_layout_bench.json
-# 6. rocprofv3: kernel-trace stats + separate PMC passes at steady state, three configs
-tools/profile_round.sh ${tag} Walker3DCustomEnv-v0 4096 > /dev/null 2>&1
+# 6. rocprofv3: kernel-trace stats + separate PMC passes at steady state, the other two configs
 tools/profile_round.sh ${tag}_stepper Walker3DStepperEnv-v0 4096 > /dev/null 2>&1
 tools/profile_round.sh ${tag}_cassie CassieEnv-v0 2048 > /dev/null 2>&1
 ls $O | grep "^${tag}" | head -80
