@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MOCCA_ABI_VERSION 2
+#define MOCCA_ABI_VERSION 3
 
 typedef struct mocca_ctx *mocca_handle;
 
@@ -86,7 +86,7 @@ int mocca_create(const void *model_blob, size_t nbytes, int task_id, int n_envs,
 int mocca_destroy(mocca_handle h);
 
 int mocca_n_envs(mocca_handle h);
-int mocca_obs_dim(mocca_handle h);   /* 52 (Custom, env_locomotion.py:58) / 65 (Stepper, :386-393) */
+int mocca_obs_dim(mocca_handle h);   /* 52 (Custom, env_locomotion.py:58) / 65 (Stepper, :386-393) / 36 (CassieEnv) / 42 (CassiePhase*, env_cassie.py:633) */
 int mocca_act_dim(mocca_handle h);   /* 21, robots.py:21-23 */
 int mocca_state_dim(mocca_handle h); /* MOCCA_STATE_DIM */
 
@@ -148,6 +148,14 @@ int mocca_set_debug_buffer(mocca_handle h, int32_t *dbg_dev);
 /* 1 if the library was compiled with a profiling switch that makes results wrong or slow by construction
  * (MOCCA_SKIP_*, MOCCA_DUMMY_VALU, MOCCA_STAMPS); the Python binding refuses such a build unless told otherwise */
 int mocca_is_diagnostic_build(void);
+
+/* The reference motion of the Cassie mocap / phase envs: what `self.traj = CassieTrajectory()` (env_cassie.py:576) holds and
+ * `base_angles / base_velocities / resetJoints / get_obs` (:589-605,636-642) read through joint_angles(t), joint_speeds(t),
+ * rod_joint_angles(t), max_time().  table_host [n_frames][MOCCA_TRAJ_STRIDE] f32 (HOST memory, copied into the handle):
+ * 14 joint angles in ordered-joint order, 14 joint speeds, 4 rod angles (right z, right y, left z, left y).  A time t maps to
+ * frame int((t mod max_time) / max_time * n_frames); t = istep * control_step / n_llc (mocap_time, :359-360), evaluated in
+ * double precision.  Required before reset / step when the blob's cassie_mode != MOCCA_CASSIE_PLAIN. */
+int mocca_set_trajectory(mocca_handle h, const float *table_host, int n_frames, double max_time, double control_step);
 
 /* name, registers, LDS and scratch of the step kernel as built (for DESIGN.md / bench) */
 int mocca_kernel_info(mocca_handle h, int *vgprs, int *sgprs, int *lds_bytes, int *scratch_bytes, int *max_blocks_per_cu);

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define MOCCA_MODEL_MAGIC 0x41434F4Du /* "MOCA" */
-#define MOCCA_MODEL_VERSION 9u
+#define MOCCA_MODEL_VERSION 10u
 
 #define MOCCA_MAX_BODIES 24
 #define MOCCA_MAX_GEOMS 32
@@ -42,6 +42,7 @@ extern "C" {
 #define MOCCA_MAX_TERRAIN_STEPS 20
 #define MOCCA_MAX_CLOSURES 2
 #define MOCCA_MAX_CTRL 16
+#define MOCCA_TRAJ_STRIDE 32 /* floats per frame of the Cassie motion table (mocca_set_trajectory) */
 
 enum { MOCCA_GEOM_SPHERE = 0, MOCCA_GEOM_CAPSULE = 1 };
 
@@ -58,6 +59,13 @@ enum {
 
 /* MoccaModel.plank_shape */
 enum { MOCCA_PLANK_BOX = 0 /* Plank, LargePlank (bullet_objects.py:92-103) */, MOCCA_PLANK_CYLINDER = 1 /* Pillar (:86-89), axis = plank z */ };
+
+/* MoccaModel.cassie_mode: which class of env_cassie.py the Cassie task runs */
+enum {
+  MOCCA_CASSIE_PLAIN = 0,        /* CassieEnv (env_cassie.py:284-479)                                                  */
+  MOCCA_CASSIE_PHASE_MOCCA = 1,  /* CassiePhaseMoccaEnv (:630-642): mocap targets, CassieMocapRewEnv reward, 42 floats */
+  MOCCA_CASSIE_PHASE_MIRROR = 2, /* CassiePhaseMirrorEnv (:645-660): the same, observation mirrored when phase > 0.5  */
+};
 
 /* task ids accepted by mocca_create() */
 enum {
@@ -193,6 +201,14 @@ typedef struct MoccaModel {
   int32_t planar;               /* CassieEnv(planar=True) (env_cassie.py:326-341): base held in the x-z plane by three bilateral
                                    rows (v_y, omega_x, omega_z) -- stands in for the missing cassie_collide_2d.urdf (:279-282) */
 
+  /* ---- Cassie mocap / phase envs (env_cassie.py:481-660); the motion itself is attached with mocca_set_trajectory ---- */
+  int32_t cassie_mode;        /* MOCCA_CASSIE_*                                                                          */
+  int32_t cassie_rsi;         /* rsi: reset at a random frame of the motion (env_cassie.py:331,364,585-588)              */
+  int32_t residual_control;   /* the action is added to the motion's angles (1) or to zero (0), env_cassie.py:434-443    */
+  int32_t rod_body[4];        /* bodies of fixed_{right,left}_achilles_rod_joint_{z,y}, the order of resetJoints (:591-596) */
+  float mocap_w[6];           /* weights of SpeedRew, JPosRew, JVelRew, OrientationRew, AngularSpeedRew, CoMRew (:484-493) */
+  float mocap_speed;          /* 0.8, the forward speed SpeedRew asks for (:498)                                         */
+
   /* ---- derived lookup tables (model.py finalize_tables): one 16-byte load instead of chains of dependent loads ---- */
   float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | terrain<<24), bits(anc_mask[body]) */
   float gp_tab[2 * MOCCA_MAX_GEOMS][4];     /* geom end point in its body frame (x, y, z), bits(body) */
@@ -225,7 +241,7 @@ typedef struct MoccaModel {
  *  24 f feet_contact[2]  25 f feet_contact[3]
  *  --- Cassie only ---
  *  3 f potential (shares linear_potential)  24..37 f jvel[14] (filtered joint speeds, env_cassie.py:451-468)
- *  38 f initial_z  39 i istep
+ *  38 f initial_z  39 i istep (mocap_time = istep * control_step / llc_frame_skip, env_cassie.py:359-360)
  */
 #define MOCCA_TASK_WORDS 40
 

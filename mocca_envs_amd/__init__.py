@@ -21,6 +21,8 @@ REGISTERED = {
     "LaikagoCustomEnv-v0": ("mocca_envs_amd.envs:LaikagoCustomEnv", {}),
     "LaikagoStepperEnv-v0": ("mocca_envs_amd.envs:LaikagoStepperEnv", {}),
     "Cassie2DEnv-v0": ("mocca_envs_amd.envs:CassieEnv", {"planar": True}),   # reference __init__.py:24-29
+    "CassiePhaseMocca2DEnv-v0": ("mocca_envs_amd.envs:CassiePhaseMoccaEnv", {"planar": True}),     # :31-36
+    "CassiePhaseMirror2DEnv-v0": ("mocca_envs_amd.envs:CassiePhaseMirrorEnv", {"planar": True}),   # :38-43
 }
 
 

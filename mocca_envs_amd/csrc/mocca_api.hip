@@ -40,6 +40,9 @@ struct mocca_ctx {
   int tape_n = 0;
   int32_t* dbg = nullptr;       // caller-owned (mocca_set_debug_buffer)
   uint64_t seed = 0;
+  float* d_traj = nullptr;      // Cassie mocap / phase envs: the motion table (mocca_set_trajectory), owned by the handle
+  int traj_n = 0;
+  double traj_tmax = 0.0, traj_cstep = 0.0;
   std::string err;
 };
 
@@ -148,8 +151,12 @@ int mocca_create(const void* model_blob, size_t nbytes, int task_id, int n_envs,
   }
   h->task_id = task_id; h->n_envs = n_envs; h->device = device;
   h->obs_dim = task_id == MOCCA_TASK_CASSIE
-                   ? 6 + 2 * h->model.n_ordered + 2
+                   ? (h->model.cassie_mode == MOCCA_CASSIE_PLAIN ? 6 + 2 * h->model.n_ordered + 2 : 12 + 2 * h->model.n_ordered + 2)  // env_cassie.py:344-346 / :633
                    : 6 + 2 * h->model.n_joints + h->model.n_feet + (task_id == MOCCA_TASK_WALKER3D_CUSTOM ? 2 : 5 * (h->model.lookbehind + 2));
+  if (task_id == MOCCA_TASK_CASSIE && (h->model.cassie_mode < MOCCA_CASSIE_PLAIN || h->model.cassie_mode > MOCCA_CASSIE_PHASE_MIRROR ||
+                                       (h->model.cassie_mode != MOCCA_CASSIE_PLAIN && h->model.n_ordered != 14))) {
+    g_err = "Cassie blob: unknown cassie_mode (the mocap / phase envs need the 14 ordered joints)"; delete h; return MOCCA_E_ARG;
+  }
   if (task_id == MOCCA_TASK_WALKER3D_STEPPER &&
       (h->model.n_planks < 1 || h->model.n_planks > MOCCA_MAX_PLANKS || h->model.lookbehind < 1 || h->model.lookbehind > 2)) {
     g_err = "Stepper blob: n_planks must be 1..4 and lookbehind 1 or 2"; delete h; return MOCCA_E_ARG;
@@ -202,6 +209,7 @@ int mocca_destroy(mocca_handle h) {
   if (h->d_dyn) (void)hipFree(h->d_dyn);
   if (h->d_task) (void)hipFree(h->d_task);
   if (h->d_terrain) (void)hipFree(h->d_terrain);
+  if (h->d_traj) (void)hipFree(h->d_traj);
   for (float* p : h->d_pvec) if (p) (void)hipFree(p);
   delete h;
   return MOCCA_OK;
@@ -227,11 +235,21 @@ static StepArgs make_args(mocca_handle h) {
   a.gain_v = h->pvec_on[2] ? h->d_pvec[2] : nullptr;
   a.gain = h->gain;
   a.dbg = h->dbg;
+  a.traj = h->d_traj; a.traj_n = h->traj_n; a.traj_tmax = h->traj_tmax; a.traj_cstep = h->traj_cstep;
   return a;
+}
+// the mocap / phase envs read their targets, reset poses and reward references from the motion table
+static int need_trajectory(mocca_handle h) {
+  if (h->task_id == MOCCA_TASK_CASSIE && h->model.cassie_mode != MOCCA_CASSIE_PLAIN && !h->d_traj) {
+    h->err = "this Cassie blob (cassie_mode != 0) needs mocca_set_trajectory before reset / step / observe";
+    return MOCCA_E_ARG;
+  }
+  return MOCCA_OK;
 }
 
 int mocca_reset(mocca_handle h, const uint8_t* mask_dev, uint64_t seed, float* obs_dev, void* stream) {
   if (!h || !obs_dev) return MOCCA_E_ARG;
+  if (need_trajectory(h) != MOCCA_OK) return MOCCA_E_ARG;
   h->seed = seed;
   DeviceGuard guard(h->device);
   StepArgs a = make_args(h);
@@ -250,6 +268,7 @@ int mocca_reset(mocca_handle h, const uint8_t* mask_dev, uint64_t seed, float* o
 int mocca_step(mocca_handle h, const float* act_dev, float* obs_dev, float* rew_dev, uint8_t* done_dev, int32_t* info_dev,
                void* stream) {
   if (!h || !act_dev || !obs_dev || !rew_dev || !done_dev) return MOCCA_E_ARG;
+  if (need_trajectory(h) != MOCCA_OK) return MOCCA_E_ARG;
   DeviceGuard guard(h->device);
   StepArgs a = make_args(h);
   a.act = act_dev; a.obs = obs_dev; a.rew = rew_dev; a.done = done_dev; a.info = info_dev;
@@ -263,6 +282,7 @@ int mocca_task_step(mocca_handle h, const float* act_dev, const int32_t* touch_d
                     float* obs_dev, float* rew_dev, uint8_t* done_dev, int32_t* info_dev, void* stream) {
   if (!h || !act_dev || !obs_dev || !rew_dev || !done_dev) return MOCCA_E_ARG;
   if (!touch_dev && h->task_id != MOCCA_TASK_CASSIE) { h->err = "mocca_task_step needs the foot contact flags"; return MOCCA_E_ARG; }
+  if (need_trajectory(h) != MOCCA_OK) return MOCCA_E_ARG;
   DeviceGuard guard(h->device);
   StepArgs a = make_args(h);
   a.act = act_dev; a.obs = obs_dev; a.rew = rew_dev; a.done = done_dev; a.info = info_dev;
@@ -301,8 +321,23 @@ int mocca_is_diagnostic_build(void) {
 #endif
 }
 
+int mocca_set_trajectory(mocca_handle h, const float* table_host, int n_frames, double max_time, double control_step) {
+  if (!h) return MOCCA_E_ARG;
+  if (!table_host || n_frames <= 0 || !(max_time > 0.0) || !(control_step > 0.0)) { h->err = "mocca_set_trajectory: empty table or non-positive times"; return MOCCA_E_ARG; }
+  DeviceGuard guard(h->device);
+  const size_t bytes = (size_t)n_frames * MOCCA_TRAJ_STRIDE * sizeof(float);
+  float* d = nullptr;
+  HIP_TRY(h, hipMalloc(&d, bytes));
+  hipError_t e = hipMemcpy(d, table_host, bytes, hipMemcpyHostToDevice);   // synchronous: no kernel in flight still reads the old table
+  if (e != hipSuccess) { (void)hipFree(d); h->err = std::string("hipMemcpy(trajectory): ") + hipGetErrorString(e); return MOCCA_E_HIP; }
+  if (h->d_traj) { (void)hipDeviceSynchronize(); (void)hipFree(h->d_traj); }
+  h->d_traj = d; h->traj_n = n_frames; h->traj_tmax = max_time; h->traj_cstep = control_step;
+  return MOCCA_OK;
+}
+
 int mocca_observe(mocca_handle h, float* obs_dev, void* stream) {
   if (!h || !obs_dev) return MOCCA_E_ARG;
+  if (need_trajectory(h) != MOCCA_OK) return MOCCA_E_ARG;
   DeviceGuard guard(h->device);
   StepArgs a = make_args(h);
   a.obs = obs_dev;

@@ -166,6 +166,10 @@ struct StepArgs {
   int tape_n;
   // optional per-env debug record of the LAST substep (mocca_set_debug_buffer): [N][MOCCA_DEBUG_WORDS] or null
   int32_t* dbg;
+  // Cassie mocap / phase envs (mocca_set_trajectory): [traj_n][MOCCA_TRAJ_STRIDE] angles 14, speeds 14, rod angles 4
+  const float* traj;
+  int traj_n;
+  double traj_tmax, traj_cstep;   // CassieTrajectory.max_time(); control_step (mocap_time = istep * control_step / n_llc, in f64)
 };
 
 // ------------------------------------------------------------------ helpers
@@ -1827,67 +1831,175 @@ DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, in
   t.prevx = L[L_BASE];
 }
 
-// ---------------- Cassie task layer (env_cassie.py:238-276, 348-479) ----------------
-// Cassie.calc_state + CassieEnv.get_obs on the state in LDS (kinematics done): 6 + 14 + 14 + 2 floats.
-// Returns pelvis z - lowest toe COM z; *finite = every robot_state entry finite.
-template <class T>
-DI float cassie_obs(ModelP M, const float* L, int lane, float initial_z, float* obs, bool* finite) {
+// ---------------- Cassie task layer (env_cassie.py:238-276, 348-479; mocap / phase variants :481-660) ----------------
+// frame of the reference motion at mocap_time() = istep * control_step / llc_frame_skip (:359-360), in double precision like
+// the reference: int((t mod T) / T * n) is a floor, fp32 time would pick the neighbouring frame now and then
+DI int traj_frame(const StepArgs& a, ModelP M, int istep, float* phase = nullptr) {
+  const double t = (double)istep * a.traj_cstep / (double)M->n_llc, T = a.traj_tmax;
+  if (phase) *phase = (float)fmod(t / T, 1.0);                                          // CassiePhaseMoccaEnv.get_obs, :639
+  const int i = (int)(fmod(t, T) / T * (double)a.traj_n);
+  return i < a.traj_n - 1 ? i : a.traj_n - 1;
+}
+
+// Cassie.calc_state (:238-276) on the state in LDS (kinematics done): everything the observation and reward variants need.
+struct CassieState {
+  float rpy[3], vel[3];   // body_rpy; body_velocity = R_z(-yaw) v
+  float nrm, sp;          // lane k < n_ordered: joint_angles[k] (normalised, float32) and joint_speeds[k]
+  float height;           // pelvis z - lowest toe COM z
+  bool finite;            // np.isfinite(robot_state).all(), :472
+};
+DI CassieState cassie_state(ModelP M, const float* L, int lane, float initial_z) {
+  CassieState cs;
   const int no = M->n_ordered;
-  float q[4] = {L[L_BASE + 3], L[L_BASE + 4], L[L_BASE + 5], L[L_BASE + 6]}, rpy[3];
-  quat_to_rpy(q, rpy);
-  const float yaw = rpy[2], cy = cosf(-yaw), sy = sinf(-yaw);
-  const float head[6] = {L[L_BASE + 2] - initial_z, cy * L[L_BASE + 7] - sy * L[L_BASE + 8],
-                         sy * L[L_BASE + 7] + cy * L[L_BASE + 8], L[L_BASE + 9], rpy[0], rpy[1]};
+  float q[4] = {L[L_BASE + 3], L[L_BASE + 4], L[L_BASE + 5], L[L_BASE + 6]};
+  quat_to_rpy(q, cs.rpy);
+  const float yaw = cs.rpy[2], cy = cosf(-yaw), sy = sinf(-yaw);
+  cs.vel[0] = cy * L[L_BASE + 7] - sy * L[L_BASE + 8];
+  cs.vel[1] = sy * L[L_BASE + 7] + cy * L[L_BASE + 8];
+  cs.vel[2] = L[L_BASE + 9];
+  const float head[6] = {L[L_BASE + 2] - initial_z, cs.vel[0], cs.vel[1], cs.vel[2], cs.rpy[0], cs.rpy[1]};
   bool fin = true;
 #pragma unroll
   for (int i = 0; i < 6; ++i) fin = fin && isfinite(head[i]);
   bool jf = true;
+  cs.nrm = 0.0f; cs.sp = 0.0f;
   if (lane < no) {
     const int b = M->ordered_body[lane];
     const float lo = M->jlo[b], hi = M->jhi[b], mid = 0.5f * (lo + hi);
-    const float nrm = 2 * (L[L_Q + b] - mid) / (hi - lo), sp = L[L_QD + b];  // bullet_utils.py:212-216
-    obs[6 + lane] = nrm;
-    obs[6 + no + lane] = sp;
-    jf = isfinite(nrm) && isfinite(sp);
+    cs.nrm = 2 * (L[L_Q + b] - mid) / (hi - lo);  // bullet_utils.py:212-216
+    cs.sp = L[L_QD + b];
+    jf = isfinite(cs.nrm) && isfinite(cs.sp);
   }
+  cs.finite = fin && (__ballot(!jf) == 0ull);
+  cs.height = L[L_BASE + 2] - fminf(L[L_FEET + 2], L[L_FEET + 5]);
+  return cs;
+}
+// CassieEnv.get_obs (:416-431): robot_state (6 + 14 + 14) + the walk target in the heading frame (2)
+DI void cassie_obs(ModelP M, const float* L, int lane, const CassieState& cs, float initial_z, float* obs) {
+  const int no = M->n_ordered;
+  if (lane < no) { obs[6 + lane] = cs.nrm; obs[6 + no + lane] = cs.sp; }
   if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) obs[i] = head[i];
+    obs[0] = L[L_BASE + 2] - initial_z; obs[1] = cs.vel[0]; obs[2] = cs.vel[1]; obs[3] = cs.vel[2]; obs[4] = cs.rpy[0]; obs[5] = cs.rpy[1];
     const float tx = M->cassie_target[0], ty = M->cassie_target[1];
-    const float dth = atan2f(ty - L[L_BASE + 1], tx - L[L_BASE]) - yaw, c = cosf(dth), sn = sinf(dth);  // get_obs :416-431
+    const float dth = atan2f(ty - L[L_BASE + 1], tx - L[L_BASE]) - cs.rpy[2], c = cosf(dth), sn = sinf(dth);
     obs[6 + 2 * no] = c * tx + sn * ty;
     obs[6 + 2 * no + 1] = -sn * tx + c * ty;
   }
-  *finite = fin && (__ballot(!jf) == 0ull);
-  return L[L_BASE + 2] - fminf(L[L_FEET + 2], L[L_FEET + 5]);
+}
+// rad_joint_angles = to_radians(joint_angles) (:243, 208-210): back from the float32 normalised angle
+DI float cassie_rad(ModelP M, int k, float nrm) {
+  const int b = M->ordered_body[k];
+  const float lo = M->jlo[b], hi = M->jhi[b];
+  return (hi - lo) * (nrm + 1.0f) / 2 + lo;
+}
+// CassieMoccaEnv.get_obs (:607-627) + CassiePhaseMoccaEnv (:636-642) + CassiePhaseMirrorEnv (:657-660), 42 floats:
+//   y z | qw qx qy qz (quaternion of body_rpy) | rad_joint_angles 14 | body_velocity 3 | body_angular_speed 3 | jvel 14 | phase_l phase_r
+// mirrored (mode 2, phase_l > 0.5): obs[left + right] = obs[right + left], then obs[neg + sideneg] *= -1 with the class's index
+// lists (:555-571,633-634,648-655): left = 6..12, 26..32, 40; right = 13..19, 33..39, 41; negated 0 3 5 21 23 25 | 6 7 26 27
+DI void cassie_mocap_obs(ModelP M, const float* L, int lane, const CassieState& cs, float jvel, float phase_l, float* obs) {
+  const int no = M->n_ordered;
+  const float phase_r = fmodf(phase_l + 0.5f, 1.0f);
+  const bool flip = M->cassie_mode == MOCCA_CASSIE_PHASE_MIRROR && phase_l > 0.5f;
+  auto put = [&](int i, float v) {
+    if (flip) {
+      if ((i >= 6 && i < 13) || (i >= 26 && i < 33)) i += 7;
+      else if ((i >= 13 && i < 20) || (i >= 33 && i < 40)) i -= 7;
+      else if (i == 40) i = 41;
+      else if (i == 41) i = 40;
+      if (i == 0 || i == 3 || i == 5 || i == 21 || i == 23 || i == 25 || i == 6 || i == 7 || i == 26 || i == 27) v = -v;
+    }
+    obs[i] = v;
+  };
+  if (lane < no) {
+    put(6 + lane, cassie_rad(M, lane, cs.nrm));
+    put(26 + lane, jvel);
+  }
+  if (lane == 0) {
+    // pybullet.getQuaternionFromEuler(body_rpy) (:608), x y z w  [UNVERIFIED-BULLET: standard ZYX composition]
+    const float hr = 0.5f * cs.rpy[0], hp = 0.5f * cs.rpy[1], hy = 0.5f * cs.rpy[2];
+    const float cr = cosf(hr), sr = sinf(hr), cp = cosf(hp), sp = sinf(hp), cy = cosf(hy), sy = sinf(hy);
+    const float qx = sr * cp * cy - cr * sp * sy, qy = cr * sp * cy + sr * cp * sy, qz = cr * cp * sy - sr * sp * cy,
+                qw = cr * cp * cy + sr * sp * sy;
+    put(0, L[L_BASE + 1]); put(1, L[L_BASE + 2]);
+    put(2, qw); put(3, qx); put(4, qy); put(5, qz);
+    put(20, cs.vel[0]); put(21, cs.vel[1]); put(22, cs.vel[2]);
+    put(23, L[L_BASE + 10]); put(24, L[L_BASE + 11]); put(25, L[L_BASE + 12]);
+    put(40, phase_l); put(41, phase_r);
+  }
+}
+// CassieMocapRewEnv.compute_rewards (:495-531): six exp(-k * penalty) terms, weighted.  jvel = this lane's finite-difference
+// joint speed (k < n_ordered); frame = the motion's frame at the NEW istep.
+DI float cassie_mocap_reward(const StepArgs& a, ModelP M, const float* L, int lane, const CassieState& cs, float jvel, int frame) {
+  const int npow = M->n_ctrl - 2;
+  float dj = 0.0f, dv = 0.0f;
+  if (lane < npow) {  // [powered_joint_inds]: the controlled joints minus the two springs
+    const int oi = M->ctrl_oidx[lane];
+    // the lane that owns ordered joint oi holds its nrm / jvel: fetch them
+    dj = a.traj[(size_t)frame * MOCCA_TRAJ_STRIDE + oi];
+    dv = a.traj[(size_t)frame * MOCCA_TRAJ_STRIDE + 14 + oi];
+  }
+  const int src = lane < npow ? M->ctrl_oidx[lane] : 0;
+  const float my_rad = cassie_rad(M, lane < M->n_ordered ? lane : 0, cs.nrm);
+  const float o_rad = __shfl(my_rad, src, 64), o_jv = __shfl(jvel, src, 64);
+  if (lane < npow) { dj -= o_rad; dv -= o_jv; } else { dj = 0.0f; dv = 0.0f; }
+  const float joint_penalty = sqrtf(wave_sum(dj * dj)), jvel_penalty = sqrtf(wave_sum(dv * dv));
+  const float ve = cs.vel[0] - M->mocap_speed, vel_error = ve * ve;
+  const float orientation = cs.rpy[0] * cs.rpy[0] + cs.rpy[1] * cs.rpy[1] + cs.rpy[2] * cs.rpy[2];
+  const float w0 = L[L_BASE + 10], w1 = L[L_BASE + 11], w2 = L[L_BASE + 12], angular = w0 * w0 + w1 * w1 + w2 * w2;
+  const float cy_ = L[L_BASE + 1] - M->init_pos[1], cz_ = L[L_BASE + 2] - M->init_pos[2], com = cy_ * cy_ + cz_ * cz_;  // base_position[1:], :515
+  return M->mocap_w[0] * expf(-4.0f * vel_error) + M->mocap_w[1] * expf(-4.0f * joint_penalty) + M->mocap_w[2] * expf(-0.4f * jvel_penalty) +
+         M->mocap_w[3] * expf(-4.0f * orientation) + M->mocap_w[4] * expf(-4.0f * angular) + M->mocap_w[5] * expf(-4.0f * com);
 }
 DI float cassie_potential(ModelP M, const float* L) {  // calc_potential :348-354
   const float dx = M->cassie_target[0] - L[L_BASE], dy = M->cassie_target[1] - L[L_BASE + 1];
   return -sqrtf(dx * dx + dy * dy) / M->control_dt;
 }
-// CassieEnv.reset (:362-378): nominal pose, at rest, no randomness
-template <class T>
-DI void cassie_reset_env(ModelP M, float* L, int lane, TaskRegs& t, float* obs) {
+// CassieEnv.reset (:362-378): nominal pose at rest.  CassieMoccaEnv.reset (:585-599): istep = np_random.randint(0, 10000) -- one
+// draw of the episode's stream, kept only under rsi (:364) -- then joints / joint speeds / rod angles of the motion at mocap_time(),
+// base moving at initial_velocity (:552).  The new filtered joint speeds (self.jvel, :357) are left in L_JVEL.
+template <class T, bool INJECT = false>
+DI void cassie_reset_env(const StepArgs& a, ModelP M, float* L, int env, int lane, TaskRegs& t, float* obs) {
   const int ep = t.episode + 1;
   t = TaskRegs{};
   t.episode = ep;
   t.gain = 1.0f;
+  const int mode = M->cassie_mode;
+  int frame = 0;
+  float phase = 0.0f;
+  if (mode != MOCCA_CASSIE_PLAIN) {
+    const float u = draw_u<INJECT>(a, env, t.episode, t.draw);
+    t.draw += 1;
+    int is = (int)(u * 10000.0f);
+    is = is > 9999 ? 9999 : is;
+    t.istep = M->cassie_rsi ? is : 0;
+    frame = traj_frame(a, M, t.istep, &phase);
+  }
   if (lane >= 1 && lane < T::NB) { L[L_Q + lane] = M->init_q[lane]; L[L_QD + lane] = 0.0f; }
+  if (lane < MOCCA_MAX_CTRL) L[L_JVEL + lane] = 0.0f;
+  wsync();
+  if (mode != MOCCA_CASSIE_PLAIN) {
+    const float* fr = a.traj + (size_t)frame * MOCCA_TRAJ_STRIDE;
+    if (lane < M->n_ordered) {
+      const int b = M->ordered_body[lane];
+      L[L_Q + b] = fr[lane]; L[L_QD + b] = fr[14 + lane]; L[L_JVEL + lane] = fr[14 + lane];
+    }
+    if (lane < 4) { L[L_Q + M->rod_body[lane]] = fr[28 + lane]; L[L_QD + M->rod_body[lane]] = 0.0f; }
+  }
   if (lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { L[L_BASE + i] = M->init_pos[i]; L[L_BASE + 7 + i] = 0; L[L_BASE + 10 + i] = 0; }
+    for (int i = 0; i < 3; ++i) { L[L_BASE + i] = M->init_pos[i]; L[L_BASE + 7 + i] = M->init_vel[i]; L[L_BASE + 10 + i] = 0; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) L[L_BASE + 3 + i] = M->init_quat[i];
   }
   if (lane < MOCCA_MAX_SLOTS) L[L_WARM + lane] = 0.0f;
-  if (lane < MOCCA_MAX_CTRL) L[L_JVEL + lane] = 0.0f;
   wsync();
   t.initz = L[L_BASE + 2];
   stage_joints<T>(M, L, lane);
   walk_kinematics<T, false>(M, L, lane, T::path_packed(lane < T::NB ? lane : 0));
   wsync();
-  bool fin;
-  cassie_obs<T>(M, L, lane, t.initz, obs, &fin);
+  const CassieState cs = cassie_state(M, L, lane, t.initz);
+  if (mode == MOCCA_CASSIE_PLAIN) cassie_obs(M, L, lane, cs, t.initz, obs);
+  else cassie_mocap_obs(M, L, lane, cs, lane < MOCCA_MAX_CTRL ? L[L_JVEL + lane] : 0.0f, phase, obs);
   t.linpot = cassie_potential(M, L);
 }
 

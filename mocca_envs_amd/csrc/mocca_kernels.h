@@ -35,9 +35,16 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   const unsigned long long ppk = T::path_packed(lane < T::NB ? lane : 0);
   if constexpr (TASK == MOCCA_TASK_CASSIE) {
     // ---- CassieEnv.step (env_cassie.py:433-479): 50 x { filter joint speeds, PD torques, one physics step }
-    const int no = M->n_ordered, nctl = M->n_ctrl;
+    const int no = M->n_ordered, nctl = M->n_ctrl, mode = M->cassie_mode;
     float target = 0.0f;  // env_cassie.py:434-443: base angle (residual control) + action, 0 for the springs
-    if (lane < nctl) target = M->ctrl_base[lane] + (lane < nctl - 2 ? a.act[(size_t)env * (nctl - 2) + lane] : 0.0f);
+    if (lane < nctl) {
+      float base = M->ctrl_base[lane];
+      if (mode != MOCCA_CASSIE_PLAIN) {  // base_angles() = traj.joint_angles(mocap_time()) at the istep the step starts from (:601-602)
+        const int f0 = traj_frame(a, M, (int)tk[T_ISTEP]);
+        base = (lane < nctl - 2 && M->residual_control) ? a.traj[(size_t)f0 * MOCCA_TRAJ_STRIDE + M->ctrl_oidx[lane]] : 0.0f;
+      }
+      target = base + (lane < nctl - 2 ? a.act[(size_t)env * (nctl - 2) + lane] : 0.0f);
+    }
     if (lane < no) {
       L[L_JVEL + lane] = __uint_as_float(tk[T_JVEL + lane]);
       L[L_Q0 + lane] = L[L_Q + M->ordered_body[lane]];
@@ -70,32 +77,41 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     }
     TaskRegs t;
     load_task(tk, t);
-    t.istep += nllc;
+    t.istep += M->n_llc;  // pd_control counts every low-level iteration (:381); the task-layer entry replays a whole env.step
+    float jv = 0.0f;
     if (lane < no) {  // :467-468 finite-difference joint velocity over the control step
-      const float jv = (L[L_Q + M->ordered_body[lane]] - L[L_Q0 + lane]) / M->control_dt;
+      jv = (L[L_Q + M->ordered_body[lane]] - L[L_Q0 + lane]) / M->control_dt;
       tk[T_JVEL + lane] = __float_as_uint(jv);
     }
     stage_joints<T>(M, L, lane);
     walk_kinematics<T, false>(M, L, lane, T::path_packed(lane < T::NB ? lane : 0));
     wsync();
     t.t += 1;
-    bool fin;
-    const float height = cassie_obs<T>(M, L, lane, t.initz, obs, &fin);
+    const CassieState cs = cassie_state(M, L, lane, t.initz);
     const float old = t.linpot;
     t.linpot = cassie_potential(M, L);
-    const float alive = height > M->alive_height ? 2.0f : -1.0f;  // compute_rewards :401-414
-    if (!fin || alive < 0.0f) t.done = 1;
+    const float alive = cs.height > M->alive_height ? 2.0f : -1.0f;  // compute_rewards :401-414
+    if (!cs.finite || alive < 0.0f) t.done = 1;
+    float rew = alive + (t.linpot - old);
+    if (mode == MOCCA_CASSIE_PLAIN) {
+      cassie_obs(M, L, lane, cs, t.initz, obs);
+    } else {  // CassieMocapRewEnv.compute_rewards replaces the reward, keeps `dead` (:495-531); get_obs of the phase envs
+      float phase;
+      const int f1 = traj_frame(a, M, t.istep, &phase);
+      rew = cassie_mocap_reward(a, M, L, lane, cs, jv, f1);
+      cassie_mocap_obs(M, L, lane, cs, jv, phase, obs);
+    }
     const int timeout = t.t >= M->max_episode_steps;
     const int dflag = (t.done ? 1 : 0) | (timeout ? 2 : 0);
     if (lane == 0) {
-      a.rew[env] = alive + (t.linpot - old);
+      a.rew[env] = rew;
       a.done[env] = (uint8_t)dflag;
       if (a.info) a.info[env] = 0;
     }
     if (a.auto_reset && dflag) {
       wsync();
-      cassie_reset_env<T>(M, L, lane, t, obs);
-      if (lane < MOCCA_MAX_CTRL) tk[T_JVEL + lane] = 0u;
+      cassie_reset_env<T, INJECT>(a, M, L, env + a.env_offset, lane, t, obs);
+      if (lane < MOCCA_MAX_CTRL) tk[T_JVEL + lane] = __float_as_uint(L[L_JVEL + lane]);
     }
     wsync();
     store_dyn(st, L, lane, T::NJ, T::NSLOT);
@@ -333,8 +349,8 @@ __global__ __launch_bounds__(64) void mocca_reset_kernel(StepArgs a) {
   load_task(tk, t, T::NFEET > 2);
   if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
   if constexpr (TASK == MOCCA_TASK_CASSIE) {
-    cassie_reset_env<T>(M, L, lane, t, a.obs + (size_t)env * a.obs_dim);
-    if (lane < MOCCA_MAX_CTRL) tk[T_JVEL + lane] = 0u;
+    cassie_reset_env<T, INJECT>(a, M, L, env + a.env_offset, lane, t, a.obs + (size_t)env * a.obs_dim);
+    if (lane < MOCCA_MAX_CTRL) tk[T_JVEL + lane] = __float_as_uint(L[L_JVEL + lane]);
   } else {
     reset_env<T, TASK, INJECT>(a, M, L, ter, env + a.env_offset, lane, t, a.obs + (size_t)env * a.obs_dim);
   }
@@ -364,8 +380,14 @@ __global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
   wsync();
   constexpr int NBO = 6 + 2 * T::NJ + T::NFEET;
   if constexpr (TASK == MOCCA_TASK_CASSIE) {
-    bool fin;
-    cassie_obs<T>(M, L, lane, t.initz, obs, &fin);
+    const CassieState cs = cassie_state(M, L, lane, t.initz);
+    if (M->cassie_mode == MOCCA_CASSIE_PLAIN) {
+      cassie_obs(M, L, lane, cs, t.initz, obs);
+    } else {
+      float phase;
+      traj_frame(a, M, t.istep, &phase);
+      cassie_mocap_obs(M, L, lane, cs, lane < MOCCA_MAX_CTRL ? __uint_as_float(tk[T_JVEL + lane]) : 0.0f, phase, obs);
+    }
     t.linpot = cassie_potential(M, L);
   } else {
     RobotObs ro = robot_obs<T>(M, L, lane, t.fc0, t.fc1, obs, t.fc2, t.fc3);

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # MOCCA_LIB_PATH selects another build of the same HIP library (A/B kernel experiments); never a CPU fallback
 LIB_PATH = os.environ.get("MOCCA_LIB_PATH") or os.path.join(HERE, "libmocca_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PARAM_AUTO_RESET, PARAM_EVAL_MODE, PARAM_CURRICULUM, PARAM_RANDOM_POSE, PARAM_HOST_RETARGET, PARAM_SEED, PARAM_ENV_OFFSET, PARAM_APPLIED_GAIN, PARAM_RANDOM_REWARD = 0, 1, 2, 3, 4, 5, 6, 7, 8
 DEBUG_WORDS = 8
 
@@ -42,6 +42,7 @@ SYMBOLS = {
     "mocca_set_param_v": (_i, [_vp, _i, _vp, _i, _vp]),
     "mocca_set_seed": (_i, [_vp, _u64]),
     "mocca_set_debug_buffer": (_i, [_vp, _vp]),
+    "mocca_set_trajectory": (_i, [_vp, _vp, _i, _d, _d]),
     "mocca_is_diagnostic_build": (_i, []),
     "mocca_kernel_info": (_i, [_vp] + [C.POINTER(_i)] * 5),
     "mocca_last_error": (C.c_char_p, [_vp]),

@@ -29,7 +29,7 @@ MAX_PAIRS = 192
 MAX_FEET = 4
 MAX_SLOTS = 40
 MAGIC = 0x41434F4D
-VERSION = 9
+VERSION = 10
 
 GEOM_SPHERE, GEOM_CAPSULE = 0, 1
 TASK_WALKER3D_CUSTOM, TASK_WALKER3D_STEPPER, TASK_CASSIE = 0, 1, 2
@@ -148,6 +148,12 @@ class MoccaModel(C.Structure):
         ("gain_cur", C.c_float * 2),
         ("init_vel", C.c_float * 3),
         ("planar", C.c_int32),
+        ("cassie_mode", C.c_int32),
+        ("cassie_rsi", C.c_int32),
+        ("residual_control", C.c_int32),
+        ("rod_body", C.c_int32 * 4),
+        ("mocap_w", C.c_float * 6),
+        ("mocap_speed", C.c_float),
         ("slot_tab", (C.c_float * 4) * MAX_SLOTS),
         ("gp_tab", (C.c_float * 4) * (2 * MAX_GEOMS)),
         ("pair_tab", (C.c_float * 4) * MAX_PAIRS),
@@ -802,7 +808,11 @@ CASSIE_SPRINGS = [4, 11]                                                        
 CASSIE_KP = np.array([100, 100, 88, 96, 50, 100, 100, 88, 96, 50, 400, 400]) / 1.9  # env_cassie.py:292-317
 
 
-def compile_cassie(planar: bool = False, power_coef: float = 1.0, residual_control: bool = True) -> MoccaModel:
+CASSIE_PLAIN, CASSIE_PHASE_MOCCA, CASSIE_PHASE_MIRROR = 0, 1, 2   # MoccaModel.cassie_mode (include/mocca_model.h)
+
+
+def compile_cassie(planar: bool = False, power_coef: float = 1.0, residual_control: bool = True, mode: int = CASSIE_PLAIN,
+                   rsi: bool = True) -> MoccaModel:
     """Cassie blob: URDF tree with inertia from file (env_cassie.py:81-99), two point-to-point loop closures
     (:114-137), per-joint damping (:57,197-201), torque limits (:41-56), the PD gains of CassieEnv (:292-319).
     Ground contact: 12 support points of each toe's convex hull (radius-0 spheres); other meshes and mesh-mesh
@@ -928,6 +938,20 @@ def compile_cassie(planar: bool = False, power_coef: float = 1.0, residual_contr
     m.alive_height = 0.6                                                     # env_cassie.py:406-412
     m.cassie_target[0], m.cassie_target[1], m.cassie_target[2] = 1000.0, 0.0, 0.0  # env_cassie.py:366
     m.planar = int(planar)                                                   # env_cassie.py:326-341 (Cassie2DEnv-v0, __init__.py:24-29)
+    # mocap / phase variants (env_cassie.py:481-660)
+    m.cassie_mode, m.cassie_rsi, m.residual_control = int(mode), int(bool(rsi)), int(bool(residual_control))
+    for k, n in enumerate(("fixed_right_achilles_rod_joint_z", "fixed_right_achilles_rod_joint_y",
+                           "fixed_left_achilles_rod_joint_z", "fixed_left_achilles_rod_joint_y")):   # resetJoints, :591-596
+        m.rod_body[k] = names.index(n)
+    if mode != CASSIE_PLAIN:
+        # CassieMocapRewEnv.__init__ (:483-493): the joint terms share what the four fixed weights leave
+        w = {"SpeedRew": 0.1, "CoMRew": 0.02 if planar else 0.05, "OrientationRew": 0.0 if planar else 0.05, "AngularSpeedRew": 0.1}
+        wleft = 1 - sum(w.values())
+        w["JPosRew"], w["JVelRew"] = wleft / 5 * 4, wleft / 5
+        for k, n in enumerate(("SpeedRew", "JPosRew", "JVelRew", "OrientationRew", "AngularSpeedRew", "CoMRew")):
+            m.mocap_w[k] = w[n]
+        m.mocap_speed = 0.8                                                  # :498
+        m.init_vel[0], m.init_vel[1], m.init_vel[2] = 0.8, 0.0, 0.0          # CassieMoccaEnv.initial_velocity, :552
     return m.finalize_tables()
 
 

@@ -31,6 +31,9 @@ TASKS = {
     "LaikagoStepperEnv-v0": M.TASK_WALKER3D_STEPPER,
     # CassieEnv(planar=True), __init__.py:24-29: the base held in the x-z plane by three bilateral rows
     "Cassie2DEnv-v0": M.TASK_CASSIE,
+    # the planar mocap / phase envs (__init__.py:31-43, env_cassie.py:481-660): Cassie topology, mocap targets and reward
+    "CassiePhaseMocca2DEnv-v0": M.TASK_CASSIE,
+    "CassiePhaseMirror2DEnv-v0": M.TASK_CASSIE,
 }
 # class attributes of the reference envs that are device parameters here
 _DEFAULT_PARAMS = {"LaikagoCustomEnv-v0": {_lib.PARAM_RANDOM_POSE: 0},    # robot_random_start = False, env_locomotion.py:863
@@ -41,6 +44,8 @@ _MODELS = {
     "Walker3DStepperEnv-v0": lambda **kw: M.compile_walker3d(M.TASK_WALKER3D_STEPPER, **kw),   # kw: plank_class = LargePlank | Plank | Pillar
     "CassieEnv-v0": lambda **kw: M.compile_cassie(**kw),
     "Cassie2DEnv-v0": lambda **kw: M.compile_cassie(planar=True, **kw),
+    "CassiePhaseMocca2DEnv-v0": lambda **kw: M.compile_cassie(planar=kw.pop("planar", True), mode=M.CASSIE_PHASE_MOCCA, **kw),
+    "CassiePhaseMirror2DEnv-v0": lambda **kw: M.compile_cassie(planar=kw.pop("planar", True), mode=M.CASSIE_PHASE_MIRROR, **kw),
     "LaikagoStepperEnv-v0": lambda **kw: M.compile_laikago(stepper=True, **kw),
     "Child3DCustomEnv-v0": M.compile_child3d,
     "MikeStepperEnv-v0": M.compile_mike,
@@ -103,6 +108,10 @@ class VecEnv:
         self.set_param(_lib.PARAM_ENV_OFFSET, self.env_offset)
         for pid, val in _DEFAULT_PARAMS.get(env_id, {}).items():
             self.set_param(pid, val)
+        self.trajectory = None
+        if self.task_id == M.TASK_CASSIE and self.model.cassie_mode != M.CASSIE_PLAIN:
+            from .trajectory import CassieTrajectory   # self.traj = CassieTrajectory(), env_cassie.py:576
+            self.set_trajectory(CassieTrajectory())
 
     # ------------------------------------------------------------------
     def _stream(self) -> C.c_void_p:
@@ -122,6 +131,14 @@ class VecEnv:
 
     def set_param(self, pid: int, value: float):
         _lib.check(self.lib.mocca_set_param(self.h, pid, float(value)), self.h)
+
+    def set_trajectory(self, traj, control_step: float = 0.03):
+        """Attach the reference motion of the Cassie mocap / phase envs (include/mocca.h mocca_set_trajectory); the table is
+        copied into the handle.  control_step = CassieEnv.control_step (env_cassie.py:287)."""
+        tab = np.ascontiguousarray(traj.table(), np.float32)
+        _lib.check(self.lib.mocca_set_trajectory(self.h, tab.ctypes.data_as(C.c_void_p), tab.shape[0], float(traj.max_time()),
+                                                 float(control_step)), self.h)
+        self.trajectory = traj
 
     def set_param_v(self, pid: int, values, broadcast: bool = False):
         """Per-env curriculum / eval_mode / applied_gain (include/mocca.h mocca_set_param_v); values: [N] (or [1] with broadcast)."""

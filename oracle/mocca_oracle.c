@@ -233,6 +233,10 @@ typedef struct {
    * tests can feed the oracle the very numbers a scripted numpy RandomState gave the reference */
   const double *tape;
   int tape_n, tape_pos;
+  /* Cassie mocap / phase envs: the reference motion (orc_set_trajectory), [traj_n][MOCCA_TRAJ_STRIDE] */
+  float *traj;
+  int traj_n;
+  double traj_tmax, traj_cstep;
 } Oracle;
 
 static real draw_uniform(Oracle *o, int env, Task *tk) {
@@ -976,36 +980,53 @@ static void delta_to_k_targets(const Oracle *o, const Dyn *s, Task *tk, const Te
 }
 
 static int obs_dim(const Oracle *o) {
-  if (o->task_id == MOCCA_TASK_CASSIE) return 6 + 2 * o->m.n_ordered + 2; /* env_cassie.py:76-79,344-346 */
+  if (o->task_id == MOCCA_TASK_CASSIE) /* env_cassie.py:76-79,344-346; the phase envs: 40 + 2 (:574,633) */
+    return o->m.cassie_mode == MOCCA_CASSIE_PLAIN ? 6 + 2 * o->m.n_ordered + 2 : 12 + 2 * o->m.n_ordered + 2;
   int base = 6 + 2 * o->m.n_joints + o->m.n_feet;
   return o->task_id == MOCCA_TASK_WALKER3D_CUSTOM ? base + 2 : base + 5 * (o->m.lookbehind + 2);
 }
 
-/* ---------------- Cassie task layer, env_cassie.py:238-276,348-479 ---------------- */
-/* Cassie.calc_state + CassieEnv.get_obs; needs kinematics() done.  Returns pelvis z - lowest toe z. */
-static real cassie_obs(Oracle *o, const Dyn *s, const Task *tk, float *obs) {
+/* ---------------- Cassie task layer, env_cassie.py:238-276,348-479; mocap / phase variants :481-660 ---------------- */
+/* frame of the reference motion at mocap_time() = istep * control_step / llc_frame_skip (:359-360): the re-created
+ * CassieTrajectory (mocca_envs_amd/trajectory.py) maps t to frame int((t mod T) / T * n) */
+static int traj_frame(const Oracle *o, int istep, real *phase) {
+  double t = (double)istep * o->traj_cstep / (double)o->m.n_llc, T = o->traj_tmax;
+  if (phase) *phase = (real)fmod(t / T, 1.0); /* CassiePhaseMoccaEnv.get_obs, :639 */
+  int i = (int)(fmod(t, T) / T * (double)o->traj_n);
+  return i < o->traj_n - 1 ? i : o->traj_n - 1;
+}
+/* joint_angles[k]: Joint.current_relative_position (bullet_utils.py:212-216) cast to float32 (env_cassie.py:239-242) */
+static float cassie_nrm(const MoccaModel *m, int k, real q) {
+  int b = m->ordered_body[k];
+  real lo = m->jlo[b], hi = m->jhi[b], mid = (real)0.5 * (lo + hi);
+  return (float)(2 * (q - mid) / (hi - lo));
+}
+/* rad_joint_angles = to_radians(joint_angles) (:243,208-210) */
+static real cassie_rad(const MoccaModel *m, int k, float nrm) {
+  int b = m->ordered_body[k];
+  real lo = m->jlo[b], hi = m->jhi[b];
+  return (hi - lo) * ((real)nrm + 1) / 2 + lo;
+}
+/* Cassie.calc_state (:238-276); needs kinematics() done.  robot_state[34] as float32 like the reference; returns pelvis z - lowest toe z. */
+static real cassie_state(Oracle *o, const Dyn *s, const Task *tk, float *rs) {
   const MoccaModel *m = &o->m;
   Work *w = &o->wk;
   int no = m->n_ordered;
   quat_to_rpy(s->quat, o->body_rpy);
   real yaw = o->body_rpy[2], cy = cos(-yaw), sy = sin(-yaw);
-  obs[0] = (float)(s->pos[2] - tk->initial_z);
-  obs[1] = (float)(cy * s->vel[0] - sy * s->vel[1]);
-  obs[2] = (float)(sy * s->vel[0] + cy * s->vel[1]);
-  obs[3] = (float)s->vel[2];
-  obs[4] = (float)o->body_rpy[0];
-  obs[5] = (float)o->body_rpy[1];
+  o->body_vel[0] = cy * s->vel[0] - sy * s->vel[1];
+  o->body_vel[1] = sy * s->vel[0] + cy * s->vel[1];
+  o->body_vel[2] = s->vel[2];
+  rs[0] = (float)(s->pos[2] - tk->initial_z);
+  rs[1] = (float)o->body_vel[0];
+  rs[2] = (float)o->body_vel[1];
+  rs[3] = (float)o->body_vel[2];
+  rs[4] = (float)o->body_rpy[0];
+  rs[5] = (float)o->body_rpy[1];
   for (int k = 0; k < no; ++k) {
-    int b = m->ordered_body[k];
-    float pos = (float)s->q[b], lo = m->jlo[b], hi = m->jhi[b];
-    float mid = 0.5f * (lo + hi); /* Joint.current_relative_position, bullet_utils.py:212-216 */
-    obs[6 + k] = 2 * (pos - mid) / (hi - lo);
-    obs[6 + no + k] = (float)s->qd[b];
+    rs[6 + k] = cassie_nrm(m, k, s->q[m->ordered_body[k]]);
+    rs[6 + no + k] = (float)s->qd[m->ordered_body[k]];
   }
-  real dx = (real)m->cassie_target[0] - s->pos[0], dy = (real)m->cassie_target[1] - s->pos[1];
-  real dth = atan2(dy, dx) - yaw, c = cos(dth), sn = sin(dth); /* get_obs :416-431 */
-  obs[6 + 2 * no] = (float)(c * (real)m->cassie_target[0] + sn * (real)m->cassie_target[1]);
-  obs[6 + 2 * no + 1] = (float)(-sn * (real)m->cassie_target[0] + c * (real)m->cassie_target[1]);
   real minz = 1e30;
   for (int k = 0; k < m->n_feet; ++k) {
     real z = s->pos[2] + w->comw[m->foot_body[k]][2];
@@ -1013,11 +1034,67 @@ static real cassie_obs(Oracle *o, const Dyn *s, const Task *tk, float *obs) {
   }
   return s->pos[2] - minz;
 }
+/* CassieEnv.get_obs (:416-431) */
+static void cassie_obs(Oracle *o, const Dyn *s, const float *rs, float *obs) {
+  const MoccaModel *m = &o->m;
+  int no = m->n_ordered;
+  for (int i = 0; i < 6 + 2 * no; ++i) obs[i] = rs[i];
+  real yaw = o->body_rpy[2];
+  real dx = (real)m->cassie_target[0] - s->pos[0], dy = (real)m->cassie_target[1] - s->pos[1];
+  real dth = atan2(dy, dx) - yaw, c = cos(dth), sn = sin(dth);
+  obs[6 + 2 * no] = (float)(c * (real)m->cassie_target[0] + sn * (real)m->cassie_target[1]);
+  obs[6 + 2 * no + 1] = (float)(-sn * (real)m->cassie_target[0] + c * (real)m->cassie_target[1]);
+}
+/* CassieMoccaEnv.get_obs (:607-627) + phases (:636-642) + the mirrored variant (:657-660): 42 floats */
+static void cassie_mocap_obs(Oracle *o, const Dyn *s, const Task *tk, const float *rs, real phase_l, float *obs) {
+  const MoccaModel *m = &o->m;
+  int no = m->n_ordered;
+  real v[42];
+  real hr = 0.5 * o->body_rpy[0], hp = 0.5 * o->body_rpy[1], hy = 0.5 * o->body_rpy[2];
+  real cr = cos(hr), sr = sin(hr), cp = cos(hp), sp = sin(hp), cy = cos(hy), sy = sin(hy);
+  /* pybullet.getQuaternionFromEuler(body_rpy), x y z w  [UNVERIFIED-BULLET: standard ZYX composition] */
+  real qx = sr * cp * cy - cr * sp * sy, qy = cr * sp * cy + sr * cp * sy, qz = cr * cp * sy - sr * sp * cy, qw = cr * cp * cy + sr * sp * sy;
+  v[0] = s->pos[1]; v[1] = s->pos[2];
+  v[2] = qw; v[3] = qx; v[4] = qy; v[5] = qz;
+  for (int k = 0; k < no; ++k) { v[6 + k] = cassie_rad(m, k, rs[6 + k]); v[26 + k] = tk->jvel[k]; }
+  for (int k = 0; k < 3; ++k) { v[20 + k] = o->body_vel[k]; v[23 + k] = s->omg[k]; }
+  v[40] = phase_l;
+  v[41] = fmod(phase_l + (real)0.5, (real)1);
+  if (m->cassie_mode == MOCCA_CASSIE_PHASE_MIRROR && phase_l > (real)0.5) {
+    /* obs[left + right] = obs[right + left]; obs[neg + sideneg] *= -1  (index lists :555-571,633-634,648-655) */
+    static const int left[15] = {6, 7, 8, 9, 10, 11, 12, 26, 27, 28, 29, 30, 31, 32, 40};
+    static const int right[15] = {13, 14, 15, 16, 17, 18, 19, 33, 34, 35, 36, 37, 38, 39, 41};
+    static const int neg[10] = {0, 3, 5, 21, 23, 25, 6, 7, 26, 27};
+    for (int k = 0; k < 15; ++k) { real tmp = v[left[k]]; v[left[k]] = v[right[k]]; v[right[k]] = tmp; }
+    for (int k = 0; k < 10; ++k) v[neg[k]] = -v[neg[k]];
+  }
+  for (int i = 0; i < 42; ++i) obs[i] = (float)v[i];
+}
+/* CassieMocapRewEnv.compute_rewards (:495-531): sum of the six weighted terms */
+static real cassie_mocap_reward(Oracle *o, const Dyn *s, const Task *tk, const float *rs, int frame) {
+  const MoccaModel *m = &o->m;
+  const float *fr = o->traj + (size_t)frame * MOCCA_TRAJ_STRIDE;
+  int npow = m->n_ctrl - 2;
+  real jp = 0, jv = 0;
+  for (int k = 0; k < npow; ++k) { /* [powered_joint_inds] */
+    int oi = m->ctrl_oidx[k];
+    real dj = (real)fr[oi] - cassie_rad(m, oi, rs[6 + oi]), dv = (real)fr[14 + oi] - tk->jvel[oi];
+    jp += dj * dj; jv += dv * dv;
+  }
+  real ve = o->body_vel[0] - (real)m->mocap_speed;
+  real orient = o->body_rpy[0] * o->body_rpy[0] + o->body_rpy[1] * o->body_rpy[1] + o->body_rpy[2] * o->body_rpy[2];
+  real ang = s->omg[0] * s->omg[0] + s->omg[1] * s->omg[1] + s->omg[2] * s->omg[2];
+  real cy_ = s->pos[1] - (real)m->init_pos[1], cz_ = s->pos[2] - (real)m->init_pos[2]; /* base_position[1:], :515 */
+  return (real)m->mocap_w[0] * exp(-4 * ve * ve) + (real)m->mocap_w[1] * exp(-4 * sqrt(jp)) + (real)m->mocap_w[2] * exp((real)-0.4 * sqrt(jv)) +
+         (real)m->mocap_w[3] * exp(-4 * orient) + (real)m->mocap_w[4] * exp(-4 * ang) + (real)m->mocap_w[5] * exp(-4 * (cy_ * cy_ + cz_ * cz_));
+}
 static real cassie_potential(const Oracle *o, const Dyn *s) { /* calc_potential :348-354 */
   real dx = (real)o->m.cassie_target[0] - s->pos[0], dy = (real)o->m.cassie_target[1] - s->pos[1];
   return -sqrt(dx * dx + dy * dy) / (real)o->m.control_dt;
 }
-static void cassie_reset(Oracle *o, int env, float *obs) { /* CassieEnv.reset :362-378 (no randomness) */
+/* CassieEnv.reset :362-378 (nominal pose, at rest); CassieMoccaEnv.reset :585-599 (istep = np_random.randint(0, 10000), kept
+ * under rsi; joints, joint speeds and rod angles of the motion at mocap_time(); base at initial_velocity :552) */
+static void cassie_reset(Oracle *o, int env, float *obs) {
   const MoccaModel *m = &o->m;
   Dyn *s = &o->dyn[env];
   Task *tk = &o->task[env];
@@ -1025,24 +1102,46 @@ static void cassie_reset(Oracle *o, int env, float *obs) { /* CassieEnv.reset :3
   memset(tk, 0, sizeof(*tk));
   tk->episode = ep; tk->applied_gain = 1;
   for (int b = 1; b <= m->n_joints; ++b) { s->q[b] = m->init_q[b]; s->qd[b] = 0; }
-  for (int k = 0; k < 3; ++k) { s->pos[k] = m->init_pos[k]; s->vel[k] = 0; s->omg[k] = 0; }
+  real phase = 0;
+  if (m->cassie_mode != MOCCA_CASSIE_PLAIN) {
+    float u = (float)draw_uniform(o, env, tk);
+    int is = (int)(u * 10000.0f);
+    is = is > 9999 ? 9999 : is;
+    tk->istep = m->cassie_rsi ? is : 0;
+    const float *fr = o->traj + (size_t)traj_frame(o, tk->istep, &phase) * MOCCA_TRAJ_STRIDE;
+    for (int k = 0; k < m->n_ordered; ++k) {
+      int b = m->ordered_body[k];
+      s->q[b] = fr[k]; s->qd[b] = fr[14 + k]; tk->jvel[k] = fr[14 + k];
+    }
+    for (int k = 0; k < 4; ++k) { s->q[m->rod_body[k]] = fr[28 + k]; s->qd[m->rod_body[k]] = 0; }
+  }
+  for (int k = 0; k < 3; ++k) { s->pos[k] = m->init_pos[k]; s->vel[k] = m->init_vel[k]; s->omg[k] = 0; }
   for (int k = 0; k < 4; ++k) s->quat[k] = m->init_quat[k];
   for (int k = 0; k < MOCCA_MAX_SLOTS; ++k) s->warm[k] = 0;
   tk->initial_z = s->pos[2];
   kinematics(m, s, &o->wk);
-  cassie_obs(o, s, tk, obs);
+  float rs[6 + 2 * MOCCA_MAX_CTRL];
+  cassie_state(o, s, tk, rs);
+  if (m->cassie_mode == MOCCA_CASSIE_PLAIN) cassie_obs(o, s, rs, obs);
+  else cassie_mocap_obs(o, s, tk, rs, phase, obs);
   tk->linear_potential = cassie_potential(o, s);
 }
-static void cassie_step(Oracle *o, int env, const float *act, float *obs, float *rew, uint8_t *done, int32_t *info) {
+static void cassie_step(Oracle *o, int env, const float *act, float *obs, float *rew, uint8_t *done, int32_t *info, int physics) {
   const MoccaModel *m = &o->m;
   Dyn *s = &o->dyn[env];
   Task *tk = &o->task[env];
   Work *w = &o->wk;
-  int nc = m->n_ctrl, no = m->n_ordered, npow = nc - 2;
+  int nc = m->n_ctrl, no = m->n_ordered, npow = nc - 2, mode = m->cassie_mode;
   real target[MOCCA_MAX_CTRL], tau[MB], q0[MOCCA_MAX_CTRL];
-  for (int k = 0; k < nc; ++k) target[k] = (real)m->ctrl_base[k] + (k < npow ? (real)act[k] : 0); /* :434-443 */
-  for (int k = 0; k < no; ++k) q0[k] = (real)(float)s->q[m->ordered_body[k]];
-  for (int it = 0; it < m->n_llc; ++it) { /* :450-459 */
+  const float *f0 = mode != MOCCA_CASSIE_PLAIN ? o->traj + (size_t)traj_frame(o, tk->istep, NULL) * MOCCA_TRAJ_STRIDE : NULL;
+  for (int k = 0; k < nc; ++k) { /* :434-443; base_angles() of the mocap envs = the motion at mocap_time() (:601-602) */
+    real base = (real)m->ctrl_base[k];
+    if (f0) base = (k < npow && m->residual_control) ? (real)f0[m->ctrl_oidx[k]] : 0;
+    target[k] = base + (k < npow ? (real)act[k] : 0);
+  }
+  /* jpos = robot.rad_joint_angles (:447,467): to_radians of the float32 normalised angles */
+  for (int k = 0; k < no; ++k) q0[k] = cassie_rad(m, k, cassie_nrm(m, k, s->q[m->ordered_body[k]]));
+  for (int it = 0; physics && it < m->n_llc; ++it) { /* :450-459 */
     for (int k = 0; k < no; ++k)
       tk->jvel[k] = (1 - (real)m->jvel_alpha) * tk->jvel[k] + (real)m->jvel_alpha * (real)(float)s->qd[m->ordered_body[k]];
     for (int b = 0; b <= m->n_joints; ++b) tau[b] = 0;
@@ -1054,21 +1153,31 @@ static void cassie_step(Oracle *o, int env, const float *act, float *obs, float 
       real t = (real)m->ctrl_kp[k] * perr + (real)m->ctrl_kd[k] * verr, lim = m->torque_limit[b];
       tau[b] = t < -lim ? -lim : (t > lim ? lim : t);
     }
-    tk->istep += 1;
     substep(o, s, tk, &o->ter[env], tau, w);
   }
+  tk->istep += m->n_llc; /* pd_control counts every low-level iteration (:381) */
   memcpy(o->dbg + 8 * env, w->dbg, sizeof(w->dbg));
-  for (int k = 0; k < no; ++k) tk->jvel[k] = ((real)(float)s->q[m->ordered_body[k]] - q0[k]) / (real)m->control_dt; /* :467-468 */
+  for (int k = 0; k < no; ++k) /* :467-468 */
+    tk->jvel[k] = (cassie_rad(m, k, cassie_nrm(m, k, s->q[m->ordered_body[k]])) - q0[k]) / (real)m->control_dt;
   tk->t += 1;
   kinematics(m, s, w);
-  real height = cassie_obs(o, s, tk, obs);
+  float rs[6 + 2 * MOCCA_MAX_CTRL];
+  real height = cassie_state(o, s, tk, rs);
   int finite = 1;
-  for (int i = 0; i < 6 + 2 * no; ++i) if (!isfinite(obs[i])) finite = 0;
+  for (int i = 0; i < 6 + 2 * no; ++i) if (!isfinite(rs[i])) finite = 0;
   real old = tk->linear_potential;
   tk->linear_potential = cassie_potential(o, s);
   real alive = height > (real)m->alive_height ? 2 : -1; /* :401-414 */
   if (!finite || alive < 0) tk->done = 1;
-  *rew = (float)(alive + (tk->linear_potential - old));
+  if (mode == MOCCA_CASSIE_PLAIN) {
+    cassie_obs(o, s, rs, obs);
+    *rew = (float)(alive + (tk->linear_potential - old));
+  } else { /* CassieMocapRewEnv.compute_rewards replaces the reward and keeps `dead` (:495-531) */
+    real phase;
+    int f1 = traj_frame(o, tk->istep, &phase);
+    *rew = (float)cassie_mocap_reward(o, s, tk, rs, f1);
+    cassie_mocap_obs(o, s, tk, rs, phase, obs);
+  }
   *info = 0;
   int timeout = tk->t >= m->max_episode_steps;
   *done = (uint8_t)((tk->done ? 1 : 0) | (timeout ? 2 : 0));
@@ -1148,7 +1257,7 @@ static void reset_env(Oracle *o, int env, float *obs) {
 
 static void step_env(Oracle *o, int env, const float *act, float *obs, float *rew, uint8_t *done, int32_t *info,
                      const int32_t *ext_touch, const int32_t *ext_target, const int32_t *ext_body) {
-  if (o->task_id == MOCCA_TASK_CASSIE) { cassie_step(o, env, act, obs, rew, done, info); return; }
+  if (o->task_id == MOCCA_TASK_CASSIE) { cassie_step(o, env, act, obs, rew, done, info, 1); return; }
   const MoccaModel *m = &o->m;
   Dyn *s = &o->dyn[env];
   Task *tk = &o->task[env];
@@ -1330,7 +1439,17 @@ API void *orc_create(const void *blob, int nbytes, int task_id, int n_envs) {
 API void orc_destroy(void *h) {
   Oracle *o = (Oracle *)h;
   if (!o) return;
-  free(o->dyn); free(o->task); free(o->ter); free(o->dbg); free(o);
+  free(o->dyn); free(o->task); free(o->ter); free(o->dbg); free(o->traj); free(o);
+}
+/* the reference motion of the Cassie mocap / phase envs (mocca_set_trajectory of include/mocca.h): copied */
+API int orc_set_trajectory(void *h, const float *table, int n_frames, double max_time, double control_step) {
+  Oracle *o = (Oracle *)h;
+  if (!o || !table || n_frames <= 0 || !(max_time > 0) || !(control_step > 0)) return -1;
+  free(o->traj);
+  o->traj = (float *)malloc((size_t)n_frames * MOCCA_TRAJ_STRIDE * sizeof(float));
+  memcpy(o->traj, table, (size_t)n_frames * MOCCA_TRAJ_STRIDE * sizeof(float));
+  o->traj_n = n_frames; o->traj_tmax = max_time; o->traj_cstep = control_step;
+  return 0;
 }
 API int orc_obs_dim(void *h) { return obs_dim((Oracle *)h); }
 API int orc_act_dim(void *h) { Oracle *o = (Oracle *)h; return o->task_id == MOCCA_TASK_CASSIE ? o->m.n_ctrl - 2 : o->m.n_joints; }

@@ -61,6 +61,8 @@ def _load(precision: str) -> C.CDLL:
     lib.orc_get_debug.argtypes = [C.c_void_p, C.c_void_p]
     lib.orc_last_lambda.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.orc_last_lambda.restype = C.c_int
+    lib.orc_set_trajectory.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
+    lib.orc_set_trajectory.restype = C.c_int
     return lib
 
 
@@ -101,6 +103,13 @@ class Oracle:
 
     def set_param(self, pid: int, v: float):
         self.lib.orc_set_param(self.h, pid, float(v))
+
+    def set_trajectory(self, table: np.ndarray, max_time: float, control_step: float):
+        """The reference motion of the Cassie mocap / phase envs: [n_frames][32] float32 (copied)."""
+        t = np.ascontiguousarray(table, np.float32)
+        assert t.ndim == 2 and t.shape[1] == 32
+        if self.lib.orc_set_trajectory(self.h, _p(t), t.shape[0], float(max_time), float(control_step)) != 0:
+            raise ValueError("orc_set_trajectory rejected the table")
 
     def reset(self, seed: int = 0, mask: Optional[np.ndarray] = None) -> np.ndarray:
         obs = np.zeros((self.n_envs, self.obs_dim), np.float32)
