@@ -370,7 +370,7 @@ class CassieEnv(EnvBase):
     llc_frame_skip = 50
     sim_frame_skip = 1
 
-    _model_extra = {}   # blob arguments of the subclasses (cassie_mode)
+    _mocap = False   # the mocap / phase subclasses: rsi and planar are blob numbers of theirs (the env id selects cassie_mode)
 
     def __init__(self, render=False, planar=False, power_coef=1.0, residual_control=True, rsi=True, **kwargs):
         # planar (Cassie2DEnv-v0, reference __init__.py:24-29): "constrains the robot movement to a 2D plane" (env_cassie.py:333).
@@ -380,8 +380,8 @@ class CassieEnv(EnvBase):
         self.planar, self.residual_control = bool(planar), bool(residual_control)
         if self.planar and self.env_id == "CassieEnv-v0":
             self.env_id = "Cassie2DEnv-v0"
-        kwargs["model_kw"] = dict(power_coef=float(power_coef), residual_control=self.residual_control, **self._model_extra)
-        if self._model_extra:   # the mocap / phase classes: rsi and planar are blob numbers of theirs
+        kwargs["model_kw"] = dict(power_coef=float(power_coef), residual_control=self.residual_control)
+        if self._mocap:
             kwargs["model_kw"].update(rsi=bool(rsi), planar=self.planar)
         super().__init__(render=render, **kwargs)
         self.rsi = rsi
@@ -415,7 +415,7 @@ class CassieMoccaEnv(CassieEnv):
 
     env_id = "CassiePhaseMocca2DEnv-v0"
     initial_velocity = [0.8, 0, 0]
-    _model_extra = {"mode": M.CASSIE_PHASE_MOCCA}
+    _mocap = True
     _obs_dim = 40
     mirror_indices = {   # env_cassie.py:554-571
         "neg_obs_inds": [0, 3, 5, 21, 23, 25],
@@ -486,7 +486,6 @@ class CassiePhaseMirrorEnv(CassiePhaseMoccaEnv):
     """env_cassie.py:645-660: left and right swapped and the lateral entries negated whenever the left phase is past 0.5."""
 
     env_id = "CassiePhaseMirror2DEnv-v0"
-    _model_extra = {"mode": M.CASSIE_PHASE_MIRROR}
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
