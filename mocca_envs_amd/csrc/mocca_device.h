@@ -1114,7 +1114,7 @@ DI void pgs_fixed_rows(const float* Acol, float a0, float a1, float a2, float a3
 //      a visit is clamp, subtract, readlane, one-lane commit, fma (pgs_fixed_rows + the friction loop)
 //   6. nu += sum_r X_r lambda_r, summed in row order through LDS
 template <class T>
-DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int32_t* dbg) {
+DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned long long ppk, int32_t* dbg) {
   STAMP_BEGIN;
   // wave-uniform scalars live in SGPRs: loop control becomes s_cmp/s_cbranch instead of exec-mask bookkeeping
   const float dt = unif(M->dt), idt = rcp(dt);
@@ -1248,78 +1248,78 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int32_t* d
   // ---- unit response X = M^-1 J^T
   // Jacobian entries go straight to LDS (the J rows sit in the part of the region the ABA no longer
   // needs: link frames / inertias, not S, U, 1/D, the factor of IA0, contacts); w = J nu is accumulated on the fly.
-  float X[T::ND];  // X holds u_b during the inward sweep, then the response
+  float X[T::ND];  // the response: base part after the base solve, joint entries as the outward sweep reaches them
   float w = 0;
-  // stores are unconditional (idle lanes write unused rows / the dummy row): a branch per body makes the
-  // compiler sink the whole force recursion below the stores and keep all 21 bodies' S/U live (~270 VGPRs)
-  float* Jrow = L + L_J + 28 * (r < MAXR ? r : MAXR);
+  float* Jrow = L + L_J + 28 * (r < MAXR ? r : MAXR);  // idle lanes write the dummy row
   float pa[6] = {0, 0, 0, 0, 0, 0}, pb[6] = {0, 0, 0, 0, 0, 0};
-  // bodies on no row's path (typically the arms) have zero Jacobian entries and carry no force: skip them
-  const unsigned anymask = wave_or(ma | mb);
-  // Rows that act on two bodies (self contacts, loop closures) carry two force paths that merge at the common
-  // ancestor; when the wave has none (the usual case for the walker) a single-path sweep does half the work.
+  // Inward sweep ALONG THE ROW'S OWN PATH: a row only loads the bodies between its body and the base (<= MAXD of them), so
+  // the sweep visits path positions, not bodies -- each lane reads the S / U / 1/D of ITS body at that depth (at most MAXW
+  // distinct addresses per position: the other lanes' reads are broadcasts).  The innovation u_k = J_k - S_k . p stays in a
+  // register indexed by the path POSITION (static), and the outward sweep -- which is unrolled over bodies -- picks
+  // position depth(b) - 1 for the rows whose path holds b.  (A loop over all bodies with wave-uniform skips cost 21 steps for
+  // the walker, and a merged two-path variant twice the arithmetic per step.)
+  // Rows that act on two bodies (self contacts, loop closures) sweep the second body's path separately (the recursion is
+  // linear in the applied force; both meet in the base's right-hand side); without such a row in the wave that pass is skipped.
 #ifdef MOCCA_NO_TWO_PATHS  // diagnostic build (tools/icache_probe.py): code-size experiment, wrong with self contacts / closures
   const bool two_paths = false;
 #else
   const bool two_paths = T::NCLOS > 0 || __ballot(kind >= 1 && bb >= 0) != 0ull;  // wave-uniform
 #endif
   STAMP(18);
-  if (two_paths) {
+  // the packed path of the row's body, from the lane that owns that body in the lane = body layout (body 0: empty path)
+  const unsigned long long pka = ((unsigned long long)(unsigned)__shfl((int)(unsigned)(ppk >> 32), ba, 64) << 32) |
+                                 (unsigned long long)(unsigned)__shfl((int)(unsigned)ppk, ba, 64);
+  {
+    float4* jz = reinterpret_cast<float4*>(Jrow);  // joint entries of bodies off the path are zero (entries 0..5: base part, below)
 #pragma unroll
-    for (int b = T::NB - 1; b >= 1; --b) {
-      if (!((anymask >> b) & 1u)) {  // wave-uniform
-        Jrow[5 + b] = 0.0f;
-        X[5 + b] = 0.0f;
-        continue;
-      }
-      const bool ina = (ma >> b) & 1u, inb = (mb >> b) & 1u;
+    for (int i = 1; i < 7; ++i) jz[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  float pu[T::MAXD], pub[T::MAXD];
+#pragma unroll
+  for (int k = T::MAXD - 1; k >= 0; --k) {
+    const int j = (int)((pka >> (5 * k)) & 31ull);
+    const bool valid = j != 31;
+    const int jj = valid ? j : 0;
+    float S[6], U[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { S[i] = L[L_S + 6 * jj + i]; U[i] = L[L_U + 6 * jj + i]; }
+    float jb = dot6(S, F);
+    if (jj == jl) jb = sgn;
+    jb = valid ? jb : 0.0f;
+    const float uu = valid ? jb - dot6(S, pa) : 0.0f;
+    const float sc = uu * L[L_INVD + jj];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pa[i] += U[i] * sc;  // sc == 0 past the end of the path
+    if (valid) Jrow[5 + jj] = jb;
+    w += jb * L[L_NU + 5 + jj];
+    pu[k] = uu;
+    pin6(pa); pin1(pu[k]); pin1(w);
+  }
+  if (two_paths) {
+    const int bq = bb >= 0 ? bb : 0;
+    const unsigned long long pkb = ((unsigned long long)(unsigned)__shfl((int)(unsigned)(ppk >> 32), bq, 64) << 32) |
+                                   (unsigned long long)(unsigned)__shfl((int)(unsigned)ppk, bq, 64);
+#pragma unroll
+    for (int k = T::MAXD - 1; k >= 0; --k) {
+      const int j = (int)((pkb >> (5 * k)) & 31ull);
+      const bool valid = j != 31;
+      const int jj = valid ? j : 0;
       float S[6], U[6];
-  #pragma unroll
-      for (int i = 0; i < 6; ++i) { S[i] = L[L_S + 6 * b + i]; U[i] = L[L_U + 6 * b + i]; }
-      float jb;
-      if (T::NCLOS > 0) jb = (ina ? dot6(S, F) : 0.0f) - (inb ? dot6(S, F2) : 0.0f);
-      else jb = dot6(S, F) * ((ina ? 1.0f : 0.0f) - (inb ? 1.0f : 0.0f));  // F2 == F without closures
-      if (b == jl) jb = sgn;
-      float pc[6];
-  #pragma unroll
-      for (int i = 0; i < 6; ++i) pc[i] = (ina ? pa[i] : 0.0f) + (inb ? pb[i] : 0.0f);
-      const float uu = jb - dot6(S, pc);
-      const float sc = uu * L[L_INVD + b];
-  #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const float pn = pc[i] + U[i] * sc;
-        pa[i] = ina ? pn : pa[i];
-        pb[i] = ina ? (inb ? 0.0f : pb[i]) : (inb ? pn : pb[i]);
-      }
-      Jrow[5 + b] = jb;
-      w += jb * L[L_NU + 5 + b];
-      X[5 + b] = uu;
-      pin6(pa); pin6(pb); pin1(X[5 + b]); pin1(w);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { S[i] = L[L_S + 6 * jj + i]; U[i] = L[L_U + 6 * jj + i]; }
+      const float jb = valid ? -dot6(S, F2) : 0.0f;   // the force on the second body is -F2
+      const float uu = valid ? jb - dot6(S, pb) : 0.0f;
+      const float sc = uu * L[L_INVD + jj];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pb[i] += U[i] * sc;
+      if (valid) Jrow[5 + jj] += jb;                  // common ancestors carry both paths' entries
+      w += jb * L[L_NU + 5 + jj];
+      pub[k] = uu;
+      pin6(pb); pin1(pub[k]); pin1(w);
     }
   } else {
 #pragma unroll
-    for (int b = T::NB - 1; b >= 1; --b) {
-      if (!((anymask >> b) & 1u)) {  // wave-uniform
-        Jrow[5 + b] = 0.0f;
-        X[5 + b] = 0.0f;
-        continue;
-      }
-      const bool ina = (ma >> b) & 1u;
-      float S[6], U[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { S[i] = L[L_S + 6 * b + i]; U[i] = L[L_U + 6 * b + i]; }
-      float jb = ina ? dot6(S, F) : 0.0f;
-      if (b == jl) jb = sgn;
-      // off the row's path no force arrives (pa is only ever advanced on the path): u_b = 0 there
-      const float uu = ina ? jb - dot6(S, pa) : 0.0f;
-      const float sc = uu * L[L_INVD + b];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) pa[i] += U[i] * sc;  // sc == 0 off the path
-      Jrow[5 + b] = jb;
-      w += jb * L[L_NU + 5 + b];
-      X[5 + b] = uu;
-      pin6(pa); pin1(X[5 + b]); pin1(w);
-    }
+    for (int k = 0; k < T::MAXD; ++k) pub[k] = 0.0f;
   }
   // Launder the LDS pointer: otherwise the compiler keeps all 21 bodies' S/U loads of the inward sweep live
   // for the outward sweep (273 VGPRs); re-reading 13 broadcast floats per body costs far less than the occupancy.
@@ -1353,7 +1353,10 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int32_t* d
       float S[6], U[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) { S[i] = L2[L_S + 6 * b + i]; U[i] = L2[L_U + 6 * b + i]; }
-      const float qdd = (X[5 + b] - dot6(U, acc[p])) * L2[L_INVD + b];
+      const int dpos = T::depth(b) - 1;  // (folds after unrolling) the body's position on every path that holds it
+      float ub = ((ma >> b) & 1u) ? pu[dpos] : 0.0f;
+      if (two_paths) ub += ((mb >> b) & 1u) ? pub[dpos] : 0.0f;
+      const float qdd = (ub - dot6(U, acc[p])) * L2[L_INVD + b];
       X[5 + b] = qdd;
 #pragma unroll
       for (int i = 0; i < 6; ++i) acc[b][i] = acc[p][i] + S[i] * qdd;
@@ -1554,7 +1557,7 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
 #endif
   STAMP(2);
 #ifndef MOCCA_SKIP_SOLVE
-  solve_constraints<T>(M, L, lane, nc, dbg);
+  solve_constraints<T>(M, L, lane, nc, ppk, dbg);
 #endif
   STAMP(3);
 #ifdef MOCCA_DUMMY_VALU  // experiment: is the kernel VALU-issue-bound?  (tools/ab.sh variants)
