@@ -117,6 +117,7 @@ static_assert(L_ABA_END <= L_TOTAL, "ABA view must fit");
 static_assert(L_JR1 + 16 * MOCCA_MAX_BODIES <= L_TOTAL && (L_JR0 % 4) == 0 && (L_JR1 % 4) == 0, "joint records must fit, 16-byte aligned");
 static_assert(L_J + (MAXR + 1) * 28 <= L_TOTAL, "Jacobian rows (+ dummy) must fit the tail of the A region");
 static_assert(L_J % 4 == 0 && L_V % 4 == 0, "16-byte alignment of broadcast rows");
+static_assert(MAXR % 2 == 0 && 3 * MAXC <= MAXR, "friction rows sit on the top 2 MAXC lanes of the row range, odd lane = second tangent");
 static_assert(L_PLANK + 12 * MOCCA_MAX_PLANKS <= L_V && L_Q0 + 16 <= L_V, "persistent region overflows into the two-view region");
 static_assert(L_TOTAL * 4 <= 10240, "more than 10 KB of LDS per wave: fewer than 16 waves per CU, the 4096-env batch no longer fits one round");
 static_assert(L_J >= L_R, "J rows may be written while S, U, 1/D, the factor of IA0 and the contacts are still being read");
@@ -1026,34 +1027,38 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
 // Step t of every lane reads a DIFFERENT J row (stride 28 floats: the 16-byte reads of 16 consecutive lanes tile all 64
 // banks, no conflicts beyond the four passes a b128 read takes anyway).  Values stay in registers until every J row has
 // been read -- A overlays the J rows.  Compile-time recursion: v[TT] must be a static register.
+// Rows are not contiguous in the wave (fixed-bound rows on lanes 0 .. r_fr - 1, friction rows on the top lanes, see fric_lane):
+// the schedule runs over DENSE row numbers 0 .. nr - 1 and maps them to lanes (dense d -> lane d below r_fr, d + gap above).
 template <class T, int TT>
-DI void delassus_dots(const float* L, const float* X, int c, int nr, int tmax, float* v) {
+DI void delassus_dots(const float* L, const float* X, int c, int nr, int tmax, int r_fr, int gap, float* v) {
   if constexpr (TT <= MAXR / 2) {
     if (TT > tmax) return;
     int rho = c + TT;
     rho = rho >= nr ? rho - nr : rho;
+    rho = rho < r_fr ? rho : rho + gap;
     const float* Jr = L + L_J + 28 * rho;
     float s = 0;
 #pragma unroll
     for (int d = 0; d < T::ND; ++d) s += Jr[d] * X[d];
     v[TT] = s;
     pin1(v[TT]);  // keeps the steps in order: hoisting the next steps' 28-register J rows above this point spills
-    delassus_dots<T, TT + 1>(L, X, c, nr, tmax, v);
+    delassus_dots<T, TT + 1>(L, X, c, nr, tmax, r_fr, gap, v);
   }
 }
 template <int TT>
-DI void delassus_store(float* L, int c, int nr, int tmax, const float* v) {
+DI void delassus_store(float* L, int c, int cl, int nr, int tmax, int r_fr, int gap, const float* v) {  // c: dense row number, cl: lane
   if constexpr (TT <= MAXR / 2) {
     if (TT > tmax) return;
     int rho = c + TT;
     rho = rho >= nr ? rho - nr : rho;
+    rho = rho < r_fr ? rho : rho + gap;
     if (TT == 0) {
-      L[L_A + (MAXR + 1) * c] = 0.0f;  // the solver works on a zero diagonal (see solve_constraints); the value stays in v[0]
+      L[L_A + (MAXR + 1) * cl] = 0.0f;  // the solver works on a zero diagonal (see solve_constraints); the value stays in v[0]
     } else {
-      L[L_A + MAXR * rho + c] = v[TT];
-      L[L_A + MAXR * c + rho] = v[TT];
+      L[L_A + MAXR * rho + cl] = v[TT];
+      L[L_A + MAXR * cl + rho] = v[TT];
     }
-    delassus_store<TT + 1>(L, c, nr, tmax, v);
+    delassus_store<TT + 1>(L, c, cl, nr, tmax, r_fr, gap, v);
   }
 }
 
@@ -1068,6 +1073,33 @@ DI void pgs_visit(float as, float& y, float& lam, float lo0) {
   const float dl = readlane(nl_ - lam, RR);
   lam = writelane_c<RR>(readlane(nl_, RR), lam);
   y = fmaf(-as, dl, y);
+}
+// a friction row: the same visit with the symmetric bound |lambda| <= lm = mu * (impulse of the contact's normal row), per lane
+template <int RR>
+DI void pgs_visit_friction(float as, float& y, float& lam, float lm) {
+  const float nl_ = __builtin_amdgcn_fmed3f(y, -lm, lm);
+  const float dl = readlane(nl_ - lam, RR);
+  lam = writelane_c<RR>(readlane(nl_, RR), lam);
+  y = fmaf(-as, dl, y);
+}
+// Friction rows live on STATIC lanes at the top of the row range: contact i owns lanes MAXR - 2 - 2i (first tangent) and
+// MAXR - 1 - 2i (second), whatever the number of limit / normal rows below them.  With the lane an immediate a friction visit is
+// the fixed-bound visit (readlane / writelane immediates, LDS offsets immediates, A entries requested two contacts ahead): ~30
+// cycles.  The former layout (friction rows right after the normals, lane = r_fr + 2i + s, a rolled loop with an exec-mask
+// commit and per-contact bound look-ups) cost ~135 cycles per visit (tools/pgs_chain_bench.hip) -- most of the solver time of
+// the contact-rich waves that set the launch time.
+constexpr int fric_lane(int i, int s) { return MAXR - 2 - 2 * i + s; }
+template <int I>
+DI void pgs_friction_rows(const float* Acol, float a0, float a1, float b0, float b1, int nc, float& y, float& lam, float invdiag, float lm) {
+  if constexpr (I < MAXC) {
+    if (I >= nc) return;
+    constexpr int IN = I + 2 < MAXC ? I + 2 : MAXC - 1;   // past the last contact: any readable row, never used
+    float n0 = Acol[MAXR * fric_lane(IN, 0)], n1 = Acol[MAXR * fric_lane(IN, 1)];
+    pgs_visit_friction<fric_lane(I, 0)>(a0 * invdiag, y, lam, lm);
+    pgs_visit_friction<fric_lane(I, 1)>(a1 * invdiag, y, lam, lm);
+    pin1(n0); pin1(n1);
+    pgs_friction_rows<I + 1>(Acol, b0, b1, n0, n1, nc, y, lam, invdiag, lm);
+  }
 }
 // fewer than four fixed-bound rows left: one uniform exit test per visit
 template <int RR, int LEFT>
@@ -1160,8 +1192,14 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
     wsync();
     return;
   }
-  // ---- my row
+  // ---- my row.  Lanes 0 .. r_fr - 1: limit, closure / planar and normal rows (fixed bounds, visited in lane order); friction rows of
+  // contact i on the static lanes fric_lane(i, 0 / 1) at the top of the range; the lanes in between own no row.
   const int r = lane;
+  const int r_fr = nl + NFIX + nc;            // first lane past the fixed-bound rows
+  const int row_gap = MAXR - nr;              // dense row number d >= r_fr sits on lane d + row_gap
+  const bool is_fric = r >= MAXR - 2 * nc && r < MAXR;
+  const bool has_row = r < r_fr || is_fric;
+  const int ci = is_fric ? (MAXR - 1 - r) >> 1 : r - nl - NFIX;   // contact of a normal / friction row
   int kind = -1, ba = 0, bb = -1, jl = -1, slot = -1;
   float F[6] = {0, 0, 0, 0, 0, 0}, sgn = 0, bias = 0, cfm = 0, lam = 0, mu = 0;
   float F2[6] = {0, 0, 0, 0, 0, 0};  // force on body bb (closures: its own pivot; self contacts: same point as F)
@@ -1204,13 +1242,11 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
     for (int x = 0; x < 6; ++x) F[x] = x == comp ? 1.0f : 0.0f;
     const float err = k == 0 ? L[L_R + 7] : (k == 1 ? -L[L_R + 1] : L[L_BASE + 1] - M->init_pos[1]);
     bias = -M->erp * err * idt;
-  } else if (r < nr) {
-    const int k = r - nl - NFIX;
-    const int i = k < nc ? k : (k - nc) >> 1;
-    const float* ct = L + L_CT + 16 * i;
+  } else if (has_row) {
+    const float* ct = L + L_CT + 16 * ci;
     float n[3] = {ct[C_N], ct[C_N + 1], ct[C_N + 2]}, P[3] = {ct[C_P], ct[C_P + 1], ct[C_P + 2]}, dir[3];
     ba = __float_as_int(ct[C_BA]); bb = __float_as_int(ct[C_BB]);
-    if (k < nc) {
+    if (!is_fric) {
       kind = 1;
       dir[0] = n[0]; dir[1] = n[1]; dir[2] = n[2];
       const float depth = ct[C_DEPTH];
@@ -1222,7 +1258,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
       kind = 2;
       float t1[3], t2[3];
       plane_space(n, t1, t2);
-      const bool second = ((k - nc) & 1) != 0;
+      const bool second = (r & 1) != 0;   // fric_lane(i, 1) is the odd lane (MAXR is even)
 #pragma unroll
       for (int x = 0; x < 3; ++x) dir[x] = second ? t2[x] : t1[x];
       mu = ct[C_MU];
@@ -1236,7 +1272,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   // ancestor masks travel with the contact records; limit / closure rows use the compile-time table (few distinct bodies)
   unsigned ma = 0u, mb = 0u;
   if (kind == 1 || kind == 2) {
-    const float* ct = L + L_CT + 16 * ((r - nl - NFIX) < nc ? (r - nl - NFIX) : ((r - nl - NFIX - nc) >> 1));
+    const float* ct = L + L_CT + 16 * ci;
     ma = __float_as_uint(ct[C_MA]); mb = __float_as_uint(ct[C_MB]);
   } else if (kind >= 0) {
     ma = M->anc_mask[ba];
@@ -1371,11 +1407,11 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   float diag;
   {
     float av[MAXR / 2 + 1];
-    const int cc = r < nr ? r : 0, tmax = nr >> 1;
-    delassus_dots<T, 0>(L, X, cc, nr, tmax, av);
-    diag = r < nr ? av[0] : 1.0f;
+    const int cc = has_row ? (r < r_fr ? r : r - row_gap) : 0, tmax = nr >> 1;   // dense row number of this lane
+    delassus_dots<T, 0>(L, X, cc, nr, tmax, r_fr, row_gap, av);
+    diag = has_row ? av[0] : 1.0f;
     wsync();  // every J row has been read: A may overwrite them
-    if (r < nr) delassus_store<0>(L, cc, nr, tmax, av);
+    if (has_row) delassus_store<0>(L, cc, r, nr, tmax, r_fr, row_gap, av);
   }
   // a row with a vanishing Jacobian (out-of-plane friction of a planar mechanism's self contact) gets zero gain, as in
   // Bullet (jacDiagABInv = 0 below SIMD_EPSILON), instead of 0 * inf
@@ -1393,51 +1429,41 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
     if (l0 != 0.0f) w += L[L_A + MAXR * rr + lc] * l0;
   }
   STAMP(20);
-  // ---- projected Gauss-Seidel, rows in lane order (limits, closures, normals, then frictions).
-  // Limit / closure / normal rows have fixed bounds; a friction row's bound is mu * (current impulse of its normal row),
-  // looked up when the friction row is visited (its normal's index is wave-uniform then) instead of being pushed to
-  // every friction lane whenever a normal row changes.  The loop is instruction-issue bound: 11 instructions per visit of
-  // a fixed-bound row (ds_read, mul, med3, sub, 2 readlane, writelane, fma, wait, 2 for the uniform exit test).
+  // ---- projected Gauss-Seidel: limits, closures, normals (lanes 0 .. r_fr - 1 in order), then the friction rows contact by contact.
+  // Limit / closure / normal rows have fixed bounds; a friction row's bound is mu * (current impulse of its normal row): every
+  // friction lane fetches its contact's normal impulse once per iteration, after the normal rows were visited (they do not change
+  // again before the next iteration).  A visit is ~30 cycles of dependent issue: med3, sub, readlane, fma (pgs_visit*).
   const int iters = uni(M->n_iters);
   const float lo0 = kind == 3 ? -1e30f : 0.0f;
-  const int r_fr = nl + NFIX + nc;  // first friction row
   const float* Acol = L + L_A + lc;
+  const int nrow_lane = is_fric ? nl + NFIX + ci : 0;   // lane of the normal row this friction row is bounded by
   float y = (bias - w) * invdiag;
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
     pgs_fixed_rows<0>(Acol, Acol[0], Acol[MAXR], Acol[2 * MAXR], Acol[3 * MAXR], r_fr, y, lam, invdiag, lo0);
-    float a = Acol[MAXR * (r_fr < MAXR ? r_fr : MAXR - 1)];
-#pragma unroll 1
-    for (int i = 0; i < nc; ++i) {  // the two friction rows of contact i share the bound mu * lam[normal row of i]
-      const float lm = mu * readlane(lam, nl + NFIX + i);
-      const int rr = r_fr + 2 * i;
-      const float a1 = Acol[MAXR * (rr + 1)], a2 = Acol[MAXR * (rr + 2 < MAXR ? rr + 2 : MAXR - 1)];  // clamp: in-bounds, unused
-      const float as = a * invdiag, as1 = a1 * invdiag;
-      float nl_ = __builtin_amdgcn_fmed3f(y, -lm, lm);
-      float dl = readlane(nl_ - lam, rr);
-      lam = setlane(nl_, rr, lam);
-      y = fmaf(-as, dl, y);
-      nl_ = __builtin_amdgcn_fmed3f(y, -lm, lm);
-      dl = readlane(nl_ - lam, rr + 1);
-      lam = setlane(nl_, rr + 1, lam);
-      y = fmaf(-as1, dl, y);
-      a = a2;
+    if (nc > 0) {  // wave-uniform
+      const float f0 = Acol[MAXR * fric_lane(0, 0)], f1 = Acol[MAXR * fric_lane(0, 1)];
+      const float g0 = Acol[MAXR * fric_lane(1, 0)], g1 = Acol[MAXR * fric_lane(1, 1)];
+      const float lm = mu * __shfl(lam, nrow_lane, 64);
+      pgs_friction_rows<0>(Acol, f0, f1, g0, g1, nc, y, lam, invdiag, lm);
     }
   }
   STAMP(8);
   // ---- apply: nu += sum_r X_r lambda_r, summed in row order through LDS
   wsync();
-  if (r < nr) {
+  if (has_row) {
 #pragma unroll
     for (int d = 0; d < T::ND; ++d) L[L_XL + 28 * r + d] = X[d] * lam;
   }
   if (lane < T::NSLOT) L[L_WARM + lane] = 0.0f;
   wsync();
-  if (kind == 1 && slot >= 0 && r < nr) L[L_WARM + slot] = lam;
+  if (kind == 1 && slot >= 0) L[L_WARM + slot] = lam;
   if (lane < T::ND) {
     float s = 0;
 #pragma unroll 1
-    for (int rr = 0; rr < nr; ++rr) s += L[L_XL + 28 * rr + lane];
+    for (int rr = 0; rr < r_fr; ++rr) s += L[L_XL + 28 * rr + lane];            // fixed-bound rows, then the friction lanes
+#pragma unroll 1
+    for (int rr = MAXR - 2 * nc; rr < MAXR; ++rr) s += L[L_XL + 28 * rr + lane];
     L[L_NU + lane] += s;
   }
   wsync();
