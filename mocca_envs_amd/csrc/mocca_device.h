@@ -255,17 +255,6 @@ DI int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }  // assert wave-
 DI float unif(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 DI float readlane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 DI int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-// lane l (wave-uniform, dynamic) of `old` takes the value its own lane holds in v: the one-lane exec mask is built on
-// the scalar unit (v_writelane with two SGPR sources would exceed the constant bus, and M0 is reserved)
-DI float setlane(float v, int l, float old) {
-  unsigned long long m, saved;  // two pairs: s_and_saveexec with source == destination does not mask anything
-  asm volatile("s_lshl_b64 %1, 1, %4\n\t"
-               "s_and_saveexec_b64 %2, %1\n\t"
-               "v_mov_b32 %0, %3\n\t"
-               "s_mov_b64 exec, %2"
-               : "+v"(old), "=&s"(m), "=&s"(saved) : "v"(v), "s"(l) : "scc");  // both scalar ops write SCC
-  return old;
-}
 template <int LANE>
 DI float writelane_c(float v, float old) {  // immediate lane select
   asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(v), "n"(LANE));

@@ -23,12 +23,18 @@ for e in Child3DCustomEnv-v0 MikeStepperEnv-v0 Walker2DCustomEnv-v0 Crab2DCustom
   python bench.py --env-id $e --steps 300 --warmup 100 --no-cpu-baseline > $O/${tag}_$(echo $e | tr 'A-Z' 'a-z' | sed 's/env-v0//')_bench.json 2>/dev/null
 done
 python bench.py --env-id Cassie2DEnv-v0 --envs 2048 --steps 100 --warmup 30 --no-cpu-baseline > $O/${tag}_cassie2d_bench.json 2>/dev/null
+python bench.py --env-id CassiePhaseMocca2DEnv-v0 --envs 2048 --steps 100 --warmup 30 --no-cpu-baseline > $O/${tag}_cassiephasemocca2d_bench.json 2>/dev/null
+python bench.py --env-id CassiePhaseMirror2DEnv-v0 --envs 2048 --steps 100 --warmup 30 --no-cpu-baseline > $O/${tag}_cassiephasemirror2d_bench.json 2>/dev/null
 # 4. per-phase timelines (diagnostic build)
 python tools/stamps.py Walker3DCustomEnv-v0 4096 > $O/${tag}_stamps_custom4096.txt 2>&1
 python tools/stamps.py Walker3DCustomEnv-v0 1024 > $O/${tag}_stamps_custom1024.txt 2>&1
 python tools/param_time.py 4096 > $O/${tag}_param_time_4096.txt 2>&1
 # 5. record layouts
 hipcc --offload-arch=gfx950 -O3 -o /tmp/layout_bench tools/layout_bench.hip && /tmp/layout_bench 4096 > $O/${tag}_layout_bench.json && /tmp/layout_bench 65536 >> $O/${tag}_layout_bench.json
+# 5b. microbenchmarks behind DESIGN.md section 6: dependent-issue latencies, PGS visit forms, workgroup placement
+hipcc --offload-arch=gfx950 -O3 -o /tmp/lat_bench tools/lat_bench.hip && /tmp/lat_bench > $O/${tag}_lat_bench.jsonl
+hipcc --offload-arch=gfx950 -O3 -o /tmp/pgs_chain_bench tools/pgs_chain_bench.hip && /tmp/pgs_chain_bench > $O/${tag}_pgs_chain_bench.jsonl
+hipcc --offload-arch=gfx950 -O3 -o /tmp/dispatch_probe tools/dispatch_probe.hip && (cd $R && /tmp/dispatch_probe > $O/${tag}_dispatch_probe.txt)
 # 6. rocprofv3: kernel-trace stats + separate PMC passes at steady state, the other two configs
 tools/profile_round.sh ${tag}_stepper Walker3DStepperEnv-v0 4096 > /dev/null 2>&1
 tools/profile_round.sh ${tag}_cassie CassieEnv-v0 2048 > /dev/null 2>&1
