@@ -1016,22 +1016,22 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
 // Step t of every lane reads a DIFFERENT J row (stride 28 floats: the 16-byte reads of 16 consecutive lanes tile all 64
 // banks, no conflicts beyond the four passes a b128 read takes anyway).  Values stay in registers until every J row has
 // been read -- A overlays the J rows.  Compile-time recursion: v[TT] must be a static register.
-// Rows are not contiguous in the wave (fixed-bound rows on lanes 0 .. r_fr - 1, friction rows on the top lanes, see fric_lane):
-// the schedule runs over DENSE row numbers 0 .. nr - 1 and maps them to lanes (dense d -> lane d below r_fr, d + gap above).
+// Rows are not contiguous in the wave (fixed-bound rows on lanes 0 .. r_fr - 1, friction rows on the top lanes, see fric_lane), but
+// the J rows are stored by DENSE row number 0 .. nr - 1, so the schedule needs one add and one wrap per step (oc = 28 c, onr = 28 nr:
+// unsigned min(o, o - onr) is the wrap); only the store maps dense numbers back to lanes (d below r_fr, d + gap above).
 template <class T, int TT>
-DI void delassus_dots(const float* L, const float* X, int c, int nr, int tmax, int r_fr, int gap, float* v) {
+DI void delassus_dots(const float* L, const float* X, int oc, int onr, int tmax, float* v) {
   if constexpr (TT <= MAXR / 2) {
     if (TT > tmax) return;
-    int rho = c + TT;
-    rho = rho >= nr ? rho - nr : rho;
-    rho = rho < r_fr ? rho : rho + gap;
-    const float* Jr = L + L_J + 28 * rho;
+    const unsigned o = (unsigned)(oc + 28 * TT);
+    const unsigned ow = o - (unsigned)onr;
+    const float* Jr = L + L_J + (int)(o < ow ? o : ow);
     float s = 0;
 #pragma unroll
     for (int d = 0; d < T::ND; ++d) s += Jr[d] * X[d];
     v[TT] = s;
     pin1(v[TT]);  // keeps the steps in order: hoisting the next steps' 28-register J rows above this point spills
-    delassus_dots<T, TT + 1>(L, X, c, nr, tmax, r_fr, gap, v);
+    delassus_dots<T, TT + 1>(L, X, oc, onr, tmax, v);
   }
 }
 template <int TT>
@@ -1275,7 +1275,8 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   // needs: link frames / inertias, not S, U, 1/D, the factor of IA0, contacts); w = J nu is accumulated on the fly.
   float X[T::ND];  // the response: base part after the base solve, joint entries as the outward sweep reaches them
   float w = 0;
-  float* Jrow = L + L_J + 28 * (r < MAXR ? r : MAXR);  // idle lanes write the dummy row
+  const int dense = has_row ? (r < r_fr ? r : r - row_gap) : MAXR;   // dense row number; lanes without a row write the dummy row
+  float* Jrow = L + L_J + 28 * dense;
   float pa[6] = {0, 0, 0, 0, 0, 0}, pb[6] = {0, 0, 0, 0, 0, 0};
   // Inward sweep ALONG THE ROW'S OWN PATH: a row only loads the bodies between its body and the base (<= MAXD of them), so
   // the sweep visits path positions, not bodies -- each lane reads the S / U / 1/D of ITS body at that depth (at most MAXW
@@ -1351,6 +1352,8 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   STAMP(19);
   int l2off = 0;  // an opaque zero offset, not an opaque pointer: a laundered pointer turns generic and its reads
   asm volatile("" : "+v"(l2off));  // become flat loads (VALU address math, both memory counters) instead of ds_read
+  l2off &= ~3;  // tells the optimiser the offset keeps 16-byte alignment: without it every read below became a ds_read2_b32 off its
+                // own v_add'ed base (the 8-bit offsets of the two-address form), 136 address adds per substep in the outward sweep
   const float* L2 = L + l2off;
   float a0[6];
   {
@@ -1396,8 +1399,8 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   float diag;
   {
     float av[MAXR / 2 + 1];
-    const int cc = has_row ? (r < r_fr ? r : r - row_gap) : 0, tmax = nr >> 1;   // dense row number of this lane
-    delassus_dots<T, 0>(L, X, cc, nr, tmax, r_fr, row_gap, av);
+    const int cc = has_row ? dense : 0, tmax = nr >> 1;
+    delassus_dots<T, 0>(L, X, 28 * cc, 28 * nr, tmax, av);
     diag = has_row ? av[0] : 1.0f;
     wsync();  // every J row has been read: A may overwrite them
     if (has_row) delassus_store<0>(L, cc, r, nr, tmax, r_fr, row_gap, av);
