@@ -1035,19 +1035,18 @@ DI void delassus_dots(const float* L, const float* X, int oc, int onr, int tmax,
   }
 }
 template <int TT>
-DI void delassus_store(float* L, int c, int cl, int nr, int tmax, int r_fr, int gap, const float* v) {  // c: dense row number, cl: lane
+DI void delassus_store(float* L, int c, int nr, int tmax, const float* v) {  // A is indexed by dense row numbers on both sides
   if constexpr (TT <= MAXR / 2) {
     if (TT > tmax) return;
-    int rho = c + TT;
-    rho = rho >= nr ? rho - nr : rho;
-    rho = rho < r_fr ? rho : rho + gap;
+    const unsigned r0 = (unsigned)(c + TT), rw = r0 - (unsigned)nr;
+    const int rho = (int)(r0 < rw ? r0 : rw);
     if (TT == 0) {
-      L[L_A + (MAXR + 1) * cl] = 0.0f;  // the solver works on a zero diagonal (see solve_constraints); the value stays in v[0]
+      L[L_A + (MAXR + 1) * c] = 0.0f;  // the solver works on a zero diagonal (see solve_constraints); the value stays in v[0]
     } else {
-      L[L_A + MAXR * rho + cl] = v[TT];
-      L[L_A + MAXR * cl + rho] = v[TT];
+      L[L_A + __mul24(MAXR, rho) + c] = v[TT];
+      L[L_A + __mul24(MAXR, c) + rho] = v[TT];
     }
-    delassus_store<TT + 1>(L, c, cl, nr, tmax, r_fr, gap, v);
+    delassus_store<TT + 1>(L, c, nr, tmax, v);
   }
 }
 
@@ -1082,8 +1081,9 @@ template <int I>
 DI void pgs_friction_rows(const float* Acol, float a0, float a1, float b0, float b1, int nc, float& y, float& lam, float invdiag, float lm) {
   if constexpr (I < MAXC) {
     if (I >= nc) return;
-    constexpr int IN = I + 2 < MAXC ? I + 2 : MAXC - 1;   // past the last contact: any readable row, never used
-    float n0 = Acol[MAXR * fric_lane(IN, 0)], n1 = Acol[MAXR * fric_lane(IN, 1)];
+    constexpr int IN = I + 2 < MAXC ? I + 2 : MAXC - 1;
+    float n0 = 0.0f, n1 = 0.0f;
+    if (I + 2 < nc) { n0 = Acol[MAXR * fric_lane(IN, 0)]; n1 = Acol[MAXR * fric_lane(IN, 1)]; }  // wave-uniform: rows of existing contacts only
     pgs_visit_friction<fric_lane(I, 0)>(a0 * invdiag, y, lam, lm);
     pgs_visit_friction<fric_lane(I, 1)>(a1 * invdiag, y, lam, lm);
     pin1(n0); pin1(n1);
@@ -1394,8 +1394,9 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   STAMP(6);
   wsync();  // all lanes are done with the ABA view: the A matrix may overwrite it
   // ---- Delassus matrix A = J M^-1 J^T, half of it computed, mirrored on store (delassus_dots / delassus_store)
-  // lanes >= MAXR own no row: they read column MAXR-1 of the dummy area instead of branching around each access
-  const int lc = lane < MAXR ? lane : MAXR - 1;
+  // A[dense row][dense column]: a lane's column is its dense row number; lanes without a row read column MAXR - 1 (any readable
+  // column would do) instead of branching around each access
+  const int lc = has_row ? dense : MAXR - 1;
   float diag;
   {
     float av[MAXR / 2 + 1];
@@ -1403,7 +1404,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
     delassus_dots<T, 0>(L, X, 28 * cc, 28 * nr, tmax, av);
     diag = has_row ? av[0] : 1.0f;
     wsync();  // every J row has been read: A may overwrite them
-    if (has_row) delassus_store<0>(L, cc, r, nr, tmax, r_fr, row_gap, av);
+    if (has_row) delassus_store<0>(L, cc, nr, tmax, av);
   }
   // a row with a vanishing Jacobian (out-of-plane friction of a planar mechanism's self contact) gets zero gain, as in
   // Bullet (jacDiagABInv = 0 below SIMD_EPSILON), instead of 0 * inf
@@ -1428,16 +1429,18 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   const int iters = uni(M->n_iters);
   const float lo0 = kind == 3 ? -1e30f : 0.0f;
   const float* Acol = L + L_A + lc;
+  const float* Acol_fr = Acol - MAXR * row_gap;   // friction visits name their rows by LANE (static): lane l holds dense row l - row_gap
   const int nrow_lane = is_fric ? nl + NFIX + ci : 0;   // lane of the normal row this friction row is bounded by
   float y = (bias - w) * invdiag;
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
     pgs_fixed_rows<0>(Acol, Acol[0], Acol[MAXR], Acol[2 * MAXR], Acol[3 * MAXR], r_fr, y, lam, invdiag, lo0);
     if (nc > 0) {  // wave-uniform
-      const float f0 = Acol[MAXR * fric_lane(0, 0)], f1 = Acol[MAXR * fric_lane(0, 1)];
-      const float g0 = Acol[MAXR * fric_lane(1, 0)], g1 = Acol[MAXR * fric_lane(1, 1)];
+      const float f0 = Acol_fr[MAXR * fric_lane(0, 0)], f1 = Acol_fr[MAXR * fric_lane(0, 1)];
+      float g0 = 0.0f, g1 = 0.0f;
+      if (nc > 1) { g0 = Acol_fr[MAXR * fric_lane(1, 0)]; g1 = Acol_fr[MAXR * fric_lane(1, 1)]; }
       const float lm = mu * __shfl(lam, nrow_lane, 64);
-      pgs_friction_rows<0>(Acol, f0, f1, g0, g1, nc, y, lam, invdiag, lm);
+      pgs_friction_rows<0>(Acol_fr, f0, f1, g0, g1, nc, y, lam, invdiag, lm);
     }
   }
   STAMP(8);
@@ -1445,7 +1448,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   wsync();
   if (has_row) {
 #pragma unroll
-    for (int d = 0; d < T::ND; ++d) L[L_XL + 28 * r + d] = X[d] * lam;
+    for (int d = 0; d < T::ND; ++d) L[L_XL + 28 * dense + d] = X[d] * lam;
   }
   if (lane < T::NSLOT) L[L_WARM + lane] = 0.0f;
   wsync();
@@ -1453,9 +1456,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   if (lane < T::ND) {
     float s = 0;
 #pragma unroll 1
-    for (int rr = 0; rr < r_fr; ++rr) s += L[L_XL + 28 * rr + lane];            // fixed-bound rows, then the friction lanes
-#pragma unroll 1
-    for (int rr = MAXR - 2 * nc; rr < MAXR; ++rr) s += L[L_XL + 28 * rr + lane];
+    for (int rr = 0; rr < nr; ++rr) s += L[L_XL + 28 * rr + lane];   // dense row order: fixed-bound rows, then the friction rows by lane
     L[L_NU + lane] += s;
   }
   wsync();
