@@ -567,23 +567,22 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
     pin1(arm); pin1(unet);                           // fetched with the level's other reads, not inside the store branch
     const float id = rcp(dsum + arm);
     const float u = unet - psum;
-    // all six U_j of the body on every lane of its 8-lane group, by DPP instead of an LDS round trip:
-    // quad broadcasts give the own quad's four values, a half-row mirror brings the other quad's
-    float U[6];
-    {
-      const float q0 = dpp_mov<0x00>(Ui), q1 = dpp_mov<0x55>(Ui), q2 = dpp_mov<0xAA>(Ui), q3 = dpp_mov<0xFF>(Ui);  // own quad lanes 0..3
-      const float Um = dpp_mov<0x141>(Ui);                                                                       // lane i <- lane 7-i
-      const float m0 = dpp_mov<0x00>(Um), m1 = dpp_mov<0x55>(Um), m2 = dpp_mov<0xAA>(Um), m3 = dpp_mov<0xFF>(Um);
-      // lanes 0-3 (first quad): own = U0..U3, mirrored quad holds (U7,U6,U5,U4) -> U4 = m3, U5 = m2
-      // lanes 4-7 (second quad): own = U4..U7, mirrored quad holds (U3,U2,U1,U0) -> U0 = m3, U1 = m2, U2 = m1, U3 = m0
-      const bool first = i < 4;
-      U[0] = first ? q0 : m3; U[1] = first ? q1 : m2; U[2] = first ? q2 : m1; U[3] = first ? q3 : m0;
-      U[4] = first ? m3 : q0; U[5] = first ? m2 : q1;
-    }
+    // row_i -= (U_i / D) U_j for the six columns j.  The six U_j are fetched by DPP, not through LDS: within the 8-lane group the
+    // first quad holds U0..U3 and the second U4..U7; a shift by four lanes inside the row of 16 brings the other quad's four
+    // values in ORDER, so LO / HI hold U0..U3 / U4..U7 on quad lanes 0..3 of EVERY lane, and column j is one fused multiply-add
+    // whose second factor is a quad broadcast of LO or HI (2 shifts + 2 selects + 6 broadcasts per level instead of 9 moves + 6 selects).
+    const float sh_dn = dpp_mov<0x114>(Ui);   // row_shr:4  lane l <- l - 4
+    const float sh_up = dpp_mov<0x104>(Ui);   // row_shl:4  lane l <- l + 4
+    const bool first = i < 4;
+    const float LO = first ? Ui : sh_dn, HI = first ? sh_up : Ui;
     const float uid = Ui * id;
     float Iac = 0.0f;
+    // (a hand-written v_fmac_f32_dpp per column saves the six quad-broadcast moves but needs its own s_nop for the DPP read hazard
+    // and measured the same: the compiler-scheduled form stays)
+    row[0] -= uid * dpp_mov<0x00>(LO); row[1] -= uid * dpp_mov<0x55>(LO); row[2] -= uid * dpp_mov<0xAA>(LO); row[3] -= uid * dpp_mov<0xFF>(LO);
+    row[4] -= uid * dpp_mov<0x00>(HI); row[5] -= uid * dpp_mov<0x55>(HI);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { row[j] -= uid * U[j]; Iac += row[j] * c[j]; }
+    for (int j = 0; j < 6; ++j) Iac += row[j] * c[j];
     const float pOut = pAi + Iac + uid * u;
     // is any body of this level consumed through LDS (its parent carries another child, or is the base)?
 #define MOCCA_VIA_LDS(sl) (T::clevel(d, sl) >= 0 && T::ccarry(T::parent(T::clevel(d, sl) >= 0 ? T::clevel(d, sl) : 0)) != T::clevel(d, sl))
@@ -597,12 +596,23 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
       L[L_U + 6 * bb + ii] = Ui;
       if (i == 0) { L[L_INVD + bb] = id; L[L_UU + bb] = u; }
     }
-    // what the slot hands to the next level in registers: its result if the body there carries it, else nothing
-    const bool fw = valid && (s == 0 ? !MOCCA_VIA_LDS(0) : s == 1 ? !MOCCA_VIA_LDS(1) : s == 2 ? !MOCCA_VIA_LDS(2) : !MOCCA_VIA_LDS(3));
-#undef MOCCA_VIA_LDS
+    // What the slot hands to the next level in registers: its result.  Only a slot whose NEXT-level body does not continue this
+    // level's chain (a chain that starts there, or this level's body is consumed through LDS) must hand over zeros, and which
+    // slots those are is known at compile time: most levels need no select at all.  (Lanes of a slot that stays empty, and the two
+    // idle lanes of a group, carry finite garbage that is never summed or stored.)
+#define MOCCA_NEEDZ(sl) (d > 1 && T::clevel(d - 1, sl) >= 0 && !(T::clevel(d, sl) >= 0 && !MOCCA_VIA_LDS(sl)))
+    if (MOCCA_NEEDZ(0) || MOCCA_NEEDZ(1) || MOCCA_NEEDZ(2) || MOCCA_NEEDZ(3)) {  // compile-time
+      const bool z = s == 0 ? MOCCA_NEEDZ(0) : s == 1 ? MOCCA_NEEDZ(1) : s == 2 ? MOCCA_NEEDZ(2) : MOCCA_NEEDZ(3);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) crow[j] = fw ? row[j] : 0.0f;
-    cpA = fw ? pOut : 0.0f;
+      for (int j = 0; j < 6; ++j) crow[j] = z ? 0.0f : row[j];
+      cpA = z ? 0.0f : pOut;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) crow[j] = row[j];
+      cpA = pOut;
+    }
+#undef MOCCA_NEEDZ
+#undef MOCCA_VIA_LDS
     if (store_m) wsync();
   }
   STAMP(10);
@@ -1382,8 +1392,9 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
 #pragma unroll
       for (int i = 0; i < 6; ++i) { S[i] = L2[L_S + 6 * b + i]; U[i] = L2[L_U + 6 * b + i]; }
       const int dpos = T::depth(b) - 1;  // (folds after unrolling) the body's position on every path that holds it
-      float ub = ((ma >> b) & 1u) ? pu[dpos] : 0.0f;
-      if (two_paths) ub += ((mb >> b) & 1u) ? pub[dpos] : 0.0f;
+      // pu[dpos] where the row's path holds b, else 0: bit b of the ancestor mask, sign-extended, ANDs the value (v_bfe_i32 + v_and)
+      float ub = __uint_as_float(__float_as_uint(pu[dpos]) & (unsigned)__builtin_amdgcn_sbfe((int)ma, b, 1));
+      if (two_paths) ub += __uint_as_float(__float_as_uint(pub[dpos]) & (unsigned)__builtin_amdgcn_sbfe((int)mb, b, 1));
       const float qdd = (ub - dot6(U, acc[p])) * L2[L_INVD + b];
       X[5 + b] = qdd;
 #pragma unroll
