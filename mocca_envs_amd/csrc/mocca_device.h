@@ -532,16 +532,28 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
   // own link data has static addresses and nothing on the chain waits for it.  Only children in another slot (the
   // second leg at the pelvis, the limbs at the base) travel through LDS.
   float crow[6] = {0, 0, 0, 0, 0, 0}, cpA = 0.0f;
+  // LDS offsets of the slot's body, carried from level to level: along a chain the body index drops by one per level, so most
+  // levels update the four offsets with one subtraction each instead of rebuilding them from a per-slot select (12 integer
+  // instructions per level).  Lanes of an empty slot point at body d (any existing body; they never store).
+  int bb = 0, o6 = 0, o6i = 0, o36 = 0;
 #pragma unroll
   for (int d = T::MAXD; d >= 1; --d) {
     // bodies of this level and their children are compile-time constants selected by the lane's slot
-    const int b = s == 0 ? T::clevel(d, 0) : s == 1 ? T::clevel(d, 1) : s == 2 ? T::clevel(d, 2) : s == 3 ? T::clevel(d, 3) : -1;
-    const bool valid = b >= 0 && i < 6;
-    const int bb = b >= 0 ? b : 0;
+#define MOCCA_CONT(sl) (T::clevel(d, sl) < 0 || (d < T::MAXD && T::clevel(d + 1 <= T::MAXD ? d + 1 : d, sl) == T::clevel(d, sl) + 1))
+    const bool sv = s == 0 ? T::clevel(d, 0) >= 0 : s == 1 ? T::clevel(d, 1) >= 0 : s == 2 ? T::clevel(d, 2) >= 0 : s == 3 ? T::clevel(d, 3) >= 0 : false;
+    const bool valid = sv && i < 6;
+    if (d < T::MAXD && MOCCA_CONT(0) && MOCCA_CONT(1) && MOCCA_CONT(2) && MOCCA_CONT(3)) {  // compile-time: every body of the level continues its slot's chain
+      bb -= 1; o6 -= 6; o6i -= 6; o36 -= 36;
+    } else {
+      const int b = s == 0 ? T::clevel(d, 0) : s == 1 ? T::clevel(d, 1) : s == 2 ? T::clevel(d, 2) : s == 3 ? T::clevel(d, 3) : -1;
+      bb = b >= 0 ? b : d;
+      o6 = 6 * bb; o6i = o6 + ii; o36 = 36 * bb + 6 * ii;
+    }
+#undef MOCCA_CONT
     float row[6], S[6], c[6], pAi;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { row[j] = L[L_M + 36 * bb + 6 * ii + j] + crow[j]; S[j] = L[L_S + 6 * bb + j]; c[j] = L[L_C + 6 * bb + j]; }
-    pAi = L[L_P + 6 * bb + ii] + cpA;
+    for (int j = 0; j < 6; ++j) { row[j] = L[L_M + o36 + j] + crow[j]; S[j] = L[L_S + o6 + j]; c[j] = L[L_C + o6 + j]; }
+    pAi = L[L_P + o6i] + cpA;
 #pragma unroll
     for (int k = 0; k < T::MAXCH; ++k) {
       // the k-th child of the slot's body, unless it is the carried one
@@ -559,7 +571,7 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
     // Branch-free on purpose: idle lanes (rows 6, 7 of a group, empty slots) run the same arithmetic on harmless data
     // and are kept out of the sums / the stores only.  Under `valid ? ... : 0` the compiler sank the LDS reads into
     // conditional blocks, each with its own wait, and nothing of the next level could be fetched ahead.
-    const float Si = i < 6 ? L[L_S + 6 * bb + ii] : 0.0f;  // the lane's own component of S (0 for the two idle lanes)
+    const float Si = i < 6 ? L[L_S + o6i] : 0.0f;  // the lane's own component of S (0 for the two idle lanes)
     const float Ui = dot6(row, S);
     const float dsum = group8_sum(Si * Ui);
     const float psum = group8_sum(Si * pAi);
@@ -590,10 +602,10 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
     if (valid) {
       if (store_m) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) L[L_M + 36 * bb + 6 * ii + j] = row[j];
-        L[L_P + 6 * bb + ii] = pOut;
+        for (int j = 0; j < 6; ++j) L[L_M + o36 + j] = row[j];
+        L[L_P + o6i] = pOut;
       }
-      L[L_U + 6 * bb + ii] = Ui;
+      L[L_U + o6i] = Ui;
       if (i == 0) { L[L_INVD + bb] = id; L[L_UU + bb] = u; }
     }
     // What the slot hands to the next level in registers: its result.  Only a slot whose NEXT-level body does not continue this
@@ -1445,13 +1457,17 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   float y = (bias - w) * invdiag;
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
-    pgs_fixed_rows<0>(Acol, Acol[0], Acol[MAXR], Acol[2 * MAXR], Acol[3 * MAXR], r_fr, y, lam, invdiag, lo0);
-    if (nc > 0) {  // wave-uniform
+    // the row counts are laundered per iteration: as loop invariants the optimiser hoisted every `RR >= r_fr` / `I >= nc` exit test of
+    // the unrolled visits out of the loop as a 64-bit lane mask each -- ~100 SGPRs, spilled to VGPR lanes and re-read per iteration
+    int rf = r_fr, ncc = nc;
+    asm volatile("" : "+s"(rf), "+s"(ncc));
+    pgs_fixed_rows<0>(Acol, Acol[0], Acol[MAXR], Acol[2 * MAXR], Acol[3 * MAXR], rf, y, lam, invdiag, lo0);
+    if (ncc > 0) {  // wave-uniform
       const float f0 = Acol_fr[MAXR * fric_lane(0, 0)], f1 = Acol_fr[MAXR * fric_lane(0, 1)];
       float g0 = 0.0f, g1 = 0.0f;
-      if (nc > 1) { g0 = Acol_fr[MAXR * fric_lane(1, 0)]; g1 = Acol_fr[MAXR * fric_lane(1, 1)]; }
+      if (ncc > 1) { g0 = Acol_fr[MAXR * fric_lane(1, 0)]; g1 = Acol_fr[MAXR * fric_lane(1, 1)]; }
       const float lm = mu * __shfl(lam, nrow_lane, 64);
-      pgs_friction_rows<0>(Acol_fr, f0, f1, g0, g1, nc, y, lam, invdiag, lm);
+      pgs_friction_rows<0>(Acol_fr, f0, f1, g0, g1, ncc, y, lam, invdiag, lm);
     }
   }
   STAMP(8);
