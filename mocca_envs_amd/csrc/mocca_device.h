@@ -88,10 +88,11 @@ enum : int {
   // ---- ABA view
   L_SQ = L_V + 0,       // [24] (free)
   L_CQ = L_V + 24,      // [24] (free)
-  L_S = L_V + 48,       // [NB][6] joint motion vectors about the base origin, world axes
-  L_U = L_V + 180,      // [NB][6] IA S
-  L_INVD = L_V + 312,   // [24] 1 / (S.U + armature)
-  L_UU = L_V + 336,     // [24] u = tau - S.pA
+  L_SV = L_V + 48,      // [NB][12] per body: S (6) joint motion vector about the base origin, world axes; V (6) = IA S / D.  One 48-byte
+                        //          record (three 16-byte reads) because every consumer wants both: an LDS instruction costs the CU's pipe
+                        //          ~3.5 cycles whatever its width, and that pipe is the busiest unit of the kernel
+  L_INVD = L_V + 312,   // [24] 1 / D,  D = S.(IA S) + armature
+  L_UU = L_V + 336,     // [24] u / D,  u = tau - S.pA
   L_A0 = L_V + 360,     // [24] Cholesky factor of IA0 (sym 21, see chol6_factor) ; [8] base spatial acceleration
   L_GP = L_V + 392,     // [NG][2][3] geom end points rel. base origin (136)
   L_CT = L_V + 528,     // [MAXC][16] contact records (192)
@@ -102,10 +103,11 @@ enum : int {
   L_M = L_V + 1168,     // [NB][36] link / articulated inertias, full 6x6 rows (lane = row in the inward pass)
   L_P = L_V + 1960,     // [NB][6]  bias forces
   L_ABA_END = L_V + 2092,
+  L_CAND = L_ABA_END,   // [MAX_PAIRS] u16 self-collision candidates (collide only: the slack the joint records 9.. used during the walk)
   // per-joint walk records, 16 floats each: [jrot * Rot(axis, q)](9) jpos(3) axis(3) qd(1).  Rebuilt by stage_joints()
   // before every walk; joints 1..8 sit where U will be written later in the substep (the walks run first), the rest
   // in the slack between the end of the ABA view and the end of the solver view.
-  L_JR0 = L_V + 180 - 16,           // record j in 1..8   at L_JR0 + 16 j   (= L_U .. L_U + 128)
+  L_JR0 = L_V + 180 - 16,           // record j in 1..8   at L_JR0 + 16 j   (the S / V records of bodies 11.., rewritten after the walk read these)
   L_JR1 = L_V + 2092 - 16 * 9,      // record j in 9..    at L_JR1 + 16 j
   // ---- solver view
   L_A = L_V,            // [MAXR][MAXR] Delassus matrix, row = updated row, column = lane
@@ -364,7 +366,7 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) L[L_R + 9 * bg + 3 * ri + i] = row[i];
       L[L_RR + 3 * bg + ri] = rr;
-      L[L_S + 6 * bg + ri] = row[0] * r3.x + row[1] * r3.y + row[2] * r3.z;  // world axis: Rot(axis, q) leaves the axis in place
+      L[L_SV + 12 * bg + ri] = row[0] * r3.x + row[1] * r3.y + row[2] * r3.z;  // world axis: Rot(axis, q) leaves the axis in place
     }
     if (lane == 63) {
 #pragma unroll
@@ -382,10 +384,10 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
   for (int i = 0; i < 3; ++i) r[i] = L[L_RR + 3 * b + i];
   if (FULL) {
     if (lane >= 1 && lane < T::NB) {
-      float a[3] = {L[L_S + 6 * b], L[L_S + 6 * b + 1], L[L_S + 6 * b + 2]}, ra[3];
+      float a[3] = {L[L_SV + 12 * b], L[L_SV + 12 * b + 1], L[L_SV + 12 * b + 2]}, ra[3];
       cross3(r, a, ra);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { S[i] = a[i]; S[3 + i] = ra[i]; L[L_S + 6 * b + 3 + i] = ra[i]; }
+      for (int i = 0; i < 3; ++i) { S[i] = a[i]; S[3 + i] = ra[i]; L[L_SV + 12 * b + 3 + i] = ra[i]; }
     }
     wsync();
 #pragma unroll
@@ -396,7 +398,7 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
       if (j != 31 && j != b) {  // ancestors; the body's own joint follows below
         const float qd = L[L_QD + j];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) v[i] += L[L_S + 6 * j + i] * qd;
+        for (int i = 0; i < 6; ++i) v[i] += L[L_SV + 12 * j + i] * qd;
       }
     }
     if (lane >= 1 && lane < T::NB) {
@@ -535,7 +537,7 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
   // LDS offsets of the slot's body, carried from level to level: along a chain the body index drops by one per level, so most
   // levels update the four offsets with one subtraction each instead of rebuilding them from a per-slot select (12 integer
   // instructions per level).  Lanes of an empty slot point at body d (any existing body; they never store).
-  int bb = 0, o6 = 0, o6i = 0, o36 = 0;
+  int bb = 0, o6 = 0, o6i = 0, o36 = 0, o12 = 0, o12i = 0;
 #pragma unroll
   for (int d = T::MAXD; d >= 1; --d) {
     // bodies of this level and their children are compile-time constants selected by the lane's slot
@@ -543,16 +545,16 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
     const bool sv = s == 0 ? T::clevel(d, 0) >= 0 : s == 1 ? T::clevel(d, 1) >= 0 : s == 2 ? T::clevel(d, 2) >= 0 : s == 3 ? T::clevel(d, 3) >= 0 : false;
     const bool valid = sv && i < 6;
     if (d < T::MAXD && MOCCA_CONT(0) && MOCCA_CONT(1) && MOCCA_CONT(2) && MOCCA_CONT(3)) {  // compile-time: every body of the level continues its slot's chain
-      bb -= 1; o6 -= 6; o6i -= 6; o36 -= 36;
+      bb -= 1; o6 -= 6; o6i -= 6; o36 -= 36; o12 -= 12; o12i -= 12;
     } else {
       const int b = s == 0 ? T::clevel(d, 0) : s == 1 ? T::clevel(d, 1) : s == 2 ? T::clevel(d, 2) : s == 3 ? T::clevel(d, 3) : -1;
       bb = b >= 0 ? b : d;
-      o6 = 6 * bb; o6i = o6 + ii; o36 = 36 * bb + 6 * ii;
+      o6 = 6 * bb; o6i = o6 + ii; o36 = 36 * bb + 6 * ii; o12 = 12 * bb; o12i = o12 + ii;
     }
 #undef MOCCA_CONT
     float row[6], S[6], c[6], pAi;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { row[j] = L[L_M + o36 + j] + crow[j]; S[j] = L[L_S + o6 + j]; c[j] = L[L_C + o6 + j]; }
+    for (int j = 0; j < 6; ++j) { row[j] = L[L_M + o36 + j] + crow[j]; S[j] = L[L_SV + o12 + j]; c[j] = L[L_C + o6 + j]; }
     pAi = L[L_P + o6i] + cpA;
 #pragma unroll
     for (int k = 0; k < T::MAXCH; ++k) {
@@ -571,7 +573,7 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
     // Branch-free on purpose: idle lanes (rows 6, 7 of a group, empty slots) run the same arithmetic on harmless data
     // and are kept out of the sums / the stores only.  Under `valid ? ... : 0` the compiler sank the LDS reads into
     // conditional blocks, each with its own wait, and nothing of the next level could be fetched ahead.
-    const float Si = i < 6 ? L[L_S + o6i] : 0.0f;  // the lane's own component of S (0 for the two idle lanes)
+    const float Si = i < 6 ? L[L_SV + o12i] : 0.0f;  // the lane's own component of S (0 for the two idle lanes)
     const float Ui = dot6(row, S);
     const float dsum = group8_sum(Si * Ui);
     const float psum = group8_sum(Si * pAi);
@@ -605,8 +607,8 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
         for (int j = 0; j < 6; ++j) L[L_M + o36 + j] = row[j];
         L[L_P + o6i] = pOut;
       }
-      L[L_U + o6i] = Ui;
-      if (i == 0) { L[L_INVD + bb] = id; L[L_UU + bb] = u; }
+      L[L_SV + o12i + 6] = uid;   // V_i = U_i / D: what the outward passes and the row sweeps multiply by
+      if (i == 0) { L[L_INVD + bb] = id; L[L_UU + bb] = u * id; }
     }
     // What the slot hands to the next level in registers: its result.  Only a slot whose NEXT-level body does not continue this
     // level's chain (a chain that starts there, or this level's body is consumed through LDS) must hand over zeros, and which
@@ -673,8 +675,8 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
       if (j != 31) {
         float U[6], S[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { a[i] += L[L_C + 6 * j + i]; U[i] = L[L_U + 6 * j + i]; S[i] = L[L_S + 6 * j + i]; }
-        qdd = (L[L_UU + j] - dot6(U, a)) * L[L_INVD + j];
+        for (int i = 0; i < 6; ++i) { a[i] += L[L_C + 6 * j + i]; U[i] = L[L_SV + 12 * j + 6 + i]; S[i] = L[L_SV + 12 * j + i]; }
+        qdd = L[L_UU + j] - dot6(U, a);   // u / D - (U / D) . a
 #pragma unroll
         for (int i = 0; i < 6; ++i) a[i] += S[i] * qdd;
       }
@@ -945,8 +947,8 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
   // survivors are compacted in pair order into a 16-bit list (the U area is not written until the ABA runs).
   // pass 2: narrow phase over the survivors only -- typically one batch of 64 instead of ceil(n_pairs / 64).
   const int npairs = uni(M->n_pairs);
-  unsigned short* cand = reinterpret_cast<unsigned short*>(L + L_U);
-  static_assert(2 * (L_INVD - L_U) >= MOCCA_MAX_PAIRS, "candidate list must hold every pair");
+  unsigned short* cand = reinterpret_cast<unsigned short*>(L + L_CAND);
+  static_assert(2 * (L_TOTAL - L_CAND) >= MOCCA_MAX_PAIRS, "candidate list must hold every pair");
   int ncand = 0;
 #pragma unroll 1
   for (int base = 0; base < npairs; base += 64) {
@@ -1302,7 +1304,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   float pa[6] = {0, 0, 0, 0, 0, 0}, pb[6] = {0, 0, 0, 0, 0, 0};
   // Inward sweep ALONG THE ROW'S OWN PATH: a row only loads the bodies between its body and the base (<= MAXD of them), so
   // the sweep visits path positions, not bodies -- each lane reads the S / U / 1/D of ITS body at that depth (at most MAXW
-  // distinct addresses per position: the other lanes' reads are broadcasts).  The innovation u_k = J_k - S_k . p stays in a
+  // distinct addresses per position: the other lanes' reads are broadcasts).  The innovation u_k = J_k - S_k . p (over D) stays in a
   // register indexed by the path POSITION (static), and the outward sweep -- which is unrolled over bodies -- picks
   // position depth(b) - 1 for the rows whose path holds b.  (A loop over all bodies with wave-uniform skips cost 21 steps for
   // the walker, and a merged two-path variant twice the arithmetic per step.)
@@ -1330,17 +1332,16 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
     const int jj = valid ? j : 0;
     float S[6], U[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { S[i] = L[L_S + 6 * jj + i]; U[i] = L[L_U + 6 * jj + i]; }
+    for (int i = 0; i < 6; ++i) { S[i] = L[L_SV + 12 * jj + i]; U[i] = L[L_SV + 12 * jj + 6 + i]; }
     float jb = dot6(S, F);
     if (jj == jl) jb = sgn;
     jb = valid ? jb : 0.0f;
     const float uu = valid ? jb - dot6(S, pa) : 0.0f;
-    const float sc = uu * L[L_INVD + jj];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) pa[i] += U[i] * sc;  // sc == 0 past the end of the path
+    for (int i = 0; i < 6; ++i) pa[i] += U[i] * uu;  // U holds V = IA S / D; uu == 0 past the end of the path
     if (valid) Jrow[5 + jj] = jb;
     w += jb * L[L_NU + 5 + jj];
-    pu[k] = uu;
+    pu[k] = uu * L[L_INVD + jj];   // what the outward sweep starts from: u / D
     pin6(pa); pin1(pu[k]); pin1(w);
   }
   if (two_paths) {
@@ -1354,15 +1355,14 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
       const int jj = valid ? j : 0;
       float S[6], U[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) { S[i] = L[L_S + 6 * jj + i]; U[i] = L[L_U + 6 * jj + i]; }
+      for (int i = 0; i < 6; ++i) { S[i] = L[L_SV + 12 * jj + i]; U[i] = L[L_SV + 12 * jj + 6 + i]; }
       const float jb = valid ? -dot6(S, F2) : 0.0f;   // the force on the second body is -F2
       const float uu = valid ? jb - dot6(S, pb) : 0.0f;
-      const float sc = uu * L[L_INVD + jj];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) pb[i] += U[i] * sc;
+      for (int i = 0; i < 6; ++i) pb[i] += U[i] * uu;
       if (valid) Jrow[5 + jj] += jb;                  // common ancestors carry both paths' entries
       w += jb * L[L_NU + 5 + jj];
-      pub[k] = uu;
+      pub[k] = uu * L[L_INVD + jj];
       pin6(pb); pin1(pub[k]); pin1(w);
     }
   } else {
@@ -1402,12 +1402,12 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
       const int p = T::parent(b);
       float S[6], U[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) { S[i] = L2[L_S + 6 * b + i]; U[i] = L2[L_U + 6 * b + i]; }
+      for (int i = 0; i < 6; ++i) { S[i] = L2[L_SV + 12 * b + i]; U[i] = L2[L_SV + 12 * b + 6 + i]; }   // U = V = IA S / D
       const int dpos = T::depth(b) - 1;  // (folds after unrolling) the body's position on every path that holds it
       // pu[dpos] where the row's path holds b, else 0: bit b of the ancestor mask, sign-extended, ANDs the value (v_bfe_i32 + v_and)
       float ub = __uint_as_float(__float_as_uint(pu[dpos]) & (unsigned)__builtin_amdgcn_sbfe((int)ma, b, 1));
       if (two_paths) ub += __uint_as_float(__float_as_uint(pub[dpos]) & (unsigned)__builtin_amdgcn_sbfe((int)mb, b, 1));
-      const float qdd = (ub - dot6(U, acc[p])) * L2[L_INVD + b];
+      const float qdd = ub - dot6(U, acc[p]);   // u / D - (IA S / D) . a_parent
       X[5 + b] = qdd;
 #pragma unroll
       for (int i = 0; i < 6; ++i) acc[b][i] = acc[p][i] + S[i] * qdd;
