@@ -97,8 +97,8 @@ enum : int {
   L_GP = L_V + 392,     // [NG][2][3] geom end points rel. base origin (136)
   L_CT = L_V + 528,     // [MAXC][16] contact records (192)
   L_ROWD = L_V + 720,   // [48] compacted limit-row candidates (int)
-  L_R = L_V + 768,      // [NB][9]
-  L_RR = L_V + 968,     // [NB][3]
+  L_RT = L_V + 768,     // [NB][3][4] body frames: row i of the rotation (3) + component i of the origin rel. the base origin: one 16-byte
+                        //            write per (body, row) lane of the walk, three 16-byte reads per consumer
   L_C = L_V + 1036,     // [NB][6]
   L_M = L_V + 1168,     // [NB][36] link / articulated inertias, full 6x6 rows (lane = row in the inward pass)
   L_P = L_V + 1960,     // [NB][6]  bias forces
@@ -122,7 +122,7 @@ static_assert(L_J % 4 == 0 && L_V % 4 == 0, "16-byte alignment of broadcast rows
 static_assert(MAXR % 2 == 0 && 3 * MAXC <= MAXR, "friction rows sit on the top 2 MAXC lanes of the row range, odd lane = second tangent");
 static_assert(L_PLANK + 12 * MOCCA_MAX_PLANKS <= L_V && L_Q0 + 16 <= L_V, "persistent region overflows into the two-view region");
 static_assert(L_TOTAL * 4 <= 10240, "more than 10 KB of LDS per wave: fewer than 16 waves per CU, the 4096-env batch no longer fits one round");
-static_assert(L_J >= L_R, "J rows may be written while S, U, 1/D, the factor of IA0 and the contacts are still being read");
+static_assert(L_J >= L_RT, "J rows may be written while S, U, 1/D, the factor of IA0 and the contacts are still being read");
 
 // contact record fields
 enum : int { C_BA = 0, C_BB = 1, C_SLOT = 2, C_P = 3, C_N = 6, C_DEPTH = 9, C_MU = 10, C_ERP = 11, C_CFM = 12, C_MA = 13, C_MB = 14 };
@@ -363,25 +363,22 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
     }
     if (bg > 0) {
       const float4 r3 = reinterpret_cast<const float4*>(L + (bg <= 8 ? L_JR0 : L_JR1) + 16 * bg)[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) L[L_R + 9 * bg + 3 * ri + i] = row[i];
-      L[L_RR + 3 * bg + ri] = rr;
+      *reinterpret_cast<float4*>(L + L_RT + 12 * bg + 4 * ri) = make_float4(row[0], row[1], row[2], rr);
       L[L_SV + 12 * bg + ri] = row[0] * r3.x + row[1] * r3.y + row[2] * r3.z;  // world axis: Rot(axis, q) leaves the axis in place
     }
     if (lane == 63) {
 #pragma unroll
-      for (int i = 0; i < 9; ++i) L[L_R + i] = Rb[i];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) L[L_RR + i] = 0.0f;
+      for (int i = 0; i < 3; ++i) *reinterpret_cast<float4*>(L + L_RT + 4 * i) = make_float4(Rb[3 * i], Rb[3 * i + 1], Rb[3 * i + 2], 0.0f);
     }
   }
   wsync();
   // ---- phase 2
   float R[9], r[3], v[6], S[6] = {0, 0, 0, 0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-  for (int i = 0; i < 9; ++i) R[i] = L[L_R + 9 * b + i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) r[i] = L[L_RR + 3 * b + i];
+  for (int i = 0; i < 3; ++i) {
+    const float4 t = *reinterpret_cast<const float4*>(L + L_RT + 12 * b + 4 * i);
+    R[3 * i] = t.x; R[3 * i + 1] = t.y; R[3 * i + 2] = t.z; r[i] = t.w;
+  }
   if (FULL) {
     if (lane >= 1 && lane < T::NB) {
       float a[3] = {L[L_SV + 12 * b], L[L_SV + 12 * b + 1], L[L_SV + 12 * b + 2]}, ra[3];
@@ -805,12 +802,12 @@ DI void geom_points(ModelP M, float* L, int lane) {
   if (lane < 2 * T::NG) {
     const f4_t t = *(CF4P)(M->gp_tab[lane]);  // point (body frame) + body id, one load
     const int b = __float_as_int(t.w);
-    float pl[3] = {t.x, t.y, t.z}, R[9], pw[3];
+    const float pl[3] = {t.x, t.y, t.z};
 #pragma unroll
-    for (int i = 0; i < 9; ++i) R[i] = L[L_R + 9 * b + i];
-    matvec3(R, pl, pw);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) L[L_GP + 3 * lane + i] = pw[i] + L[L_RR + 3 * b + i];
+    for (int i = 0; i < 3; ++i) {
+      const float4 fr = *reinterpret_cast<const float4*>(L + L_RT + 12 * b + 4 * i);   // row i of the rotation, origin component i
+      L[L_GP + 3 * lane + i] = fr.x * pl[0] + fr.y * pl[1] + fr.z * pl[2] + fr.w;
+    }
   }
 }
 
@@ -1230,12 +1227,12 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
     kind = 3;
     float Pa[3], Pb[3], Ra[9], Rb[9], la[3], lb[3];
 #pragma unroll
-    for (int x = 0; x < 9; ++x) { Ra[x] = L[L_R + 9 * ba + x]; Rb[x] = L[L_R + 9 * bb + x]; }
+    for (int x = 0; x < 9; ++x) { Ra[x] = L[L_RT + 12 * ba + 4 * (x / 3) + x % 3]; Rb[x] = L[L_RT + 12 * bb + 4 * (x / 3) + x % 3]; }
 #pragma unroll
     for (int x = 0; x < 3; ++x) { la[x] = M->cl_point_a[c][x]; lb[x] = M->cl_point_b[c][x]; }
     matvec3(Ra, la, Pa); matvec3(Rb, lb, Pb);
 #pragma unroll
-    for (int x = 0; x < 3; ++x) { Pa[x] += L[L_RR + 3 * ba + x]; Pb[x] += L[L_RR + 3 * bb + x]; }
+    for (int x = 0; x < 3; ++x) { Pa[x] += L[L_RT + 12 * ba + 4 * x + 3]; Pb[x] += L[L_RT + 12 * bb + 4 * x + 3]; }
     float dir[3] = {ax == 0 ? 1.0f : 0.0f, ax == 1 ? 1.0f : 0.0f, ax == 2 ? 1.0f : 0.0f}, pn[3];
     cross3(Pa, dir, pn);
 #pragma unroll
@@ -1253,7 +1250,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
     kind = 3; ba = 0; bb = -1;
 #pragma unroll
     for (int x = 0; x < 6; ++x) F[x] = x == comp ? 1.0f : 0.0f;
-    const float err = k == 0 ? L[L_R + 7] : (k == 1 ? -L[L_R + 1] : L[L_BASE + 1] - M->init_pos[1]);
+    const float err = k == 0 ? L[L_RT + 9] /* R[2][1] */ : (k == 1 ? -L[L_RT + 1] /* R[0][1] */ : L[L_BASE + 1] - M->init_pos[1]);
     bias = -M->erp * err * idt;
   } else if (has_row) {
     const float* ct = L + L_CT + 16 * ci;
