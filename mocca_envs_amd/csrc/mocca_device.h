@@ -1098,26 +1098,33 @@ DI void pgs_visit_friction(float as, float& y, float& lam, float lm) {
 // commit and per-contact bound look-ups) cost ~135 cycles per visit (tools/pgs_chain_bench.hip) -- most of the solver time of
 // the contact-rich waves that set the launch time.
 constexpr int fric_lane(int i, int s) { return MAXR - 2 - 2 * i + s; }
+// The solver re-reads the same column of A in each of its iterations.  The gains of the first PGS_REG_ROWS fixed-bound rows and of
+// the first PGS_REG_CONTACTS contacts' friction rows -- already multiplied by the lane's 1 / (A_cc + cfm) -- are fetched ONCE per
+// substep into registers (static indices: the visits are unrolled); a typical env (12 rows) then runs its five iterations without a
+// single LDS read, and a visit loses its multiply.  Rows past the window keep the per-iteration LDS reads, requested a group ahead.
+constexpr int PGS_REG_ROWS = 16, PGS_REG_CONTACTS = 4;
 template <int I>
-DI void pgs_friction_rows(const float* Acol, float a0, float a1, float b0, float b1, int nc, float& y, float& lam, float invdiag, float lm) {
+DI void pgs_friction_rows(const float* Acol, const float* af, float a0, float a1, float b0, float b1, int nc, float& y, float& lam, float invdiag, float lm) {
   if constexpr (I < MAXC) {
     if (I >= nc) return;
     constexpr int IN = I + 2 < MAXC ? I + 2 : MAXC - 1;
     float n0 = 0.0f, n1 = 0.0f;
-    if (I + 2 < nc) { n0 = Acol[MAXR * fric_lane(IN, 0)]; n1 = Acol[MAXR * fric_lane(IN, 1)]; }  // wave-uniform: rows of existing contacts only
-    pgs_visit_friction<fric_lane(I, 0)>(a0 * invdiag, y, lam, lm);
-    pgs_visit_friction<fric_lane(I, 1)>(a1 * invdiag, y, lam, lm);
+    if constexpr (I + 2 >= PGS_REG_CONTACTS) {
+      if (I + 2 < nc) { n0 = Acol[MAXR * fric_lane(IN, 0)]; n1 = Acol[MAXR * fric_lane(IN, 1)]; }  // wave-uniform: rows of existing contacts only
+    }
+    pgs_visit_friction<fric_lane(I, 0)>(I < PGS_REG_CONTACTS ? af[2 * (I < PGS_REG_CONTACTS ? I : 0)] : a0 * invdiag, y, lam, lm);
+    pgs_visit_friction<fric_lane(I, 1)>(I < PGS_REG_CONTACTS ? af[2 * (I < PGS_REG_CONTACTS ? I : 0) + 1] : a1 * invdiag, y, lam, lm);
     pin1(n0); pin1(n1);
-    pgs_friction_rows<I + 1>(Acol, b0, b1, n0, n1, nc, y, lam, invdiag, lm);
+    pgs_friction_rows<I + 1>(Acol, af, b0, b1, n0, n1, nc, y, lam, invdiag, lm);
   }
 }
 // fewer than four fixed-bound rows left: one uniform exit test per visit
 template <int RR, int LEFT>
-DI void pgs_fixed_tail(float a0, float a1, float a2, int r_fr, float& y, float& lam, float invdiag, float lo0) {
+DI void pgs_fixed_tail(const float* ar, float a0, float a1, float a2, int r_fr, float& y, float& lam, float invdiag, float lo0) {
   if constexpr (RR < MAXR && LEFT > 0) {
     if (RR >= r_fr) return;
-    pgs_visit<RR>(a0 * invdiag, y, lam, lo0);
-    pgs_fixed_tail<RR + 1, LEFT - 1>(a1, a2, 0.0f, r_fr, y, lam, invdiag, lo0);
+    pgs_visit<RR>(RR < PGS_REG_ROWS ? ar[RR < PGS_REG_ROWS ? RR : 0] : a0 * invdiag, y, lam, lo0);
+    pgs_fixed_tail<RR + 1, LEFT - 1>(ar, a1, a2, 0.0f, r_fr, y, lam, invdiag, lo0);
   }
 }
 // Fixed-bound rows are visited in GROUPS OF FOUR (compile-time recursion = guaranteed unrolling; readlane / writelane indices and
@@ -1125,23 +1132,26 @@ DI void pgs_fixed_tail(float a0, float a1, float a2, int r_fr, float& y, float& 
 // requested from LDS before this group's visits start -- a visit is ~30 cycles of dependent issue, an LDS round trip is more than
 // two of them, so the former two-visits-ahead prefetch left every visit waiting.  The last one to three rows take pgs_fixed_tail.
 template <int RR>
-DI void pgs_fixed_rows(const float* Acol, float a0, float a1, float a2, float a3, int r_fr, float& y, float& lam, float invdiag, float lo0) {
+DI void pgs_fixed_rows(const float* Acol, const float* ar, float a0, float a1, float a2, float a3, int r_fr, float& y, float& lam, float invdiag, float lo0) {
   if constexpr (RR + 4 <= MAXR) {
     if (RR + 4 <= r_fr) {
       constexpr int R4 = RR + 4 < MAXR ? RR + 4 : MAXR - 1, R5 = RR + 5 < MAXR ? RR + 5 : MAXR - 1;   // past the last row: any
       constexpr int R6 = RR + 6 < MAXR ? RR + 6 : MAXR - 1, R7 = RR + 7 < MAXR ? RR + 7 : MAXR - 1;   // readable row, never used
-      float n0 = Acol[MAXR * R4], n1 = Acol[MAXR * R5], n2 = Acol[MAXR * R6], n3 = Acol[MAXR * R7];
-      pgs_visit<RR>(a0 * invdiag, y, lam, lo0);
-      pgs_visit<RR + 1>(a1 * invdiag, y, lam, lo0);
-      pgs_visit<RR + 2>(a2 * invdiag, y, lam, lo0);
-      pgs_visit<RR + 3>(a3 * invdiag, y, lam, lo0);
+      float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, n3 = 0.0f;
+      if constexpr (RR + 4 >= PGS_REG_ROWS) { n0 = Acol[MAXR * R4]; n1 = Acol[MAXR * R5]; n2 = Acol[MAXR * R6]; n3 = Acol[MAXR * R7]; }
+      constexpr bool reg = RR + 3 < PGS_REG_ROWS;   // PGS_REG_ROWS is a multiple of four: a group is all-register or all-LDS
+      pgs_visit<RR>(reg ? ar[reg ? RR : 0] : a0 * invdiag, y, lam, lo0);
+      pgs_visit<RR + 1>(reg ? ar[reg ? RR + 1 : 0] : a1 * invdiag, y, lam, lo0);
+      pgs_visit<RR + 2>(reg ? ar[reg ? RR + 2 : 0] : a2 * invdiag, y, lam, lo0);
+      pgs_visit<RR + 3>(reg ? ar[reg ? RR + 3 : 0] : a3 * invdiag, y, lam, lo0);
       pin1(n0); pin1(n1); pin1(n2); pin1(n3);   // keeps the optimiser from sinking the reads into the group that uses them
-      pgs_fixed_rows<RR + 4>(Acol, n0, n1, n2, n3, r_fr, y, lam, invdiag, lo0);
+      pgs_fixed_rows<RR + 4>(Acol, ar, n0, n1, n2, n3, r_fr, y, lam, invdiag, lo0);
       return;
     }
   }
-  pgs_fixed_tail<RR, 3>(a0, a1, a2, r_fr, y, lam, invdiag, lo0);
+  pgs_fixed_tail<RR, 3>(ar, a0, a1, a2, r_fr, y, lam, invdiag, lo0);
 }
+static_assert(PGS_REG_ROWS % 4 == 0 && PGS_REG_ROWS <= MAXR && PGS_REG_CONTACTS <= MAXC, "register window of the solver");
 
 // ------------------------------------------------------------------ constraint rows + PGS
 // lane = row.  See oracle solve_constraints() for the reference formulation.
@@ -1452,19 +1462,28 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   const float* Acol_fr = Acol - MAXR * row_gap;   // friction visits name their rows by LANE (static): lane l holds dense row l - row_gap
   const int nrow_lane = is_fric ? nl + NFIX + ci : 0;   // lane of the normal row this friction row is bounded by
   float y = (bias - w) * invdiag;
+  // this lane's gains of the first rows, scaled once (pgs_fixed_rows / pgs_friction_rows); rows that do not exist give unused values
+  float ar[PGS_REG_ROWS], af[2 * PGS_REG_CONTACTS];
+#pragma unroll
+  for (int k = 0; k < PGS_REG_ROWS; ++k) ar[k] = Acol[MAXR * k] * invdiag;
+#pragma unroll
+  for (int k = 0; k < PGS_REG_CONTACTS; ++k) {
+    af[2 * k] = 0.0f; af[2 * k + 1] = 0.0f;
+    if (k < nc) { af[2 * k] = Acol_fr[MAXR * fric_lane(k, 0)] * invdiag; af[2 * k + 1] = Acol_fr[MAXR * fric_lane(k, 1)] * invdiag; }  // wave-uniform
+  }
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
     // the row counts are laundered per iteration: as loop invariants the optimiser hoisted every `RR >= r_fr` / `I >= nc` exit test of
     // the unrolled visits out of the loop as a 64-bit lane mask each -- ~100 SGPRs, spilled to VGPR lanes and re-read per iteration
     int rf = r_fr, ncc = nc;
     asm volatile("" : "+s"(rf), "+s"(ncc));
-    pgs_fixed_rows<0>(Acol, Acol[0], Acol[MAXR], Acol[2 * MAXR], Acol[3 * MAXR], rf, y, lam, invdiag, lo0);
+    pgs_fixed_rows<0>(Acol, ar, 0.0f, 0.0f, 0.0f, 0.0f, rf, y, lam, invdiag, lo0);
     if (ncc > 0) {  // wave-uniform
-      const float f0 = Acol_fr[MAXR * fric_lane(0, 0)], f1 = Acol_fr[MAXR * fric_lane(0, 1)];
-      float g0 = 0.0f, g1 = 0.0f;
-      if (ncc > 1) { g0 = Acol_fr[MAXR * fric_lane(1, 0)]; g1 = Acol_fr[MAXR * fric_lane(1, 1)]; }
+      float f0 = 0.0f, f1 = 0.0f, g0 = 0.0f, g1 = 0.0f;
+      if (PGS_REG_CONTACTS < 1) { f0 = Acol_fr[MAXR * fric_lane(0, 0)]; f1 = Acol_fr[MAXR * fric_lane(0, 1)]; }
+      if (PGS_REG_CONTACTS < 2 && ncc > 1) { g0 = Acol_fr[MAXR * fric_lane(1, 0)]; g1 = Acol_fr[MAXR * fric_lane(1, 1)]; }
       const float lm = mu * __shfl(lam, nrow_lane, 64);
-      pgs_friction_rows<0>(Acol_fr, f0, f1, g0, g1, ncc, y, lam, invdiag, lm);
+      pgs_friction_rows<0>(Acol_fr, af, f0, f1, g0, g1, ncc, y, lam, invdiag, lm);
     }
   }
   STAMP(8);
