@@ -86,8 +86,7 @@ enum : int {
   L_Q0 = 184,     // [16] Cassie: joint angles at the start of the env.step (finite-difference jvel, :467-468)
   L_V = 216,
   // ---- ABA view
-  L_SQ = L_V + 0,       // [24] (free)
-  L_CQ = L_V + 24,      // [24] (free)
+  L_B0 = L_V + 0,       // [6][8] base: rows of its articulated inertia + bias component (ABA base solve)
   L_SV = L_V + 48,      // [NB][12] per body: S (6) joint motion vector about the base origin, world axes; V (6) = IA S / D.  One 48-byte
                         //          record (three 16-byte reads) because every consumer wants both: an LDS instruction costs the CU's pipe
                         //          ~3.5 cycles whatever its width, and that pipe is the busiest unit of the kernel
@@ -627,26 +626,36 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
     if (store_m) wsync();
   }
   STAMP(10);
-  // base: every lane computes the same 6x6 solve (uniform data, broadcast LDS reads)
+  // base: the six lanes of the first group each add up ONE ROW of the base's articulated inertia (own link + the children, which all
+  // arrive through LDS) and its bias component, park row + bias as eight floats, and every lane reads the 6 x 8 block back for the
+  // (redundant, wave-uniform) 6x6 solve: 12 + 2 + 12 LDS instructions instead of a 51-instruction gather of four upper triangles.
   {
-    float IA[21], pA[6];
+    float rowb[6], pb_ = L[L_P + ii];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = i; j < 6; ++j) IA[sym(i, j)] = L[L_M + 6 * i + j];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) pA[i] = L[L_P + i];
+    for (int j = 0; j < 6; ++j) rowb[j] = L[L_M + 6 * ii + j];
 #pragma unroll
     for (int k = 0; k < T::MAXCH; ++k) {
-      const int ch = T::child(0, k);
+      const int ch = T::cchild(0, k);
       if (ch >= 0) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-          for (int j = i; j < 6; ++j) IA[sym(i, j)] += L[L_M + 36 * ch + 6 * i + j];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) pA[i] += L[L_P + 6 * ch + i];
+        for (int j = 0; j < 6; ++j) rowb[j] += L[L_M + 36 * ch + 6 * ii + j];
+        pb_ += L[L_P + 6 * ch + ii];
       }
+    }
+    if (lane < 6) {
+      float4* dst = reinterpret_cast<float4*>(L + L_B0 + 8 * lane);
+      dst[0] = make_float4(rowb[0], rowb[1], rowb[2], rowb[3]);
+      dst[1] = make_float4(rowb[4], rowb[5], pb_, 0.0f);
+    }
+    wsync();
+    float IA[21], pA[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const float4 lo = *reinterpret_cast<const float4*>(L + L_B0 + 8 * i), hi = *reinterpret_cast<const float4*>(L + L_B0 + 8 * i + 4);
+      const float rr_[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+#pragma unroll
+      for (int j = i; j < 6; ++j) IA[sym(i, j)] = rr_[j];
+      pA[i] = hi.z;
     }
     float Ai[21], a0[6];
     chol6_factor(IA, Ai);
@@ -1102,7 +1111,11 @@ constexpr int fric_lane(int i, int s) { return MAXR - 2 - 2 * i + s; }
 // the first PGS_REG_CONTACTS contacts' friction rows -- already multiplied by the lane's 1 / (A_cc + cfm) -- are fetched ONCE per
 // substep into registers (static indices: the visits are unrolled); a typical env (12 rows) then runs its five iterations without a
 // single LDS read, and a visit loses its multiply.  Rows past the window keep the per-iteration LDS reads, requested a group ahead.
-constexpr int PGS_REG_ROWS = 16, PGS_REG_CONTACTS = 4;
+#ifndef MOCCA_PGS_REG_ROWS   // window sizes (tools/flag_sweep.sh)
+#define MOCCA_PGS_REG_ROWS 16
+#define MOCCA_PGS_REG_CONTACTS 4
+#endif
+constexpr int PGS_REG_ROWS = MOCCA_PGS_REG_ROWS, PGS_REG_CONTACTS = MOCCA_PGS_REG_CONTACTS;
 template <int I>
 DI void pgs_friction_rows(const float* Acol, const float* af, float a0, float a1, float b0, float b1, int nc, float& y, float& lam, float invdiag, float lm) {
   if constexpr (I < MAXC) {
