@@ -87,21 +87,22 @@ enum : int {
   L_V = 216,
   // ---- ABA view
   L_B0 = L_V + 0,       // [6][8] base: rows of its articulated inertia + bias component (ABA base solve)
-  L_SV = L_V + 48,      // [NB][12] per body: S (6) joint motion vector about the base origin, world axes; V (6) = IA S / D.  One 48-byte
-                        //          record (three 16-byte reads) because every consumer wants both: an LDS instruction costs the CU's pipe
-                        //          ~3.5 cycles whatever its width, and that pipe is the busiest unit of the kernel
-  L_INVD = L_V + 312,   // [24] 1 / D,  D = S.(IA S) + armature
-  L_UU = L_V + 336,     // [24] u / D,  u = tau - S.pA
-  L_A0 = L_V + 360,     // [24] Cholesky factor of IA0 (sym 21, see chol6_factor) ; [8] base spatial acceleration
-  L_GP = L_V + 392,     // [NG][2][3] geom end points rel. base origin (136)
-  L_CT = L_V + 528,     // [MAXC][16] contact records (192)
-  L_ROWD = L_V + 720,   // [48] compacted limit-row candidates (int)
-  L_RT = L_V + 768,     // [NB][3][4] body frames: row i of the rotation (3) + component i of the origin rel. the base origin: one 16-byte
+  // One 80-byte record per body with everything the passes over the tree read together (an LDS instruction costs the CU's pipe
+  // ~3.5 cycles whatever its width, and that pipe is the busiest unit of the kernel):
+  //   S (6) joint motion vector about the base origin, world axes | V (6) = IA S / D | c (6) velocity-product acceleration |
+  //   u / D (u = tau - S.pA; before the ABA: the net joint torque) | 1 / D, D = S.(IA S) + armature (before the ABA: the armature)
+  // Row sweeps read floats 0..11 (three 16-byte reads), the ABA outward walk 0..18 (five), the inward pass S and c (four).
+  SVS = 20, SV_V = 6, SV_C = 12, SV_UU = 18, SV_INVD = 19,
+  L_SV = L_V + 48,      // [22][SVS]
+  L_A0 = L_V + 488,     // [24] Cholesky factor of IA0 (sym 21, see chol6_factor) ; [8] base spatial acceleration
+  L_GP = L_V + 520,     // [NG][2][3] geom end points rel. base origin (136)
+  L_CT = L_V + 656,     // [MAXC][16] contact records (192)
+  L_ROWD = L_V + 848,   // [48] compacted limit-row candidates (int)
+  L_RT = L_V + 896,     // [NB][3][4] body frames: row i of the rotation (3) + component i of the origin rel. the base origin: one 16-byte
                         //            write per (body, row) lane of the walk, three 16-byte reads per consumer
-  L_C = L_V + 1036,     // [NB][6]
-  L_M = L_V + 1168,     // [NB][36] link / articulated inertias, full 6x6 rows (lane = row in the inward pass)
-  L_P = L_V + 1960,     // [NB][6]  bias forces
-  L_ABA_END = L_V + 2092,
+  L_M = L_V + 1160,     // [NB][36] link / articulated inertias, full 6x6 rows (lane = row in the inward pass)
+  L_P = L_V + 1952,     // [NB][6]  bias forces
+  L_ABA_END = L_V + 2084,
   L_CAND = L_ABA_END,   // [MAX_PAIRS] u16 self-collision candidates (collide only: the slack the joint records 9.. used during the walk)
   // per-joint walk records, 16 floats each: [jrot * Rot(axis, q)](9) jpos(3) axis(3) qd(1).  Rebuilt by stage_joints()
   // before every walk; joints 1..8 sit where U will be written later in the substep (the walks run first), the rest
@@ -367,7 +368,7 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
     if (bg > 0) {
       const float4 r3 = reinterpret_cast<const float4*>(L + (bg <= 8 ? L_JR0 : L_JR1) + JRS * bg)[3];
       *reinterpret_cast<float4*>(L + L_RT + 12 * bg + 4 * ri) = make_float4(row[0], row[1], row[2], rr);
-      L[L_SV + 12 * bg + ri] = row[0] * r3.x + row[1] * r3.y + row[2] * r3.z;  // world axis: Rot(axis, q) leaves the axis in place
+      L[L_SV + SVS * bg + ri] = row[0] * r3.x + row[1] * r3.y + row[2] * r3.z;  // world axis: Rot(axis, q) leaves the axis in place
     }
     if (lane == 63) {
 #pragma unroll
@@ -384,10 +385,10 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
   }
   if (FULL) {
     if (lane >= 1 && lane < T::NB) {
-      float a[3] = {L[L_SV + 12 * b], L[L_SV + 12 * b + 1], L[L_SV + 12 * b + 2]}, ra[3];
+      float a[3] = {L[L_SV + SVS * b], L[L_SV + SVS * b + 1], L[L_SV + SVS * b + 2]}, ra[3];
       cross3(r, a, ra);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { S[i] = a[i]; S[3 + i] = ra[i]; L[L_SV + 12 * b + 3 + i] = ra[i]; }
+      for (int i = 0; i < 3; ++i) { S[i] = a[i]; S[3 + i] = ra[i]; L[L_SV + SVS * b + 3 + i] = ra[i]; }
     }
     wsync();
 #pragma unroll
@@ -398,7 +399,7 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
       if (j != 31 && j != b) {  // ancestors; the body's own joint follows below
         const float qd = L[L_QD + j];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) v[i] += L[L_SV + 12 * j + i] * qd;
+        for (int i = 0; i < 6; ++i) v[i] += L[L_SV + SVS * j + i] * qd;
       }
     }
     if (lane >= 1 && lane < T::NB) {
@@ -428,7 +429,7 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
       }
     if (FULL) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) L[L_C + 6 * b + i] = c[i];  // (S of the base is never read)
+      for (int i = 0; i < 6; ++i) L[L_SV + SVS * b + SV_C + i] = c[i];  // (S of the base is never read)
       // spatial inertia about the base origin, world axes
       const float ixx = inl[0], iyy = inl[1], izz = inl[2], ixy = inl[3], ixz = inl[4], iyz = inl[5];
       float Il[9] = {ixx, ixy, ixz, ixy, iyy, iyz, ixz, iyz, izz}, Tm[9], Iw[9];
@@ -470,8 +471,8 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
       for (int i = 0; i < 6; ++i) L[L_P + 6 * b + i] = p[i];
       // staged for the inward pass (which overwrites both slots with 1/D and u): joint armature and the net joint
       // torque, so that the level loop reads LDS only -- its global loads were hoisted above all levels and spilled
-      L[L_INVD + b] = jarm;
-      L[L_UU + b] = L[L_TAU + b] - jdamp * L[L_QD + b];
+      L[L_SV + SVS * b + SV_INVD] = jarm;
+      L[L_SV + SVS * b + SV_UU] = L[L_TAU + b] - jdamp * L[L_QD + b];
     }
   }
 }
@@ -537,7 +538,7 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
   // LDS offsets of the slot's body, carried from level to level: along a chain the body index drops by one per level, so most
   // levels update the four offsets with one subtraction each instead of rebuilding them from a per-slot select (12 integer
   // instructions per level).  Lanes of an empty slot point at body d (any existing body; they never store).
-  int bb = 0, o6 = 0, o6i = 0, o36 = 0, o12 = 0, o12i = 0;
+  int bb = 0, o6i = 0, o36 = 0, osv = 0, osvi = 0;
 #pragma unroll
   for (int d = T::MAXD; d >= 1; --d) {
     // bodies of this level and their children are compile-time constants selected by the lane's slot
@@ -545,16 +546,16 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
     const bool sv = s == 0 ? T::clevel(d, 0) >= 0 : s == 1 ? T::clevel(d, 1) >= 0 : s == 2 ? T::clevel(d, 2) >= 0 : s == 3 ? T::clevel(d, 3) >= 0 : false;
     const bool valid = sv && i < 6;
     if (d < T::MAXD && MOCCA_CONT(0) && MOCCA_CONT(1) && MOCCA_CONT(2) && MOCCA_CONT(3)) {  // compile-time: every body of the level continues its slot's chain
-      bb -= 1; o6 -= 6; o6i -= 6; o36 -= 36; o12 -= 12; o12i -= 12;
+      bb -= 1; o6i -= 6; o36 -= 36; osv -= SVS; osvi -= SVS;
     } else {
       const int b = s == 0 ? T::clevel(d, 0) : s == 1 ? T::clevel(d, 1) : s == 2 ? T::clevel(d, 2) : s == 3 ? T::clevel(d, 3) : -1;
       bb = b >= 0 ? b : d;
-      o6 = 6 * bb; o6i = o6 + ii; o36 = 36 * bb + 6 * ii; o12 = 12 * bb; o12i = o12 + ii;
+      o6i = 6 * bb + ii; o36 = 36 * bb + 6 * ii; osv = SVS * bb; osvi = osv + ii;
     }
 #undef MOCCA_CONT
     float row[6], S[6], c[6], pAi;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { row[j] = L[L_M + o36 + j] + crow[j]; S[j] = L[L_SV + o12 + j]; c[j] = L[L_C + o6 + j]; }
+    for (int j = 0; j < 6; ++j) { row[j] = L[L_M + o36 + j] + crow[j]; S[j] = L[L_SV + osv + j]; c[j] = L[L_SV + osv + SV_C + j]; }
     pAi = L[L_P + o6i] + cpA;
 #pragma unroll
     for (int k = 0; k < T::MAXCH; ++k) {
@@ -573,11 +574,11 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
     // Branch-free on purpose: idle lanes (rows 6, 7 of a group, empty slots) run the same arithmetic on harmless data
     // and are kept out of the sums / the stores only.  Under `valid ? ... : 0` the compiler sank the LDS reads into
     // conditional blocks, each with its own wait, and nothing of the next level could be fetched ahead.
-    const float Si = i < 6 ? L[L_SV + o12i] : 0.0f;  // the lane's own component of S (0 for the two idle lanes)
+    const float Si = i < 6 ? L[L_SV + osvi] : 0.0f;  // the lane's own component of S (0 for the two idle lanes)
     const float Ui = dot6(row, S);
     const float dsum = group8_sum(Si * Ui);
     const float psum = group8_sum(Si * pAi);
-    float arm = L[L_INVD + bb], unet = L[L_UU + bb];  // staged by the walk: joint armature, net joint torque
+    float arm = L[L_SV + osv + SV_INVD], unet = L[L_SV + osv + SV_UU];  // staged by the walk: joint armature, net joint torque
     pin1(arm); pin1(unet);                           // fetched with the level's other reads, not inside the store branch
     const float id = rcp(dsum + arm);
     const float u = unet - psum;
@@ -607,8 +608,8 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
         for (int j = 0; j < 6; ++j) L[L_M + o36 + j] = row[j];
         L[L_P + o6i] = pOut;
       }
-      L[L_SV + o12i + 6] = uid;   // V_i = U_i / D: what the outward passes and the row sweeps multiply by
-      if (i == 0) { L[L_INVD + bb] = id; L[L_UU + bb] = u * id; }
+      L[L_SV + osvi + SV_V] = uid;   // V_i = U_i / D: what the outward passes and the row sweeps multiply by
+      if (i == 0) { L[L_SV + osv + SV_INVD] = id; L[L_SV + osv + SV_UU] = u * id; }
     }
     // What the slot hands to the next level in registers: its result.  Only a slot whose NEXT-level body does not continue this
     // level's chain (a chain that starts there, or this level's body is consumed through LDS) must hand over zeros, and which
@@ -685,8 +686,8 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
       if (j != 31) {
         float U[6], S[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { a[i] += L[L_C + 6 * j + i]; U[i] = L[L_SV + 12 * j + 6 + i]; S[i] = L[L_SV + 12 * j + i]; }
-        qdd = L[L_UU + j] - dot6(U, a);   // u / D - (U / D) . a
+        for (int i = 0; i < 6; ++i) { a[i] += L[L_SV + SVS * j + SV_C + i]; U[i] = L[L_SV + SVS * j + SV_V + i]; S[i] = L[L_SV + SVS * j + i]; }
+        qdd = L[L_SV + SVS * j + SV_UU] - dot6(U, a);   // u / D - (U / D) . a
 #pragma unroll
         for (int i = 0; i < 6; ++i) a[i] += S[i] * qdd;
       }
@@ -1356,7 +1357,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
     const int jj = valid ? j : 0;
     float S[6], U[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { S[i] = L[L_SV + 12 * jj + i]; U[i] = L[L_SV + 12 * jj + 6 + i]; }
+    for (int i = 0; i < 6; ++i) { S[i] = L[L_SV + SVS * jj + i]; U[i] = L[L_SV + SVS * jj + SV_V + i]; }
     float jb = dot6(S, F);
     if (jj == jl) jb = sgn;
     jb = valid ? jb : 0.0f;
@@ -1365,7 +1366,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
     for (int i = 0; i < 6; ++i) pa[i] += U[i] * uu;  // U holds V = IA S / D; uu == 0 past the end of the path
     if (valid) Jrow[5 + jj] = jb;
     w += jb * L[L_NU + 5 + jj];
-    pu[k] = uu * L[L_INVD + jj];   // what the outward sweep starts from: u / D
+    pu[k] = uu * L[L_SV + SVS * jj + SV_INVD];   // what the outward sweep starts from: u / D
     pin6(pa); pin1(pu[k]); pin1(w);
   }
   if (two_paths) {
@@ -1379,14 +1380,14 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
       const int jj = valid ? j : 0;
       float S[6], U[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) { S[i] = L[L_SV + 12 * jj + i]; U[i] = L[L_SV + 12 * jj + 6 + i]; }
+      for (int i = 0; i < 6; ++i) { S[i] = L[L_SV + SVS * jj + i]; U[i] = L[L_SV + SVS * jj + SV_V + i]; }
       const float jb = valid ? -dot6(S, F2) : 0.0f;   // the force on the second body is -F2
       const float uu = valid ? jb - dot6(S, pb) : 0.0f;
 #pragma unroll
       for (int i = 0; i < 6; ++i) pb[i] += U[i] * uu;
       if (valid) Jrow[5 + jj] += jb;                  // common ancestors carry both paths' entries
       w += jb * L[L_NU + 5 + jj];
-      pub[k] = uu * L[L_INVD + jj];
+      pub[k] = uu * L[L_SV + SVS * jj + SV_INVD];
       pin6(pb); pin1(pub[k]); pin1(w);
     }
   } else {
@@ -1426,7 +1427,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
       const int p = T::parent(b);
       float S[6], U[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) { S[i] = L2[L_SV + 12 * b + i]; U[i] = L2[L_SV + 12 * b + 6 + i]; }   // U = V = IA S / D
+      for (int i = 0; i < 6; ++i) { S[i] = L2[L_SV + SVS * b + i]; U[i] = L2[L_SV + SVS * b + SV_V + i]; }   // U = V = IA S / D
       const int dpos = T::depth(b) - 1;  // (folds after unrolling) the body's position on every path that holds it
       // pu[dpos] where the row's path holds b, else 0: bit b of the ancestor mask, sign-extended, ANDs the value (v_bfe_i32 + v_and)
       float ub = __uint_as_float(__float_as_uint(pu[dpos]) & (unsigned)__builtin_amdgcn_sbfe((int)ma, b, 1));
