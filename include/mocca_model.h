@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define MOCCA_MODEL_MAGIC 0x41434F4Du /* "MOCA" */
-#define MOCCA_MODEL_VERSION 10u
+#define MOCCA_MODEL_VERSION 11u
 
 #define MOCCA_MAX_BODIES 24
 #define MOCCA_MAX_GEOMS 32
@@ -91,7 +91,7 @@ typedef struct MoccaModel {
 
   /* ---- joints (index = body, entry 0 unused) ---- */
   float jpos[MOCCA_MAX_BODIES][3];
-  float jrot[MOCCA_MAX_BODIES][9]; /* row-major, parent <- body at q=0 */
+  float jrot[MOCCA_MAX_BODIES][9]; /* row-major, parent <- body at q=0; entry 0 = identity (the kinematics walk multiplies by it past the end of a path) */
   float jaxis[MOCCA_MAX_BODIES][3];
   float jlo[MOCCA_MAX_BODIES];
   float jhi[MOCCA_MAX_BODIES];

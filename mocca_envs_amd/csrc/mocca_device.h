@@ -104,15 +104,11 @@ enum : int {
   L_P = L_V + 1952,     // [NB][6]  bias forces
   L_ABA_END = L_V + 2084,
   L_CAND = L_ABA_END,   // [MAX_PAIRS] u16 self-collision candidates (collide only: the slack the joint records 9.. used during the walk)
-  // per-joint walk records, 16 floats each: [jrot * Rot(axis, q)](9) jpos(3) axis(3) qd(1).  Rebuilt by stage_joints()
-  // before every walk; joints 1..8 sit where U will be written later in the substep (the walks run first), the rest
-  // in the slack between the end of the ABA view and the end of the solver view.
-  // Stride JRS = 20 floats, not 16: the joints visited at one path position by the lanes of a wave (up to MAXW of them) then start in
-  // different LDS banks (16 j mod 64 put joints 9, 17 and 21 of the walker -- the step of depth 4 -- on the same banks, a 3-way conflict
-  // on each of the three 16-byte reads).
-  JRS = 20,
-  L_JR0 = L_V + 180 - JRS,          // record j in 1..8   at L_JR0 + JRS j  (S / V records and 1/D, u/D slots: all rewritten after the walk read these)
-  L_JR1 = L_V + 2332 - JRS * MOCCA_MAX_BODIES,   // record j in 9..  at L_JR1 + JRS j  (ends with the region; the head lies over bias forces written later)
+  // per-joint walk records, 16 floats each: [jrot * Rot(axis, q)](9) jpos(3) axis(3) qd(1), rebuilt by stage_joints() before every
+  // walk IN THE BODY RECORDS (L_SV + SVS j: what those hold is dead by then, and the walk writes S only after its last record read).
+  // Record 0 is the identity (the blob's joint 0), which a packed path names past its end: the walk composes a fixed number of
+  // records without a branch.  At the 20-float stride the joints visited at one path position by the lanes of a wave (up to MAXW of
+  // them) start in different LDS banks (16 j mod 64 put joints 9, 17 and 21 of the walker on the same banks: a 3-way conflict).
   // ---- solver view
   L_A = L_V,            // [MAXR][MAXR] Delassus matrix, row = updated row, column = lane
   L_J = L_V + 960,      // [MAXR][28] Jacobian rows (tail of the A region)
@@ -120,7 +116,7 @@ enum : int {
   L_TOTAL = L_V + MAXR * MAXR + 28,  // + one dummy J row for lanes that own no row (A-row prefetches clamp to row MAXR - 1)
 };
 static_assert(L_ABA_END <= L_TOTAL, "ABA view must fit");
-static_assert(L_JR1 + JRS * MOCCA_MAX_BODIES <= L_TOTAL && (L_JR0 % 4) == 0 && (L_JR1 % 4) == 0 && JRS % 4 == 0 && L_JR0 + JRS * 9 <= L_A0, "joint records must fit, 16-byte aligned");
+static_assert(L_SV % 4 == 0 && SVS % 4 == 0 && SVS >= 16, "joint records live in the body records, 16-byte aligned");
 static_assert(L_J + (MAXR + 1) * 28 <= L_TOTAL, "Jacobian rows (+ dummy) must fit the tail of the A region");
 static_assert(L_J % 4 == 0 && L_V % 4 == 0, "16-byte alignment of broadcast rows");
 static_assert(MAXR % 2 == 0 && 3 * MAXC <= MAXR, "friction rows sit on the top 2 MAXC lanes of the row range, odd lane = second tangent");
@@ -353,20 +349,18 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
     float rr = 0.0f;
 #pragma unroll
     for (int k = 0; k < T::MAXD; ++k) {
-      const int j = (int)((pk3 >> (5 * k)) & 31ull);
-      if (j != 31) {
-        // the joint's record was staged by stage_joints(): 16-byte LDS reads, none of them on the dependent chain
-        const float4* jr = reinterpret_cast<const float4*>(L + (j <= 8 ? L_JR0 : L_JR1) + JRS * j);
-        const float4 r0 = jr[0], r1 = jr[1], r2 = jr[2];
-        rr += row[0] * r2.y + row[1] * r2.z + row[2] * r2.w;  // offset of the joint in the parent frame
-        const float n0 = row[0] * r0.x + row[1] * r0.w + row[2] * r1.z;
-        const float n1 = row[0] * r0.y + row[1] * r1.x + row[2] * r1.w;
-        const float n2 = row[0] * r0.z + row[1] * r1.y + row[2] * r2.x;
-        row[0] = n0; row[1] = n1; row[2] = n2;
-      }
+      const int j = (int)((pk3 >> (5 * k)) & 31ull);  // 0 past the end of the path: the identity record
+      // the joint's record was staged by stage_joints(): 16-byte LDS reads, none of them on the dependent chain
+      const float4* jr = reinterpret_cast<const float4*>(L + L_SV + SVS * j);
+      const float4 r0 = jr[0], r1 = jr[1], r2 = jr[2];
+      rr += row[0] * r2.y + row[1] * r2.z + row[2] * r2.w;  // offset of the joint in the parent frame
+      const float n0 = row[0] * r0.x + row[1] * r0.w + row[2] * r1.z;
+      const float n1 = row[0] * r0.y + row[1] * r1.x + row[2] * r1.w;
+      const float n2 = row[0] * r0.z + row[1] * r1.y + row[2] * r2.x;
+      row[0] = n0; row[1] = n1; row[2] = n2;
     }
     if (bg > 0) {
-      const float4 r3 = reinterpret_cast<const float4*>(L + (bg <= 8 ? L_JR0 : L_JR1) + JRS * bg)[3];
+      const float4 r3 = reinterpret_cast<const float4*>(L + L_SV + SVS * bg)[3];
       *reinterpret_cast<float4*>(L + L_RT + 12 * bg + 4 * ri) = make_float4(row[0], row[1], row[2], rr);
       L[L_SV + SVS * bg + ri] = row[0] * r3.x + row[1] * r3.y + row[2] * r3.z;  // world axis: Rot(axis, q) leaves the axis in place
     }
@@ -396,7 +390,7 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
 #pragma unroll
     for (int k = 0; k < T::MAXD; ++k) {
       const int j = (int)((ppk >> (5 * k)) & 31ull);  // the lane's packed path: no table access
-      if (j != 31 && j != b) {  // ancestors; the body's own joint follows below
+      if (j != 0 && j != b) {  // ancestors; the body's own joint follows below
         const float qd = L[L_QD + j];
 #pragma unroll
         for (int i = 0; i < 6; ++i) v[i] += L[L_SV + SVS * j + i] * qd;
@@ -683,7 +677,7 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
 #pragma unroll
     for (int k = 0; k < T::MAXD; ++k) {
       const int j = (int)((ppk >> (5 * k)) & 31ull);
-      if (j != 31) {
+      if (j != 0) {
         float U[6], S[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) { a[i] += L[L_SV + SVS * j + SV_C + i]; U[i] = L[L_SV + SVS * j + SV_V + i]; S[i] = L[L_SV + SVS * j + i]; }
@@ -1353,8 +1347,8 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
 #pragma unroll
   for (int k = T::MAXD - 1; k >= 0; --k) {
     const int j = (int)((pka >> (5 * k)) & 31ull);
-    const bool valid = j != 31;
-    const int jj = valid ? j : 0;
+    const bool valid = j != 0;   // 0: past the end of the path (body 0's record is read, the selects below discard it)
+    const int jj = j;
     float S[6], U[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) { S[i] = L[L_SV + SVS * jj + i]; U[i] = L[L_SV + SVS * jj + SV_V + i]; }
@@ -1376,8 +1370,8 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
 #pragma unroll
     for (int k = T::MAXD - 1; k >= 0; --k) {
       const int j = (int)((pkb >> (5 * k)) & 31ull);
-      const bool valid = j != 31;
-      const int jj = valid ? j : 0;
+      const bool valid = j != 0;
+      const int jj = j;
       float S[6], U[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) { S[i] = L[L_SV + SVS * jj + i]; U[i] = L[L_SV + SVS * jj + SV_V + i]; }
@@ -1589,7 +1583,7 @@ DI void fast_sincos(float q, float* s, float* c) {
 // Rodrigues formula out of that loop (they were re-done per (lane, path step), with the load latency on the chain).
 template <class T>
 DI void stage_joints(ModelP M, float* L, int lane) {
-  if (lane >= 1 && lane < T::NB) {
+  if (lane < T::NB) {   // lane 0 stages the identity (blob joint 0, q[0] = 0)
     const int j = lane;
     float s, cq;
     fast_sincos(L[L_Q + j], &s, &cq);
@@ -1603,7 +1597,7 @@ DI void stage_joints(ModelP M, float* L, int lane) {
     Rq[3] = t * ax[0] * ax[1] + s * ax[2];   Rq[4] = cq + t * ax[1] * ax[1];          Rq[5] = t * ax[1] * ax[2] - s * ax[0];
     Rq[6] = t * ax[0] * ax[2] - s * ax[1];   Rq[7] = t * ax[1] * ax[2] + s * ax[0];   Rq[8] = cq + t * ax[2] * ax[2];
     matmul3(jr, Rq, Tl);
-    float4* rec = reinterpret_cast<float4*>(L + (j <= 8 ? L_JR0 : L_JR1) + JRS * j);
+    float4* rec = reinterpret_cast<float4*>(L + L_SV + SVS * j);
     rec[0] = make_float4(Tl[0], Tl[1], Tl[2], Tl[3]);
     rec[1] = make_float4(Tl[4], Tl[5], Tl[6], Tl[7]);
     rec[2] = make_float4(Tl[8], M->jpos[j][0], M->jpos[j][1], M->jpos[j][2]);

@@ -29,7 +29,7 @@ MAX_PAIRS = 192
 MAX_FEET = 4
 MAX_SLOTS = 40
 MAGIC = 0x41434F4D
-VERSION = 10
+VERSION = 11
 
 GEOM_SPHERE, GEOM_CAPSULE = 0, 1
 TASK_WALKER3D_CUSTOM, TASK_WALKER3D_STEPPER, TASK_CASSIE = 0, 1, 2
@@ -175,6 +175,12 @@ class MoccaModel(C.Structure):
         """Fill the derived lookup tables from the primary fields (call after any edit of geoms / pairs)."""
         def bits(i: int) -> float:
             return float(np.array([i & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0])
+        # joint record 0 is the identity: the kinematics walk composes it for the path positions past a body's depth
+        for k in range(9):
+            self.jrot[0][k] = 1.0 if k in (0, 4, 8) else 0.0
+        for k in range(3):
+            self.jpos[0][k] = 0.0
+            self.jaxis[0][k] = 1.0 if k == 2 else 0.0
         for g in range(self.n_geoms):
             ne = 2 if self.g_type[g] == GEOM_CAPSULE else 1
             b = self.g_body[g]
@@ -1150,7 +1156,7 @@ def topology_header(m: MoccaModel, name: str = "Walker3D") -> str:
     lines += [
         "};",
         "__device__ static const unsigned long long kPathPk%s[%d] = %s;" % (
-            name, nb, arr(["0x%xull" % sum(((path[b][k] if path[b][k] >= 0 else 31) << (5 * k)) for k in range(maxd)) for b in range(nb)])),
+            name, nb, arr(["0x%xull" % sum(((path[b][k] if path[b][k] >= 0 else 0) << (5 * k)) for k in range(maxd)) for b in range(nb)])),
         "struct Topo%s {" % name,
         "  static constexpr int NB = %d;        // bodies incl. floating base" % nb,
         "  static constexpr int NJ = %d;        // hinges" % (nb - 1),
@@ -1179,7 +1185,7 @@ def topology_header(m: MoccaModel, name: str = "Walker3D") -> str:
         "  static constexpr int ccarry(int b) { constexpr int t[%d] = %s; return b < 0 ? -1 : t[b]; }" % (nb, arr(carry)),
         "  static constexpr int cchild(int b, int k) { constexpr int t[%d][%d] = {%s}; return b < 0 ? -1 : t[b][k]; }"
         % (nb, maxc, ", ".join(arr(sorted(c, reverse=True) + [-1] * (maxc - len(c))) for c in children)),
-        "  // the lane's own root->body path, 5 bits per step (31 = none): loaded once per kernel, two VGPRs, then",
+        "  // the lane's own root->body path, 5 bits per step (0 = past the end: joints are numbered from 1): loaded once per kernel, two VGPRs, then",
         "  // every path step is a v_bfe -- no table access inside the walks",
         "  static __device__ __forceinline__ unsigned long long path_packed(int b) { return kPathPk%s[b]; }" % name,
         "};",
