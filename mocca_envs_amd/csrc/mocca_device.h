@@ -1660,7 +1660,23 @@ DI void quat_to_rpy(const float* q, float* rpy) {  // pybullet.getEulerFromQuate
   }
 }
 
-struct RobotObs { float rpy[3]; int jal; float spd; float height; bool finite; };
+// roll, pitch and the HEADING (cos yaw, sin yaw) of the base.  Nothing downstream needs the yaw angle itself: R_z(-yaw) v, the target
+// bearing sin / cos (atan2(dy, dx) - yaw) and the stepping-stone deltas are rational in (cos yaw, sin yaw), which come straight from the
+// quaternion -- no atan2f / sinf / cosf chain (six libm calls per env.step for the Custom task, three more per stepping stone).
+DI void quat_to_rp_heading(const float* q, float* rp, float* cy, float* sy) {  // same branches as quat_to_rpy
+  const float x = q[0], y = q[1], z = q[2], w = q[3];
+  const float sarg = -2 * (x * z - w * y);
+  if (sarg <= -0.99999f) { rp[1] = -1.5707963267948966f; rp[0] = 0; const float yaw = 2 * atan2f(x, -y); *cy = cosf(yaw); *sy = sinf(yaw); }
+  else if (sarg >= 0.99999f) { rp[1] = 1.5707963267948966f; rp[0] = 0; const float yaw = 2 * atan2f(-x, y); *cy = cosf(yaw); *sy = sinf(yaw); }
+  else {
+    rp[0] = atan2f(2 * (y * z + w * x), w * w - x * x - y * y + z * z);
+    rp[1] = asinf(sarg);
+    const float A = 2 * (x * y + w * z), B = w * w + x * x - y * y - z * z, n = rsq(A * A + B * B);  // A^2 + B^2 = cos^2(pitch) > 2e-5 here
+    *cy = B * n; *sy = A * n;
+  }
+}
+
+struct RobotObs { float rpy[3]; /* [2] unused: see cy, sy */ float cy, sy; int jal; float spd; float height; bool finite; };
 
 // WalkerBase.calc_state (robots.py:42-95): writes obs[0 .. 6+2NJ+NFEET) ; needs kinematics done (L_FEET).
 // lane j < NJ keeps its scaled joint speed in the return value for the energy term.
@@ -1668,9 +1684,10 @@ template <class T>
 DI RobotObs robot_obs(ModelP M, float* L, int lane, float fc0, float fc1, float* obs, float fc2 = 0.0f, float fc3 = 0.0f) {
   RobotObs ro;
   float q[4] = {L[L_BASE + 3], L[L_BASE + 4], L[L_BASE + 5], L[L_BASE + 6]};
-  quat_to_rpy(q, ro.rpy);
-  const float yaw = ro.rpy[2], cy = cosf(-yaw), sy = sinf(-yaw);
-  const float vx = cy * L[L_BASE + 7] - sy * L[L_BASE + 8], vy = sy * L[L_BASE + 7] + cy * L[L_BASE + 8], vz = L[L_BASE + 9];
+  quat_to_rp_heading(q, ro.rpy, &ro.cy, &ro.sy);
+  ro.rpy[2] = 0.0f;
+  // body_vel = R_z(-yaw) v  (robots.py:63-71)
+  const float vx = ro.cy * L[L_BASE + 7] + ro.sy * L[L_BASE + 8], vy = ro.cy * L[L_BASE + 8] - ro.sy * L[L_BASE + 7], vz = L[L_BASE + 9];
   float minz = fminf(L[L_FEET + 2], L[L_FEET + 5]);
   if constexpr (T::NFEET > 2) minz = fminf(minz, fminf(L[L_FEET + 8], L[L_FEET + 11]));
   const float height = L[L_BASE + 2] - minz;
@@ -1732,12 +1749,14 @@ DI void store_task(uint32_t* tk, const TaskRegs& t, bool quadruped = false) {
 }
 
 // calc_potential, env_locomotion.py:143-158
-DI void calc_potential(ModelP M, const float* L, TaskRegs& t, float yaw, float* dist, float* ang) {
+// *dist = distance to the walk target; *cd, *sd = dist * cos / sin (angle_to_target), angle_to_target = atan2(dy, dx) - yaw
+DI void calc_potential(ModelP M, const float* L, TaskRegs& t, const RobotObs& ro, float* dist, float* cd, float* sd) {
   const float dx = t.wt[0] - L[L_BASE], dy = t.wt[1] - L[L_BASE + 1];
-  *ang = atan2f(dy, dx) - yaw;
+  *cd = dx * ro.cy + dy * ro.sy;
+  *sd = dy * ro.cy - dx * ro.sy;
   *dist = sqrtf(dx * dx + dy * dy);
   t.linpot = -(*dist) / M->control_dt;
-  t.angpot = cosf(*ang);
+  t.angpot = *dist > 0.0f ? *cd / *dist : ro.cy;   // cos(angle_to_target); atan2(0, 0) = 0
 }
 template <bool INJECT>
 DI void randomize_target(const StepArgs& a, int env, TaskRegs& t, bool eval_mode) {  // env_locomotion.py:67-74
@@ -1753,15 +1772,14 @@ DI void randomize_target(const StepArgs& a, int env, TaskRegs& t, bool eval_mode
   t.draw += 1;
   t.stopf = u2 < 0.5f ? 30.0f : 60.0f;
 }
-DI void softsign_tail(float dist, float ang, float* o2) {
-  const float s = dist * sinf(ang), c = dist * cosf(ang);
+DI void softsign_tail(float s, float c, float* o2) {  // s, c = dist * sin / cos (angle_to_target), env_locomotion.py:124-127
   o2[0] = s / (1 + fabsf(s));
   o2[1] = c / (1 + fabsf(c));
 }
 
 // delta_to_k_targets, env_locomotion.py:712-759: lookbehind j rows before the next step, then lookahead 2 rows from it, indices
 // clamped at both ends; a stop repeats the next step.  Lane 0 writes the 5 (j + 2) floats; sets walk_target (index -1).
-DI void delta_to_k_targets(ModelP M, const float* L, const float* ter, TaskRegs& t, float yaw, int lane, float* out) {
+DI void delta_to_k_targets(ModelP M, const float* L, const float* ter, TaskRegs& t, const RobotObs& ro, int lane, float* out) {
   const int N = t.nsi, TT = MOCCA_MAX_TERRAIN_STEPS, j = M->lookbehind, nt = j + 2;
 #pragma unroll 1
   for (int i = 0; i < nt; ++i) {
@@ -1771,10 +1789,9 @@ DI void delta_to_k_targets(ModelP M, const float* L, const float* ter, TaskRegs&
     const float* tt = ter + 6 * v;
     if (i == nt - 1) { t.wt[0] = tt[0]; t.wt[1] = tt[1]; t.wt[2] = tt[2]; }
     const float dx = tt[0] - L[L_BASE], dy = tt[1] - L[L_BASE + 1], dz = tt[2] - L[L_BASE + 2];
-    const float ang = atan2f(dy, dx) - yaw, dist = sqrtf(dx * dx + dy * dy);
-    if (lane == 0) {
-      out[5 * i + 0] = sinf(ang) * dist;
-      out[5 * i + 1] = cosf(ang) * dist;
+    if (lane == 0) {   // sin / cos (atan2(dy, dx) - yaw) * dist
+      out[5 * i + 0] = dy * ro.cy - dx * ro.sy;
+      out[5 * i + 1] = dx * ro.cy + dy * ro.sy;
       out[5 * i + 2] = dz;
       out[5 * i + 3] = tt[4];
       out[5 * i + 4] = tt[5];
@@ -1892,18 +1909,18 @@ DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, in
   wsync();
   const int nbo = 6 + 2 * T::NJ + T::NFEET;
   RobotObs ro = robot_obs<T>(M, L, lane, 0.0f, 0.0f, obs);
-  float dist, ang;
+  float dist, cd, sd;
   if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
-    calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+    calc_potential(M, L, t, ro, &dist, &cd, &sd);
     if (lane == 0) {
-      softsign_tail(dist, ang, obs + nbo);
+      softsign_tail(sd, cd, obs + nbo);
       if (M->task_flags & MOCCA_TASKF_RESET_TAIL_ZERO) { obs[nbo] = 0.0f; obs[nbo + 1] = 0.0f; }  // Walker2DCustomEnv.reset, :299-300
     }
   } else {
     generate_terrain<INJECT>(a, M, env, t, L, ter, lane);
     t.nsi = M->lookbehind;                                                             // :499
-    delta_to_k_targets(M, L, ter, t, ro.rpy[2], lane, obs + nbo);
-    calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+    delta_to_k_targets(M, L, ter, t, ro, lane, obs + nbo);
+    calc_potential(M, L, t, ro, &dist, &cd, &sd);
   }
   t.prevx = L[L_BASE];
 }

@@ -184,8 +184,8 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     RobotObs ro = robot_obs<T>(M, L, lane, t.fc0, t.fc1, obs, t.fc2, t.fc3);
     if (!ro.finite) t.done = 1;                                                        // :205-207
     const float old = t.linpot;
-    float dist, ang;
-    calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+    float dist, cd, sd;
+    calc_potential(M, L, t, ro, &dist, &cd, &sd);
     const float progress = t.linpot - old;
     float posture = 0.0f;
     const float pitch = ro.rpy[1], roll = ro.rpy[0];
@@ -208,10 +208,10 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
       randomize_target<INJECT>(a, env + a.env_offset, t, evalm);
       t.wt[0] += t.dist * cosf(t.angle);
       t.wt[1] += t.dist * sinf(t.angle);
-      calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+      calc_potential(M, L, t, ro, &dist, &cd, &sd);
     }
     rew = progress + bonus - energy + tall - posture - joints;                         // :121-122
-    if (lane == 0) softsign_tail(dist, ang, obs + NBO);
+    if (lane == 0) softsign_tail(sd, cd, obs + NBO);
     if (M->task_flags & MOCCA_TASKF_NEVER_DONE) t.done = 0;                            // Walker2DCustomEnv.step, :302-309
   } else {
     // env_locomotion.py:515-568
@@ -249,8 +249,8 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     }
     // calc_base_reward :598-630
     const float old = t.linpot;
-    float dist, ang;
-    calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+    float dist, cd, sd;
+    calc_potential(M, L, t, ro, &dist, &cd, &sd);
     float progress = t.linpot - old;
     float posture = 0.0f, tall;
     const float pitch = ro.rpy[1], roll = ro.rpy[0];
@@ -291,8 +291,8 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     if (reached && t.trc == 1 && t.nsi != last) step_bonus = 50.0f * powf(2.718f, -powf(fdmin, M->step_bonus_smoothness) / 0.25f);
     if ((t.nsi == last || t.stop) && dist < 0.15f) bonus = 2.0f;
     __threadfence_block();
-    delta_to_k_targets(M, L, ter, t, ro.rpy[2], lane, obs + NBO);
-    if (cur_idx != t.nsi) calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+    delta_to_k_targets(M, L, ter, t, ro, lane, obs + NBO);
+    if (cur_idx != t.nsi) calc_potential(M, L, t, ro, &dist, &cd, &sd);
     if (!a.random_reward) {
       rew = progress - energy + step_bonus + bonus + tall - posture - joints;          // :528-531
     } else {                                                                           // :533-547
@@ -391,13 +391,13 @@ __global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
     t.linpot = cassie_potential(M, L);
   } else {
     RobotObs ro = robot_obs<T>(M, L, lane, t.fc0, t.fc1, obs, t.fc2, t.fc3);
-    float dist, ang;
+    float dist, cd, sd;
     if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
-      calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
-      if (lane == 0) softsign_tail(dist, ang, obs + NBO);
+      calc_potential(M, L, t, ro, &dist, &cd, &sd);
+      if (lane == 0) softsign_tail(sd, cd, obs + NBO);
     } else {
-      delta_to_k_targets(M, L, ter, t, ro.rpy[2], lane, obs + NBO);
-      calc_potential(M, L, t, ro.rpy[2], &dist, &ang);
+      delta_to_k_targets(M, L, ter, t, ro, lane, obs + NBO);
+      calc_potential(M, L, t, ro, &dist, &cd, &sd);
     }
     t.prevx = L[L_BASE];
   }
