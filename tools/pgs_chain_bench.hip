@@ -100,6 +100,29 @@ __global__ __launch_bounds__(64) void k_d(float* o, long long* cyc, int iters, i
   o[blockIdx.x * 64 + threadIdx.x] = y + lam;
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
+// E: three-link chain z -> v_max -> v_readlane -> v_fma -> z with the bound lo - lambda formed off the chain and lambda updated by a
+// constant lane mask (z = y - lambda is what every lane carries; the gain of a lane's own row is 1, so z_r drops by the step itself)
+template <int RR> __device__ __forceinline__ void visit_e(float& z, float& lam, float as, float lo) {
+  if constexpr (RR < 48) {
+    const float bnd = lo - lam;                                    // off the chain: lam_r is known since the previous iteration
+    float t;
+    asm("v_max_f32 %0, %1, %2" : "=v"(t) : "v"(z), "v"(bnd));      // plain v_max: no canonicalisation sequence
+    const float d = readlane(t, RR);
+    z = fmaf(-as, d, z);
+    float inc;
+    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(inc) : "v"(d), "s"(1ull << RR));
+    lam += inc;
+    visit_e<RR + 1>(z, lam, as, lo);
+  }
+}
+__global__ __launch_bounds__(64) void k_e(float* o, long long* cyc, int iters) {
+  float z = 0.01f * threadIdx.x - 0.2f, lam = 0.0f, as = 0.001f * (threadIdx.x + 1);
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) visit_e<0>(z, lam, as, 0.0f);
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  o[blockIdx.x * 64 + threadIdx.x] = z + lam;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
 __global__ __launch_bounds__(64) void k_a(float* o, long long* cyc, int iters) {
   float y = 0.01f * threadIdx.x - 0.2f, lam = 0.0f, as = 0.001f * (threadIdx.x + 1);
   const long long t0 = __builtin_amdgcn_s_memtime();
@@ -128,6 +151,14 @@ int main() {
       double s = 0; for (int i = 0; i < 1024; ++i) s += h[i];
       printf("{\"waves_per_simd\": %d, \"form\": \"%s\", \"cycles_per_visit\": %.1f}\n", waves, v == 0 ? "A med3-sub-readlane-fma" : "B max-readlane-fma", s / 1024 / (48.0 * iters));
     }
+  }
+  for (int waves : {1, 4}) {
+    const int blocks = 256 * 4 * waves, iters = 200;
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(k_e, dim3(blocks), dim3(64), 0, 0, d, c, iters);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h, c, sizeof(long long) * 1024, hipMemcpyDeviceToHost);
+    double s = 0; for (int i = 0; i < 1024; ++i) s += h[i];
+    printf("{\"waves_per_simd\": %d, \"form\": \"E max-readlane-fma, bound and lambda off the chain\", \"cycles_per_visit\": %.1f}\n", waves, s / 1024 / (48.0 * iters));
   }
   for (int waves : {1, 4}) {
     const int blocks = 256 * 4 * waves, iters = 200, nc = 12;
