@@ -1110,12 +1110,14 @@ constexpr int fric_lane(int i, int s) { return MAXR - 2 - 2 * i + s; }
 // the first PGS_REG_CONTACTS contacts' friction rows -- already multiplied by the lane's 1 / (A_cc + cfm) -- are fetched ONCE per
 // substep into registers (static indices: the visits are unrolled); a typical env (12 rows) then runs its five iterations without a
 // single LDS read, and a visit loses its multiply.  Rows past the window keep the per-iteration LDS reads, requested a group ahead.
-#ifndef MOCCA_PGS_REG_ROWS   // window sizes (tools/flag_sweep.sh)
-#define MOCCA_PGS_REG_ROWS 16
-#define MOCCA_PGS_REG_CONTACTS 4
+// Window sizes by topology (tools/flag_sweep_env.sh): 16 rows + 4 contacts for the walkers (mean 12 rows; larger windows measure the
+// same), 24 + 12 for Cassie, whose closures, planar rows and a dozen toe points put ~45 rows in every substep (-1.8 %).
+#ifdef MOCCA_PGS_REG_ROWS   // override for sweeps
+template <class T> struct PgsWin { static constexpr int ROWS = MOCCA_PGS_REG_ROWS, CONTACTS = MOCCA_PGS_REG_CONTACTS; };
+#else
+template <class T> struct PgsWin { static constexpr int ROWS = T::NCLOS > 0 ? 24 : 16, CONTACTS = T::NCLOS > 0 ? 12 : 4; };
 #endif
-constexpr int PGS_REG_ROWS = MOCCA_PGS_REG_ROWS, PGS_REG_CONTACTS = MOCCA_PGS_REG_CONTACTS;
-template <int I>
+template <int PGS_REG_ROWS, int PGS_REG_CONTACTS, int I>
 DI void pgs_friction_rows(const float* Acol, const float* af, float a0, float a1, float b0, float b1, int nc, float& y, float& lam, float invdiag, float lm) {
   if constexpr (I < MAXC) {
     if (I >= nc) return;
@@ -1127,23 +1129,23 @@ DI void pgs_friction_rows(const float* Acol, const float* af, float a0, float a1
     pgs_visit_friction<fric_lane(I, 0)>(I < PGS_REG_CONTACTS ? af[2 * (I < PGS_REG_CONTACTS ? I : 0)] : a0 * invdiag, y, lam, lm);
     pgs_visit_friction<fric_lane(I, 1)>(I < PGS_REG_CONTACTS ? af[2 * (I < PGS_REG_CONTACTS ? I : 0) + 1] : a1 * invdiag, y, lam, lm);
     pin1(n0); pin1(n1);
-    pgs_friction_rows<I + 1>(Acol, af, b0, b1, n0, n1, nc, y, lam, invdiag, lm);
+    pgs_friction_rows<PGS_REG_ROWS, PGS_REG_CONTACTS, I + 1>(Acol, af, b0, b1, n0, n1, nc, y, lam, invdiag, lm);
   }
 }
 // fewer than four fixed-bound rows left: one uniform exit test per visit
-template <int RR, int LEFT>
+template <int PGS_REG_ROWS, int RR, int LEFT>
 DI void pgs_fixed_tail(const float* ar, float a0, float a1, float a2, int r_fr, float& y, float& lam, float invdiag, float lo0) {
   if constexpr (RR < MAXR && LEFT > 0) {
     if (RR >= r_fr) return;
     pgs_visit<RR>(RR < PGS_REG_ROWS ? ar[RR < PGS_REG_ROWS ? RR : 0] : a0 * invdiag, y, lam, lo0);
-    pgs_fixed_tail<RR + 1, LEFT - 1>(ar, a1, a2, 0.0f, r_fr, y, lam, invdiag, lo0);
+    pgs_fixed_tail<PGS_REG_ROWS, RR + 1, LEFT - 1>(ar, a1, a2, 0.0f, r_fr, y, lam, invdiag, lo0);
   }
 }
 // Fixed-bound rows are visited in GROUPS OF FOUR (compile-time recursion = guaranteed unrolling; readlane / writelane indices and
 // LDS offsets are immediates): one uniform exit test per group instead of per visit, and the four A entries of the NEXT group are
 // requested from LDS before this group's visits start -- a visit is ~30 cycles of dependent issue, an LDS round trip is more than
 // two of them, so the former two-visits-ahead prefetch left every visit waiting.  The last one to three rows take pgs_fixed_tail.
-template <int RR>
+template <int PGS_REG_ROWS, int RR>
 DI void pgs_fixed_rows(const float* Acol, const float* ar, float a0, float a1, float a2, float a3, int r_fr, float& y, float& lam, float invdiag, float lo0) {
   if constexpr (RR + 4 <= MAXR) {
     if (RR + 4 <= r_fr) {
@@ -1157,13 +1159,12 @@ DI void pgs_fixed_rows(const float* Acol, const float* ar, float a0, float a1, f
       pgs_visit<RR + 2>(reg ? ar[reg ? RR + 2 : 0] : a2 * invdiag, y, lam, lo0);
       pgs_visit<RR + 3>(reg ? ar[reg ? RR + 3 : 0] : a3 * invdiag, y, lam, lo0);
       pin1(n0); pin1(n1); pin1(n2); pin1(n3);   // keeps the optimiser from sinking the reads into the group that uses them
-      pgs_fixed_rows<RR + 4>(Acol, ar, n0, n1, n2, n3, r_fr, y, lam, invdiag, lo0);
+      pgs_fixed_rows<PGS_REG_ROWS, RR + 4>(Acol, ar, n0, n1, n2, n3, r_fr, y, lam, invdiag, lo0);
       return;
     }
   }
-  pgs_fixed_tail<RR, 3>(ar, a0, a1, a2, r_fr, y, lam, invdiag, lo0);
+  pgs_fixed_tail<PGS_REG_ROWS, RR, 3>(ar, a0, a1, a2, r_fr, y, lam, invdiag, lo0);
 }
-static_assert(PGS_REG_ROWS % 4 == 0 && PGS_REG_ROWS <= MAXR && PGS_REG_CONTACTS <= MAXC, "register window of the solver");
 
 // ------------------------------------------------------------------ constraint rows + PGS
 // lane = row.  See oracle solve_constraints() for the reference formulation.
@@ -1475,6 +1476,8 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   const int nrow_lane = is_fric ? nl + NFIX + ci : 0;   // lane of the normal row this friction row is bounded by
   float y = (bias - w) * invdiag;
   // this lane's gains of the first rows, scaled once (pgs_fixed_rows / pgs_friction_rows); rows that do not exist give unused values
+  constexpr int PGS_REG_ROWS = PgsWin<T>::ROWS, PGS_REG_CONTACTS = PgsWin<T>::CONTACTS;
+  static_assert(PGS_REG_ROWS % 4 == 0 && PGS_REG_ROWS <= MAXR && PGS_REG_CONTACTS <= MAXC, "register window of the solver");
   float ar[PGS_REG_ROWS], af[2 * PGS_REG_CONTACTS];
 #pragma unroll
   for (int k = 0; k < PGS_REG_ROWS; ++k) ar[k] = Acol[MAXR * k] * invdiag;
@@ -1489,13 +1492,13 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
     // the unrolled visits out of the loop as a 64-bit lane mask each -- ~100 SGPRs, spilled to VGPR lanes and re-read per iteration
     int rf = r_fr, ncc = nc;
     asm volatile("" : "+s"(rf), "+s"(ncc));
-    pgs_fixed_rows<0>(Acol, ar, 0.0f, 0.0f, 0.0f, 0.0f, rf, y, lam, invdiag, lo0);
+    pgs_fixed_rows<PGS_REG_ROWS, 0>(Acol, ar, 0.0f, 0.0f, 0.0f, 0.0f, rf, y, lam, invdiag, lo0);
     if (ncc > 0) {  // wave-uniform
       float f0 = 0.0f, f1 = 0.0f, g0 = 0.0f, g1 = 0.0f;
       if (PGS_REG_CONTACTS < 1) { f0 = Acol_fr[MAXR * fric_lane(0, 0)]; f1 = Acol_fr[MAXR * fric_lane(0, 1)]; }
       if (PGS_REG_CONTACTS < 2 && ncc > 1) { g0 = Acol_fr[MAXR * fric_lane(1, 0)]; g1 = Acol_fr[MAXR * fric_lane(1, 1)]; }
       const float lm = mu * __shfl(lam, nrow_lane, 64);
-      pgs_friction_rows<0>(Acol_fr, af, f0, f1, g0, g1, ncc, y, lam, invdiag, lm);
+      pgs_friction_rows<PGS_REG_ROWS, PGS_REG_CONTACTS, 0>(Acol_fr, af, f0, f1, g0, g1, ncc, y, lam, invdiag, lm);
     }
   }
   STAMP(8);
