@@ -96,6 +96,11 @@ def parse_args(argv=None):
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU (4096 = the metric's config; 8192 = configs[4])")
     ap.add_argument("--env-id", default=ENV_ID)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preroll", type=int, default=1000,
+                    help="data preparation, before the W warm-up steps: env-steps that age the freshly reset batch into the steady-state mix of "
+                         "episode ages and contact counts (SURVEY 8d config 2 asks for >= 200; 1000 = one max_episode_steps, so TimeLimit truncations "
+                         "are in the mix) and bring the GPU to its operating clocks -- after idling the first ~50 ms of launches run 9 %% slow "
+                         "(tools/ramp_probe.py, profiles/r02_ramp_probe.txt); untimed, reported in config.preroll_steps")
     ap.add_argument("--curriculum", type=int, default=None, help="Stepper envs: curriculum 0..9 (SURVEY 8d config 3)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise launch / rendezvous / reporting only (CPU tests)")
     ap.add_argument("--host-io", action="store_true",
@@ -175,6 +180,9 @@ def main():
         g.manual_seed(1 + rank)
         tape = torch.rand(64, args.envs, env.act_dim, device=dev, generator=g) * 2 - 1  # U(-1,1) action tape, looped
 
+        # the synthetic input of this metric is a batch of envs in mid-episode, not 4096 identical first frames: age it
+        for i in range(args.preroll):
+            env.step(tape[(i + 17) % 64])
         n_done = torch.zeros((), device=dev)
         for i in range(args.warmup):
             _, _, done, _ = env.step(tape[i % 64])
@@ -244,7 +252,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.env_id}, {args.envs} envs/GPU, {terrain}, U(-1,1) action tape, auto-reset",
                        "envs_per_gpu": args.envs, "parallelism": f"independent env shards x{world}, no collective",
-                       "reset_fraction_per_step": reset_frac},
+                       "reset_fraction_per_step": reset_frac, "preroll_steps": args.preroll},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mocca_step_kernel", "kernel_ms": kern_ms,
