@@ -1459,10 +1459,16 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   wsync();
   STAMP(7);
   // warm-start impulses act before the first iteration (normal rows only)
+  // (a wave without a warm impulse skips the reads; otherwise two rows per trip, every product added -- a zero impulse adds zero)
+  if (__ballot(lam != 0.0f) != 0ull) {
+    int rr = nl + NFIX;
+    const int rend = nl + NFIX + nc;
 #pragma unroll 1
-  for (int rr = nl + NFIX; rr < nl + NFIX + nc; ++rr) {
-    const float l0 = readlane(lam, rr);
-    if (l0 != 0.0f) w += L[L_A + MAXR * rr + lc] * l0;
+    for (; rr + 2 <= rend; rr += 2) {
+      const float g0 = L[L_A + MAXR * rr + lc], g1 = L[L_A + MAXR * rr + MAXR + lc];
+      w += g0 * readlane(lam, rr); w += g1 * readlane(lam, rr + 1);
+    }
+    if (rr < rend) w += L[L_A + MAXR * rr + lc] * readlane(lam, rr);
   }
   STAMP(20);
   // ---- projected Gauss-Seidel: limits, closures, normals (lanes 0 .. r_fr - 1 in order), then the friction rows contact by contact.
@@ -1512,9 +1518,17 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   wsync();
   if (kind == 1 && slot >= 0) L[L_WARM + slot] = lam;
   if (lane < T::ND) {
+    // dense row order: fixed-bound rows, then the friction rows by lane.  Four reads in flight per round trip, summed in the same order:
+    // one read per trip made this loop an LDS-latency chain as long as the row count, on exactly the waves the launch waits for
     float s = 0;
+    int rr = 0;
 #pragma unroll 1
-    for (int rr = 0; rr < nr; ++rr) s += L[L_XL + 28 * rr + lane];   // dense row order: fixed-bound rows, then the friction rows by lane
+    for (; rr + 4 <= nr; rr += 4) {
+      const float x0 = L[L_XL + 28 * rr + lane], x1 = L[L_XL + 28 * rr + 28 + lane], x2 = L[L_XL + 28 * rr + 56 + lane], x3 = L[L_XL + 28 * rr + 84 + lane];
+      s += x0; s += x1; s += x2; s += x3;
+    }
+#pragma unroll 1
+    for (; rr < nr; ++rr) s += L[L_XL + 28 * rr + lane];
     L[L_NU + lane] += s;
   }
   wsync();
