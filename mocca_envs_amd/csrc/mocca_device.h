@@ -262,6 +262,19 @@ DI float writelane_c(float v, float old) {  // immediate lane select
   asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(v), "n"(LANE));
   return old;
 }
+// old with lane LANE replaced by that lane's v: one v_cndmask on a constant lane mask (SALU moves) -- the v_readlane + v_writelane pair
+// that did the same took two VALU issues
+template <int LANE>
+DI float commit_lane(float v, float old) {
+  float r;
+  unsigned long long m;  // built next to its use: as an operand the 60 masks of the unrolled solver were hoisted to kernel entry and spilled
+  // (s_mov / s_bitset1 leave SCC alone: the visits sit between the s_cmp and the s_cbranch of the solver's uniform exit tests)
+  if constexpr (LANE < 31)
+    asm("s_mov_b64 %1, %4\n\tv_cndmask_b32 %0, %2, %3, %1" : "=v"(r), "=&s"(m) : "v"(old), "v"(v), "n"(1u << LANE));
+  else
+    asm("s_mov_b64 %1, 0\n\ts_bitset1_b64 %1, %4\n\tv_cndmask_b32 %0, %2, %3, %1" : "=v"(r), "=&s"(m) : "v"(old), "v"(v), "n"(LANE));
+  return r;
+}
 DI int lane_rank(unsigned long long mask) {  // number of set bits below this lane
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
@@ -1088,7 +1101,7 @@ template <int RR>
 DI void pgs_visit(float as, float& y, float& lam, float lo0) {
   const float nl_ = __builtin_amdgcn_fmed3f(y, lo0, 1e30f);
   const float dl = readlane(nl_ - lam, RR);
-  lam = writelane_c<RR>(readlane(nl_, RR), lam);
+  lam = commit_lane<RR>(nl_, lam);
   y = fmaf(-as, dl, y);
 }
 // a friction row: the same visit with the symmetric bound |lambda| <= lm = mu * (impulse of the contact's normal row), per lane
@@ -1096,7 +1109,7 @@ template <int RR>
 DI void pgs_visit_friction(float as, float& y, float& lam, float lm) {
   const float nl_ = __builtin_amdgcn_fmed3f(y, -lm, lm);
   const float dl = readlane(nl_ - lam, RR);
-  lam = writelane_c<RR>(readlane(nl_, RR), lam);
+  lam = commit_lane<RR>(nl_, lam);
   y = fmaf(-as, dl, y);
 }
 // Friction rows live on STATIC lanes at the top of the row range: contact i owns lanes MAXR - 2 - 2i (first tangent) and
@@ -1128,7 +1141,7 @@ DI void pgs_friction_rows(const float* Acol, const float* af, float a0, float a1
     }
     pgs_visit_friction<fric_lane(I, 0)>(I < PGS_REG_CONTACTS ? af[2 * (I < PGS_REG_CONTACTS ? I : 0)] : a0 * invdiag, y, lam, lm);
     pgs_visit_friction<fric_lane(I, 1)>(I < PGS_REG_CONTACTS ? af[2 * (I < PGS_REG_CONTACTS ? I : 0) + 1] : a1 * invdiag, y, lam, lm);
-    pin1(n0); pin1(n1);
+    if constexpr (I + 2 >= PGS_REG_CONTACTS) { pin1(n0); pin1(n1); }
     pgs_friction_rows<PGS_REG_ROWS, PGS_REG_CONTACTS, I + 1>(Acol, af, b0, b1, n0, n1, nc, y, lam, invdiag, lm);
   }
 }
@@ -1158,7 +1171,7 @@ DI void pgs_fixed_rows(const float* Acol, const float* ar, float a0, float a1, f
       pgs_visit<RR + 1>(reg ? ar[reg ? RR + 1 : 0] : a1 * invdiag, y, lam, lo0);
       pgs_visit<RR + 2>(reg ? ar[reg ? RR + 2 : 0] : a2 * invdiag, y, lam, lo0);
       pgs_visit<RR + 3>(reg ? ar[reg ? RR + 3 : 0] : a3 * invdiag, y, lam, lo0);
-      pin1(n0); pin1(n1); pin1(n2); pin1(n3);   // keeps the optimiser from sinking the reads into the group that uses them
+      if constexpr (RR + 4 >= PGS_REG_ROWS) { pin1(n0); pin1(n1); pin1(n2); pin1(n3); }   // keeps the optimiser from sinking the reads into the group that uses them
       pgs_fixed_rows<PGS_REG_ROWS, RR + 4>(Acol, ar, n0, n1, n2, n3, r_fr, y, lam, invdiag, lo0);
       return;
     }
