@@ -1891,8 +1891,10 @@ DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, in
   t.gain = a.gain_v ? a.gain_v[env - a.env_offset] : a.gain;  // robot.applied_gain persists across resets (robots.py:16,33)
   if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
     randomize_target<INJECT>(a, env, t, live_eval_mode(a, env - a.env_offset));
-    t.wt[0] = t.dist * cosf(t.angle);
-    t.wt[1] = t.dist * sinf(t.angle);
+    float sa, ca;
+    fast_sincos(t.angle, &sa, &ca);   // |angle| <= pi / 2: no large-argument path needed
+    t.wt[0] = t.dist * ca;
+    t.wt[1] = t.dist * sa;
     t.wt[2] = 1.0f;
   } else {
     t.gain = M->gain_cur[0] + (M->gain_cur[1] - M->gain_cur[0]) * t.cur / 9;           // applied_gain_curriculum[curriculum], :369,489
@@ -1904,14 +1906,19 @@ DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, in
     int src = b;  // robots.py:182-188 mirror: swap right/left, negate abdomen z/x
     float sgn = 1.0f;
     if (t.mirrored) {
-      const int j = b - 1;
-#pragma unroll 1
-      for (int k = 0; k < M->n_mirror_side; ++k) {
-        if (M->mirror_right[k] == j) src = M->mirror_left[k] + 1;
-        if (M->mirror_left[k] == j) src = M->mirror_right[k] + 1;
+      // both tables in one batch of scalar loads (rolled, every entry was its own ~200-cycle round trip -- at the end of exactly the
+      // waves the launch waits for: a fallen robot is a heavy wave AND a reset)
+      const int j = b - 1, nms = M->n_mirror_side, nmn = M->n_mirror_neg;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int mr = M->mirror_right[k], ml = M->mirror_left[k];
+        if (k < nms) {
+          if (mr == j) src = ml + 1;
+          if (ml == j) src = mr + 1;
+        }
       }
-#pragma unroll 1
-      for (int k = 0; k < M->n_mirror_neg; ++k) if (M->mirror_neg[k] == j) sgn = -1.0f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) if (k < nmn && M->mirror_neg[k] == j) sgn = -1.0f;
     }
     const float base = sgn * M->init_q[src];
     float qn = base;

@@ -206,8 +206,10 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     if ((float)t.close >= t.stopf && !a.host_retarget) {                               // :214-222
       t.close = 0;
       randomize_target<INJECT>(a, env + a.env_offset, t, evalm);
-      t.wt[0] += t.dist * cosf(t.angle);
-      t.wt[1] += t.dist * sinf(t.angle);
+      float sa, ca;
+      fast_sincos(t.angle, &sa, &ca);
+      t.wt[0] += t.dist * ca;
+      t.wt[1] += t.dist * sa;
       calc_potential(M, L, t, ro, &dist, &cd, &sd);
     }
     rew = progress + bonus - energy + tall - posture - joints;                         // :121-122
