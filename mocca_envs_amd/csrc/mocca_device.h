@@ -1830,7 +1830,7 @@ DI void delta_to_k_targets(ModelP M, const float* L, const float* ter, TaskRegs&
 }
 
 // generate_step_placements, env_locomotion.py:395-441: 100 uniforms (5 x 20) -> 20 x 6 table in `ter`.
-// Lanes draw in parallel (counter-based RNG), lane 0 runs the cumulative sums.
+// Lanes draw in parallel (counter-based RNG) and each builds one row; the cumulative sums run over the lanes in row order.
 template <bool INJECT>
 DI void generate_terrain(const StepArgs& a, ModelP M, int env, TaskRegs& t, float* L, float* ter, int lane) {
   const float DEG = 3.14159265358979323846f / 180.0f, HP = 1.5707963267948966f;
@@ -1841,35 +1841,45 @@ DI void generate_terrain(const StepArgs& a, ModelP M, int env, TaskRegs& t, floa
   for (int k = lane; k < 5 * N; k += 64) u[k] = draw_u<INJECT>(a, env, t.episode, t.draw + k);
   t.draw += 5 * N;
   wsync();
-  if (lane == 0) {
+  // lane = table row for everything but the four running sums (heading, x, y, z), which walk the rows in order with one v_readlane per
+  // row and quantity -- the summation order of the reference's np.cumsum.  (One lane running the whole table -- four libm calls per row
+  // on a 20-step dependent chain -- took 35 k cycles, at the end of the very waves a launch waits for.)
+  {
+    const int i = lane < N ? lane : N - 1;   // the other lanes shadow the last row and store nothing
     const float d0 = M->dist_range[0], d1 = M->dist_range[1], sep = M->init_step_separation, dx_min = M->step_radius * 2.5f;
     const float dist_lo = d0, dist_hi = d0 + (d1 - d0) * cur / 9;
     const float yaw_lo = -M->yaw_range_deg * ratio * DEG, yaw_hi = M->yaw_range_deg * ratio * DEG;
     const float pit_lo = -M->pitch_range_deg * ratio * DEG + HP, pit_hi = M->pitch_range_deg * ratio * DEG + HP;
     const float tl_lo = -M->tilt_range_deg * ratio * DEG, tl_hi = M->tilt_range_deg * ratio * DEG;
-    float x = 0, y = 0, z = 0, phi = 0;
+    float dr = dist_lo + (dist_hi - dist_lo) * u[i];
+    float dphi = yaw_lo + (yaw_hi - yaw_lo) * u[N + i];
+    float dth = pit_lo + (pit_hi - pit_lo) * u[2 * N + i];
+    float xt = tl_lo + (tl_hi - tl_lo) * u[3 * N + i];
+    float yt = tl_lo + (tl_hi - tl_lo) * u[4 * N + i];
+    if (i == 0) { dr = 0; dphi = 0; dth = HP; }
+    if (i == 1 || i == 2) { dr = sep; dphi = 0; dth = HP; }
+    if (i < 3) { xt = 0; yt = 0; }
+    float phi = 0, run = 0;
 #pragma unroll 1
-    for (int i = 0; i < N; ++i) {
-      float dr = dist_lo + (dist_hi - dist_lo) * u[i];
-      float dphi = yaw_lo + (yaw_hi - yaw_lo) * u[N + i];
-      float dth = pit_lo + (pit_hi - pit_lo) * u[2 * N + i];
-      float xt = tl_lo + (tl_hi - tl_lo) * u[3 * N + i];
-      float yt = tl_lo + (tl_hi - tl_lo) * u[4 * N + i];
-      if (i == 0) { dr = 0; dphi = 0; dth = HP; }
-      if (i == 1 || i == 2) { dr = sep; dphi = 0; dth = HP; }
-      if (i < 3) { xt = 0; yt = 0; }
-      phi += dphi;
-      float dx = dr * sinf(dth) * cosf(phi);
-      const float dy = dr * sinf(dth) * sinf(phi), dz = dr * cosf(dth);
-      if (i >= 2) {
-        const float ax = fabsf(dx), mx = ax > dx_min ? ax : dx_min;
-        const float sg = dx > 0 ? 1.0f : (dx < 0 ? -1.0f : 0.0f);
-        dx = sg * (mx < d1 ? mx : d1);
-      }
-      x += dx; y += dy; z += dz;
+    for (int k = 0; k < N; ++k) { run += readlane(dphi, k); if (lane == k) phi = run; }
+    if (lane >= N) phi = run;
+    float dx = dr * sinf(dth) * cosf(phi);
+    const float dy = dr * sinf(dth) * sinf(phi), dz = dr * cosf(dth);
+    if (i >= 2) {
+      const float ax = fabsf(dx), mx = ax > dx_min ? ax : dx_min;
+      const float sg = dx > 0 ? 1.0f : (dx < 0 ? -1.0f : 0.0f);
+      dx = sg * (mx < d1 ? mx : d1);
+    }
+    float x = 0, y = 0, z = 0, rx = 0, ry = 0, rz = 0;
+#pragma unroll 1
+    for (int k = 0; k < N; ++k) {
+      rx += readlane(dx, k); ry += readlane(dy, k); rz += readlane(dz, k);
+      if (lane == k) { x = rx; y = ry; z = rz; }
+    }
+    if (lane < N) {
       ter[6 * i] = x; ter[6 * i + 1] = y; ter[6 * i + 2] = z; ter[6 * i + 3] = phi; ter[6 * i + 4] = xt; ter[6 * i + 5] = yt;
     }
-    ter[120] = 0.0f; ter[121] = 1.0f; ter[122] = 2.0f; ter[123] = 3.0f;
+    if (lane == 0) { ter[120] = 0.0f; ter[121] = 1.0f; ter[122] = 2.0f; ter[123] = 3.0f; }
   }
   wsync();
 }
