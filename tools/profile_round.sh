@@ -56,3 +56,5 @@ t = {"kernel": "mocca_step_kernel", "envs_per_launch": envs, "kernel_source_sha2
      "source": f"profiles/{tag}_pmc_summary.json"}
 json.dump(t, open(f"{O}/{tag}_traffic.json", "w"), indent=1)
 PY
+# the raw per-dispatch traces are bulky (gpurun merges at most 64 MiB back): only the summaries above are kept
+find $O -maxdepth 1 -type d \( -name "${tag}_pmc_*" -o -name "${tag}_trace" \) -exec rm -rf {} +
