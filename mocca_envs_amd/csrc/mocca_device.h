@@ -289,10 +289,14 @@ DI unsigned wave_or(unsigned v) {
   v = dpp_or<0x140>(v);  // row_mirror: every lane now holds its row's OR
   return (unsigned)(readlane_i((int)v, 0) | readlane_i((int)v, 16) | readlane_i((int)v, 32) | readlane_i((int)v, 48));
 }
+// sum over the wave, result uniform: DPP butterflies inside each row of 16, then one readlane per row (six dependent ds_bpermute round
+// trips before -- on the reward path every wave runs after its last substep)
 DI float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror: every lane now holds its row's sum
+  return (readlane(v, 0) + readlane(v, 16)) + (readlane(v, 32) + readlane(v, 48));
 }
 
 // Philox4x32-10; identical to oracle/mocca_oracle.c so device resets are reproducible on the host
