@@ -1072,9 +1072,20 @@ DI void delassus_dots(const float* L, const float* X, int oc, int onr, int tmax,
     const unsigned o = (unsigned)(oc + 28 * TT);
     const unsigned ow = o - (unsigned)onr;
     const float* Jr = L + L_J + (int)(o < ow ? o : ow);
-    float s = 0;
+    float s;
+    if constexpr (T::NCLOS > 0) {
+      // Cassie runs two waves per SIMD (2048 envs) with ~45 rows per substep: the 28-term dot is a latency chain there, two chains halve it
+      // (at four waves per SIMD the other waves fill the gaps and the split measured nothing)
+      float s0 = 0, s1 = 0;
 #pragma unroll
-    for (int d = 0; d < T::ND; ++d) s += Jr[d] * X[d];
+      for (int d = 0; d + 1 < T::ND; d += 2) { s0 += Jr[d] * X[d]; s1 += Jr[d + 1] * X[d + 1]; }
+      if constexpr (T::ND & 1) s0 += Jr[T::ND - 1] * X[T::ND - 1];
+      s = s0 + s1;
+    } else {
+      s = 0;
+#pragma unroll
+      for (int d = 0; d < T::ND; ++d) s += Jr[d] * X[d];
+    }
     v[TT] = s;
     pin1(v[TT]);  // keeps the steps in order: hoisting the next steps' 28-register J rows above this point spills
     delassus_dots<T, TT + 1>(L, X, oc, onr, tmax, v);
