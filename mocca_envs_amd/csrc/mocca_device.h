@@ -731,8 +731,12 @@ DI void plane_space(const float* n, float* t1, float* t2) {  // btPlaneSpace1
     t2[0] = -n[2] * t1[1]; t2[1] = n[2] * t1[0]; t2[2] = a * k;
   }
 }
+DI void fast_sincos(float q, float* s, float* c);
+// (plank tilts and headings are a few radians at most: fast_sincos, < 1 ulp there; six libm calls per live plank and env.step cost every
+// Stepper wave ~700 VALU instructions of argument reduction in its prologue)
 DI void euler_to_mat(float roll, float pitch, float yaw, float* R) {
-  const float cr = cosf(roll), sr = sinf(roll), cp = cosf(pitch), sp = sinf(pitch), cy = cosf(yaw), sy = sinf(yaw);
+  float cr, sr, cp, sp, cy, sy;
+  fast_sincos(roll, &sr, &cr); fast_sincos(pitch, &sp, &cp); fast_sincos(yaw, &sy, &cy);
   R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
   R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
   R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
@@ -1878,8 +1882,10 @@ DI void generate_terrain(const StepArgs& a, ModelP M, int env, TaskRegs& t, floa
 #pragma unroll 1
     for (int k = 0; k < N; ++k) { run += readlane(dphi, k); if (lane == k) phi = run; }
     if (lane >= N) phi = run;
-    float dx = dr * sinf(dth) * cosf(phi);
-    const float dy = dr * sinf(dth) * sinf(phi), dz = dr * cosf(dth);
+    float sth, cth, sph, cph;
+    fast_sincos(dth, &sth, &cth); fast_sincos(phi, &sph, &cph);
+    float dx = dr * sth * cph;
+    const float dy = dr * sth * sph, dz = dr * cth;
     if (i >= 2) {
       const float ax = fabsf(dx), mx = ax > dx_min ? ax : dx_min;
       const float sg = dx > 0 ? 1.0f : (dx < 0 ? -1.0f : 0.0f);
