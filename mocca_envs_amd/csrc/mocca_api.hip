@@ -68,6 +68,15 @@ static int check_topology_t(const MoccaModel& m, const char* name, std::string& 
       err = std::string("model blob tree differs from the compiled topology (") + name + ")";
       return MOCCA_E_TOPOLOGY;
     }
+  for (int b = 1; b < T::NB; ++b)
+    if (T::massless(b)) {   // the ABA inward pass does not read the link inertia of a level that holds only such links
+      bool zero = m.mass[b] == 0.0f;
+      for (int i = 0; i < 6; ++i) zero = zero && m.inertia[b][i] == 0.0f;
+      if (!zero) {
+        err = std::string("model blob gives mass to a link the compiled topology treats as massless (") + name + ")";
+        return MOCCA_E_TOPOLOGY;
+      }
+    }
   if (m.n_pairs > 0 && 6 * T::NG > L_CT - L_GP) {
     err = std::string("this topology's geom points overlap the contact records: blobs with self-collision pairs are not supported (") + name + ")";
     return MOCCA_E_ARG;

@@ -566,8 +566,20 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
 #undef MOCCA_CONT
     float row[6], S[6], c[6], pAi;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { row[j] = L[L_M + o36 + j] + crow[j]; S[j] = L[L_SV + osv + j]; c[j] = L[L_SV + osv + SV_C + j]; }
-    pAi = L[L_P + o6i] + cpA;
+    for (int j = 0; j < 6; ++j) { S[j] = L[L_SV + osv + j]; c[j] = L[L_SV + osv + SV_C + j]; }
+    // a level that holds only massless links (the intermediate links of the multi-hinge joints: two of the walker's eight levels)
+    // has nothing to read: its link inertias and bias forces are zero (mocca_create() checks the blob against T::massless)
+#define MOCCA_NOMASS(sl) (T::clevel(d, sl) < 0 || T::massless(T::clevel(d, sl)))
+    if (MOCCA_NOMASS(0) && MOCCA_NOMASS(1) && MOCCA_NOMASS(2) && MOCCA_NOMASS(3)) {   // compile-time
+#pragma unroll
+      for (int j = 0; j < 6; ++j) row[j] = crow[j];
+      pAi = cpA;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) row[j] = L[L_M + o36 + j] + crow[j];
+      pAi = L[L_P + o6i] + cpA;
+    }
+#undef MOCCA_NOMASS
 #pragma unroll
     for (int k = 0; k < T::MAXCH; ++k) {
       // the k-th child of the slot's body, unless it is the carried one

@@ -1181,6 +1181,10 @@ def topology_header(m: MoccaModel, name: str = "Walker3D") -> str:
         "  // (a dependent global table load per tree level / path step is what dominated the latency-bound phases)",
         "  static constexpr int clevel(int d, int s) { constexpr int t[%d][%d] = {%s}; return t[d][s]; }"
         % (maxd + 1, maxw, ", ".join(arr(l) for l in levels)),
+        "  // links without mass or inertia (the intermediate links of multi-hinge joints): a tree level that holds only such links skips the",
+        "  // reads of its (all-zero) link inertia and bias force in the ABA inward pass; mocca_create() checks the blob against this table",
+        "  static constexpr bool massless(int b) { constexpr bool t[%d] = %s; return b >= 0 && t[b]; }"
+        % (nb, arr(["true" if (m.mass[b] == 0.0 and all(m.inertia[b][i] == 0.0 for i in range(6)) and b > 0) else "false" for b in range(nb)])),
         "  // the child whose articulated inertia stays in registers (same slot, next level), -1 if none",
         "  static constexpr int ccarry(int b) { constexpr int t[%d] = %s; return b < 0 ? -1 : t[b]; }" % (nb, arr(carry)),
         "  static constexpr int cchild(int b, int k) { constexpr int t[%d][%d] = {%s}; return b < 0 ? -1 : t[b][k]; }"
