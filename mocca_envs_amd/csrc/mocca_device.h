@@ -657,6 +657,7 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
   // base: the six lanes of the first group each add up ONE ROW of the base's articulated inertia (own link + the children, which all
   // arrive through LDS) and its bias component, park row + bias as eight floats, and every lane reads the 6 x 8 block back for the
   // (redundant, wave-uniform) 6x6 solve: 12 + 2 + 12 LDS instructions instead of a 51-instruction gather of four upper triangles.
+  float abase[6];
   {
     float rowb[6], pb_ = L[L_P + ii];
 #pragma unroll
@@ -691,9 +692,9 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < 21; ++i) L[L_A0 + i] = Ai[i];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) L[L_A0 + 24 + i] = -a0[i];
     }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) abase[i] = -a0[i];   // every lane solved the same system: the base acceleration needs no LDS round trip
     wsync();
   }
   STAMP(11);
@@ -702,7 +703,7 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
     const int b = lane < T::NB ? lane : 0;
     float a[6], qdd = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) a[i] = L[L_A0 + 24 + i];
+    for (int i = 0; i < 6; ++i) a[i] = abase[i];
 #pragma unroll
     for (int k = 0; k < T::MAXD; ++k) {
       const int j = (int)((ppk >> (5 * k)) & 31ull);
