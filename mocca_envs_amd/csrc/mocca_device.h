@@ -532,7 +532,7 @@ DI void chol6_solve(const float* F, const float* b, float* x) {
 // ABA inward pass (lane = body of the current level) + base solve + outward pass (lane = body).
 // Leaves S, U, 1/D, u, the factor of IA0 in LDS for the row sweeps and the new generalised velocity in L_NU.
 template <class T>
-DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
+DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk, float* Afac) {
   STAMP_BEGIN;
   // ---- inward pass, one tree level at a time.  8 lanes per body (lane i < 6 owns row i of the 6x6
   // articulated inertia), up to MAXW = 4 bodies per level: ~45 VALU per level instead of ~260 with one
@@ -689,13 +689,12 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk) {
     float Ai[21], a0[6];
     chol6_factor(IA, Ai);
     chol6_solve(Ai, pA, a0);
-    if (lane == 0) {
+    // every lane solved the same system: the base acceleration needs no LDS round trip, and the factor travels to the row sweeps in
+    // scalar registers (uniform by construction; it used to cost six 16-byte LDS writes, a barrier and six reads per substep)
 #pragma unroll
-      for (int i = 0; i < 21; ++i) L[L_A0 + i] = Ai[i];
-    }
+    for (int i = 0; i < 21; ++i) Afac[i] = unif(Ai[i]);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) abase[i] = -a0[i];   // every lane solved the same system: the base acceleration needs no LDS round trip
-    wsync();
+    for (int i = 0; i < 6; ++i) abase[i] = -a0[i];
   }
   STAMP(11);
   // outward pass: lane = body, walk from the root accumulating the spatial acceleration
@@ -1224,7 +1223,7 @@ DI void pgs_fixed_rows(const float* Acol, const float* ar, float a0, float a1, f
 //      a visit is clamp, subtract, readlane, one-lane commit, fma (pgs_fixed_rows + the friction loop)
 //   6. nu += sum_r X_r lambda_r, summed in row order through LDS
 template <class T>
-DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned long long ppk, int32_t* dbg) {
+DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned long long ppk, int32_t* dbg, const float* Afac) {
   STAMP_BEGIN;
   // wave-uniform scalars live in SGPRs: loop control becomes s_cmp/s_cbranch instead of exec-mask bookkeeping
   const float dt = unif(M->dt), idt = rcp(dt);
@@ -1444,7 +1443,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   const float* L2 = L + l2off;
   float a0[6];
   {
-    float rhs[6], Ai[21];
+    float rhs[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const float jb = F[i] * sa - F2[i] * sb;
@@ -1452,9 +1451,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
       w += jb * L[L_NU + i];
       rhs[i] = jb - (pa[i] + pb[i]);
     }
-#pragma unroll
-    for (int i = 0; i < 21; ++i) Ai[i] = L2[L_A0 + i];
-    chol6_solve(Ai, rhs, a0);
+    chol6_solve(Afac, rhs, a0);
 #pragma unroll
     for (int i = 0; i < 6; ++i) X[i] = a0[i];
   }
@@ -1682,6 +1679,7 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
   wsync();
   STAMP(15);
   int nc = 0;
+  float Afac[21] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // Cholesky factor of the base's articulated inertia (aba_passes -> solve_constraints)
 #ifdef MOCCA_SKIP_COLLIDE  // profiling builds only (tools/ablate.sh): results are wrong by construction
   ContactFlags fl = {0, 0, 0, 0, 0, 0, 0};
 #else
@@ -1689,11 +1687,11 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
 #endif
   STAMP(1);
 #ifndef MOCCA_SKIP_ABA
-  aba_passes<T>(M, L, lane, ppk);
+  aba_passes<T>(M, L, lane, ppk, Afac);
 #endif
   STAMP(2);
 #ifndef MOCCA_SKIP_SOLVE
-  solve_constraints<T>(M, L, lane, nc, ppk, dbg);
+  solve_constraints<T>(M, L, lane, nc, ppk, dbg, Afac);
 #endif
   STAMP(3);
 #ifdef MOCCA_DUMMY_VALU  // experiment: is the kernel VALU-issue-bound?  (tools/ab.sh variants)
