@@ -94,7 +94,7 @@ enum : int {
   // Row sweeps read floats 0..11 (three 16-byte reads), the ABA outward walk 0..18 (five), the inward pass S and c (four).
   SVS = 20, SV_V = 6, SV_C = 12, SV_UU = 18, SV_INVD = 19,
   L_SV = L_V + 48,      // [22][SVS]
-  L_A0 = L_V + 488,     // [24] Cholesky factor of IA0 (sym 21, see chol6_factor) ; [8] base spatial acceleration
+  L_A0 = L_V + 488,     // [32] free (the Cholesky factor of IA0 and the base acceleration travel in registers: aba_passes -> solve_constraints)
   L_GP = L_V + 520,     // [NG][2][3] geom end points rel. base origin (136)
   L_CT = L_V + 656,     // [MAXC][16] contact records (192)
   L_ROWD = L_V + 848,   // [48] compacted limit-row candidates (int)
@@ -530,7 +530,8 @@ DI void chol6_solve(const float* F, const float* b, float* x) {
 }
 
 // ABA inward pass (lane = body of the current level) + base solve + outward pass (lane = body).
-// Leaves S, U, 1/D, u, the factor of IA0 in LDS for the row sweeps and the new generalised velocity in L_NU.
+// Leaves S, V = U / D, 1/D, u / D in LDS and the factor of IA0 in Afac (scalar registers) for the row sweeps, and the new generalised
+// velocity in L_NU.
 template <class T>
 DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk, float* Afac) {
   STAMP_BEGIN;
