@@ -428,9 +428,10 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
     matvec3(R, cl, cw);
 #pragma unroll
     for (int i = 0; i < 3; ++i) cw[i] += r[i];
-    // COM of each foot LINK (getLinkState[0], bullet_utils.py:106) for the observation
+    // COM of each foot LINK (getLinkState[0], bullet_utils.py:106) for the observation: only the walk that precedes an observation
+    // (FULL = false) needs it -- inside the substeps nothing reads L_FEET
 #pragma unroll
-    for (int f = 0; f < T::NFEET; ++f)
+    for (int f = 0; f < (FULL ? 0 : T::NFEET); ++f)
       if (b == M->foot_body[f]) {
         const float fp[3] = {M->foot_point[f][0], M->foot_point[f][1], M->foot_point[f][2]};  // uniform: scalar loads
         float fw[3];
