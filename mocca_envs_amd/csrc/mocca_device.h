@@ -619,8 +619,17 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk, float* 
     float Iac = 0.0f;
     // (a hand-written v_fmac_f32_dpp per column saves the six quad-broadcast moves but needs its own s_nop for the DPP read hazard
     // and measured the same: the compiler-scheduled form stays)
-    row[0] -= uid * dpp_mov<0x00>(LO); row[1] -= uid * dpp_mov<0x55>(LO); row[2] -= uid * dpp_mov<0xAA>(LO); row[3] -= uid * dpp_mov<0xFF>(LO);
-    row[4] -= uid * dpp_mov<0x00>(HI); row[5] -= uid * dpp_mov<0x55>(HI);
+    const float nuid = -uid;   // negated once: with a plain multiplicand the six updates are v_fmac_f32 (VOP2), which takes the quad broadcast as a DPP source
+    // the optimiser keeps the quad broadcast as its own v_mov_b32_dpp per column; one block with the DPP read hazard (two wait states after
+    // the selects that wrote LO / HI) paid once saves those six moves per level
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %6, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %6, %8 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %6, %8 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %6, %8 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %7, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %7, %8 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf"
+        : "+v"(row[0]), "+v"(row[1]), "+v"(row[2]), "+v"(row[3]), "+v"(row[4]), "+v"(row[5]) : "v"(LO), "v"(HI), "v"(nuid));
 #pragma unroll
     for (int j = 0; j < 6; ++j) Iac += row[j] * c[j];
     const float pOut = pAi + Iac + uid * u;
