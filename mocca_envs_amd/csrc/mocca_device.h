@@ -253,6 +253,20 @@ DI float group8_sum(float t) {
   t += dpp_mov<0x141>(t);  // row_half_mirror
   return t;
 }
+// the same for two values at once, as six v_add_f32_dpp: the two chains cover each other's DPP read hazard (the optimiser emitted the first
+// step of each as v_mov_b32_dpp + v_fmac and part of the last ones as moves + adds)
+DI void group8_sum2(float& a, float& b) {
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf"
+      : "+v"(a), "+v"(b));
+}
 DI int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }  // assert wave-uniformity: value moves to an SGPR
 DI float unif(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 DI float readlane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
@@ -601,8 +615,8 @@ DI void aba_passes(ModelP M, float* L, int lane, unsigned long long ppk, float* 
     // conditional blocks, each with its own wait, and nothing of the next level could be fetched ahead.
     const float Si = i < 6 ? L[L_SV + osvi] : 0.0f;  // the lane's own component of S (0 for the two idle lanes)
     const float Ui = dot6(row, S);
-    const float dsum = group8_sum(Si * Ui);
-    const float psum = group8_sum(Si * pAi);
+    float dsum = Si * Ui, psum = Si * pAi;
+    group8_sum2(dsum, psum);
     float arm = L[L_SV + osv + SV_INVD], unet = L[L_SV + osv + SV_UU];  // staged by the walk: joint armature, net joint torque
     pin1(arm); pin1(unet);                           // fetched with the level's other reads, not inside the store branch
     const float id = rcp(dsum + arm);
