@@ -1425,7 +1425,8 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
     float jb = dot6(S, F);
     if (jj == jl) jb = sgn;
     jb = valid ? jb : 0.0f;
-    const float uu = valid ? jb - dot6(S, pa) : 0.0f;
+    // (at the first position pa is still zero: without fast-math the six products with 0 are not folded)
+    const float uu = valid ? (k == T::MAXD - 1 ? jb : jb - dot6(S, pa)) : 0.0f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) pa[i] += U[i] * uu;  // U holds V = IA S / D; uu == 0 past the end of the path
     if (valid) Jrow[5 + jj] = jb;
@@ -1446,7 +1447,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
 #pragma unroll
       for (int i = 0; i < 6; ++i) { S[i] = L[L_SV + SVS * jj + i]; U[i] = L[L_SV + SVS * jj + SV_V + i]; }
       const float jb = valid ? -dot6(S, F2) : 0.0f;   // the force on the second body is -F2
-      const float uu = valid ? jb - dot6(S, pb) : 0.0f;
+      const float uu = valid ? (k == T::MAXD - 1 ? jb : jb - dot6(S, pb)) : 0.0f;
 #pragma unroll
       for (int i = 0; i < 6; ++i) pb[i] += U[i] * uu;
       if (valid) Jrow[5 + jj] += jb;                  // common ancestors carry both paths' entries
