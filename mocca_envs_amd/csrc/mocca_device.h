@@ -235,6 +235,20 @@ DI void symmv6(const float* A, const float* x, float* o) {
     o[i] = s;
   }
 }
+// the same for a spatial inertia [[Ic, m c^x], [(m c^x)^T, m 1]]: its twelve structural zeros are skipped (same order of the remaining terms;
+// without fast-math the optimiser keeps every `+ 0 * x`)
+DI void spatial_inertia_mv(const float* A, const float* x, float* o) {
+  constexpr unsigned long long Z = (1ull << 3) | (1ull << 10) | (1ull << 17) | (1ull << 18) | (1ull << 22) | (1ull << 23) |
+                                   (1ull << 25) | (1ull << 27) | (1ull << 29) | (1ull << 32) | (1ull << 33) | (1ull << 34);   // bit 6 i + j
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float s = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      if (!((Z >> (6 * i + j)) & 1ull)) s += A[sym(i, j)] * x[j];
+    o[i] = s;
+  }
+}
 DI float rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32, 1 ulp
 DI float rsq(float x) { return __builtin_amdgcn_rsqf(x); }      // v_rsq_f32
 // Pin values at a program point.  SelectionDAG linearises un-chained ALU nodes freely inside a basic block, so
@@ -477,7 +491,7 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
       I[sym(2, 3)] = -ms * cw[1]; I[sym(2, 4)] = ms * cw[0];  I[sym(2, 5)] = 0;
       I[sym(3, 3)] = ms; I[sym(3, 4)] = 0; I[sym(3, 5)] = 0; I[sym(4, 4)] = ms; I[sym(4, 5)] = 0; I[sym(5, 5)] = ms;
       float Iv[6], p[6];
-      symmv6(I, v, Iv);
+      spatial_inertia_mv(I, v, Iv);
       crf(v, Iv, p);
       // gravity through the COM
       const float fz = -M->gravity * ms;
