@@ -34,6 +34,7 @@ hipcc --offload-arch=gfx950 -O3 -o /tmp/layout_bench tools/layout_bench.hip && /
 # 5b. microbenchmarks behind DESIGN.md section 6: dependent-issue latencies, PGS visit forms, workgroup placement
 hipcc --offload-arch=gfx950 -O3 -o /tmp/lat_bench tools/lat_bench.hip && /tmp/lat_bench > $O/${tag}_lat_bench.jsonl
 hipcc --offload-arch=gfx950 -O3 -o /tmp/pgs_chain_bench tools/pgs_chain_bench.hip && /tmp/pgs_chain_bench > $O/${tag}_pgs_chain_bench.jsonl
+hipcc --offload-arch=gfx950 -O3 -o /tmp/lds_width_bench tools/lds_width_bench.hip && /tmp/lds_width_bench > $O/${tag}_lds_width_bench.jsonl
 hipcc --offload-arch=gfx950 -O3 -o /tmp/dispatch_probe tools/dispatch_probe.hip && (cd $R && /tmp/dispatch_probe > $O/${tag}_dispatch_probe.txt)
 # 6. rocprofv3: kernel-trace stats + separate PMC passes at steady state, the other two configs
 tools/profile_round.sh ${tag}_stepper Walker3DStepperEnv-v0 4096 > /dev/null 2>&1
