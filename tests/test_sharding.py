@@ -85,6 +85,12 @@ def test_bench_launches_its_own_ranks():
     assert "x2" in out["config"]["parallelism"]
     out = _bench("--gpus", "1", "--steps", "2", "--dry-run", "--envs", "8192")
     assert out["n_gpus"] == 1 and out["config"]["envs_per_gpu"] == 8192
+    # the contract's fields, and the untimed pre-roll is declared in the line (it is data preparation, not part of W or K)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in out, key
+    assert out["steps"] == 2 and out["config"]["preroll_steps"] == 1000 and out["dtype"] == "f32" and out["vs_baseline"] is None
+    assert _bench("--gpus", "1", "--steps", "2", "--dry-run", "--preroll", "7")["config"]["preroll_steps"] == 7
 
 
 def test_bench_as_a_torchrun_rank():
