@@ -58,9 +58,9 @@ typedef float f4_t __attribute__((ext_vector_type(4)));  // native vector: loada
 typedef const MOCCA_AS_CONST f4_t* CF4P;
 
 #ifndef MOCCA_PRIO_T3  // row-count thresholds of the issue priorities 3 / 2 / 1 (solve_constraints)
-#define MOCCA_PRIO_T3 36
-#define MOCCA_PRIO_T2 26
-#define MOCCA_PRIO_T1 18
+#define MOCCA_PRIO_T3 28   // re-tuned on the 116 us kernel (36 / 26 / 18 before: +0.7 %; no priorities at all: +13 %)
+#define MOCCA_PRIO_T2 20
+#define MOCCA_PRIO_T1 14
 #endif
 constexpr int MAXR = 48;  // rows held by one wave (MoccaModel.max_rows must be <= MAXR)
 constexpr int MAXC = 12;  // contacts            (MoccaModel.max_contacts <= MAXC)
