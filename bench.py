@@ -102,6 +102,9 @@ def parse_args(argv=None):
                          "are in the mix) and bring the GPU to its operating clocks -- after idling the first ~50 ms of launches run 9 %% slow "
                          "(tools/ramp_probe.py, profiles/r02_ramp_probe.txt); untimed, reported in config.preroll_steps")
     ap.add_argument("--curriculum", type=int, default=None, help="Stepper envs: curriculum 0..9 (SURVEY 8d config 3)")
+    ap.add_argument("--prio", default=None,
+                    help="TUNING ONLY: t1,t2,t3 row-count thresholds of the step kernel's issue priorities (MOCCA_PARAM_ISSUE_PRIORITY) in place of "
+                         "the env id's default; timing only, results do not depend on it")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise launch / rendezvous / reporting only (CPU tests)")
     ap.add_argument("--host-io", action="store_true",
                     help="also time the loop with actions coming from pinned host memory and obs / reward / done copied back to the host "
@@ -175,6 +178,9 @@ def main():
         env = VecEnv(args.env_id, args.envs, device=local_rank, auto_reset=True, seed=1000, env_offset=lo)
         if args.curriculum is not None:
             env.set_param(2, args.curriculum)  # MOCCA_PARAM_CURRICULUM: takes effect at reset
+        if args.prio:
+            t1, t2, t3 = (int(x) for x in args.prio.split(","))
+            env.set_param(9, t1 + 64 * t2 + 4096 * t3)  # MOCCA_PARAM_ISSUE_PRIORITY
         env.reset()
         g = torch.Generator(device=dev)
         g.manual_seed(1 + rank)

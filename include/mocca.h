@@ -61,6 +61,10 @@ enum {
                                     the host in task words 30..37 before each step (the single-env classes: np_random stays on the host) */
   MOCCA_PARAM_APPLIED_GAIN = 7, /* set_robot_params({"applied_gain": g}), env_base.py:108-115 / robots.py:16,33: acts on the
                                    next apply_action; the Stepper overwrites it at reset from its curriculum (:489) */
+  MOCCA_PARAM_ISSUE_PRIORITY = 9, /* TIMING ONLY (no reference counterpart, results do not depend on it): constraint-row counts above which a
+                                     wave runs at issue priority 1 / 2 / 3 in the step kernel, packed t1 + 64 t2 + 4096 t3 (each 0..63).
+                                     A launch lasts as long as its slowest wave and an env's cost grows with its rows, so the best
+                                     thresholds follow the batch's row distribution; default 14 / 20 / 28 (flat-ground walker) */
 };
 
 /* words of the per-env debug record (mocca_set_debug_buffer): the active set of the LAST physics substep */

@@ -39,6 +39,7 @@ struct mocca_ctx {
   const float* tape = nullptr;  // caller-owned (mocca_set_draw_tape)
   int tape_n = 0;
   int32_t* dbg = nullptr;       // caller-owned (mocca_set_debug_buffer)
+  int prio = MOCCA_PRIO_T1 + 64 * MOCCA_PRIO_T2 + 4096 * MOCCA_PRIO_T3;   // MOCCA_PARAM_ISSUE_PRIORITY
   uint64_t seed = 0;
   float* d_traj = nullptr;      // Cassie mocap / phase envs: the motion table (mocca_set_trajectory), owned by the handle
   int traj_n = 0;
@@ -244,6 +245,7 @@ static StepArgs make_args(mocca_handle h) {
   a.gain_v = h->pvec_on[2] ? h->d_pvec[2] : nullptr;
   a.gain = h->gain;
   a.dbg = h->dbg;
+  a.prio = h->prio;
   a.traj = h->d_traj; a.traj_n = h->traj_n; a.traj_tmax = h->traj_tmax; a.traj_cstep = h->traj_cstep;
   return a;
 }
@@ -416,6 +418,10 @@ int mocca_set_param(mocca_handle h, int param_id, double value) {
     case MOCCA_PARAM_HOST_RETARGET: h->host_retarget = value != 0; break;
     case MOCCA_PARAM_SEED: h->seed = (uint64_t)value; break;
     case MOCCA_PARAM_ENV_OFFSET: h->env_offset = (int)value; break;
+    case MOCCA_PARAM_ISSUE_PRIORITY:
+      if (value < 0 || value >= 262144) { h->err = "MOCCA_PARAM_ISSUE_PRIORITY is t1 + 64 t2 + 4096 t3 with each threshold in 0..63"; return MOCCA_E_ARG; }
+      h->prio = (int)value;
+      break;
     case MOCCA_PARAM_RANDOM_REWARD:
       if (value != 0 && value != 1 && value != 2) { h->err = "MOCCA_PARAM_RANDOM_REWARD is 0, 1 or 2"; return MOCCA_E_ARG; }
       h->random_reward = (int)value; break;

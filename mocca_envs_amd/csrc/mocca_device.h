@@ -57,7 +57,7 @@ typedef const MOCCA_AS_CONST MoccaModel* ModelP;
 typedef float f4_t __attribute__((ext_vector_type(4)));  // native vector: loadable through any address space
 typedef const MOCCA_AS_CONST f4_t* CF4P;
 
-#ifndef MOCCA_PRIO_T3  // row-count thresholds of the issue priorities 3 / 2 / 1 (solve_constraints)
+#ifndef MOCCA_PRIO_T3  // default row-count thresholds of the issue priorities 3 / 2 / 1 (solve_constraints; MOCCA_PARAM_ISSUE_PRIORITY)
 #define MOCCA_PRIO_T3 28   // re-tuned on the 116 us kernel (36 / 26 / 18 before: +0.7 %; no priorities at all: +13 %)
 #define MOCCA_PRIO_T2 20
 #define MOCCA_PRIO_T1 14
@@ -173,6 +173,7 @@ struct StepArgs {
   const float* traj;
   int traj_n;
   double traj_tmax, traj_cstep;   // CassieTrajectory.max_time(); control_step (mocap_time = istep * control_step / n_llc, in f64)
+  int prio;   // MOCCA_PARAM_ISSUE_PRIORITY: row-count thresholds of the issue priorities 1 / 2 / 3, 6 bits each
 };
 
 // ------------------------------------------------------------------ helpers
@@ -1262,7 +1263,7 @@ DI void pgs_fixed_rows(const float* Acol, const float* ar, float a0, float a1, f
 //      a visit is clamp, subtract, readlane, one-lane commit, fma (pgs_fixed_rows + the friction loop)
 //   6. nu += sum_r X_r lambda_r, summed in row order through LDS
 template <class T>
-DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned long long ppk, int32_t* dbg, const float* Afac) {
+DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned long long ppk, int32_t* dbg, const float* Afac, int prio) {
   STAMP_BEGIN;
   // wave-uniform scalars live in SGPRs: loop control becomes s_cmp/s_cbranch instead of exec-mask bookkeeping
   const float dt = unif(M->dt), idt = rcp(dt);
@@ -1297,9 +1298,9 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   // its row count (an env lying on the ground has 48 rows, a standing one ~20).  Issue priority follows the row count,
   // so heavy waves run at nearly their stand-alone speed while light ones -- which have slack -- yield.  nr is in an
   // SGPR: each branch is s_cmp / s_cbranch around one s_setprio (which ignores EXEC).
-  if (nr > MOCCA_PRIO_T3) __builtin_amdgcn_s_setprio(3);
-  else if (nr > MOCCA_PRIO_T2) __builtin_amdgcn_s_setprio(2);
-  else if (nr > MOCCA_PRIO_T1) __builtin_amdgcn_s_setprio(1);
+  if (nr > ((prio >> 12) & 63)) __builtin_amdgcn_s_setprio(3);
+  else if (nr > ((prio >> 6) & 63)) __builtin_amdgcn_s_setprio(2);
+  else if (nr > (prio & 63)) __builtin_amdgcn_s_setprio(1);
   else __builtin_amdgcn_s_setprio(0);
   wsync();
   STAMP(16);
@@ -1708,7 +1709,7 @@ DI void stage_joints(ModelP M, float* L, int lane) {
 // one physics substep (what stepSimulation does numSubSteps times, bullet_utils.py:346-353)
 template <class T, int TASK>
 DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next_step_index,
-                        unsigned long long ppk, int32_t* dbg) {
+                        unsigned long long ppk, int32_t* dbg, int prio) {
   STAMP(30);
   stage_joints<T>(M, L, lane);
   STAMP(29);
@@ -1731,7 +1732,7 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
 #endif
   STAMP(2);
 #ifndef MOCCA_SKIP_SOLVE
-  solve_constraints<T>(M, L, lane, nc, ppk, dbg, Afac);
+  solve_constraints<T>(M, L, lane, nc, ppk, dbg, Afac, prio);
 #endif
   STAMP(3);
 #ifdef MOCCA_DUMMY_VALU  // experiment: is the kernel VALU-issue-bound?  (tools/ab.sh variants)

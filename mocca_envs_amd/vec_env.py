@@ -39,6 +39,18 @@ TASKS = {
 _DEFAULT_PARAMS = {"LaikagoCustomEnv-v0": {_lib.PARAM_RANDOM_POSE: 0},    # robot_random_start = False, env_locomotion.py:863
                    "LaikagoStepperEnv-v0": {_lib.PARAM_RANDOM_POSE: 0}}   # :899
 
+# Issue-priority thresholds of the step kernel (PARAM_ISSUE_PRIORITY; timing only, results do not depend on them): constraint-row counts
+# above which a wave runs at priority 1 / 2 / 3.  The best set follows the batch's row distribution -- measured per env id with
+# tools/prio_sweep.sh on one MI355X (profiles/r02_prio_sweep.txt); ids not listed keep the library's default (14, 20, 28: the flat-ground
+# walker).  The stepping-stone walkers carry more rows as the curriculum rises: their thresholds grow with it (x 1.29 at curriculum 9).
+_ISSUE_PRIORITY = {"LaikagoCustomEnv-v0": (3, 6, 10), "LaikagoStepperEnv-v0": (4, 8, 12)}
+_ISSUE_PRIORITY_CURRICULUM = {"Walker3DStepperEnv-v0": (14, 20, 28), "MikeStepperEnv-v0": (14, 20, 28)}
+
+
+def _pack_prio(t):
+    return int(t[0]) + 64 * int(t[1]) + 4096 * int(t[2])
+
+
 _MODELS = {
     "Walker3DCustomEnv-v0": lambda **kw: M.compile_walker3d(M.TASK_WALKER3D_CUSTOM, **kw),
     "Walker3DStepperEnv-v0": lambda **kw: M.compile_walker3d(M.TASK_WALKER3D_STEPPER, **kw),   # kw: plank_class = LargePlank | Plank | Pillar
@@ -108,6 +120,8 @@ class VecEnv:
         self.set_param(_lib.PARAM_ENV_OFFSET, self.env_offset)
         for pid, val in _DEFAULT_PARAMS.get(env_id, {}).items():
             self.set_param(pid, val)
+        if env_id in _ISSUE_PRIORITY:
+            self.set_param(_lib.PARAM_ISSUE_PRIORITY, _pack_prio(_ISSUE_PRIORITY[env_id]))
         self.trajectory = None
         if self.task_id == M.TASK_CASSIE and self.model.cassie_mode != M.CASSIE_PLAIN:
             from .trajectory import CassieTrajectory   # self.traj = CassieTrajectory(), env_cassie.py:576
@@ -131,6 +145,10 @@ class VecEnv:
 
     def set_param(self, pid: int, value: float):
         _lib.check(self.lib.mocca_set_param(self.h, pid, float(value)), self.h)
+        if pid == _lib.PARAM_CURRICULUM and self.env_id in _ISSUE_PRIORITY_CURRICULUM:   # timing only, see _ISSUE_PRIORITY
+            k = 1.0 + 0.29 * min(9.0, max(0.0, float(value))) / 9.0
+            base = _ISSUE_PRIORITY_CURRICULUM[self.env_id]
+            _lib.check(self.lib.mocca_set_param(self.h, _lib.PARAM_ISSUE_PRIORITY, float(_pack_prio([min(63, round(k * t)) for t in base]))), self.h)
 
     def set_trajectory(self, traj, control_step: float = 0.03):
         """Attach the reference motion of the Cassie mocap / phase envs (include/mocca.h mocca_set_trajectory); the table is

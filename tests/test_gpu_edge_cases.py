@@ -187,3 +187,27 @@ def test_seed_is_a_full_64_bit_key():
         differ |= not torch.equal(oa, ob)
     assert differ
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_issue_priority_thresholds_change_timing_only():
+    """MOCCA_PARAM_ISSUE_PRIORITY (include/mocca.h) moves waves between the hardware's issue priorities: same results bit for bit."""
+    import torch
+    from mocca_envs_amd import lib as _lib
+    from mocca_envs_amd.vec_env import VecEnv
+    outs = []
+    for prio in (None, 2 + 64 * 4 + 4096 * 6, 40 + 64 * 50 + 4096 * 60):
+        env = VecEnv("Walker3DStepperEnv-v0", 256, auto_reset=True, seed=5)
+        if prio is not None:
+            env.set_param(_lib.PARAM_ISSUE_PRIORITY, prio)
+        env.reset()
+        g = torch.Generator(device="cuda").manual_seed(3)
+        for _ in range(40):
+            o, r, d, _i = env.step(torch.rand(256, env.act_dim, device="cuda", generator=g) * 2 - 1)
+        outs.append((o.clone(), r.clone(), d.clone(), env.get_state().clone()))
+        with pytest.raises(Exception):
+            env.set_param(_lib.PARAM_ISSUE_PRIORITY, 1 << 18)
+        env.close()
+    for k in (1, 2):
+        for a, b in zip(outs[0], outs[k]):
+            assert torch.equal(a, b)
