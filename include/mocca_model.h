@@ -235,7 +235,7 @@ typedef struct MoccaModel {
  *  --- stepper only ---
  *  16 i next_step_index 17 i target_reached_count 18 i stop_on_next_step
  *  19 i set_stop_on_next_step 20 i curriculum 21 f applied_gain
- *  22 f prev_body_x  23 reserved
+ *  22 f prev_body_x  23 i constraint rows of the last physics substep (issue-priority hint for the next step: timing only)
  *  30..37 f reward weights of this step (Stepper with MOCCA_PARAM_RANDOM_REWARD, env_locomotion.py:533-547)
  *  --- quadrupeds only (n_feet == 4) ---
  *  24 f feet_contact[2]  25 f feet_contact[3]

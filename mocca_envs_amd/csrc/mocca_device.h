@@ -1262,8 +1262,16 @@ DI void pgs_fixed_rows(const float* Acol, const float* ar, float a0, float a1, f
 //   5. projected Gauss-Seidel in row order on the zero-diagonal matrix: every lane carries its own unclamped impulse,
 //      a visit is clamp, subtract, readlane, one-lane commit, fma (pgs_fixed_rows + the friction loop)
 //   6. nu += sum_r X_r lambda_r, summed in row order through LDS
+// issue priority of a wave with nr constraint rows (thresholds: MOCCA_PARAM_ISSUE_PRIORITY, 6 bits each); nr is wave-uniform (SGPR):
+// each branch is s_cmp / s_cbranch around one s_setprio (which ignores EXEC)
+DI void set_issue_priority(int nr, int prio) {
+  if (nr > ((prio >> 12) & 63)) __builtin_amdgcn_s_setprio(3);
+  else if (nr > ((prio >> 6) & 63)) __builtin_amdgcn_s_setprio(2);
+  else if (nr > (prio & 63)) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
 template <class T>
-DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned long long ppk, int32_t* dbg, const float* Afac, int prio) {
+DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned long long ppk, int32_t* dbg, const float* Afac, int prio, int& rows_out) {
   STAMP_BEGIN;
   // wave-uniform scalars live in SGPRs: loop control becomes s_cmp/s_cbranch instead of exec-mask bookkeeping
   const float dt = unif(M->dt), idt = rcp(dt);
@@ -1298,10 +1306,8 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   // its row count (an env lying on the ground has 48 rows, a standing one ~20).  Issue priority follows the row count,
   // so heavy waves run at nearly their stand-alone speed while light ones -- which have slack -- yield.  nr is in an
   // SGPR: each branch is s_cmp / s_cbranch around one s_setprio (which ignores EXEC).
-  if (nr > ((prio >> 12) & 63)) __builtin_amdgcn_s_setprio(3);
-  else if (nr > ((prio >> 6) & 63)) __builtin_amdgcn_s_setprio(2);
-  else if (nr > (prio & 63)) __builtin_amdgcn_s_setprio(1);
-  else __builtin_amdgcn_s_setprio(0);
+  set_issue_priority(nr, prio);
+  rows_out = nr;
   wsync();
   STAMP(16);
   if (nr == 0) {  // nothing touches, no limit near: nothing to solve (uniform branch)
@@ -1709,7 +1715,7 @@ DI void stage_joints(ModelP M, float* L, int lane) {
 // one physics substep (what stepSimulation does numSubSteps times, bullet_utils.py:346-353)
 template <class T, int TASK>
 DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next_step_index,
-                        unsigned long long ppk, int32_t* dbg, int prio) {
+                        unsigned long long ppk, int32_t* dbg, int prio, int& rows_out) {
   STAMP(30);
   stage_joints<T>(M, L, lane);
   STAMP(29);
@@ -1732,7 +1738,7 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
 #endif
   STAMP(2);
 #ifndef MOCCA_SKIP_SOLVE
-  solve_constraints<T>(M, L, lane, nc, ppk, dbg, Afac, prio);
+  solve_constraints<T>(M, L, lane, nc, ppk, dbg, Afac, prio, rows_out);
 #endif
   STAMP(3);
 #ifdef MOCCA_DUMMY_VALU  // experiment: is the kernel VALU-issue-bound?  (tools/ab.sh variants)

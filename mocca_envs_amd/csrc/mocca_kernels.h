@@ -53,6 +53,8 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
     wsync();
     const int nllc = INJECT ? 0 : M->n_llc;
+    int last_rows = uni((int)tk[T_RES23]);
+    if (!INJECT) set_issue_priority(last_rows, a.prio);
 #pragma unroll 1
     for (int it = 0; it < nllc; ++it) {
       ModelP Ms = M;
@@ -73,8 +75,9 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
         L[L_TAU + b] = tq < -lim ? -lim : (tq > lim ? lim : tq);
       }
       wsync();
-      substep<T, TASK>(Ms, L, ln, nullptr, 0, pk, dbg, a.prio);
+      substep<T, TASK>(Ms, L, ln, nullptr, 0, pk, dbg, a.prio, last_rows);
     }
+    if (!INJECT && lane == 0) tk[T_RES23] = (uint32_t)last_rows;
     TaskRegs t;
     load_task(tk, t);
     t.istep += M->n_llc;  // pd_control counts every low-level iteration (:381); the task-layer entry replays a whole env.step
@@ -136,6 +139,10 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   ContactFlags fl = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int nsub = INJECT ? 0 : M->n_substeps;
   const int nsi0 = TASK == MOCCA_TASK_WALKER3D_STEPPER ? (int)tk[T_NSI] : 0;
+  // the env's row count at the end of the step before (task word 23) sets the issue priority until the first substep knows better:
+  // a heavy env is almost always still heavy, and more than half of a substep runs before its own count is known
+  int last_rows = uni((int)tk[T_RES23]);
+  if (!INJECT) set_issue_priority(last_rows, a.prio);
 #pragma unroll 1
   for (int s = 0; s < nsub; ++s) {
     // launder the model pointer: keeps LICM from hoisting dozens of loop-invariant model loads out of the
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     int ln = lane;  // same for lane-derived offsets and predicates (recomputing them costs a few instructions)
     unsigned long long pk = ppk;  // laundered too: otherwise every (ppk >> 5k) & 31 and the addresses derived from it
     asm volatile("" : "+s"(Ms), "+v"(ln), "+v"(pk));  // are hoisted out of the loop and spilled
-    fl = substep<T, TASK>(Ms, L, ln, ter, nsi0, pk, dbg, a.prio);
+    fl = substep<T, TASK>(Ms, L, ln, ter, nsi0, pk, dbg, a.prio, last_rows);
   }
   if constexpr (INJECT) {  // getContactPoints results handed in by the caller (robots.py:74-86, env_locomotion.py:634-650, :880-890)
     const int32_t* tc = a.inj_touch + (size_t)env * T::NFEET;
@@ -157,6 +164,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     }
     if (a.inj_body) fl.body_touch = a.inj_body[env] != 0;
   }
+  if (!INJECT && lane == 0) tk[T_RES23] = (uint32_t)last_rows;
   STAMP(27);  // substeps done
   TaskRegs t;
   load_task(tk, t, T::NFEET > 2);
