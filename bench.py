@@ -106,6 +106,8 @@ def parse_args(argv=None):
                     help="TUNING ONLY: t1,t2,t3 row-count thresholds of the step kernel's issue priorities (MOCCA_PARAM_ISSUE_PRIORITY) in place of "
                          "the env id's default; timing only, results do not depend on it")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise launch / rendezvous / reporting only (CPU tests)")
+    ap.add_argument("--test-barrier-delay", type=float, default=0.0,
+                    help="TEST ONLY: every rank sleeps this many seconds inside each barrier (a slow rendezvous); the timed window must not see it")
     ap.add_argument("--host-io", action="store_true",
                     help="also time the loop with actions coming from pinned host memory and obs / reward / done copied back to the host "
                          "every step (the PCIe-inclusive rate quoted in DESIGN.md; reported beside `value`, never as it)")
@@ -121,13 +123,37 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def visible_gpus() -> int:
+    """GPUs of this node, counted WITHOUT loading a HIP runtime: the KFD topology lists one node per agent, and the GPU agents are
+    the ones with SIMDs (CPU nodes report simd_count 0).  HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES narrow the set.  Returns -1 when
+    the topology is not readable (the ranks then find out themselves and fail with a non-zero exit code)."""
+    import glob
+    n, seen = 0, False
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        seen = True
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    if not seen:
+        return -1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args) -> int:
-    """`python bench.py --gpus N` without torchrun: spawn the N ranks.  Nothing here may touch the GPU (a process that has
-    initialised HIP must not be replaced or forked on this pool); device_count() does not."""
+    """`python bench.py --gpus N` without torchrun: spawn the N ranks.  The parent's only job is to start children and relay rank
+    0's line: it imports neither torch nor any HIP library (a process that has initialised HIP must not be replaced or forked on
+    this pool), and counts the GPUs from the KFD topology in /sys."""
     if not args.dry_run:
-        import torch
-        have = torch.cuda.device_count()
-        if have < args.gpus and not args.oversubscribe:
+        have = visible_gpus()
+        if 0 <= have < args.gpus and not args.oversubscribe:
             print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
             return 2
     port = _free_port()
@@ -162,11 +188,21 @@ def main():
     from mocca_envs_amd import sharding
     lo, hi = sharding.env_range(rank, world, args.envs)
     reset_frac, kern_ms, kinfo, env, host_io_ms = 0.0, 0.0, {}, None, None
-    if args.dry_run:
+
+    def barrier():
+        # start / stop rendezvous over gloo (CPU, TCP): milliseconds across 8 processes -- always OUTSIDE the rank's clock
+        if args.test_barrier_delay > 0:
+            time.sleep(args.test_barrier_delay)
         if dist is not None:
             dist.barrier()
-        elapsed = sharding.max_over_ranks(1e-3 * args.steps * (1 + rank), dist)
-        kern_ms = 1.0
+
+    if args.dry_run:
+        barrier()
+        t0 = time.perf_counter()
+        time.sleep(1e-3 * args.steps * (1 + rank))   # stands in for the K launches + synchronize: rank r takes (r + 1) ms per step
+        elapsed_rank = time.perf_counter() - t0
+        barrier()
+        kern_ms = 1.0 + rank
     else:
         import torch
         if args.oversubscribe:
@@ -194,9 +230,12 @@ def main():
             _, _, done, _ = env.step(tape[i % 64])
             n_done += (done != 0).sum()  # reset fraction is sampled during warm-up, outside the timed region
         reset_frac = float(n_done.item()) / max(1, args.envs * args.warmup)
+        # The K timed steps are bracketed by barrier + synchronize on both sides.  Each rank's clock runs from its release out of the
+        # start barrier to the return of ITS OWN synchronize after the K-th launch; the stop barrier comes after the clock is read
+        # (a gloo barrier over TCP costs 0.1 - 1 ms across 8 processes, the same order as the 2.6 ms window of --steps 20), and the
+        # job's time is the MAX of the per-rank times.
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        barrier()
         torch.cuda.synchronize()
         # HIP events on the stream the kernel is launched on (torch's current stream is the one handed to mocca_step)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -206,11 +245,9 @@ def main():
             env.step(tape[i % 64])
         ev1.record()
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        elapsed_rank = time.perf_counter() - t0
+        barrier()
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        elapsed = sharding.max_over_ranks(elapsed, dist)
         kern_ms = ev0.elapsed_time(ev1) / args.steps  # back-to-back launches: average launch duration incl. launch gaps
         kinfo = env.kernel_info()
         host_io_ms = None
@@ -228,6 +265,8 @@ def main():
                 torch.cuda.synchronize()          # the host policy needs this step's observation before it can act
             host_io_ms = 1e3 * (time.perf_counter() - t1) / args.steps
 
+    elapsed = sharding.max_over_ranks(elapsed_rank, dist)
+    per_rank = sharding.gather_over_ranks([1e3 * elapsed_rank / args.steps, kern_ms], dist)   # [world][2]
     if rank == 0:
         traffic, valu, pmc_note = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -265,6 +304,9 @@ def main():
                          "algorithmic_bytes_per_launch": algo * args.envs,
                          "note": "path is latency/VALU-bound by construction (SURVEY.md 8d); HBM fraction reported per contract"},
             "kernel_info": kinfo,
+            # one entry per rank (rank order): wall ms per step of the rank's own K steps, and its HIP-event kernel time; `ms_per_step`
+            # above is the max of the first list
+            "per_rank": {"ms_per_step": [r[0] for r in per_rank], "kernel_ms": [r[1] for r in per_rank]},
         }
         if pmc_note:
             out["roofline"]["traffic_note"] = pmc_note

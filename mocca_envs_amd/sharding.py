@@ -24,6 +24,17 @@ def max_over_ranks(seconds: float, dist=None, device=None) -> float:
     return float(t.item())
 
 
+def gather_over_ranks(values, dist=None):
+    """[world][len(values)] floats, rank order: every rank's own numbers (per-rank step time, kernel time) for the report."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [[float(v) for v in values]]
+    import torch
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(x) for x in o] for o in out]
+
+
 def aggregate_throughput(envs_per_rank: int, world: int, steps: int, seconds: float) -> float:
     """Whole-job env-steps/s: all ranks' envs x steps over the slowest rank's time."""
     return envs_per_rank * world * steps / seconds

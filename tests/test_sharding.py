@@ -78,11 +78,15 @@ def _bench(*argv, env=None):
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus N` (no torchrun) spawns N ranks, rendezvous over gloo on 127.0.0.1, reports n_gpus = N and the
     whole-job rate over the SLOWEST rank's time (the dry run makes rank r take (r + 1) ms per step)."""
-    out = _bench("--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run")
+    out = _bench("--gpus", "2", "--steps", "40", "--warmup", "1", "--dry-run")
     assert out["n_gpus"] == 2 and out["dry_run"] and out["scaling"] == "weak"
-    assert abs(out["ms_per_step"] - 2.0) < 1e-6                          # rank 1's time, not rank 0's
-    assert abs(out["value"] - 2 * 4096 * 4 / (4 * 2e-3)) < 1e-3
+    assert 2.0 <= out["ms_per_step"] < 2.3                                # rank 1's time (a 80 ms sleep), not rank 0's
+    assert abs(out["value"] - 2 * 4096 / (1e-3 * out["ms_per_step"])) < 1e-3 * out["value"]
     assert "x2" in out["config"]["parallelism"]
+    # every rank's own numbers travel in the line; ms_per_step is the max of the per-rank list
+    pr = out["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and len(pr["kernel_ms"]) == 2 and pr["kernel_ms"] == [1.0, 2.0]
+    assert 1.0 <= pr["ms_per_step"][0] < 1.3 and out["ms_per_step"] == max(pr["ms_per_step"])
     out = _bench("--gpus", "1", "--steps", "2", "--dry-run", "--envs", "8192")
     assert out["n_gpus"] == 1 and out["config"]["envs_per_gpu"] == 8192
     # the contract's fields, and the untimed pre-roll is declared in the line (it is data preparation, not part of W or K)
@@ -91,6 +95,28 @@ def test_bench_launches_its_own_ranks():
         assert key in out, key
     assert out["steps"] == 2 and out["config"]["preroll_steps"] == 1000 and out["dtype"] == "f32" and out["vs_baseline"] is None
     assert _bench("--gpus", "1", "--steps", "2", "--dry-run", "--preroll", "7")["config"]["preroll_steps"] == 7
+
+
+def test_a_slow_barrier_stays_outside_the_timed_window():
+    """The start / stop rendezvous is a gloo barrier over TCP: every rank's clock stops at its own synchronize, BEFORE the stop
+    barrier.  A barrier that takes 0.25 s (25 x the 10 ms window of this run) must not show up in ms_per_step or value."""
+    out = _bench("--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run", "--test-barrier-delay", "0.25")
+    assert 2.0 <= out["ms_per_step"] < 3.0, out["ms_per_step"]           # 5 steps x 2 ms on rank 1; with the barrier inside: > 50 ms
+    assert out["value"] > 2 * 4096 / 3e-3
+
+
+def test_the_launcher_counts_gpus_without_a_hip_runtime():
+    """`python bench.py --gpus N` is a parent that only spawns ranks: it must not import torch (which loads the HIP runtime)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.argv = ['bench.py', '--gpus', '2', '--steps', '1', '--dry-run']; sys.path.insert(0, %r); import bench; "
+            "n = bench.visible_gpus(); assert isinstance(n, int) and n >= -1; "
+            "rc = bench.self_launch(bench.parse_args()); "
+            "assert 'torch' not in sys.modules, 'the launcher imported torch'; sys.exit(rc)" % root)
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
 
 
 def test_bench_as_a_torchrun_rank():

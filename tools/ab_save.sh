@@ -1,4 +1,5 @@
 #!/bin/bash
-# Save the current kernel sources as arm A of tools/ab.sh (.ab_src/ travels to the GPU box, is not tracked by git)
+# Build the CURRENT kernel sources as arm A of tools/ab.sh: .ab/libA.so (a binary, git-ignored, travels to the GPU box; delete .ab/
+# when the experiment is over).  Run here, before editing the sources for arm B.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-mkdir -p $R/.ab_src && cp $R/mocca_envs_amd/csrc/*.h $R/mocca_envs_amd/csrc/*.hip $R/.ab_src/
+mkdir -p $R/.ab && python -m mocca_envs_amd.build --out $R/.ab/libA.so "$@" && rm -rf $R/.ab/libA.so.objs
