@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MOCCA_ABI_VERSION 3
+#define MOCCA_ABI_VERSION 4
 
 typedef struct mocca_ctx *mocca_handle;
 
@@ -60,15 +60,19 @@ enum {
                                     U(0.8, 1.2) numbers drawn every step.  1: drawn in the kernel (8 draws per step); 2: supplied by
                                     the host in task words 30..37 before each step (the single-env classes: np_random stays on the host) */
   MOCCA_PARAM_APPLIED_GAIN = 7, /* set_robot_params({"applied_gain": g}), env_base.py:108-115 / robots.py:16,33: acts on the
-                                   next apply_action; the Stepper overwrites it at reset from its curriculum (:489) */
+                                   next apply_action; the Stepper overwrites it at reset from its curriculum (:489).  The scalar form has
+                                   no stream argument: the value is written into the task records by the next call that takes a stream,
+                                   on that stream.  A later mocca_set_task restores the snapshot's per-env gains (word 21); the handle's
+                                   own copy -- what a Custom env's reset writes -- stays at the last value set here */
   MOCCA_PARAM_ISSUE_PRIORITY = 9, /* TIMING ONLY (no reference counterpart, results do not depend on it): constraint-row counts above which a
                                      wave runs at issue priority 1 / 2 / 3 in the step kernel, packed t1 + 64 t2 + 4096 t3 (each 0..63).
                                      A launch lasts as long as its slowest wave and an env's cost grows with its rows, so the best
                                      thresholds follow the batch's row distribution; default 14 / 20 / 28 (flat-ground walker) */
 };
 
-/* words of the per-env debug record (mocca_set_debug_buffer): the active set of the LAST physics substep */
-#define MOCCA_DEBUG_WORDS 8
+/* words of the per-env debug record (mocca_set_debug_buffer): words 0..11 the active set of the LAST physics substep, words 12..15
+ * cumulative over every substep since the caller last cleared the buffer */
+#define MOCCA_DEBUG_WORDS 16
 enum {
   MOCCA_DBG_ROWS = 0,        /* constraint rows solved                                  */
   MOCCA_DBG_LIMIT_ROWS = 1,  /* of which joint-limit rows                               */
@@ -78,6 +82,16 @@ enum {
   MOCCA_DBG_LIMITS_LO = 5,   /* bit 2j + side: limit candidate of joint j (0 lower, 1 upper) */
   MOCCA_DBG_LIMITS_HI = 6,
   MOCCA_DBG_SELF = 7,        /* self-collision pairs within the margin                  */
+  MOCCA_DBG_CLAMP_LO = 8,    /* bit l: the row on solver lane l ended the LAST PGS iteration on a bound (unilateral rows at 0, friction  */
+  MOCCA_DBG_CLAMP_HI = 9,    /* rows at +-mu lambda_n).  Lanes: limit / closure / planar / normal rows 0.. in row order, friction rows */
+                             /* of contact i on lanes 46 - 2i and 47 - 2i                                                               */
+  MOCCA_DBG_CLAMPSIG_LO = 10, /* the same mask folded over ALL iterations: sig = rotl64(sig, 7) ^ mask -- every discrete decision the   */
+  MOCCA_DBG_CLAMPSIG_HI = 11, /* solver took in the substep                                                                             */
+  /* cap pressure (Bullet has neither cap), cumulative: */
+  MOCCA_DBG_CAP_CONTACTS = 12, /* substeps in which more contacts were within the margin than max_contacts                             */
+  MOCCA_DBG_CAP_ROWS = 13,     /* substeps in which limit + closure + 3 x (kept contacts) rows exceeded max_rows                        */
+  MOCCA_DBG_SUBSTEPS = 14,     /* substeps counted                                                                                      */
+  MOCCA_DBG_ROWS_WANTED = 15,  /* largest row count an uncapped solver would have held                                                  */
 };
 
 int mocca_abi_version(void);
@@ -149,6 +163,12 @@ int mocca_set_param_v(mocca_handle h, int param_id, const float *values_dev, int
 int mocca_set_seed(mocca_handle h, uint64_t seed);
 /* dbg_dev [N][MOCCA_DEBUG_WORDS] i32 receives the active set of each env's last substep on every mocca_step; NULL stops it */
 int mocca_set_debug_buffer(mocca_handle h, int32_t *dbg_dev);
+/* Terminal observations under MOCCA_PARAM_AUTO_RESET.  The reference's step() returns the observation of the FINAL state together with
+ * done (env_locomotion.py:128-141), and so does gym's TimeLimit wrapper on truncation (__init__.py:55); with auto-reset mocca_step's
+ * obs_dev row of a finished env already holds the first observation of its next episode.  final_obs_dev [N][obs_dim] f32 (caller-owned,
+ * NULL detaches): on every mocca_step the row of each env whose done byte is non-zero receives that final observation -- bit-identical
+ * to what the same step returns with auto-reset off; rows of the other envs are left untouched. */
+int mocca_set_terminal_obs_buffer(mocca_handle h, float *final_obs_dev);
 /* 1 if the library was compiled with a profiling switch that makes results wrong or slow by construction
  * (MOCCA_SKIP_*, MOCCA_DUMMY_VALU, MOCCA_STAMPS); the Python binding refuses such a build unless told otherwise */
 int mocca_is_diagnostic_build(void);

@@ -34,6 +34,8 @@ struct mocca_ctx {
   float* d_terrain = nullptr;
   int auto_reset = 0, eval_mode = 0, random_pose = 1, curriculum = 0, host_retarget = 0, env_offset = 0, random_reward = 0;
   float gain = 1.0f;
+  bool gain_pending = false;   // a scalar MOCCA_PARAM_APPLIED_GAIN not yet written into the task records (flush_pending)
+  float* final_obs = nullptr;  // caller-owned (mocca_set_terminal_obs_buffer)
   float* d_pvec[3] = {nullptr, nullptr, nullptr};  // per-env curriculum / eval_mode / applied_gain (mocca_set_param_v), lazily allocated
   bool pvec_on[3] = {false, false, false};
   const float* tape = nullptr;  // caller-owned (mocca_set_draw_tape)
@@ -58,6 +60,17 @@ static thread_local std::string g_err;
     }                                                                            \
   } while (0)
 
+// does the blob give mass or inertia to a link the compiled topology T treats as massless?
+template <class T>
+static bool massive_intermediates(const MoccaModel& m) {
+  for (int b = 1; b < T::NB; ++b)
+    if (T::massless(b)) {
+      bool zero = m.mass[b] == 0.0f;
+      for (int i = 0; i < 6; ++i) zero = zero && m.inertia[b][i] == 0.0f;
+      if (!zero) return true;
+    }
+  return false;
+}
 template <class T>
 static int check_topology_t(const MoccaModel& m, const char* name, std::string& err) {
   if (m.n_bodies != T::NB || m.n_joints != T::NJ || m.n_geoms > T::NG || m.n_slots > T::NSLOT || m.n_closures != T::NCLOS) {
@@ -69,28 +82,30 @@ static int check_topology_t(const MoccaModel& m, const char* name, std::string& 
       err = std::string("model blob tree differs from the compiled topology (") + name + ")";
       return MOCCA_E_TOPOLOGY;
     }
-  for (int b = 1; b < T::NB; ++b)
-    if (T::massless(b)) {   // the ABA inward pass does not read the link inertia of a level that holds only such links
-      bool zero = m.mass[b] == 0.0f;
-      for (int i = 0; i < 6; ++i) zero = zero && m.inertia[b][i] == 0.0f;
-      if (!zero) {
-        err = std::string("model blob gives mass to a link the compiled topology treats as massless (") + name + ")";
-        return MOCCA_E_TOPOLOGY;
-      }
-    }
+  if (massive_intermediates<T>(m)) {   // the ABA inward pass of T does not read the link inertia of a level that holds only such links
+    err = std::string("model blob gives mass to a link the compiled topology treats as massless (") + name + ")";   // (check_topology picks the
+    return MOCCA_E_TOPOLOGY;                                                                                      // ...Massive instance first)
+  }
   if (m.n_pairs > 0 && 6 * T::NG > L_CT - L_GP) {
     err = std::string("this topology's geom points overlap the contact records: blobs with self-collision pairs are not supported (") + name + ")";
     return MOCCA_E_ARG;
   }
-  if (m.max_rows > MAXR || m.max_contacts > MAXC || m.max_rows < 1 + 3 * T::NCLOS || m.n_pairs > MOCCA_MAX_PAIRS || m.n_feet != T::NFEET ||
+  if (m.max_rows > MAXR || m.max_contacts > MAXC || m.max_rows < 1 + 3 * T::NCLOS + (T::NCLOS > 0 && m.planar ? 3 : 0) || m.n_pairs > MOCCA_MAX_PAIRS || m.n_feet != T::NFEET ||
       m.n_ctrl > MOCCA_MAX_CTRL || m.n_ordered > MOCCA_MAX_CTRL) {
-    err = "model blob caps exceed the kernel's (max_rows <= 48, max_contacts <= 12, n_feet as compiled)";
+    err = "model blob caps exceed the kernel's (max_rows <= 48 and >= 1 + the closure / planar rows, max_contacts <= 12, n_feet as compiled)";
     return MOCCA_E_ARG;
   }
   return MOCCA_OK;
 }
 static int check_topology(const MoccaModel& m, int task_id, int* topo, std::string& err) {
-  if (task_id == MOCCA_TASK_CASSIE) { *topo = TOPO_CASSIE; return check_topology_t<TopoCassie>(m, "TopoCassie", err); }
+  // A blob that gives mass or inertia to the intermediate links of multi-hinge joints (PyBullet's importer may: pybullet_dump.py) runs on
+  // the instance of the same tree that reads every link's inertia in the ABA inward pass.
+  if (task_id == MOCCA_TASK_CASSIE) {
+    if (m.n_bodies == TopoCassie::NB && massive_intermediates<TopoCassie>(m)) {
+      *topo = TOPO_CASSIE_MASSIVE; return check_topology_t<TopoCassieMassive>(m, "TopoCassieMassive", err);
+    }
+    *topo = TOPO_CASSIE; return check_topology_t<TopoCassie>(m, "TopoCassie", err);
+  }
   if (task_id == MOCCA_TASK_WALKER3D_CUSTOM && m.n_bodies == TopoWalker2D::NB) {
     *topo = TOPO_WALKER2D; return check_topology_t<TopoWalker2D>(m, "TopoWalker2D", err);
   }
@@ -99,6 +114,9 @@ static int check_topology(const MoccaModel& m, int task_id, int* topo, std::stri
   }
   if ((task_id == MOCCA_TASK_WALKER3D_CUSTOM || task_id == MOCCA_TASK_WALKER3D_STEPPER) && m.n_bodies == TopoLaikago::NB) {
     *topo = TOPO_LAIKAGO; return check_topology_t<TopoLaikago>(m, "TopoLaikago", err);   // LaikagoCustomEnv / LaikagoStepperEnv
+  }
+  if (m.n_bodies == TopoWalker3D::NB && massive_intermediates<TopoWalker3D>(m)) {
+    *topo = TOPO_WALKER3D_MASSIVE; return check_topology_t<TopoWalker3DMassive>(m, "TopoWalker3DMassive", err);
   }
   *topo = TOPO_WALKER3D;
   return check_topology_t<TopoWalker3D>(m, "TopoWalker3D", err);
@@ -247,7 +265,17 @@ static StepArgs make_args(mocca_handle h) {
   a.dbg = h->dbg;
   a.prio = h->prio;
   a.traj = h->d_traj; a.traj_n = h->traj_n; a.traj_tmax = h->traj_tmax; a.traj_cstep = h->traj_cstep;
+  a.final_obs = h->final_obs;
   return a;
+}
+// A scalar MOCCA_PARAM_APPLIED_GAIN is written into the task records (word T_GAIN, what apply_action reads) by the NEXT call that takes
+// a stream, on that stream: ordered against the caller's in-flight steps, which also write the word (store_task).
+static int flush_pending(mocca_handle h, hipStream_t s) {
+  if (!h->gain_pending) return MOCCA_OK;
+  hipLaunchKernelGGL(set_task_word_kernel, dim3((h->n_envs + 255) / 256), dim3(256), 0, s, h->d_task, (int)T_GAIN, (const float*)nullptr, h->gain, 1, h->n_envs);
+  HIP_TRY(h, hipGetLastError());
+  h->gain_pending = false;
+  return MOCCA_OK;
 }
 // the mocap / phase envs read their targets, reset poses and reward references from the motion table
 static int need_trajectory(mocca_handle h) {
@@ -266,6 +294,7 @@ int mocca_reset(mocca_handle h, const uint8_t* mask_dev, uint64_t seed, float* o
   StepArgs a = make_args(h);
   a.mask = mask_dev; a.obs = obs_dev;
   hipStream_t s = (hipStream_t)stream;
+  if (int rc = flush_pending(h, s)) return rc;
   if (h->tape) {  // recorded draws instead of Philox (mocca_set_draw_tape)
     a.tape = h->tape; a.tape_n = h->tape_n;
     launch_taped_reset(h->topo, h->task_id, h->n_envs, s, a);
@@ -284,6 +313,7 @@ int mocca_step(mocca_handle h, const float* act_dev, float* obs_dev, float* rew_
   StepArgs a = make_args(h);
   a.act = act_dev; a.obs = obs_dev; a.rew = rew_dev; a.done = done_dev; a.info = info_dev;
   hipStream_t s = (hipStream_t)stream;
+  if (int rc = flush_pending(h, s)) return rc;
   dispatch<LaunchStep>(h->topo, h->task_id, h->n_envs, s, a);
   HIP_TRY(h, hipGetLastError());
   return MOCCA_OK;
@@ -300,6 +330,7 @@ int mocca_task_step(mocca_handle h, const float* act_dev, const int32_t* touch_d
   a.inj_touch = touch_dev; a.inj_target = target_dev; a.inj_body = body_dev;
   a.tape = h->tape; a.tape_n = h->tape_n;
   a.dbg = nullptr;
+  if (int rc = flush_pending(h, (hipStream_t)stream)) return rc;
   launch_task_step(h->topo, h->task_id, h->n_envs, (hipStream_t)stream, a);
   HIP_TRY(h, hipGetLastError());
   return MOCCA_OK;
@@ -314,6 +345,12 @@ int mocca_set_draw_tape(mocca_handle h, const float* tape_dev, int n_per_env) {
 int mocca_set_debug_buffer(mocca_handle h, int32_t* dbg_dev) {
   if (!h) return MOCCA_E_ARG;
   h->dbg = dbg_dev;
+  return MOCCA_OK;
+}
+
+int mocca_set_terminal_obs_buffer(mocca_handle h, float* final_obs_dev) {
+  if (!h) return MOCCA_E_ARG;
+  h->final_obs = final_obs_dev;
   return MOCCA_OK;
 }
 
@@ -353,6 +390,7 @@ int mocca_observe(mocca_handle h, float* obs_dev, void* stream) {
   StepArgs a = make_args(h);
   a.obs = obs_dev;
   hipStream_t s = (hipStream_t)stream;
+  if (int rc = flush_pending(h, s)) return rc;
   dispatch<LaunchObserve>(h->topo, h->task_id, h->n_envs, s, a);
   HIP_TRY(h, hipGetLastError());
   return MOCCA_OK;
@@ -377,12 +415,16 @@ int mocca_set_state(mocca_handle h, const float* state_dev, void* stream) {
 int mocca_get_task(mocca_handle h, uint32_t* task_dev, void* stream) {
   if (!h || !task_dev) return MOCCA_E_ARG;
   DeviceGuard guard(h->device);
+  if (int rc = flush_pending(h, (hipStream_t)stream)) return rc;
   HIP_TRY(h, hipMemcpyAsync(task_dev, h->d_task, (size_t)h->n_envs * MOCCA_TASK_WORDS * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return MOCCA_OK;
 }
 int mocca_set_task(mocca_handle h, const uint32_t* task_dev, void* stream) {
   if (!h || !task_dev) return MOCCA_E_ARG;
   DeviceGuard guard(h->device);
+  // a restored snapshot wins over an earlier scalar applied_gain: every env's T_GAIN is the snapshot's; the handle's own copy (what a
+  // Custom env's reset writes, robot.applied_gain persists across resets) keeps the value of the last mocca_set_param
+  h->gain_pending = false;
   HIP_TRY(h, hipMemcpyAsync(h->d_task, task_dev, (size_t)h->n_envs * MOCCA_TASK_WORDS * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return MOCCA_OK;
 }
@@ -405,15 +447,9 @@ int mocca_set_param(mocca_handle h, int param_id, double value) {
     case MOCCA_PARAM_AUTO_RESET: h->auto_reset = value != 0; break;
     case MOCCA_PARAM_EVAL_MODE: h->eval_mode = value != 0; h->pvec_on[1] = false; break;
     case MOCCA_PARAM_CURRICULUM: h->curriculum = (int)value < 0 ? 0 : ((int)value > 9 ? 9 : (int)value); h->pvec_on[0] = false; break;
-    case MOCCA_PARAM_APPLIED_GAIN: {  // acts on the next apply_action: the task records carry the value the kernel uses
-      h->gain = (float)value; h->pvec_on[2] = false;
-      DeviceGuard guard(h->device);
-      const float g = (float)value;
-      hipLaunchKernelGGL(set_task_word_kernel, dim3((h->n_envs + 255) / 256), dim3(256), 0, 0, h->d_task, (int)T_GAIN, (const float*)nullptr, g, 1, h->n_envs);
-      HIP_TRY(h, hipGetLastError());
-      HIP_TRY(h, hipStreamSynchronize(0));
-      break;
-    }
+    case MOCCA_PARAM_APPLIED_GAIN:  // acts on the next apply_action: the task records carry the value the kernel uses; this call has no
+      h->gain = (float)value; h->pvec_on[2] = false; h->gain_pending = true;   // stream, so the write is enqueued by the next call that has
+      break;                                                                    // one (flush_pending), ordered on the caller's stream
     case MOCCA_PARAM_RANDOM_POSE: h->random_pose = value != 0; break;
     case MOCCA_PARAM_HOST_RETARGET: h->host_retarget = value != 0; break;
     case MOCCA_PARAM_SEED: h->seed = (uint64_t)value; break;

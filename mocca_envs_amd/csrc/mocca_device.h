@@ -37,6 +37,12 @@
 
 namespace mocca {
 
+// The same trees with NO link treated as massless: mocca_create() selects these instances for a blob that gives mass or inertia to the
+// intermediate links of the multi-hinge joints (what a PyBullet dump may report, pybullet_dump.from_pybullet_dump) -- the ABA inward pass
+// then reads every level's link inertia and bias force.  Everything else (tables, paths, levels) is inherited.
+struct TopoWalker3DMassive : TopoWalker3D { static constexpr bool massless(int) { return false; } };
+struct TopoCassieMassive : TopoCassie { static constexpr bool massless(int) { return false; } };
+
 #ifdef MOCCA_STAMPS  // diagnostic build only (tools/stamps.py): raw s_memtime marks of the last substep of every wave
 // Plain fire-and-forget stores, no waits and no atomics (an atomic + s_waitcnt per mark cost more than the small phases).
 constexpr int STAMP_SLOTS = 32, STAMP_WAVES = 8192;
@@ -96,6 +102,9 @@ enum : int {
   L_SV = L_V + 48,      // [22][SVS]
   L_A0 = L_V + 488,     // [32] free (the Cholesky factor of IA0 and the base acceleration travel in registers: aba_passes -> solve_constraints)
   L_GP = L_V + 520,     // [NG][2][3] geom end points rel. base origin (136)
+  L_OBS = L_V + 520,    // [<= 136] task layer (after the substeps: the geom points are dead): the observation is assembled here and leaves
+                        //          in one coalesced store -- twice for an env that ends under auto-reset (terminal observation, then the
+                        //          first observation of the next episode)
   L_CT = L_V + 656,     // [MAXC][16] contact records (192)
   L_ROWD = L_V + 848,   // [48] compacted limit-row candidates (int)
   L_RT = L_V + 896,     // [NB][3][4] body frames: row i of the rotation (3) + component i of the origin rel. the base origin: one 16-byte
@@ -174,6 +183,9 @@ struct StepArgs {
   int traj_n;
   double traj_tmax, traj_cstep;   // CassieTrajectory.max_time(); control_step (mocap_time = istep * control_step / n_llc, in f64)
   int prio;   // MOCCA_PARAM_ISSUE_PRIORITY: row-count thresholds of the issue priorities 1 / 2 / 3, 6 bits each
+  // optional (mocca_set_terminal_obs_buffer): [N][obs_dim]; the row of an env that ends under auto-reset receives the observation of
+  // its final state (what the reference's step() returns with done, env_locomotion.py:128-141) before `obs` gets the next episode's first
+  float* final_obs;
 };
 
 // ------------------------------------------------------------------ helpers
@@ -916,7 +928,7 @@ struct ContactFlags { int touch0, touch1, target0, target1, touch2, touch3, body
 // Contacts are compacted in slot order, then pair order (the oracle's priority), up to max_contacts.
 template <class T, int TASK>
 DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next_step_index,
-                        int* nc_out, int32_t* dbg) {
+                        int* nc_out, int32_t* dbg, int* nc_wanted) {
   STAMP_BEGIN;
   const float margin = unif(M->contact_margin);
   ContactFlags fl = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -994,6 +1006,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
     fl.target1 = __ballot(active && gfoot == 1 && is_target) != 0ull;
   }
   int nc = __popcll(am);
+  const int n_terrain = nc;   // before the cap (debug record: cap pressure)
   int n_self = 0;
   unsigned long long kept = am;
   if (nc > maxc) {
@@ -1110,6 +1123,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
     dbg[3] = (int32_t)(unsigned)am; dbg[4] = (int32_t)(unsigned)(am >> 32); dbg[7] = n_self;
   }
   *nc_out = nc;
+  *nc_wanted = n_terrain + n_self;
   return fl;
 }
 
@@ -1271,7 +1285,7 @@ DI void set_issue_priority(int nr, int prio) {
   else __builtin_amdgcn_s_setprio(0);
 }
 template <class T>
-DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned long long ppk, int32_t* dbg, const float* Afac, int prio, int& rows_out) {
+DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wanted, unsigned long long ppk, int32_t* dbg, const float* Afac, int prio, int& rows_out) {
   STAMP_BEGIN;
   // wave-uniform scalars live in SGPRs: loop control becomes s_cmp/s_cbranch instead of exec-mask bookkeeping
   const float dt = unif(M->dt), idt = rcp(dt);
@@ -1290,8 +1304,18 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
     const int rk = lane_rank(lm);
     if (act && rk < maxr) reinterpret_cast<int*>(L)[L_ROWD + rk] = lane;
     nl = uni(__popcll(lm));
+    if (dbg && lane == 0) {
+      dbg[5] = (int32_t)(unsigned)lm; dbg[6] = (int32_t)(unsigned)(lm >> 32);
+      // cap pressure, CUMULATIVE over the substeps since the host last cleared the record (MOCCA_DBG_CAP_*): how often the 12-contact /
+      // 48-row caps -- which Bullet does not have -- drop something, and the largest row count an uncapped solver would have held
+      const int nfix = 3 * T::NCLOS + ((T::NCLOS > 0 && M->planar) ? 3 : 0), mc = M->max_contacts;
+      const int wanted = nl + nfix + 3 * nc_wanted;
+      dbg[12] += nc_wanted > mc ? 1 : 0;
+      dbg[13] += nl + nfix + 3 * (nc_wanted < mc ? nc_wanted : mc) > maxr ? 1 : 0;
+      dbg[14] += 1;
+      if (wanted > dbg[15]) dbg[15] = wanted;
+    }
     if (nl > maxr) nl = maxr;
-    if (dbg && lane == 0) { dbg[5] = (int32_t)(unsigned)lm; dbg[6] = (int32_t)(unsigned)(lm >> 32); }
   }
   constexpr int NCL = 3 * T::NCLOS;  // point-to-point closure rows sit between the limit and the contact rows
   // CassieEnv(planar=True): three more bilateral rows hold the base in the x-z plane (omega_x, omega_z, v_y); only the Cassie
@@ -1311,6 +1335,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
   wsync();
   STAMP(16);
   if (nr == 0) {  // nothing touches, no limit near: nothing to solve (uniform branch)
+    if (dbg && lane == 0) { dbg[8] = 0; dbg[9] = 0; dbg[10] = 0; dbg[11] = 0; }
     if (lane < T::NSLOT) L[L_WARM + lane] = 0.0f;
     wsync();
     return;
@@ -1581,6 +1606,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
     af[2 * k] = 0.0f; af[2 * k + 1] = 0.0f;
     if (k < nc) { af[2 * k] = Acol_fr[MAXR * fric_lane(k, 0)] * invdiag; af[2 * k + 1] = Acol_fr[MAXR * fric_lane(k, 1)] * invdiag; }  // wave-uniform
   }
+  unsigned long long clamp_sig = 0ull, clamp_last = 0ull;   // debug record only
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
     // the row counts are laundered per iteration: as loop invariants the optimiser hoisted every `RR >= r_fr` / `I >= nc` exit test of
@@ -1588,13 +1614,23 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, unsigned l
     int rf = r_fr, ncc = nc;
     asm volatile("" : "+s"(rf), "+s"(ncc));
     pgs_fixed_rows<PGS_REG_ROWS, 0>(Acol, ar, 0.0f, 0.0f, 0.0f, 0.0f, rf, y, lam, invdiag, lo0);
+    float lm = 0.0f;
     if (ncc > 0) {  // wave-uniform
       float f0 = 0.0f, f1 = 0.0f, g0 = 0.0f, g1 = 0.0f;
       if (PGS_REG_CONTACTS < 1) { f0 = Acol_fr[MAXR * fric_lane(0, 0)]; f1 = Acol_fr[MAXR * fric_lane(0, 1)]; }
       if (PGS_REG_CONTACTS < 2 && ncc > 1) { g0 = Acol_fr[MAXR * fric_lane(1, 0)]; g1 = Acol_fr[MAXR * fric_lane(1, 1)]; }
-      const float lm = mu * __shfl(lam, nrow_lane, 64);
+      lm = mu * __shfl(lam, nrow_lane, 64);
       pgs_friction_rows<PGS_REG_ROWS, PGS_REG_CONTACTS, 0>(Acol_fr, af, f0, f1, g0, g1, ncc, y, lam, invdiag, lm);
     }
+    if (dbg) {  // wave-uniform, off the product path: which rows this iteration left ON a bound (the solver's discrete decisions)
+      const bool clamped = has_row && (kind == 2 ? fabsf(lam) == lm : (kind != 3 && lam == 0.0f));
+      clamp_last = __ballot(clamped);
+      clamp_sig = ((clamp_sig << 7) | (clamp_sig >> 57)) ^ clamp_last;
+    }
+  }
+  if (dbg && lane == 0) {
+    dbg[8] = (int32_t)(unsigned)clamp_last; dbg[9] = (int32_t)(unsigned)(clamp_last >> 32);
+    dbg[10] = (int32_t)(unsigned)clamp_sig; dbg[11] = (int32_t)(unsigned)(clamp_sig >> 32);
   }
   STAMP(8);
   // ---- apply: nu += sum_r X_r lambda_r, summed in row order through LDS
@@ -1725,12 +1761,12 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
   geom_points<T>(M, L, lane);
   wsync();
   STAMP(15);
-  int nc = 0;
+  int nc = 0, nc_wanted = 0;
   float Afac[21] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // Cholesky factor of the base's articulated inertia (aba_passes -> solve_constraints)
 #ifdef MOCCA_SKIP_COLLIDE  // profiling builds only (tools/ablate.sh): results are wrong by construction
   ContactFlags fl = {0, 0, 0, 0, 0, 0, 0};
 #else
-  ContactFlags fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc, dbg);
+  ContactFlags fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc, dbg, &nc_wanted);
 #endif
   STAMP(1);
 #ifndef MOCCA_SKIP_ABA
@@ -1738,7 +1774,7 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
 #endif
   STAMP(2);
 #ifndef MOCCA_SKIP_SOLVE
-  solve_constraints<T>(M, L, lane, nc, ppk, dbg, Afac, prio, rows_out);
+  solve_constraints<T>(M, L, lane, nc, nc_wanted, ppk, dbg, Afac, prio, rows_out);
 #endif
   STAMP(3);
 #ifdef MOCCA_DUMMY_VALU  // experiment: is the kernel VALU-issue-bound?  (tools/ab.sh variants)

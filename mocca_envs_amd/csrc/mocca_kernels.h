@@ -13,6 +13,20 @@ namespace mocca {
 #define MOCCA_WAVES_PER_EU 4
 #endif
 
+// the observation assembled in LDS (L_OBS) leaves in one coalesced store
+DI void flush_obs(const float* L, float* dst, int lane, int obs_dim) {
+#pragma unroll 1
+  for (int k = lane; k < obs_dim; k += 64) dst[k] = L[L_OBS + k];
+}
+// An env that ends under auto-reset: its terminal observation goes to the caller's optional buffer (mocca_set_terminal_obs_buffer) before
+// the reset overwrites L_OBS with the first observation of the next episode.  The reference returns the final state together with done
+// (env_locomotion.py:128-141) and gym's TimeLimit wrapper does too (__init__.py:55): a trainer bootstraps from it on truncation.
+DI void keep_terminal_obs(const StepArgs& a, const float* L, int env, int lane) {
+  wsync();
+  if (a.final_obs) flush_obs(L, a.final_obs + (size_t)env * a.obs_dim, lane, a.obs_dim);
+  wsync();
+}
+
 // --------------------------------------------------------------------------------------------
 // kernels: one 64-lane workgroup (= one wavefront) per environment
 // --------------------------------------------------------------------------------------------
@@ -27,7 +41,8 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   float* st = a.dyn + (size_t)env * DYN_STRIDE;
   uint32_t* tk = a.task + (size_t)env * MOCCA_TASK_WORDS;
   float* ter = TASK == MOCCA_TASK_WALKER3D_STEPPER ? a.terrain + (size_t)env * TERRAIN_STRIDE : nullptr;
-  float* obs = a.obs + (size_t)env * a.obs_dim;
+  float* obs_out = a.obs + (size_t)env * a.obs_dim;
+  float* obs = L + L_OBS;   // assembled in LDS, stored once at the end (flush_obs)
   int32_t* dbg = a.dbg ? a.dbg + (size_t)env * MOCCA_DEBUG_WORDS : nullptr;
 
   load_dyn(st, L, lane, T::NJ, T::NSLOT);
@@ -112,11 +127,12 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
       if (a.info) a.info[env] = 0;
     }
     if (a.auto_reset && dflag) {
-      wsync();
+      keep_terminal_obs(a, L, env, lane);
       cassie_reset_env<T, INJECT>(a, M, L, env + a.env_offset, lane, t, obs);
       if (lane < MOCCA_MAX_CTRL) tk[T_JVEL + lane] = __float_as_uint(L[L_JVEL + lane]);
     }
     wsync();
+    flush_obs(L, obs_out, lane, a.obs_dim);
     store_dyn(st, L, lane, T::NJ, T::NSLOT);
     if (lane == 0) store_task(tk, t);
     return;
@@ -333,10 +349,11 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   }
   STAMP(26);  // observation + reward done
   if (a.auto_reset && dflag) {
-    wsync();
+    keep_terminal_obs(a, L, env, lane);
     reset_env<T, TASK, INJECT>(a, M, L, ter, env + a.env_offset, lane, t, obs);
   }
   wsync();
+  flush_obs(L, obs_out, lane, a.obs_dim);
   store_dyn(st, L, lane, T::NJ, T::NSLOT);
   if (lane == 0) store_task(tk, t, T::NFEET > 2);
   STAMP(25);  // reset (if any) + write-back done
@@ -359,12 +376,13 @@ __global__ __launch_bounds__(64) void mocca_reset_kernel(StepArgs a) {
   load_task(tk, t, T::NFEET > 2);
   if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
   if constexpr (TASK == MOCCA_TASK_CASSIE) {
-    cassie_reset_env<T, INJECT>(a, M, L, env + a.env_offset, lane, t, a.obs + (size_t)env * a.obs_dim);
+    cassie_reset_env<T, INJECT>(a, M, L, env + a.env_offset, lane, t, L + L_OBS);
     if (lane < MOCCA_MAX_CTRL) tk[T_JVEL + lane] = __float_as_uint(L[L_JVEL + lane]);
   } else {
-    reset_env<T, TASK, INJECT>(a, M, L, ter, env + a.env_offset, lane, t, a.obs + (size_t)env * a.obs_dim);
+    reset_env<T, TASK, INJECT>(a, M, L, ter, env + a.env_offset, lane, t, L + L_OBS);
   }
   wsync();
+  flush_obs(L, a.obs + (size_t)env * a.obs_dim, lane, a.obs_dim);
   store_dyn(st, L, lane, T::NJ, T::NSLOT);
   if (lane == 0) store_task(tk, t, T::NFEET > 2);
 }
@@ -379,7 +397,7 @@ __global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
   const float* st = a.dyn + (size_t)env * DYN_STRIDE;
   uint32_t* tk = a.task + (size_t)env * MOCCA_TASK_WORDS;
   const float* ter = TASK == MOCCA_TASK_WALKER3D_STEPPER ? a.terrain + (size_t)env * TERRAIN_STRIDE : nullptr;
-  float* obs = a.obs + (size_t)env * a.obs_dim;
+  float* obs = L + L_OBS;
   load_dyn(st, L, lane, T::NJ, T::NSLOT);
   TaskRegs t;
   load_task(tk, t, T::NFEET > 2);
@@ -411,16 +429,22 @@ __global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
     }
     t.prevx = L[L_BASE];
   }
+  wsync();
+  flush_obs(L, a.obs + (size_t)env * a.obs_dim, lane, a.obs_dim);
   if (lane == 0) store_task(tk, t, T::NFEET > 2);
 }
 
 
 // compiled topologies: the tree of the blob selects the kernel instance
-enum { TOPO_WALKER3D = 0, TOPO_CASSIE = 1, TOPO_WALKER2D = 2, TOPO_CRAB2D = 3, TOPO_LAIKAGO = 4 };
+enum { TOPO_WALKER3D = 0, TOPO_CASSIE = 1, TOPO_WALKER2D = 2, TOPO_CRAB2D = 3, TOPO_LAIKAGO = 4,
+       TOPO_WALKER3D_MASSIVE = 5, TOPO_CASSIE_MASSIVE = 6 /* the same trees, no link treated as massless (mocca_device.h) */ };
 // kernel selection by (topology, task id)
 template <template <class, int> class Launcher, class... Args>
 static void dispatch(int topo, int task_id, Args... args) {
   if (topo == TOPO_CASSIE) Launcher<TopoCassie, MOCCA_TASK_CASSIE>::run(args...);
+  else if (topo == TOPO_CASSIE_MASSIVE) Launcher<TopoCassieMassive, MOCCA_TASK_CASSIE>::run(args...);
+  else if (topo == TOPO_WALKER3D_MASSIVE && task_id == MOCCA_TASK_WALKER3D_CUSTOM) Launcher<TopoWalker3DMassive, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
+  else if (topo == TOPO_WALKER3D_MASSIVE) Launcher<TopoWalker3DMassive, MOCCA_TASK_WALKER3D_STEPPER>::run(args...);
   else if (topo == TOPO_WALKER2D) Launcher<TopoWalker2D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
   else if (topo == TOPO_CRAB2D) Launcher<TopoCrab2D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
   else if (topo == TOPO_LAIKAGO && task_id == MOCCA_TASK_WALKER3D_STEPPER) Launcher<TopoLaikago, MOCCA_TASK_WALKER3D_STEPPER>::run(args...);

@@ -12,10 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # MOCCA_LIB_PATH selects another build of the same HIP library (A/B kernel experiments); never a CPU fallback
 LIB_PATH = os.environ.get("MOCCA_LIB_PATH") or os.path.join(HERE, "libmocca_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PARAM_AUTO_RESET, PARAM_EVAL_MODE, PARAM_CURRICULUM, PARAM_RANDOM_POSE, PARAM_HOST_RETARGET, PARAM_SEED, PARAM_ENV_OFFSET, PARAM_APPLIED_GAIN, PARAM_RANDOM_REWARD = 0, 1, 2, 3, 4, 5, 6, 7, 8
 PARAM_ISSUE_PRIORITY = 9   # timing only: row-count thresholds of the step kernel's issue priorities, t1 + 64 t2 + 4096 t3
-DEBUG_WORDS = 8
+DEBUG_WORDS = 16
 
 # every symbol include/mocca.h declares: (name, restype, argtypes)
 _vp, _i, _u64, _sz, _d = C.c_void_p, C.c_int, C.c_uint64, C.c_size_t, C.c_double
@@ -43,6 +43,7 @@ SYMBOLS = {
     "mocca_set_param_v": (_i, [_vp, _i, _vp, _i, _vp]),
     "mocca_set_seed": (_i, [_vp, _u64]),
     "mocca_set_debug_buffer": (_i, [_vp, _vp]),
+    "mocca_set_terminal_obs_buffer": (_i, [_vp, _vp]),
     "mocca_set_trajectory": (_i, [_vp, _vp, _i, _d, _d]),
     "mocca_is_diagnostic_build": (_i, []),
     "mocca_kernel_info": (_i, [_vp] + [C.POINTER(_i)] * 5),

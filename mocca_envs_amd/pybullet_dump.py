@@ -185,6 +185,63 @@ def from_pybullet_dump(dump: Mapping[str, np.ndarray], template: M.MoccaModel, j
     return out.finalize_tables()
 
 
+def link_bodies(dump: Mapping[str, np.ndarray], template: M.MoccaModel, joint_names: Sequence[str]) -> np.ndarray:
+    """[n_links + 1] blob body each Bullet link moves with (index 0 = Bullet's base, 1 + j = link j): itself if the link carries one of
+    the template's hinges, else its nearest such ancestor."""
+    names = [str(n) for n in dump["joint_names"]]
+    parent = np.asarray(dump["parent_index"]).astype(int)
+    body_of_link = {names.index(joint_names[b - 1]): b for b in range(1, template.n_bodies)}
+    out = np.zeros(len(names) + 1, int)
+    for j in range(len(names)):
+        k = j
+        while k >= 0 and k not in body_of_link:
+            k = parent[k]
+        out[1 + j] = body_of_link[k] if k >= 0 else 0
+    return out
+
+
+def body_frames(m: M.MoccaModel, state_row) -> list:
+    """World frames of the blob's bodies at a state row (base pos 3, quat 4, ..., q at 13..): forward kinematics in numpy."""
+    st = np.asarray(state_row, float)
+    fr = [_T(_qmat(st[3:7]), st[0:3])]
+    for b in range(1, m.n_bodies):
+        ax, q = np.array(list(m.jaxis[b])), st[13 + b - 1]
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        Rq = np.eye(3) + np.sin(q) * K + (1 - np.cos(q)) * (K @ K)
+        fr.append(fr[m.parent[b]] @ _T(np.array(list(m.jrot[b])).reshape(3, 3) @ Rq, list(m.jpos[b])))
+    return fr
+
+
+def warm_start_from_contacts(m: M.MoccaModel, bodies_of_links: np.ndarray, state_row, contact_rows, dt: Optional[float] = None) -> np.ndarray:
+    """[n_slots] warm-start normal impulses for the step that FOLLOWS `state_row`, from the contact points Bullet reported after the step
+    that produced it (tools/dump_pybullet_trace.py `contact_points`: link, other link, position xyz, normal xyz, normal force).  Bullet
+    warm-starts its solver with the impulses of the frame before; a teacher-forced state alone does not carry them.  A ground contact
+    on link l is credited to the terrain slot of l's body whose geom end point lies closest to the contact position; the impulse of
+    the last substep is force x dt.  Self contacts (other link >= 0) have no slot in this solver (they start from zero here too)."""
+    dt = float(m.dt) if dt is None else dt
+    warm = np.zeros(m.n_slots)
+    fr = None
+    for row in np.asarray(contact_rows, float):
+        link, other, force = int(row[0]), int(row[1]), row[8]
+        if link < -1 or other >= 0 or force <= 0:
+            continue
+        body = int(bodies_of_links[link + 1])
+        fr = fr or body_frames(m, state_row)
+        best, best_d = -1, 1e30
+        for g in range(m.n_geoms):
+            if m.g_body[g] != body or not m.g_terrain[g]:
+                continue
+            ends = [list(m.g_p1[g])] + ([list(m.g_p2[g])] if m.g_type[g] == M.GEOM_CAPSULE else [])
+            for e, pl in enumerate(ends):
+                c = fr[body].apply(pl)
+                d = np.linalg.norm(c - np.array([0, 0, m.g_radius[g]]) - row[2:5])   # contact position = sphere centre - r e_z on flat ground
+                if d < best_d:
+                    best, best_d = m.g_slot[g] + e, d
+        if best >= 0:
+            warm[best] += force * dt
+    return warm
+
+
 def synthetic_dump(m: M.MoccaModel, joint_names: Sequence[str], fixed_children: Dict[int, float] = None) -> Dict[str, np.ndarray]:
     """The record tools/dump_pybullet_trace.py WOULD write for a Bullet multibody equal to blob `m` (tests: loader round trip).
     Inertial frames are the principal-axes frames at the COM, as Bullet reports them.  `fixed_children`: {body: fraction}

@@ -83,12 +83,16 @@ class VecEnv:
     step(actions[N, 21]) -> (obs[N, obs_dim], reward[N], done[N] uint8, info[N] int32), all on
     `device`.  done bit0 = terminated (reference `self.done`), bit1 = TimeLimit (1000 steps,
     /root/reference/mocca_envs/__init__.py:55).  With auto_reset=True a finished env is reset
-    inside the same launch and `obs` is the first observation of its next episode.
+    inside the same launch and `obs` is the first observation of its next episode; with
+    terminal_obs=True `self.terminal_obs[i]` then holds the observation of env i's FINAL state
+    (what the reference's step() returns together with done, env_locomotion.py:128-141 -- the
+    value a PPO-style trainer bootstraps from on a TimeLimit truncation); rows of envs that did
+    not finish in this step keep their old content.
     """
 
     def __init__(self, env_id: str = "Walker3DCustomEnv-v0", n_envs: int = 1, device: Optional[int] = None,
                  auto_reset: bool = True, seed: int = 0, model_blob: Optional[bytes] = None, env_offset: int = 0,
-                 **model_kw):
+                 terminal_obs: bool = False, **model_kw):
         if env_id not in TASKS:
             raise KeyError(f"{env_id!r} has no GPU stepper yet; available: {sorted(TASKS)}")
         if not torch.cuda.is_available():
@@ -124,6 +128,9 @@ class VecEnv:
             self.set_param(pid, val)
         if env_id in _ISSUE_PRIORITY:
             self.set_param(_lib.PARAM_ISSUE_PRIORITY, _pack_prio(_ISSUE_PRIORITY[env_id]))
+        self.terminal_obs = None
+        if terminal_obs:
+            self.keep_terminal_obs(True)
         self.trajectory = None
         if self.task_id == M.TASK_CASSIE and self.model.cassie_mode != M.CASSIE_PLAIN:
             from .trajectory import CassieTrajectory   # self.traj = CassieTrajectory(), env_cassie.py:576
@@ -183,8 +190,15 @@ class VecEnv:
         self._tape = torch.as_tensor(tape, dtype=torch.float32).to(self.device).contiguous().reshape(self.n_envs, -1)
         _lib.check(self.lib.mocca_set_draw_tape(self.h, C.c_void_p(self._tape.data_ptr()), self._tape.shape[1]), self.h)
 
+    def keep_terminal_obs(self, on: bool = True) -> Optional[torch.Tensor]:
+        """Attach (or detach) the terminal-observation buffer [N][obs_dim] (include/mocca.h mocca_set_terminal_obs_buffer)."""
+        self.terminal_obs = torch.zeros(self.n_envs, self.obs_dim, dtype=torch.float32, device=self.device) if on else None
+        _lib.check(self.lib.mocca_set_terminal_obs_buffer(self.h, C.c_void_p(self.terminal_obs.data_ptr()) if on else None), self.h)
+        return self.terminal_obs
+
     def set_debug(self, on: bool = True) -> Optional[torch.Tensor]:
-        """Attach (or detach) the per-env active-set record of the last substep: [N][8] int32, words MOCCA_DBG_*."""
+        """Attach (or detach) the per-env debug record: [N][16] int32, words MOCCA_DBG_* (0..11 the active set of the last substep
+        incl. the solver's clamp mask / signature, 12..15 cumulative cap pressure: zero the tensor to restart the count)."""
         self.debug = torch.zeros(self.n_envs, _lib.DEBUG_WORDS, dtype=torch.int32, device=self.device) if on else None
         _lib.check(self.lib.mocca_set_debug_buffer(self.h, C.c_void_p(self.debug.data_ptr()) if on else None), self.h)
         return self.debug

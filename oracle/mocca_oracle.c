@@ -41,6 +41,8 @@ typedef REAL real;
 #define NDOF_MAX (6 + MB)
 #define MAX_CONTACTS 16 /* storage; the live caps are MoccaModel.max_contacts / max_rows */
 #define MAX_ROWS 64
+#define DBG_WORDS 16    /* MOCCA_DEBUG_WORDS of include/mocca.h */
+#define KERNEL_MAXR 48  /* the HIP solver's lane layout (mocca_device.h MAXR): friction rows of contact i sit on lanes 46 - 2i, 47 - 2i */
 
 #if defined(__GNUC__)
 #define API __attribute__((visibility("default")))
@@ -214,7 +216,8 @@ typedef struct {
   real row_mu[MAX_ROWS];
   int row_slot[MAX_ROWS];
   /* active set of the last substep, same words as the HIP path's debug record (include/mocca.h MOCCA_DBG_*) */
-  int32_t dbg[8];
+  int32_t dbg[DBG_WORDS]; /* words 12..15: THIS substep's cap flags / count / wanted rows, accumulated per env by dbg_commit() */
+  int nc_wanted;          /* contacts within the margin before the max_contacts cap */
 } Work;
 
 typedef struct {
@@ -226,7 +229,7 @@ typedef struct {
   Task *task;
   Terrain *ter;
   Work wk;
-  int32_t *dbg; /* [n_envs][8]: copy of wk.dbg after each env's last substep */
+  int32_t *dbg; /* [n_envs][DBG_WORDS]: words 0..11 of wk.dbg after each env's last substep, words 12..15 accumulated (orc_clear_debug) */
   real feet_xyz[MOCCA_MAX_FEET][3];
   real body_rpy[3], body_vel[3];
   /* optional uniform tape: when set, every random draw pops from it instead of Philox, so the golden
@@ -631,6 +634,7 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
         if (m->g_body[ga] == m->foot_body[f] || m->g_body[gb] == m->foot_body[f]) w->foot_touch[f] = 1;
   }
   w->dbg[3] = (int32_t)(uint32_t)slot_mask; w->dbg[4] = (int32_t)(uint32_t)(slot_mask >> 32); w->dbg[7] = n_self;
+  w->nc_wanted = ncand + n_self;
 }
 
 /* ------------------------------------------------------------------ */
@@ -740,6 +744,14 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
   w->nr = nr;
   w->dbg[0] = nr; w->dbg[1] = first_normal - 3 * m->n_closures - n_planar; w->dbg[2] = nc;
   w->dbg[5] = (int32_t)(uint32_t)limit_mask; w->dbg[6] = (int32_t)(uint32_t)(limit_mask >> 32);
+  { /* cap pressure of this substep (MOCCA_DBG_CAP_*): Bullet has neither cap */
+    int nl_raw = __builtin_popcountll(limit_mask), nfix = 3 * m->n_closures + (m->planar ? 3 : 0);
+    int kept = w->nc_wanted < m->max_contacts ? w->nc_wanted : m->max_contacts;
+    w->dbg[12] = w->nc_wanted > m->max_contacts;
+    w->dbg[13] = nl_raw + nfix + 3 * kept > m->max_rows;
+    w->dbg[14] = 1;
+    w->dbg[15] = nl_raw + nfix + 3 * w->nc_wanted;
+  }
   /* --- responses, Delassus matrix, initial velocities --- */
   for (int r = 0; r < nr; ++r) minv_apply(m, w, w->J[r], w->Mi[r]);
   for (int r = 0; r < nr; ++r)
@@ -758,7 +770,10 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
     if (w->lam[r] != 0)
       for (int c = 0; c < nr; ++c) w->w[c] += w->A[r][c] * w->lam[r];
   /* --- projected Gauss-Seidel --- */
+  uint64_t clamp_sig = 0, clamp_last = 0; /* MOCCA_DBG_CLAMP*: rows left ON a bound, by the HIP solver's lane numbers */
+  int first_fric = first_normal + nc;
   for (int it = 0; it < m->n_iters; ++it) {
+    clamp_last = 0;
     for (int r = 0; r < nr; ++r) {
       real lo = 0, hi = (real)1e30;
       if (w->row_kind[r] == 3) lo = (real)-1e30;
@@ -777,8 +792,16 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
       w->lam[r] = nl;
       if (dl != 0)
         for (int c = 0; c < nr; ++c) w->w[c] += w->A[r][c] * dl;
+      {
+        int clamped = w->row_kind[r] == 2 ? fabs(nl) == hi : (w->row_kind[r] != 3 && nl == 0);
+        int lane = r < first_fric ? r : KERNEL_MAXR - 2 - 2 * ((r - first_fric) / 2) + ((r - first_fric) & 1);
+        if (clamped) clamp_last |= (uint64_t)1 << lane;
+      }
     }
+    clamp_sig = ((clamp_sig << 7) | (clamp_sig >> 57)) ^ clamp_last;
   }
+  w->dbg[8] = (int32_t)(uint32_t)clamp_last; w->dbg[9] = (int32_t)(uint32_t)(clamp_last >> 32);
+  w->dbg[10] = (int32_t)(uint32_t)clamp_sig; w->dbg[11] = (int32_t)(uint32_t)(clamp_sig >> 32);
   /* --- apply --- */
   for (int k = 0; k < nd; ++k) {
     real a = 0;
@@ -830,6 +853,14 @@ static void substep(const Oracle *o, Dyn *s, const Task *tk, const Terrain *tr, 
   nq[3] = dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2];
   real nn = 1 / sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
   for (int k = 0; k < 4; ++k) q[k] = nq[k] * nn;
+}
+
+/* debug record of env `env` after a substep: words 0..11 = this substep's active set, 12..15 cumulative (include/mocca.h) */
+static void dbg_commit(Oracle *o, int env, const Work *w) {
+  int32_t *d = o->dbg + (size_t)DBG_WORDS * env;
+  memcpy(d, w->dbg, 12 * sizeof(int32_t));
+  d[12] += w->dbg[12]; d[13] += w->dbg[13]; d[14] += w->dbg[14];
+  if (w->dbg[15] > d[15]) d[15] = w->dbg[15];
 }
 
 /* ------------------------------------------------------------------ */
@@ -1154,9 +1185,9 @@ static void cassie_step(Oracle *o, int env, const float *act, float *obs, float 
       tau[b] = t < -lim ? -lim : (t > lim ? lim : t);
     }
     substep(o, s, tk, &o->ter[env], tau, w);
+    dbg_commit(o, env, w);
   }
   tk->istep += m->n_llc; /* pd_control counts every low-level iteration (:381) */
-  memcpy(o->dbg + 8 * env, w->dbg, sizeof(w->dbg));
   for (int k = 0; k < no; ++k) /* :467-468 */
     tk->jvel[k] = (cassie_rad(m, k, cassie_nrm(m, k, s->q[m->ordered_body[k]])) - q0[k]) / (real)m->control_dt;
   tk->t += 1;
@@ -1273,8 +1304,7 @@ static void step_env(Oracle *o, int env, const float *act, float *obs, float *re
   }
   int touch[MOCCA_MAX_FEET] = {0}, target[MOCCA_MAX_FEET] = {0}, body_touch = 0;
   if (!ext_touch) {
-    for (int k = 0; k < m->n_substeps; ++k) substep(o, s, tk, tr, tau, w);
-    memcpy(o->dbg + 8 * env, w->dbg, sizeof(w->dbg));
+    for (int k = 0; k < m->n_substeps; ++k) { substep(o, s, tk, tr, tau, w); dbg_commit(o, env, w); }
     /* contact queries after stepSimulation see the manifolds of the LAST substep's collision pass */
     for (int k = 0; k < m->n_feet; ++k) { touch[k] = w->foot_touch[k]; target[k] = w->foot_target[k]; }
     body_touch = w->body_touch;
@@ -1432,7 +1462,7 @@ API void *orc_create(const void *blob, int nbytes, int task_id, int n_envs) {
   o->dyn = (Dyn *)calloc(n_envs, sizeof(Dyn));
   o->task = (Task *)calloc(n_envs, sizeof(Task));
   o->ter = (Terrain *)calloc(n_envs, sizeof(Terrain));
-  o->dbg = (int32_t *)calloc((size_t)n_envs * 8, sizeof(int32_t));
+  o->dbg = (int32_t *)calloc((size_t)n_envs * DBG_WORDS, sizeof(int32_t));
   for (int e = 0; e < n_envs; ++e) { o->dyn[e].quat[3] = 1; o->task[e].applied_gain = 1; o->task[e].episode = -1; }
   return o;
 }
@@ -1656,8 +1686,12 @@ API int orc_last_lambda(void *h, double *lam, int32_t *kind) {
   for (int r = 0; r < o->wk.nr; ++r) { lam[r] = o->wk.lam[r]; kind[r] = o->wk.row_kind[r]; }
   return o->wk.nr;
 }
-/* active set of every env's last substep: [n_envs][8] int32, words as MOCCA_DBG_* (include/mocca.h) */
+/* debug record of every env: [n_envs][MOCCA_DEBUG_WORDS] int32, words as MOCCA_DBG_* (include/mocca.h) */
 API void orc_get_debug(void *h, int32_t *out) {
   Oracle *o = (Oracle *)h;
-  memcpy(out, o->dbg, (size_t)o->n_envs * 8 * sizeof(int32_t));
+  memcpy(out, o->dbg, (size_t)o->n_envs * DBG_WORDS * sizeof(int32_t));
+}
+API void orc_clear_debug(void *h) {
+  Oracle *o = (Oracle *)h;
+  memset(o->dbg, 0, (size_t)o->n_envs * DBG_WORDS * sizeof(int32_t));
 }

@@ -59,6 +59,7 @@ def _load(precision: str) -> C.CDLL:
     lib.orc_last_contacts.argtypes = [C.c_void_p, C.c_void_p]
     lib.orc_last_contacts.restype = C.c_int
     lib.orc_get_debug.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_clear_debug.argtypes = [C.c_void_p]
     lib.orc_last_lambda.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.orc_last_lambda.restype = C.c_int
     lib.orc_set_trajectory.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
@@ -222,7 +223,11 @@ class Oracle:
         return lam[:n], kind[:n]
 
     def get_debug(self) -> np.ndarray:
-        """Active set of every env's last substep, [N][8] int32 (words: include/mocca.h MOCCA_DBG_*)."""
-        out = np.zeros((self.n_envs, 8), np.int32)
+        """Debug record of every env, [N][16] int32 (include/mocca.h MOCCA_DBG_*): words 0..11 the active set of the last substep
+        (rows, contacts, slot / limit masks, PGS clamp mask and signature), words 12..15 cumulative cap pressure."""
+        out = np.zeros((self.n_envs, 16), np.int32)
         self.lib.orc_get_debug(self.h, _p(out))
         return out
+
+    def clear_debug(self):
+        self.lib.orc_clear_debug(self.h)

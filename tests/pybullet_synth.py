@@ -1,0 +1,82 @@
+"""Test infrastructure: the record tools/dump_pybullet_trace.py WOULD write (format_version 2), synthesised without PyBullet.
+
+The multibody part comes from pybullet_dump.synthetic_dump (a compiled blob re-expressed in PyBullet's frame conventions, optionally
+with fixed links split off and with mass on the intermediate links of the multi-hinge joints); the traces come from the f64 oracle
+running the blob LOADED BACK from that record -- so the oracle reproduces them exactly and the HIP path to fp32 accuracy.  That says
+nothing about Bullet; it proves that loader, harness and both steppers are wired for the day a real file arrives."""
+import numpy as np
+
+from mocca_envs_amd import model as M
+from mocca_envs_amd import pybullet_dump as PD
+from oracle.oracle import Oracle
+
+NJ = 21
+MAX_CP = 24
+
+
+def massive_template(mass: float = 0.08, inertia: float = 2e-4) -> M.MoccaModel:
+    """Walker3D with mass and inertia on the nine intermediate links of its multi-hinge joints (what Bullet's MJCF importer may report:
+    SURVEY Appendix D [UNVERIFIED-BULLET]); the compiled model keeps them massless."""
+    m = M.compile_walker3d()
+    n = 0
+    for b in range(1, m.n_bodies):
+        if m.mass[b] == 0.0:
+            m.mass[b] = mass
+            for k in range(3):
+                m.inertia[b][k] = inertia * (1 + 0.3 * k)
+                m.com[b][k] = 0.01 * (k - 1)
+            n += 1
+    assert n == 9
+    return m.finalize_tables()
+
+
+def _contact_rows(o: Oracle, m: M.MoccaModel, link_of_body, base_pos):
+    """Bullet-style contact rows of the oracle's last substep: link, other, position (world), normal, normal force = impulse / dt."""
+    rows = np.zeros((MAX_CP, 9))
+    rows[:, 0] = -2
+    lam, kind = o.last_lambda()
+    normals = lam[kind == 1]
+    for k, c in enumerate(o.last_contacts()[:MAX_CP]):
+        a, b = int(c[0]), int(c[1])
+        rows[k] = [link_of_body[a], -1 if b < 0 else link_of_body[b], *(c[3:6] + base_pos), *c[6:9], normals[k] / m.dt if k < len(normals) else 0.0]
+    return rows
+
+
+def synthetic_record(template: M.MoccaModel = None, fixed_children=None, n_trace: int = 40, n_free: int = 120, seed: int = 0):
+    """(record dict in the dump tool's format, the blob loaded from it)."""
+    tm = template or M.compile_walker3d()
+    g = PD.synthetic_dump(tm, M.WALKER3D_JOINT_NAMES, fixed_children=fixed_children or {2: 0.25})
+    m = PD.from_pybullet_dump(g, tm, M.WALKER3D_JOINT_NAMES)
+    bodies = PD.link_bodies(g, tm, M.WALKER3D_JOINT_NAMES)
+    link_of_body = {0: -1}
+    for j in range(len(bodies) - 1):
+        link_of_body.setdefault(int(bodies[1 + j]), j)   # the first link of a body is the one that carries its hinge
+    gains = np.array([m.gain[b] for b in range(1, NJ + 1)])
+    o = Oracle(m.to_bytes(), 0, 1, "f64")
+    o.reset(seed=seed)
+    rng = np.random.default_rng(seed)
+    before, after, torques, cps = [], [], [], []
+    for t in range(n_trace):
+        a = rng.uniform(-1, 1, NJ).astype(np.float32)
+        before.append(o.get_state()[0, :13 + 2 * NJ].copy())
+        o.step(a[None])
+        st = o.get_state()[0]
+        after.append(st[:13 + 2 * NJ].copy()); torques.append(gains * a)
+        cps.append(_contact_rows(o, m, link_of_body, st[0:3]))
+    rec = dict(g, format_version=np.array(2), before=np.array(before), after=np.array(after), torques=np.array(torques),
+               contact_points=np.array(cps))
+    for tag, scale in (("free", 1.0), ("free03", 0.3)):
+        o = Oracle(m.to_bytes(), 0, 1, "f64")
+        o.reset(seed=seed)
+        st0 = np.zeros((1, o.state_dim))
+        st0[0, :3] = list(m.init_pos); st0[0, 6] = 1.0
+        st0[0, 13:13 + NJ] = [m.init_q[b] for b in range(1, NJ + 1)]
+        o.set_state(st0)
+        rng = np.random.default_rng(0)
+        states, actions = [o.get_state()[0, :13 + 2 * NJ].copy()], []
+        for t in range(n_free):
+            a = (scale * rng.uniform(-1, 1, NJ)).astype(np.float32)
+            o.step(a[None])
+            states.append(o.get_state()[0, :13 + 2 * NJ].copy()); actions.append(a.astype(np.float64))
+        rec[f"{tag}_states"], rec[f"{tag}_actions"] = np.array(states), np.array(actions)
+    return rec, m

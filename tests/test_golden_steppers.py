@@ -9,7 +9,7 @@ from mocca_envs_amd import host_logic as H
 from mocca_envs_amd import model as M
 from oracle.oracle import PARAM_CURRICULUM, PARAM_RANDOM_POSE, PARAM_RANDOM_REWARD, Oracle
 
-REW_TOL = {"f64": 5e-6, "f32": 6e-2}     # LaikagoStepper doubles the progress term (a difference of O(300) potentials)
+REW_TOL = {"f64": 5e-6, "f32": 1e-3}     # LaikagoStepper doubles the progress term (a difference of O(300) potentials)
 
 
 @pytest.fixture(scope="module")
@@ -78,13 +78,13 @@ def test_laikago_stepper_episodes(sg, prec, tol):
         tk = orc.get_task()[0]
         assert abs(tk[21] - float(g("applied_gain"))) < 1e-6 and int(tk[16]) == 2        # next_step_index starts at lookbehind
         # the fake client reports the feet at the origin at reset: height (entry 0) is not comparable, the four target rows are
-        np.testing.assert_allclose(obs0[0, 1:], g("reset_obs")[1:], atol=20 * tol)
+        np.testing.assert_allclose(obs0[0, 1:], g("reset_obs")[1:], atol=5 * tol)
         states, touch, target, body, actions = g("states"), g("touch"), g("target"), g("body"), g("actions")
         for t in range(len(states)):
             full = np.zeros((1, orc.state_dim)); full[0, :sd] = states[t]
             orc.set_state(full)
             o, r, d, info = orc.task_step(actions[t][None], touch[t][None], target[t][None], body[t:t + 1])
-            np.testing.assert_allclose(o[0], g("obs")[t], atol=20 * tol, err_msg=f"ep{ep} t{t} obs")
+            np.testing.assert_allclose(o[0], g("obs")[t], atol=5 * tol, err_msg=f"ep{ep} t{t} obs")
             assert (d[0] & 1) == int(g("done")[t]), f"ep{ep} t{t} done"
             np.testing.assert_allclose(r[0], g("rew")[t], atol=REW_TOL[prec], err_msg=f"ep{ep} t{t} reward")
             assert int(info[0]) == int(g("next_step_index")[t]), f"ep{ep} t{t} next_step_index"
@@ -119,8 +119,8 @@ def test_random_reward_episode(sg, prec, tol):
         full = np.zeros((1, orc.state_dim)); full[0, :55] = states[t]
         orc.set_state(full)
         o, r, d, info = orc.task_step(actions[t][None], touch[t][None], target[t][None])
-        np.testing.assert_allclose(o[0], g("obs")[t], atol=20 * tol)
-        np.testing.assert_allclose(r[0], g("rew")[t], atol={"f64": 5e-6, "f32": 4e-2}[prec], err_msg=f"t{t} reward")
+        np.testing.assert_allclose(o[0], g("obs")[t], atol=5 * tol)
+        np.testing.assert_allclose(r[0], g("rew")[t], atol={"f64": 5e-6, "f32": 5e-4}[prec], err_msg=f"t{t} reward")
         w = orc.get_task()[0][30:38]
         assert (w >= 0.8).all() and (w < 1.2).all()
         np.testing.assert_allclose(w @ terms[t], g("rew")[t], atol=1e-9 if prec == "f64" else 1e-4)    # the weights ARE the reference's draws

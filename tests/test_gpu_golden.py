@@ -22,9 +22,11 @@ from mocca_envs_amd import model as M
 pytestmark = pytest.mark.gpu
 
 TOL = 3e-5          # fp32 task arithmetic (the oracle's f32 build is held to 2e-5 .. 3e-5)
-OBS_TOL = 20 * TOL
-# reward = progress + ...: progress is the difference of two potentials of O(300) (distance * 60 Hz) in fp32
-REW_TOL = 4e-2
+OBS_TOL = 1e-4      # observations are O(1) (clipped to +-5): a few ulp of fp32 through atan2 / asin / the heading rotation
+# reward = progress + ...: progress is the difference of two potentials of O(300) (distance * 60 Hz), one fp32 ulp of which is 3e-5;
+# measured worst case of the f32 oracle over the same goldens: 6.4e-5 (Custom), 2.0e-4 (Stepper).  At this tolerance a wrong weight
+# fails the replay: joints_at_limit_cost 0.1 -> 0.09 moves the reward by 0.01 per joint at its limit, stall_torque_cost by ~0.03.
+REW_TOL = 5e-4
 REPL = 3            # replicas of the episode in the batch: every wave must produce the same bits
 
 
@@ -226,7 +228,10 @@ def test_cassie_steps_against_the_reference_code_on_the_gpu():
     env = VecEnv("CassieEnv-v0", REPL, auto_reset=False, seed=0)
     obs0 = env.reset().cpu().numpy()
     np.testing.assert_allclose(obs0[0], g["ep0_obs"][0], atol=1e-5)
-    errs = []
+    from oracle.oracle import Oracle
+    orc = Oracle(env.model.to_bytes(), M.TASK_CASSIE, 1, "f32")
+    orc.reset(seed=0)
+    errs, errs32, rerr, rerr32 = [], [], [], []
     for ep in range(2):
         env.reset()
         for t, a in enumerate(g[f"ep{ep}_actions"]):
@@ -241,13 +246,25 @@ def test_cassie_steps_against_the_reference_code_on_the_gpu():
             o = o.cpu().numpy()[0]
             want = g[f"ep{ep}_obs"][t + 1]
             errs.append(np.abs(o - want) / (1e-3 + 1e-3 * np.abs(want)))
-            # 50 stiff fp32 iterations from an f64 state: joint speeds (entries 20..33) carry the largest rounding error
-            np.testing.assert_allclose(o, want, atol=2e-2, rtol=2e-2, err_msg=f"ep{ep} t{t}")
-            assert abs(float(r[0]) - g[f"ep{ep}_rew"][t]) < 0.15, (ep, t, float(r[0]), g[f"ep{ep}_rew"][t])
+            rerr.append(abs(float(r[0]) - g[f"ep{ep}_rew"][t]))
             assert bool(int(d[0]) & 1) == bool(g[f"ep{ep}_done"][t]), (ep, t)
-    e = np.concatenate(errs)
-    print(f"\nCassie GPU vs reference-code-over-f64-oracle, one env.step: median {np.median(e):.3g} p99 {np.percentile(e, 99):.3g} max {e.max():.3g} units")
-    assert np.median(e) < 0.5
+            # the yardstick: the scalar f32 oracle from the same state, same task record -- what fp32 arithmetic itself costs over
+            # the 50 stiff PD + physics iterations of one env.step (the golden comes from f64 physics)
+            st = np.zeros((1, orc.state_dim)); st[0, :len(g[f"ep{ep}_pre_state"][t])] = g[f"ep{ep}_pre_state"][t]
+            orc.set_state(st); orc.set_task(tk[:1])
+            oc, rc, dc, _ = orc.step(a[None].astype(np.float32))
+            errs32.append(np.abs(oc[0] - want) / (1e-3 + 1e-3 * np.abs(want)))
+            rerr32.append(abs(float(rc[0]) - g[f"ep{ep}_rew"][t]))
+    e, e32 = np.concatenate(errs), np.concatenate(errs32)
+    q = lambda x, p: float(np.percentile(x, p))
+    print(f"\nCassie vs reference-code-over-f64-oracle, one env.step, units of 1e-3 (1 + |x|): GPU median {np.median(e):.3g} p99 {q(e, 99):.3g} "
+          f"max {e.max():.3g} | f32 oracle median {np.median(e32):.3g} p99 {q(e32, 99):.3g} max {e32.max():.3g}; reward error GPU max "
+          f"{max(rerr):.3g}, f32 oracle max {max(rerr32):.3g}")
+    # no further from the reference than 3 x the f32 oracle is (floors: 0.02 / 0.2 / 1 units; reward 2e-3)
+    assert np.median(e) < 3 * np.median(e32) + 0.02, (np.median(e), np.median(e32))
+    assert q(e, 99) < 3 * q(e32, 99) + 0.2, (q(e, 99), q(e32, 99))
+    assert e.max() < 3 * e32.max() + 1.0, (e.max(), e32.max())
+    assert max(rerr) < 3 * max(rerr32) + 2e-3, (max(rerr), max(rerr32))
     env.close()
 
 

@@ -4,19 +4,40 @@
 Writes pybullet_walker3d.npz with
   * the multibody Bullet actually builds from walker3d.xml: per link getDynamicsInfo (mass, local inertia diagonal,
     inertial frame), getJointInfo (names, axes, limits, parent frames, damping), getCollisionShapeData;
-  * a teacher-forcing trace of N steps: state before (base pose/velocity, q, qd), the 21 torques applied, state after
+  * a TEACHER-FORCING trace of N steps: state before (base pose/velocity, q, qd), the 21 torques applied, state after
     one stepSimulation with the reference's parameters (fixedTimeStep 1/60, 4 substeps, 5 iterations, contact ERP 0.9),
-    foot contact flags.
+    foot contact flags, and the contact points Bullet reports after the step (link, position, normal, normal force):
+    Bullet warm-starts its solver with the impulses it applied in the frame before, which the state alone does not carry;
+  * a FREE-RUNNING rollout (BASELINE.json's north star: "joint state within 1e-4 of PyBullet over 1000 steps"): from the
+    reference's reset pose (base at (0, 0, 1.32), "running_start" joint angles of robots.py:296-302, at rest, no noise, no
+    mirror) N steps of U(-1, 1) actions from numpy.random.default_rng(0) WITHOUT any restart: free_actions [N][21],
+    free_states [N + 1][55], free_contacts per step.  A second rollout with the actions scaled by 0.3 (the robot stays on
+    its feet longer, so more of the 1000 steps compare states rather than tumbling chaos): free03_*.
 The loader side is mocca_envs_amd/pybullet_dump.py (from_pybullet_dump: model blob from this record, no importer
-assumptions left) and tests/test_pybullet_trace.py (skipped while the file is absent): it feeds every "before" state
-through the f64 oracle and through the HIP stepper and bounds the one-step error against Bullet's "after" by the north
-star's 1e-4 -- the number that cannot be produced in the build image.  Copy the file to
-tests/golden/pybullet_walker3d.npz.
+assumptions left) and tests/test_pybullet_trace.py (the branches on the real file are skipped while it is absent): every
+"before" state goes through the f64 oracle and through the HIP stepper and the one-step error against Bullet's "after" is
+bounded by the north star's 1e-4; the free-running rollouts are replayed from free_states[0] and the joint-state error is
+reported at steps 1 / 10 / 100 / 1000.  Copy the file to tests/golden/pybullet_walker3d.npz.
 Usage: python tools/dump_pybullet_trace.py /path/to/mocca_envs/data 1000
 """
 import sys
 
 import numpy as np
+
+MAX_CP = 24   # contact points kept per step (padded with link = -2)
+GAINS = np.array([60, 80, 60, 80, 60, 100, 90, 60, 80, 60, 100, 90, 60, 60, 60, 50, 60, 60, 60, 50, 60], float)  # robots.py:168,234-256
+
+
+def running_start():
+    """Walker3D.set_base_pose("running_start"), robots.py:296-302 (indices into ordered_joints)."""
+    q = np.zeros(21)
+    q[[5, 6]] = -np.pi / 8
+    q[10] = np.pi / 10
+    q[[13, 17]] = np.pi / 3
+    q[14] = -np.pi / 6
+    q[18] = np.pi / 6
+    q[[16, 20]] = np.pi / 3
+    return q
 
 
 def main(data_dir, n_steps):
@@ -30,7 +51,7 @@ def main(data_dir, n_steps):
     flags = p.MJCF_COLORS_FROM_FILE | p.URDF_USE_SELF_COLLISION | p.URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS
     robot = p.loadMJCF(f"{data_dir}/robots/walker3d.xml", flags=flags)[0]
     nj = p.getNumJoints(robot)
-    out = {"n_links": np.array(nj)}
+    out = {"n_links": np.array(nj), "format_version": np.array(2)}
     jinfo = [p.getJointInfo(robot, j) for j in range(nj)]
     out["joint_names"] = np.array([ji[1].decode() for ji in jinfo])
     out["link_names"] = np.array([ji[12].decode() for ji in jinfo])
@@ -55,8 +76,6 @@ def main(data_dir, n_steps):
     act = [j for j in range(nj) if not jinfo[j][1].decode().startswith(("jointfix", "ignore"))]
     for j in range(nj):
         p.setJointMotorControl2(robot, j, p.POSITION_CONTROL, positionGain=0.1, velocityGain=0.1, force=0)
-    gains = np.array([60, 80, 60, 80, 60, 100, 90, 60, 80, 60, 100, 90, 60, 60, 60, 50, 60, 60, 60, 50, 60], float)
-    rng = np.random.default_rng(0)
     feet = [list(out["link_names"]).index(n) for n in ("right_foot", "left_foot")]
 
     def snap():
@@ -65,23 +84,57 @@ def main(data_dir, n_steps):
         js = p.getJointStates(robot, act)
         return np.concatenate([pos, orn, lin, ang, [s[0] for s in js], [s[1] for s in js]])
 
-    p.resetBasePositionAndOrientation(robot, [0, 0, 1.32], [0, 0, 0, 1])
-    before, after, torques, contacts, feet_pos = [], [], [], [], []
+    def contact_points():
+        """[MAX_CP][9]: link on the robot (-1 base, -2 padding), other body's link (-1 for the ground plane, >= 0 self contact with
+        that link), position on the robot xyz, normal (towards the robot) xyz, normal force.  Impulse of the LAST substep =
+        normal force x (1/240)."""
+        rows = np.full((MAX_CP, 9), 0.0)
+        rows[:, 0] = -2
+        cps = p.getContactPoints(bodyA=robot)
+        for k, c in enumerate(cps[:MAX_CP]):
+            other = -1 if c[2] == plane else c[4]
+            rows[k] = [c[3], other, *c[5], *c[7], c[9]]
+        return rows, len(cps)
+
+    def place(q):
+        p.resetBasePositionAndOrientation(robot, [0, 0, 1.32], [0, 0, 0, 1])
+        p.resetBaseVelocity(robot, [0, 0, 0], [0, 0, 0])
+        for k, j in enumerate(act):
+            p.resetJointState(robot, j, float(q[k]), 0.0)
+
+    # ---- teacher-forcing trace
+    rng = np.random.default_rng(0)
+    place(np.zeros(21))
+    before, after, torques, contacts, feet_pos, cpts, ncp = [], [], [], [], [], [], []
     for t in range(n_steps):
         a = rng.uniform(-1, 1, 21)
         before.append(snap())
-        p.setJointMotorControlArray(robot, act, p.TORQUE_CONTROL, forces=list(gains * a))
+        p.setJointMotorControlArray(robot, act, p.TORQUE_CONTROL, forces=list(GAINS * a))
         p.stepSimulation()
-        after.append(snap()); torques.append(gains * a)
+        after.append(snap()); torques.append(GAINS * a)
         contacts.append([int(any(c[2] == plane for c in p.getContactPoints(bodyA=robot, linkIndexA=f))) for f in feet])
         feet_pos.append([p.getLinkState(robot, f)[0] for f in feet])
+        cp, n = contact_points()
+        cpts.append(cp); ncp.append(n)
         if after[-1][2] < 0.5:  # fallen: restart from the initial pose
-            p.resetBasePositionAndOrientation(robot, [0, 0, 1.32], [0, 0, 0, 1])
-            p.resetBaseVelocity(robot, [0, 0, 0], [0, 0, 0])
-            for j in act:
-                p.resetJointState(robot, j, 0.0, 0.0)
+            place(np.zeros(21))
     out.update(before=np.array(before), after=np.array(after), torques=np.array(torques), feet_contact=np.array(contacts),
-               feet_pos=np.array(feet_pos))
+               feet_pos=np.array(feet_pos), contact_points=np.array(cpts), n_contact_points=np.array(ncp))
+
+    # ---- free-running rollouts: no restart, whatever happens to the robot
+    for tag, scale in (("free", 1.0), ("free03", 0.3)):
+        rng = np.random.default_rng(0)
+        place(running_start())
+        states, actions, cpts, fc = [snap()], [], [], []
+        for t in range(n_steps):
+            a = scale * rng.uniform(-1, 1, 21)
+            p.setJointMotorControlArray(robot, act, p.TORQUE_CONTROL, forces=list(GAINS * a))
+            p.stepSimulation()
+            states.append(snap()); actions.append(a)
+            cpts.append(contact_points()[0])
+            fc.append([int(any(c[2] == plane for c in p.getContactPoints(bodyA=robot, linkIndexA=f))) for f in feet])
+        out.update({f"{tag}_states": np.array(states), f"{tag}_actions": np.array(actions), f"{tag}_contact_points": np.array(cpts),
+                    f"{tag}_feet_contact": np.array(fc)})
     np.savez_compressed("pybullet_walker3d.npz", **out)
     print("wrote pybullet_walker3d.npz")
 
