@@ -30,6 +30,23 @@ def massive_template(mass: float = 0.08, inertia: float = 2e-4) -> M.MoccaModel:
     return m.finalize_tables()
 
 
+def upright_reset(m: M.MoccaModel, rec, template: M.MoccaModel) -> M.MoccaModel:
+    """The synthetic record puts Bullet's base frame at the root link's COM with its PRINCIPAL axes (the most general thing
+    getDynamicsInfo can report); the loader keeps init_pos / init_quat, because the reference resets Bullet's base frame to those
+    values (bullet_utils.py:97-102) whatever that frame is.  For the synthetic robot to start in the template's physical pose -- upright,
+    feet on the ground -- its reset pose must be the template's, expressed for the moved frame."""
+    import dense_reference as D
+    base = np.asarray(rec["_base_inertial_in_template_base"])
+    C0t, C0R = base[:3], base[3:].reshape(3, 3)
+    R0 = D._quat_mat(np.array(list(template.init_quat)))
+    p, q = np.array(list(template.init_pos)) + R0 @ C0t, D._mat_quat(R0 @ C0R)
+    for k in range(3):
+        m.init_pos[k] = p[k]
+    for k in range(4):
+        m.init_quat[k] = q[k]
+    return m
+
+
 def _contact_rows(o: Oracle, m: M.MoccaModel, link_of_body, base_pos):
     """Bullet-style contact rows of the oracle's last substep: link, other, position (world), normal, normal force = impulse / dt."""
     rows = np.zeros((MAX_CP, 9))
@@ -46,7 +63,7 @@ def synthetic_record(template: M.MoccaModel = None, fixed_children=None, n_trace
     """(record dict in the dump tool's format, the blob loaded from it)."""
     tm = template or M.compile_walker3d()
     g = PD.synthetic_dump(tm, M.WALKER3D_JOINT_NAMES, fixed_children=fixed_children or {2: 0.25})
-    m = PD.from_pybullet_dump(g, tm, M.WALKER3D_JOINT_NAMES)
+    m = upright_reset(PD.from_pybullet_dump(g, tm, M.WALKER3D_JOINT_NAMES), g, tm)
     bodies = PD.link_bodies(g, tm, M.WALKER3D_JOINT_NAMES)
     link_of_body = {0: -1}
     for j in range(len(bodies) - 1):
@@ -69,7 +86,7 @@ def synthetic_record(template: M.MoccaModel = None, fixed_children=None, n_trace
         o = Oracle(m.to_bytes(), 0, 1, "f64")
         o.reset(seed=seed)
         st0 = np.zeros((1, o.state_dim))
-        st0[0, :3] = list(m.init_pos); st0[0, 6] = 1.0
+        st0[0, :3] = list(m.init_pos); st0[0, 3:7] = list(m.init_quat)
         st0[0, 13:13 + NJ] = [m.init_q[b] for b in range(1, NJ + 1)]
         o.set_state(st0)
         rng = np.random.default_rng(0)
