@@ -109,6 +109,34 @@ def test_custom_env_episodes_on_the_gpu(golden):
     assert retargets >= 1, "the scripts must drive the in-kernel re-target (env_locomotion.py:214-222) at least once"
 
 
+@pytest.mark.parametrize("field,factor", [("joints_at_limit_cost", 0.9), ("stall_torque_cost", 0.87), ("electricity_cost", 0.99)])
+def test_the_reward_tolerance_catches_a_wrong_weight(golden, field, factor):
+    """Mutation check of REW_TOL: the same replay with ONE reward weight off by 10 % (joints_at_limit_cost 0.1 -> 0.09), by 0.03
+    (stall_torque_cost 0.225 -> 0.196) or by 1 % (electricity_cost) must FAIL on the GPU.  At the former tolerance of 4e-2 the first
+    two passed."""
+    import torch
+    from mocca_envs_amd import lib as L
+    from mocca_envs_amd.vec_env import VecEnv
+    g = lambda k: golden[f"custom_ep0_{k}"]
+    m = M.compile_walker3d()
+    setattr(m, field, getattr(m, field) * factor)
+    env = VecEnv("Walker3DCustomEnv-v0", REPL, auto_reset=False, seed=0, model_blob=m.to_bytes())
+    env.set_param(L.PARAM_EVAL_MODE, int(g("eval_mode")))
+    env.set_draw_tape(np.tile(np.asarray(g("tape"), np.float32)[None], (REPL, 1)))
+    env.reset()
+    states, touch, actions = g("states"), g("touch"), g("actions")
+    worst = 0.0
+    for t in range(len(states)):
+        _set_state(env, states[t][:55])
+        a = torch.from_numpy(np.tile(actions[t][None].astype(np.float32), (REPL, 1)))
+        _, r, _, _ = env.task_step(a, np.tile(np.asarray(touch[t], np.int32).reshape(1, 2), (REPL, 1)), None, None)
+        if np.isfinite(g("rew")[t]):
+            worst = max(worst, abs(float(r[0]) - float(g("rew")[t])))
+    print(f"{field} x {factor}: worst reward error {worst:.3e} (tolerance {REW_TOL:.0e})")
+    assert worst > 2 * REW_TOL, f"a wrong {field} would pass the golden replay"
+    env.close()
+
+
 def test_stepper_env_episodes_on_the_gpu(golden):
     """3 scripted Walker3DStepperEnv episodes: the foot / target state machine up to the last step, stop windows,
     >120-frame release, plank recycling, step and target bonuses -- env_locomotion.py:472-479, 515-568, 632-693."""
