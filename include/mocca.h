@@ -104,8 +104,8 @@ int mocca_create(const void *model_blob, size_t nbytes, int task_id, int n_envs,
 int mocca_destroy(mocca_handle h);
 
 int mocca_n_envs(mocca_handle h);
-int mocca_obs_dim(mocca_handle h);   /* 52 (Custom, env_locomotion.py:58) / 65 (Stepper, :386-393) / 36 (CassieEnv) / 42 (CassiePhase*, env_cassie.py:633) */
-int mocca_act_dim(mocca_handle h);   /* 21, robots.py:21-23 */
+int mocca_obs_dim(mocca_handle h);   /* 52 (Custom, env_locomotion.py:58; Planner, :1003-1005) / 65 (Stepper, :386-393) / 36 (CassieEnv) / 42 (CassiePhase*, env_cassie.py:633) */
+int mocca_act_dim(mocca_handle h);   /* 21, robots.py:21-23 (the planner envs too: the kernel takes the base controller's joint actions) */
 int mocca_state_dim(mocca_handle h); /* MOCCA_STATE_DIM */
 
 /* env.reset() (env_locomotion.py:79-109 / :481-513) for every env whose mask byte is non-zero
@@ -180,6 +180,15 @@ int mocca_is_diagnostic_build(void);
  * frame int((t mod max_time) / max_time * n_frames); t = istep * control_step / n_llc (mocap_time, :359-360), evaluated in
  * double precision.  Required before reset / step when the blob's cassie_mode != MOCCA_CASSIE_PLAIN. */
 int mocca_set_trajectory(mocca_handle h, const float *table_host, int n_frames, double max_time, double control_step);
+
+/* The terrain of the planner envs: what `self.terrain = HeightField(...); self.terrain.reload(data=filename)` builds
+ * (env_locomotion.py:1011-1021, bullet_objects.py:338-393: createCollisionShape(GEOM_HEIGHTFIELD, meshScale [1/scale, 1/scale, 1]), body at
+ * z = (max + min) / 2, lateralFriction 1, contactStiffness 30000, contactDamping 1000 -- the last three are blob numbers).
+ * heights_host [rows][cols] f32 (HOST memory, copied into the handle; x runs along the columns), `scale` grid points per metre.  The grid is
+ * centred on the origin, every cell two triangles split from (ix + 1, iy) to (ix, iy + 1); spheres / capsule ends collide with the closest
+ * of the eight triangles around the nearest grid point; outside the grid there is no ground.  One grid shared by all envs of the handle
+ * (the reference loads the same file for every env).  Required before reset / step / observe with MOCCA_TASK_WALKER3D_PLANNER. */
+int mocca_set_heightfield(mocca_handle h, const float *heights_host, int rows, int cols, double scale);
 
 /* name, registers, LDS and scratch of the step kernel as built (for DESIGN.md / bench) */
 int mocca_kernel_info(mocca_handle h, int *vgprs, int *sgprs, int *lds_bytes, int *scratch_bytes, int *max_blocks_per_cu);

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define MOCCA_MODEL_MAGIC 0x41434F4Du /* "MOCA" */
-#define MOCCA_MODEL_VERSION 11u
+#define MOCCA_MODEL_VERSION 12u
 
 #define MOCCA_MAX_BODIES 24
 #define MOCCA_MAX_GEOMS 32
@@ -72,6 +72,10 @@ enum {
   MOCCA_TASK_WALKER3D_CUSTOM = 0,  /* env_locomotion.py:37-282; also Child3D (:317-327), Walker2D / Crab2D (:285-314), Laikago (:854-890) by blob */
   MOCCA_TASK_WALKER3D_STEPPER = 1, /* env_locomotion.py:330-840; also MikeStepperEnv (:843-851) with a Mike blob       */
   MOCCA_TASK_CASSIE = 2,           /* env_cassie.py:284-479 (CassieEnv, 3-D) */
+  MOCCA_TASK_WALKER3D_PLANNER = 3, /* env_locomotion.py:982-1128 (Walker3DPlannerEnv; MikePlannerEnv :1131-1133 with a Mike blob): the robot
+                                      walks on a height field (bullet_objects.py:338-441, attached with mocca_set_heightfield) towards a
+                                      target drawn once per episode; the low-level policy that turns the planner's 15 numbers into the 21
+                                      joint actions is external (a pickled network, :1022-1033): the kernel takes the 21 actions */
 };
 
 typedef struct MoccaModel {
@@ -209,8 +213,21 @@ typedef struct MoccaModel {
   float mocap_w[6];           /* weights of SpeedRew, JPosRew, JVelRew, OrientationRew, AngularSpeedRew, CoMRew (:484-493) */
   float mocap_speed;          /* 0.8, the forward speed SpeedRew asks for (:498)                                         */
 
+  /* ---- Walker3DPlannerEnv / MikePlannerEnv (env_locomotion.py:982-1133) ---- */
+  int32_t g_torso[MOCCA_MAX_GEOMS]; /* 1 if the geom belongs to the LINK robot_torso_name ("waist", :992) names: the episode ends when that
+                                       link touches anything, terrain or robot (getContactPoints(linkIndexA=robot_torso_id), :1104-1110) */
+  float target_range;               /* 16: walk target xy ~ U(-16, 16)^2, z = the height field under it (:1060-1062)                  */
+  float fall_z;                     /* -5: "free falling off terrain" (:1108)                                                          */
+  /* ---- contact manifolds ---- */
+  int32_t manifold_max;             /* 0: every terrain slot within the margin is a contact.  k > 0: per LINK at most k terrain contacts
+                                       survive -- Bullet keeps a 4-point manifold per pair of collision objects (btPersistentManifold,
+                                       MANIFOLD_CACHE_SIZE 4) [UNVERIFIED-BULLET], so Cassie's twelve hull points per toe (one convex
+                                       mesh in cassie_collide.urdf) give 4 contacts, not 12: the deepest, the one farthest from it,
+                                       and the two farthest to either side of the line through those two                              */
+  int32_t reserved_[7];
+
   /* ---- derived lookup tables (model.py finalize_tables): one 16-byte load instead of chains of dependent loads ---- */
-  float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | terrain<<24), bits(anc_mask[body]) */
+  float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | terrain<<24 | (foot + 1)<<25 | torso<<28), bits(anc_mask[body]) */
   float gp_tab[2 * MOCCA_MAX_GEOMS][4];     /* geom end point in its body frame (x, y, z), bits(body) */
   float pair_tab[MOCCA_MAX_PAIRS][4];       /* bits(geom_a | geom_b<<8 | body_a<<16 | body_b<<24), radius_a, radius_b,
                                                broad-phase reach = half_len_a + half_len_b + radius_a + radius_b (padded; + contact_margin at run time) */

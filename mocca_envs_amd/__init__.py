@@ -23,6 +23,8 @@ REGISTERED = {
     "Cassie2DEnv-v0": ("mocca_envs_amd.envs:CassieEnv", {"planar": True}),   # reference __init__.py:24-29
     "CassiePhaseMocca2DEnv-v0": ("mocca_envs_amd.envs:CassiePhaseMoccaEnv", {"planar": True}),     # :31-36
     "CassiePhaseMirror2DEnv-v0": ("mocca_envs_amd.envs:CassiePhaseMirrorEnv", {"planar": True}),   # :38-43
+    "Walker3DPlannerEnv-v0": ("mocca_envs_amd.envs:Walker3DPlannerEnv", {}),                       # :82-86
+    "MikePlannerEnv-v0": ("mocca_envs_amd.envs:MikePlannerEnv", {}),                               # :88-92
 }
 
 

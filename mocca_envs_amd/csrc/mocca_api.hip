@@ -46,6 +46,9 @@ struct mocca_ctx {
   float* d_traj = nullptr;      // Cassie mocap / phase envs: the motion table (mocca_set_trajectory), owned by the handle
   int traj_n = 0;
   double traj_tmax = 0.0, traj_cstep = 0.0;
+  float* d_hf = nullptr;        // planner envs: the height field (mocca_set_heightfield), owned by the handle
+  int hf_rows = 0, hf_cols = 0;
+  float hf_scale = 0.0f;
   std::string err;
 };
 
@@ -112,6 +115,10 @@ static int check_topology(const MoccaModel& m, int task_id, int* topo, std::stri
   if (task_id == MOCCA_TASK_WALKER3D_CUSTOM && m.n_bodies == TopoCrab2D::NB) {
     *topo = TOPO_CRAB2D; return check_topology_t<TopoCrab2D>(m, "TopoCrab2D", err);
   }
+  if (task_id == MOCCA_TASK_WALKER3D_PLANNER && m.n_bodies != TopoWalker3D::NB) {
+    err = "the planner task runs on the Walker3D tree (Walker3DPlannerEnv, MikePlannerEnv)";
+    return MOCCA_E_TOPOLOGY;
+  }
   if ((task_id == MOCCA_TASK_WALKER3D_CUSTOM || task_id == MOCCA_TASK_WALKER3D_STEPPER) && m.n_bodies == TopoLaikago::NB) {
     *topo = TOPO_LAIKAGO; return check_topology_t<TopoLaikago>(m, "TopoLaikago", err);   // LaikagoCustomEnv / LaikagoStepperEnv
   }
@@ -162,7 +169,8 @@ int mocca_create(const void* model_blob, size_t nbytes, int task_id, int n_envs,
   *out = nullptr;
   if (!model_blob || nbytes != sizeof(MoccaModel)) { g_err = "model blob has the wrong size"; return MOCCA_E_ARG; }
   if (n_envs <= 0) { g_err = "n_envs must be positive"; return MOCCA_E_ARG; }
-  if (task_id != MOCCA_TASK_WALKER3D_CUSTOM && task_id != MOCCA_TASK_WALKER3D_STEPPER && task_id != MOCCA_TASK_CASSIE) {
+  if (task_id != MOCCA_TASK_WALKER3D_CUSTOM && task_id != MOCCA_TASK_WALKER3D_STEPPER && task_id != MOCCA_TASK_CASSIE &&
+      task_id != MOCCA_TASK_WALKER3D_PLANNER) {
     g_err = "unknown task id"; return MOCCA_E_ARG;
   }
   mocca_ctx* h = new (std::nothrow) mocca_ctx();
@@ -180,7 +188,7 @@ int mocca_create(const void* model_blob, size_t nbytes, int task_id, int n_envs,
   h->task_id = task_id; h->n_envs = n_envs; h->device = device;
   h->obs_dim = task_id == MOCCA_TASK_CASSIE
                    ? (h->model.cassie_mode == MOCCA_CASSIE_PLAIN ? 6 + 2 * h->model.n_ordered + 2 : 12 + 2 * h->model.n_ordered + 2)  // env_cassie.py:344-346 / :633
-                   : 6 + 2 * h->model.n_joints + h->model.n_feet + (task_id == MOCCA_TASK_WALKER3D_CUSTOM ? 2 : 5 * (h->model.lookbehind + 2));
+                   : 6 + 2 * h->model.n_joints + h->model.n_feet + (task_id == MOCCA_TASK_WALKER3D_STEPPER ? 5 * (h->model.lookbehind + 2) : 2);
   if (task_id == MOCCA_TASK_CASSIE && (h->model.cassie_mode < MOCCA_CASSIE_PLAIN || h->model.cassie_mode > MOCCA_CASSIE_PHASE_MIRROR ||
                                        (h->model.cassie_mode != MOCCA_CASSIE_PLAIN && h->model.n_ordered != 14))) {
     g_err = "Cassie blob: unknown cassie_mode (the mocap / phase envs need the 14 ordered joints)"; delete h; return MOCCA_E_ARG;
@@ -238,6 +246,7 @@ int mocca_destroy(mocca_handle h) {
   if (h->d_task) (void)hipFree(h->d_task);
   if (h->d_terrain) (void)hipFree(h->d_terrain);
   if (h->d_traj) (void)hipFree(h->d_traj);
+  if (h->d_hf) (void)hipFree(h->d_hf);
   for (float* p : h->d_pvec) if (p) (void)hipFree(p);
   delete h;
   return MOCCA_OK;
@@ -266,6 +275,7 @@ static StepArgs make_args(mocca_handle h) {
   a.prio = h->prio;
   a.traj = h->d_traj; a.traj_n = h->traj_n; a.traj_tmax = h->traj_tmax; a.traj_cstep = h->traj_cstep;
   a.final_obs = h->final_obs;
+  a.hf = h->d_hf; a.hf_rows = h->hf_rows; a.hf_cols = h->hf_cols; a.hf_scale = h->hf_scale;
   return a;
 }
 // A scalar MOCCA_PARAM_APPLIED_GAIN is written into the task records (word T_GAIN, what apply_action reads) by the NEXT call that takes
@@ -281,6 +291,10 @@ static int flush_pending(mocca_handle h, hipStream_t s) {
 static int need_trajectory(mocca_handle h) {
   if (h->task_id == MOCCA_TASK_CASSIE && h->model.cassie_mode != MOCCA_CASSIE_PLAIN && !h->d_traj) {
     h->err = "this Cassie blob (cassie_mode != 0) needs mocca_set_trajectory before reset / step / observe";
+    return MOCCA_E_ARG;
+  }
+  if (h->task_id == MOCCA_TASK_WALKER3D_PLANNER && !h->d_hf) {   // the planner envs stand on the height field
+    h->err = "the planner task needs mocca_set_heightfield before reset / step / observe";
     return MOCCA_E_ARG;
   }
   return MOCCA_OK;
@@ -380,6 +394,20 @@ int mocca_set_trajectory(mocca_handle h, const float* table_host, int n_frames, 
   if (e != hipSuccess) { (void)hipFree(d); h->err = std::string("hipMemcpy(trajectory): ") + hipGetErrorString(e); return MOCCA_E_HIP; }
   if (h->d_traj) { (void)hipDeviceSynchronize(); (void)hipFree(h->d_traj); }
   h->d_traj = d; h->traj_n = n_frames; h->traj_tmax = max_time; h->traj_cstep = control_step;
+  return MOCCA_OK;
+}
+
+int mocca_set_heightfield(mocca_handle h, const float* heights_host, int rows, int cols, double scale) {
+  if (!h) return MOCCA_E_ARG;
+  if (!heights_host || rows < 2 || cols < 2 || !(scale > 0.0)) { h->err = "mocca_set_heightfield: needs at least 2 x 2 heights and a positive scale"; return MOCCA_E_ARG; }
+  DeviceGuard guard(h->device);
+  const size_t bytes = (size_t)rows * cols * sizeof(float);
+  float* d = nullptr;
+  HIP_TRY(h, hipMalloc(&d, bytes));
+  hipError_t e = hipMemcpy(d, heights_host, bytes, hipMemcpyHostToDevice);   // synchronous
+  if (e != hipSuccess) { (void)hipFree(d); h->err = std::string("hipMemcpy(heightfield): ") + hipGetErrorString(e); return MOCCA_E_HIP; }
+  if (h->d_hf) { (void)hipDeviceSynchronize(); (void)hipFree(h->d_hf); }   // no kernel in flight still reads the old grid
+  h->d_hf = d; h->hf_rows = rows; h->hf_cols = cols; h->hf_scale = (float)scale;
   return MOCCA_OK;
 }
 

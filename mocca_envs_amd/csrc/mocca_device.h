@@ -183,6 +183,10 @@ struct StepArgs {
   int traj_n;
   double traj_tmax, traj_cstep;   // CassieTrajectory.max_time(); control_step (mocap_time = istep * control_step / n_llc, in f64)
   int prio;   // MOCCA_PARAM_ISSUE_PRIORITY: row-count thresholds of the issue priorities 1 / 2 / 3, 6 bits each
+  // planner envs (mocca_set_heightfield): heights[hf_rows][hf_cols], x along the columns, hf_scale grid points per metre; shared by all envs
+  const float* hf;
+  int hf_rows, hf_cols;
+  float hf_scale;
   // optional (mocca_set_terminal_obs_buffer): [N][obs_dim]; the row of an env that ends under auto-reset receives the observation of
   // its final state (what the reference's step() returns with done, env_locomotion.py:128-141) before `obs` gets the next episode's first
   float* final_obs;
@@ -860,6 +864,86 @@ DI float sphere_cylinder(const float* l, float rad, const float* Rb, const float
   matvec3(Rb, nl, n);
   return dist - rad;
 }
+// ---- height field of the planner envs (bullet_objects.py:338-441; geometry conventions in the oracle's sphere_heightfield)
+DI void closest_on_triangle(const float* p, const float* a, const float* b, const float* c, float* q) {  // Ericson 5.1.5
+  float ab[3], ac[3], ap[3], bp[3], cp[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { ab[k] = b[k] - a[k]; ac[k] = c[k] - a[k]; ap[k] = p[k] - a[k]; bp[k] = p[k] - b[k]; cp[k] = p[k] - c[k]; }
+  const float d1 = dot3(ab, ap), d2 = dot3(ac, ap), d3 = dot3(ab, bp), d4 = dot3(ac, bp), d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+  const float vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+  float v, w;   // q = a + v ab + w ac
+  if (d1 <= 0 && d2 <= 0) { v = 0; w = 0; }
+  else if (d3 >= 0 && d4 <= d3) { v = 1; w = 0; }
+  else if (vc <= 0 && d1 >= 0 && d3 <= 0) { v = d1 / (d1 - d3); w = 0; }
+  else if (d6 >= 0 && d5 <= d6) { v = 0; w = 1; }
+  else if (vb <= 0 && d2 >= 0 && d6 <= 0) { v = 0; w = d2 / (d2 - d6); }
+  else if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); v = 1 - w; }
+  else { const float den = 1.0f / (va + vb + vc); v = vb * den; w = vc * den; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) q[k] = a[k] + ab[k] * v + ac[k] * w;
+}
+// signed gap and world normal of a sphere (world centre C) against the height field: the closest of the eight triangles of the 2 x 2 cells
+// around the grid point nearest to the centre; 1e30 where there is no terrain
+DI float sphere_heightfield(const float* __restrict__ hf, int rows, int cols, float sc, const float* C, float rad, float reach, float* n) {
+  float gap = 1e30f;
+  n[0] = 0; n[1] = 0; n[2] = 1;
+  const float cell = 1.0f / sc, hx = 0.5f * (float)(cols - 1), hy = 0.5f * (float)(rows - 1);
+  const float fx = C[0] * sc + hx, fy = C[1] * sc + hy;
+  if (!(fx >= -1.0f && fx <= (float)cols && fy >= -1.0f && fy <= (float)rows)) return gap;
+  const int iv = (int)floorf(fx + 0.5f), jv = (int)floorf(fy + 0.5f);
+  // the nine grid points around it (clamped reads; cells outside the grid are skipped below)
+  float hv[3][3];
+  float hmax = -1e30f;
+#pragma unroll
+  for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+    for (int di = 0; di < 3; ++di) {
+      int i = iv - 1 + di, j = jv - 1 + dj;
+      i = i < 0 ? 0 : (i > cols - 1 ? cols - 1 : i);
+      j = j < 0 ? 0 : (j > rows - 1 ? rows - 1 : j);
+      hv[dj][di] = hf[j * cols + i];
+      hmax = fmaxf(hmax, hv[dj][di]);
+    }
+  if (C[2] - reach > hmax) return gap;   // above everything nearby: no contact possible (exact: every triangle lies below hmax)
+#pragma unroll
+  for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+    for (int di = 0; di < 2; ++di) {
+      const int i = iv - 1 + di, j = jv - 1 + dj;
+      if (i < 0 || j < 0 || i > cols - 2 || j > rows - 2) continue;
+      const float x0 = ((float)i - hx) * cell, y0 = ((float)j - hy) * cell;
+      const float v00[3] = {x0, y0, hv[dj][di]}, v10[3] = {x0 + cell, y0, hv[dj][di + 1]};
+      const float v01[3] = {x0, y0 + cell, hv[dj + 1][di]}, v11[3] = {x0 + cell, y0 + cell, hv[dj + 1][di + 1]};
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float* a = t == 0 ? v00 : v10;
+        const float* b = t == 0 ? v10 : v11;
+        const float* c = v01;
+        float q[3], e1[3], e2[3], tn[3], d[3];
+        closest_on_triangle(C, a, b, c, q);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { e1[k] = b[k] - a[k]; e2[k] = c[k] - a[k]; d[k] = C[k] - q[k]; }
+        cross3(e1, e2, tn);
+        const float il = rsq(dot3(tn, tn));
+        const float side = ((C[0] - a[0]) * tn[0] + (C[1] - a[1]) * tn[1] + (C[2] - a[2]) * tn[2]) * il;
+        const float d2 = dot3(d, d), id = rsq(d2);
+        float dist = d2 * id, nn[3];
+        if (side >= 0 && d2 > 1e-18f) { nn[0] = d[0] * id; nn[1] = d[1] * id; nn[2] = d[2] * id; }
+        else { dist = d2 > 0 ? -dist : 0.0f; nn[0] = tn[0] * il; nn[1] = tn[1] * il; nn[2] = tn[2] * il; }
+        if (dist - rad < gap) { gap = dist - rad; n[0] = nn[0]; n[1] = nn[1]; n[2] = nn[2]; }
+      }
+    }
+  return gap;
+}
+// HeightField.get_height_at (bullet_objects.py:348-353), indices clamped to the grid
+DI float hf_height_at(const float* hf, int rows, int cols, float sc, float x, float y) {
+  const float ox = (float)rows / sc * 0.5f, oy = (float)cols / sc * 0.5f;
+  int ix = (int)((x + ox) * sc), iy = (int)((y + oy) * sc);
+  ix = ix < 0 ? 0 : (ix > cols - 1 ? cols - 1 : ix);
+  iy = iy < 0 ? 0 : (iy > rows - 1 ? rows - 1 : iy);
+  return hf[iy * cols + ix];
+}
+
 DI float clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
 DI void seg_seg(const float* p1, const float* q1, const float* p2, const float* q2, float* c1, float* c2) {
   // closest points of two segments (Ericson 5.1.9); quotients through v_rcp_f32 (1 ulp) instead of IEEE division
@@ -922,13 +1006,14 @@ DI void stage_planks(ModelP M, float* L, int lane, const float* ter) {
   wsync();
 }
 
+struct HeightFieldArgs { const float* data; int rows, cols; float scale; };   // planner envs; data == nullptr otherwise
 struct ContactFlags { int touch0, touch1, target0, target1, touch2, touch3, body_touch, target2, target3; };  // feet 2, 3: quadrupeds; body_touch: a non-foot link on the terrain
 
 // lane = terrain contact slot, then self-collision pairs strided over the wave.
 // Contacts are compacted in slot order, then pair order (the oracle's priority), up to max_contacts.
 template <class T, int TASK>
 DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next_step_index,
-                        int* nc_out, int32_t* dbg, int* nc_wanted) {
+                        int* nc_out, int32_t* dbg, int* nc_wanted, const HeightFieldArgs& hfa) {
   STAMP_BEGIN;
   const float margin = unif(M->contact_margin);
   ContactFlags fl = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -936,7 +1021,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
   // ---- terrain: lane -> (geom, end)
   bool active = false;
   float n[3] = {0, 0, 1}, P[3] = {0, 0, 0}, gap = 1e30f, mu = 0, erp = M->erp, cfm = 0;
-  int body = -1, slot = lane, is_target = 0, gfoot = -1;
+  int body = -1, slot = lane, is_target = 0, gfoot = -1, gtorso = 0;
   unsigned bmask = 0u;
   if (lane < T::NSLOT) {
     const f4_t st = *(CF4P)(M->slot_tab[lane]);  // radius, friction, ids, ancestor mask
@@ -945,12 +1030,21 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
     bmask = __float_as_uint(st.w);
     if ((ids >> 24) & 1) {  // flags: bit 24 terrain, bits 25.. foot index + 1
       gfoot = ((ids >> 25) & 7) - 1;
+      gtorso = (ids >> 28) & 1;
       float C[3], Cw[3];
       const float rad = st.x, gfric = st.y;
 #pragma unroll
       for (int i = 0; i < 3; ++i) { C[i] = L[L_GP + 3 * (2 * g + e) + i]; Cw[i] = C[i] + L[L_BASE + i]; }
       body = ids & 0xFF;
-      if (TASK != MOCCA_TASK_WALKER3D_STEPPER) {
+      if (TASK == MOCCA_TASK_WALKER3D_PLANNER) {
+        // height field (HeightField.reload: lateralFriction 1.0, contactStiffness 30000, contactDamping 1000, bullet_objects.py:386-393)
+        gap = sphere_heightfield(hfa.data, hfa.rows, hfa.cols, hfa.scale, Cw, rad, rad + margin, n);
+        mu = M->plank_friction * gfric;
+        const float kk = M->plank_stiffness, cc = M->plank_damping, dt = M->dt;
+        const float ikc = rcp(dt * kk + cc);
+        erp = dt * kk * ikc;
+        cfm = ikc * rcp(dt);
+      } else if (TASK != MOCCA_TASK_WALKER3D_STEPPER) {
         gap = Cw[2] - rad;
         mu = M->ground_friction * gfric;
       } else {
@@ -1004,6 +1098,8 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
     }
     fl.target0 = __ballot(active && gfoot == 0 && is_target) != 0ull;
     fl.target1 = __ballot(active && gfoot == 1 && is_target) != 0ull;
+    // Walker3DPlannerEnv: the torso link touches anything -> done (env_locomotion.py:1104-1110); the terrain here, robot links below
+    if (TASK == MOCCA_TASK_WALKER3D_PLANNER) fl.body_touch = __ballot(active && gtorso) != 0ull;
   }
   int nc = __popcll(am);
   const int n_terrain = nc;   // before the cap (debug record: cap pressure)
@@ -1095,6 +1191,11 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
       }
     }
     const unsigned long long hm = __ballot(hit);
+    if (TASK == MOCCA_TASK_WALKER3D_PLANNER && hm != 0ull) {   // rare: a self contact; does it involve a geom of the torso link?
+      int tor = 0;
+      if (hit) { const int ids2 = __float_as_int((*(CF4P)(M->pair_tab[cand[base + lane]])).x); tor = M->g_torso[ids2 & 0xFF] | M->g_torso[(ids2 >> 8) & 0xFF]; }
+      if (__ballot(hit && tor) != 0ull) fl.body_touch = 1;
+    }
     if (TASK == MOCCA_TASK_WALKER3D_STEPPER) {  // calc_feet_state counts any contact of a foot link
       const int f0 = M->foot_body[0], f1 = M->foot_body[1];
       if (__ballot(hit && (ba == f0 || bb == f0)) != 0ull) fl.touch0 = 1;
@@ -1751,7 +1852,7 @@ DI void stage_joints(ModelP M, float* L, int lane) {
 // one physics substep (what stepSimulation does numSubSteps times, bullet_utils.py:346-353)
 template <class T, int TASK>
 DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next_step_index,
-                        unsigned long long ppk, int32_t* dbg, int prio, int& rows_out) {
+                        unsigned long long ppk, int32_t* dbg, int prio, int& rows_out, const HeightFieldArgs& hfa = HeightFieldArgs{nullptr, 0, 0, 0.0f}) {
   STAMP(30);
   stage_joints<T>(M, L, lane);
   STAMP(29);
@@ -1766,7 +1867,7 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
 #ifdef MOCCA_SKIP_COLLIDE  // profiling builds only (tools/ablate.sh): results are wrong by construction
   ContactFlags fl = {0, 0, 0, 0, 0, 0, 0};
 #else
-  ContactFlags fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc, dbg, &nc_wanted);
+  ContactFlags fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc, dbg, &nc_wanted, hfa);
 #endif
   STAMP(1);
 #ifndef MOCCA_SKIP_ABA
@@ -2021,7 +2122,7 @@ DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, in
     t.wt[0] = t.dist * ca;
     t.wt[1] = t.dist * sa;
     t.wt[2] = 1.0f;
-  } else {
+  } else if (TASK == MOCCA_TASK_WALKER3D_STEPPER) {
     t.gain = M->gain_cur[0] + (M->gain_cur[1] - M->gain_cur[0]) * t.cur / 9;           // applied_gain_curriculum[curriculum], :369,489
   }
   t.mirrored = draw_u<INJECT>(a, env, t.episode, t.draw) < 0.5f;
@@ -2072,7 +2173,17 @@ DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, in
   const int nbo = 6 + 2 * T::NJ + T::NFEET;
   RobotObs ro = robot_obs<T>(M, L, lane, 0.0f, 0.0f, obs);
   float dist, cd, sd;
-  if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
+  if (TASK == MOCCA_TASK_WALKER3D_PLANNER) {
+    // Walker3DPlannerEnv.reset (:1060-1073): AFTER robot.reset, the target: xy ~ U(-16, 16)^2, z = the height field under it
+    const float R = M->target_range;
+    const float ux = draw_u<INJECT>(a, env, t.episode, t.draw), uy = draw_u<INJECT>(a, env, t.episode, t.draw + 1);
+    t.draw += 2;
+    t.wt[0] = -R + 2.0f * R * ux;
+    t.wt[1] = -R + 2.0f * R * uy;
+    t.wt[2] = hf_height_at(a.hf, a.hf_rows, a.hf_cols, a.hf_scale, t.wt[0], t.wt[1]);
+    calc_potential(M, L, t, ro, &dist, &cd, &sd);
+    if (lane == 0) softsign_tail(sd, cd, obs + nbo);
+  } else if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
     calc_potential(M, L, t, ro, &dist, &cd, &sd);
     if (lane == 0) {
       softsign_tail(sd, cd, obs + nbo);

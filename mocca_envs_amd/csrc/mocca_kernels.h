@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     int ln = lane;  // same for lane-derived offsets and predicates (recomputing them costs a few instructions)
     unsigned long long pk = ppk;  // laundered too: otherwise every (ppk >> 5k) & 31 and the addresses derived from it
     asm volatile("" : "+s"(Ms), "+v"(ln), "+v"(pk));  // are hoisted out of the loop and spilled
-    fl = substep<T, TASK>(Ms, L, ln, ter, nsi0, pk, dbg, a.prio, last_rows);
+    fl = substep<T, TASK>(Ms, L, ln, ter, nsi0, pk, dbg, a.prio, last_rows, HeightFieldArgs{a.hf, a.hf_rows, a.hf_cols, a.hf_scale});
   }
   if constexpr (INJECT) {  // getContactPoints results handed in by the caller (robots.py:74-86, env_locomotion.py:634-650, :880-890)
     const int32_t* tc = a.inj_touch + (size_t)env * T::NFEET;
@@ -200,7 +200,20 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   constexpr int NBO = 6 + 2 * T::NJ + T::NFEET;
   float rew = 0.0f;
   int info = 0;
-  if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
+  if (TASK == MOCCA_TASK_WALKER3D_PLANNER) {
+    // Walker3DPlannerEnv.step (env_locomotion.py:1075-1128).  calc_state() is called without contact ids there: feet_contact keeps the zeros
+    // of robot.reset.  reward = progress; the second term of the reference, log(max(1, base_value)) / 3, is the external base controller's
+    // value estimate and is added by the caller.
+    t.fc0 = 0.0f; t.fc1 = 0.0f; t.fc2 = 0.0f; t.fc3 = 0.0f;
+    RobotObs ro = robot_obs<T>(M, L, lane, 0.0f, 0.0f, obs);
+    const float old = t.linpot;
+    float dist, cd, sd;
+    calc_potential(M, L, t, ro, &dist, &cd, &sd);
+    rew = t.linpot - old;
+    // done = done or relative torso height < termination_height or z < -5 or the torso link touches anything (:1103-1111)
+    if (ro.height < M->termination_height || L[L_BASE + 2] < M->fall_z || fl.body_touch) t.done = 1;
+    if (lane == 0) softsign_tail(sd, cd, obs + NBO);
+  } else if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
     const bool evalm = live_eval_mode(a, env);
     if (evalm) { t.wt[0] = t.prevx + 4.0f; t.wt[1] = 0.0f; t.wt[2] = 1.0f; }  // env_locomotion.py:115-116
     t.fc0 = (float)fl.touch0; t.fc1 = (float)fl.touch1;                                // robots.py:74-86
@@ -420,7 +433,7 @@ __global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
   } else {
     RobotObs ro = robot_obs<T>(M, L, lane, t.fc0, t.fc1, obs, t.fc2, t.fc3);
     float dist, cd, sd;
-    if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {
+    if (TASK == MOCCA_TASK_WALKER3D_CUSTOM || TASK == MOCCA_TASK_WALKER3D_PLANNER) {
       calc_potential(M, L, t, ro, &dist, &cd, &sd);
       if (lane == 0) softsign_tail(sd, cd, obs + NBO);
     } else {
@@ -443,6 +456,8 @@ template <template <class, int> class Launcher, class... Args>
 static void dispatch(int topo, int task_id, Args... args) {
   if (topo == TOPO_CASSIE) Launcher<TopoCassie, MOCCA_TASK_CASSIE>::run(args...);
   else if (topo == TOPO_CASSIE_MASSIVE) Launcher<TopoCassieMassive, MOCCA_TASK_CASSIE>::run(args...);
+  else if (topo == TOPO_WALKER3D_MASSIVE && task_id == MOCCA_TASK_WALKER3D_PLANNER) Launcher<TopoWalker3DMassive, MOCCA_TASK_WALKER3D_PLANNER>::run(args...);
+  else if (topo == TOPO_WALKER3D && task_id == MOCCA_TASK_WALKER3D_PLANNER) Launcher<TopoWalker3D, MOCCA_TASK_WALKER3D_PLANNER>::run(args...);
   else if (topo == TOPO_WALKER3D_MASSIVE && task_id == MOCCA_TASK_WALKER3D_CUSTOM) Launcher<TopoWalker3DMassive, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
   else if (topo == TOPO_WALKER3D_MASSIVE) Launcher<TopoWalker3DMassive, MOCCA_TASK_WALKER3D_STEPPER>::run(args...);
   else if (topo == TOPO_WALKER2D) Launcher<TopoWalker2D, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);

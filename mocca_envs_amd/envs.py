@@ -360,6 +360,88 @@ class LaikagoStepperEnv(Walker3DStepperEnv):
     step_bonus_smoothness = 6
 
 
+class Walker3DPlannerEnv(EnvBase):
+    """env_locomotion.py:982-1128: the walker on the height field, steered by a 15-number plan that a low-level "base controller"
+    turns into the 21 joint actions.
+
+    The reference unpickles that controller (`MikePlannerBase.pt`, a torch actor-critic whose class is not in its tree,
+    :1022-1033); here it is INJECTED: `base_controller(base_obs[65]) -> (value, action[21])`, the very call the reference makes
+    (`self.query_base_controller`, :1093-1094).  Without one, `step` raises.  `load_base_controller(path)` does what the reference
+    does when torch and the pickled class are importable."""
+
+    env_id = "Walker3DPlannerEnv-v0"
+    task_id = M.TASK_WALKER3D_PLANNER
+    robot_random_start = True
+    robot_init_position = [-15.5, -15.5, 1.32]
+    robot_init_velocity = None
+    robot_torso_name = "waist"
+    termination_height = 0.5
+    action_scale = 2
+    base_lookahead, base_lookbehind, base_step_param_dim = 2, 1, 5
+
+    def __init__(self, base_controller=None, **kwargs):
+        kwargs.pop("remove_ground", None)
+        super().__init__(**kwargs)
+        from .terrain import HeightField
+        self.terrain = HeightField(H.HEIGHT_FIELD_SIZE, H.HEIGHT_FIELD_SCALE)      # create_terrain, :1011-1021
+        self.terrain.reload(data=H.HEIGHT_FIELD_FILE, rng=self.np_random)
+        self.query_base_controller = base_controller
+        self.robot_obs_dim = self.robot.observation_space.shape[0]
+        high = np.inf * np.ones(self.robot_obs_dim + 2)
+        self.observation_space = gym.spaces.Box(-high, high, dtype=np.float32)
+        high = np.inf * np.ones((self.base_lookahead + self.base_lookbehind) * self.base_step_param_dim)
+        self.action_space = gym.spaces.Box(-high, high, dtype=np.float32)
+
+    def load_base_controller(self, filename):
+        """The reference's loader (:1022-1033): needs torch and the module that defines the pickled policy class on the path."""
+        import torch
+        actor_critic = torch.load(filename, map_location="cpu")
+
+        def inference(o):
+            with torch.no_grad():
+                value, action, _ = actor_critic.act(torch.from_numpy(o).unsqueeze(0), deterministic=True)
+                return value.squeeze().numpy(), action.squeeze().numpy()
+
+        self.query_base_controller = inference
+        return inference
+
+    def reset(self):
+        self.timestep, self.done = 0, False
+        q, self.robot.mirrored = H.reset_pose(self.robot.np_random, self.model, self.robot_random_start)
+        xy = self.np_random.uniform(-16, 16, 2)                                     # :1060-1062
+        z = self.terrain.get_height_at(*xy)
+        self.walk_target = np.array((*xy, z), dtype=np.float32)
+        self._episode = getattr(self, "_episode", -1) + 1
+        task = H.task_record(walk_target=self.walk_target.astype(np.float64), mirrored=int(self.robot.mirrored), episode=self._episode)
+        self._push(H.initial_state(self.model, q), task)
+        obs = self._vec.observe()[0].cpu().numpy().astype(np.float64)
+        self.robot_state = obs[:self.robot_obs_dim].copy()
+        self._pull_robot()
+        return obs
+
+    def step(self, action):
+        if self.query_base_controller is None:
+            raise RuntimeError("Walker3DPlannerEnv needs a base controller: pass base_controller=callable(base_obs) -> (value, action[21]) "
+                               "or call load_base_controller(path)")
+        self.timestep += 1
+        base_obs = np.concatenate((self.robot_state, np.asarray(action, dtype=np.float64) * self.action_scale))   # :1093
+        base_value, base_action = self.query_base_controller(base_obs.astype(np.float32))
+        obs, progress, done, _ = self._step_device(base_action)
+        self._pull_robot()
+        self.robot_state = obs[:self.robot_obs_dim].copy()
+        self.progress = progress
+        reward = progress + np.log(max(1, float(base_value))) / 3                                                  # :1101
+        self.done = done
+        return obs, reward, self.done, {}
+
+
+class MikePlannerEnv(Walker3DPlannerEnv):
+    """env_locomotion.py:1131-1133."""
+
+    env_id = "MikePlannerEnv-v0"
+    robot_init_position = [-15.5, -15.5, 1.05]
+
+
 class CassieEnv(EnvBase):
     """env_cassie.py:284-479: CassieEnv-v0 and, with planar=True, Cassie2DEnv-v0.  The reference class is not importable in the
     reference snapshot; this follows its text, pinned by tests/golden/make_golden_cassie.py."""

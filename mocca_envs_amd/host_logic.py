@@ -158,3 +158,75 @@ def mirror_indices(mdl: M.MoccaModel, stepper: bool):
         steps_neg = np.array([(i * 5 + 0, i * 5 + 3) for i in range(n_targets)], dtype=np.int64).flatten()
         neg_obs = np.concatenate((robot_neg, steps_neg + robot_obs_dim))
     return (neg_obs.astype(np.int64), right_obs.astype(np.int64), left_obs.astype(np.int64), neg.copy(), right.copy(), left.copy())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Height-field terrain of the planner envs (bullet_objects.py:338-441, misc_utils.py:4-58); pinned by tests/test_golden_planner.py
+# ---------------------------------------------------------------------------------------------------------------------
+HEIGHT_FIELD_FILE = "height_field_map_0.npy"   # Walker3DPlannerEnv.create_terrain, env_locomotion.py:1015-1021
+HEIGHT_FIELD_SIZE, HEIGHT_FIELD_SCALE = (128, 128), 4
+
+
+def height_at(data2d: np.ndarray, scale: float, x: float, y: float) -> float:
+    """HeightField.get_height_at (bullet_objects.py:348-353): data2d[int((y + oy) * scale), int((x + ox) * scale)] with
+    ox, oy = data_size / scale / 2 -- the grid point below-left of (x, y) on a grid whose point 0 sits at -size / scale / 2
+    (half a cell off Bullet's centred grid; the reference uses it for the z of the walk target only)."""
+    rows, cols = data2d.shape
+    ox, oy = rows / scale / 2, cols / scale / 2
+    return float(data2d[int((y + oy) * scale), int((x + ox) * scale)])
+
+
+def _fade(t):
+    return t * t * t * (t * (6 * t - 15) + 10)
+
+
+def perlin_noise_2d(shape, res, rng) -> np.ndarray:
+    """Perlin noise on a shape[0] x shape[1] grid with res[0] x res[1] lattice cells (misc_utils.generate_perlin_noise_2d):
+    (res + 1)^2 unit gradients from rng.rand, corner ramps blended with the quintic fade, scaled by sqrt(2).  Same draws, same values."""
+    n0, n1 = shape
+    r0, r1 = res
+    theta = 2 * np.pi * rng.rand(r0 + 1, r1 + 1)
+    gx, gy = np.cos(theta), np.sin(theta)
+    per0, per1 = n0 // r0, n1 // r1                  # pixels per lattice cell
+    i, j = np.arange(n0), np.arange(n1)
+    ci, cj = (i // per0)[:, None], (j // per1)[None, :]                      # lattice cell of each pixel
+    u = ((i * (r0 / n0)) % 1)[:, None] * np.ones((1, n1))                    # position inside the cell
+    v = np.ones((n0, 1)) * ((j * (r1 / n1)) % 1)[None, :]
+
+    def ramp(di, dj):
+        return (u - di) * gx[ci + di, cj + dj] + (v - dj) * gy[ci + di, cj + dj]
+
+    fu, fv = _fade(u), _fade(v)
+    low = ramp(0, 0) * (1 - fu) + fu * ramp(1, 0)
+    high = ramp(0, 1) * (1 - fu) + fu * ramp(1, 1)
+    return np.sqrt(2) * ((1 - fv) * low + fv * high)
+
+
+def fractal_noise_2d(shape, res, octaves: int = 1, persistence: float = 0.5, rng=None) -> np.ndarray:
+    """Sum of `octaves` Perlin layers, lattice doubling and amplitude x persistence per layer (misc_utils.generate_fractal_noise_2d)."""
+    rng = rng or np.random
+    total, freq, amp = np.zeros(shape), 1, 1.0
+    for _ in range(octaves):
+        total += amp * perlin_noise_2d(shape, (freq * res[0], freq * res[1]), rng)
+        freq, amp = 2 * freq, amp * persistence
+    return total
+
+
+def random_height_field(rng, size=HEIGHT_FIELD_SIZE, scale: float = HEIGHT_FIELD_SCALE, n_peaks: int = 256) -> np.ndarray:
+    """HeightField.get_random_height_field (bullet_objects.py:395-441), flat array of size[0] * size[1] heights: 256 super-Gaussian
+    peaks (height U(0.1, 3), centre uniform on the field, spreads U(1, 16), even exponents 2 .. 10) divided by the scale, plus two
+    octaves of fractal noise, minus the mean of the 5 x 5 corner platform, which is flattened first.  Draw order preserved."""
+    height = rng.uniform(0.1, 3, size=n_peaks)
+    half_x, half_y = size[0] / scale / 2, size[1] / scale / 2
+    cx, cy = rng.uniform(-half_x, half_x, size=n_peaks), rng.uniform(-half_y, half_y, size=n_peaks)
+    sx, sy = rng.uniform(1, 16, size=n_peaks), rng.uniform(1, 16, size=n_peaks)
+    ex, ey = rng.randint(1, 6, size=n_peaks) * 2, rng.randint(1, 6, size=n_peaks) * 2
+    gx, gy = np.linspace(-half_x, half_x, size[0]), np.linspace(-half_y, half_y, size[1])
+    field = np.zeros(size)
+    for k in range(n_peaks):       # one peak at a time keeps the temporary at the size of the field, not 256 x the field
+        field += height[k] * np.exp(-(((gx - cx[k]) ** ex[k]) / sx[k])[:, None] - (((gy - cy[k]) ** ey[k]) / sy[k])[None, :])
+    flat = field.flatten() / scale + fractal_noise_2d(size, (4, 4), 2, 1, rng).flatten()
+    corner = flat.reshape(size)[0:5, 0:5]          # a view: the platform the robot starts on, at the corner it starts in
+    level = corner.mean()
+    corner[:] = level
+    return flat - level

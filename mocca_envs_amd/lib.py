@@ -45,6 +45,7 @@ SYMBOLS = {
     "mocca_set_debug_buffer": (_i, [_vp, _vp]),
     "mocca_set_terminal_obs_buffer": (_i, [_vp, _vp]),
     "mocca_set_trajectory": (_i, [_vp, _vp, _i, _d, _d]),
+    "mocca_set_heightfield": (_i, [_vp, _vp, _i, _i, _d]),
     "mocca_is_diagnostic_build": (_i, []),
     "mocca_kernel_info": (_i, [_vp] + [C.POINTER(_i)] * 5),
     "mocca_last_error": (C.c_char_p, [_vp]),

@@ -29,10 +29,10 @@ MAX_PAIRS = 192
 MAX_FEET = 4
 MAX_SLOTS = 40
 MAGIC = 0x41434F4D
-VERSION = 11
+VERSION = 12
 
 GEOM_SPHERE, GEOM_CAPSULE = 0, 1
-TASK_WALKER3D_CUSTOM, TASK_WALKER3D_STEPPER, TASK_CASSIE = 0, 1, 2
+TASK_WALKER3D_CUSTOM, TASK_WALKER3D_STEPPER, TASK_CASSIE, TASK_WALKER3D_PLANNER = 0, 1, 2, 3
 TASK_WORDS = 40
 TASKF_NEVER_DONE, TASKF_RESET_TAIL_ZERO, TASKF_BODY_CONTACT, TASKF_QUADRUPED_STEPPER = 1, 2, 4, 8  # MoccaModel.task_flags (include/mocca_model.h)
 PLANK_BOX, PLANK_CYLINDER = 0, 1
@@ -154,6 +154,11 @@ class MoccaModel(C.Structure):
         ("rod_body", C.c_int32 * 4),
         ("mocap_w", C.c_float * 6),
         ("mocap_speed", C.c_float),
+        ("g_torso", C.c_int32 * MAX_GEOMS),
+        ("target_range", C.c_float),
+        ("fall_z", C.c_float),
+        ("manifold_max", C.c_int32),
+        ("reserved_", C.c_int32 * 7),
         ("slot_tab", (C.c_float * 4) * MAX_SLOTS),
         ("gp_tab", (C.c_float * 4) * (2 * MAX_GEOMS)),
         ("pair_tab", (C.c_float * 4) * MAX_PAIRS),
@@ -193,7 +198,8 @@ class MoccaModel(C.Structure):
                 sl = self.g_slot[g] + e
                 self.slot_tab[sl][0] = self.g_radius[g]
                 self.slot_tab[sl][1] = self.g_friction[g]
-                self.slot_tab[sl][2] = bits(b | (g << 8) | (e << 16) | ((1 if self.g_terrain[g] else 0) << 24) | ((self.g_foot[g] + 1) << 25))
+                self.slot_tab[sl][2] = bits(b | (g << 8) | (e << 16) | ((1 if self.g_terrain[g] else 0) << 24) | ((self.g_foot[g] + 1) << 25) |
+                                               ((1 if self.g_torso[g] else 0) << 28))
                 self.slot_tab[sl][3] = bits(self.anc_mask[b])
         for k in range(self.n_pairs):
             ga, gb = self.pair_a[k], self.pair_b[k]
@@ -529,6 +535,7 @@ def compile_model(
     init_quat_xyzw: Sequence[float] = (0.0, 0.0, 0.0, 1.0),
     link_mass: Optional[Dict[str, float]] = None,
     plank_class: str = "LargePlank",
+    torso_name: Optional[str] = None,
 ) -> MoccaModel:
     flat, bl_parent, _ = _flatten(root, base_ref)
     nb = len(flat)
@@ -627,6 +634,11 @@ def compile_model(
         m.foot_body[k] = names.index(fbdy.hinges[-1].name)
     for gi in range(m.n_geoms):   # MJCF feet: every geom of the foot body belongs to the foot link
         m.g_foot[gi] = next((k for k in range(m.n_feet) if m.foot_body[k] == m.g_body[gi]), -1)
+    if torso_name is not None:    # robot_torso_name (env_locomotion.py:992): the link that carries the MJCF body of that name
+        tb = names.index(find_body(root, torso_name).hinges[-1].name)
+        for gi, (b, g, bl) in enumerate(geoms):
+            m.g_torso[gi] = int(b == tb and bl == flat[tb].bullet_link)
+    m.target_range, m.fall_z = 16.0, -5.0     # env_locomotion.py:1060, :1108
     for k in range(m.n_feet):     # ... and the foot link is the body itself: its COM is what getLinkState reports
         for i in range(3):
             m.foot_point[k][i] = m.com[m.foot_body[k]][i]
@@ -689,9 +701,19 @@ def walker3d_running_start() -> Dict[str, float]:
     return {n: float(v) for n, v in zip(WALKER3D_JOINT_NAMES, q)}
 
 
+def _planner_params(m: "MoccaModel") -> "MoccaModel":
+    """Walker3DPlannerEnv's class attributes and its terrain's contact parameters (env_locomotion.py:982-996, bullet_objects.py:386-393)."""
+    m.termination_height = 0.5                                                       # :995
+    m.plank_friction, m.plank_stiffness, m.plank_damping = 1.0, 30000.0, 1000.0      # HeightField.reload changeDynamics
+    return m.finalize_tables()
+
+
 def compile_walker3d(task: int = TASK_WALKER3D_CUSTOM, **kw) -> MoccaModel:
-    """Walker3D blob.  `task` only changes the initial base position (env_locomotion.py:339)."""
-    init_pos = (0.0, 0.0, 1.32) if task == TASK_WALKER3D_CUSTOM else (0.3, 0.0, 1.32)
+    """Walker3D blob.  `task` changes the initial base position (env_locomotion.py:339, :989) and, for the planner env, the
+    termination height and the torso link."""
+    init_pos = {TASK_WALKER3D_CUSTOM: (0.0, 0.0, 1.32), TASK_WALKER3D_STEPPER: (0.3, 0.0, 1.32), TASK_WALKER3D_PLANNER: (-15.5, -15.5, 1.32)}[task]
+    if task == TASK_WALKER3D_PLANNER:
+        kw.setdefault("torso_name", "waist")                # robot_torso_name, :992
     # walker3d.xml:4 <joint armature="0.01" damping=".1">.  The armature is what keeps the
     # three-hinge shoulder (massless intermediate links, z range up to 120 deg, walker3d.xml:67-69)
     # away from the gimbal singularity where ABA's D_i -> 0; see DESIGN.md "Model assumptions".
@@ -707,7 +729,7 @@ def compile_walker3d(task: int = TASK_WALKER3D_CUSTOM, **kw) -> MoccaModel:
         mirror_neg=[0, 2],                                  # robots.py:288
         **kw,
     )
-    return m
+    return _planner_params(m) if task == TASK_WALKER3D_PLANNER else m
 
 
 def walker3d_crawl() -> Dict[str, float]:
@@ -747,11 +769,15 @@ def compile_mike(**kw) -> MoccaModel:
     from .mjcf_tables import mike_description
     kw.setdefault("joint_damping", 0.1)     # mike.xml:4
     kw.setdefault("joint_armature", 0.01)
-    return compile_model(mike_description(), foot_names=["right_foot", "left_foot"],
-                         init_q_by_name=walker3d_running_start(),  # env_locomotion.py:360
-                         init_pos=(0.3, 0.0, 1.0),               # env_locomotion.py:845
-                         link_mass={"abdomen_y": 8.0},           # the link carrying MJCF body "waist", robots.py:507-510
-                         **_WALKER3D_MIRROR, **kw)
+    planner = kw.pop("planner", False)      # MikePlannerEnv (env_locomotion.py:1131-1133): starts at (-15.5, -15.5, 1.05)
+    if planner:
+        kw.setdefault("torso_name", "waist")
+    m = compile_model(mike_description(), foot_names=["right_foot", "left_foot"],
+                      init_q_by_name=walker3d_running_start(),  # env_locomotion.py:360
+                      init_pos=(-15.5, -15.5, 1.05) if planner else (0.3, 0.0, 1.0),   # :1133 / :845
+                      link_mass={"abdomen_y": 8.0},           # the link carrying MJCF body "waist", robots.py:507-510
+                      **_WALKER3D_MIRROR, **kw)
+    return _planner_params(m) if planner else m
 
 
 def _compile_planar(description, damping: float, armature: float, self_collision: bool, mirror_right, mirror_left, **kw) -> MoccaModel:

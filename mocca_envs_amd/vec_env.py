@@ -34,6 +34,10 @@ TASKS = {
     # the planar mocap / phase envs (__init__.py:31-43, env_cassie.py:481-660): Cassie topology, mocap targets and reward
     "CassiePhaseMocca2DEnv-v0": M.TASK_CASSIE,
     "CassiePhaseMirror2DEnv-v0": M.TASK_CASSIE,
+    # the walkers on the height field (env_locomotion.py:982-1133): Walker3D / Mike tree x Planner task; the kernel takes the 21 joint
+    # actions of the (external) base controller, the planner's 15 numbers are the caller's business
+    "Walker3DPlannerEnv-v0": M.TASK_WALKER3D_PLANNER,
+    "MikePlannerEnv-v0": M.TASK_WALKER3D_PLANNER,
 }
 # class attributes of the reference envs that are device parameters here
 _DEFAULT_PARAMS = {"LaikagoCustomEnv-v0": {_lib.PARAM_RANDOM_POSE: 0},    # robot_random_start = False, env_locomotion.py:863
@@ -66,6 +70,8 @@ _MODELS = {
     "Walker2DCustomEnv-v0": M.compile_walker2d,
     "Crab2DCustomEnv-v0": M.compile_crab2d,
     "LaikagoCustomEnv-v0": M.compile_laikago,
+    "Walker3DPlannerEnv-v0": lambda **kw: M.compile_walker3d(M.TASK_WALKER3D_PLANNER, **kw),
+    "MikePlannerEnv-v0": lambda **kw: M.compile_mike(planner=True, **kw),
 }
 _DEFAULT_ENV_OF_TASK = {M.TASK_WALKER3D_CUSTOM: "Walker3DCustomEnv-v0", M.TASK_WALKER3D_STEPPER: "Walker3DStepperEnv-v0",
                         M.TASK_CASSIE: "CassieEnv-v0"}
@@ -131,6 +137,10 @@ class VecEnv:
         self.terminal_obs = None
         if terminal_obs:
             self.keep_terminal_obs(True)
+        self.height_field = None
+        if self.task_id == M.TASK_WALKER3D_PLANNER:
+            from .terrain import load_height_field   # self.terrain.reload(data="height_field_map_0.npy"), env_locomotion.py:1015-1021
+            self.set_heightfield(*load_height_field())
         self.trajectory = None
         if self.task_id == M.TASK_CASSIE and self.model.cassie_mode != M.CASSIE_PLAIN:
             from .trajectory import CassieTrajectory   # self.traj = CassieTrajectory(), env_cassie.py:576
@@ -166,6 +176,15 @@ class VecEnv:
         _lib.check(self.lib.mocca_set_trajectory(self.h, tab.ctypes.data_as(C.c_void_p), tab.shape[0], float(traj.max_time()),
                                                  float(control_step)), self.h)
         self.trajectory = traj
+
+    def set_heightfield(self, heights, scale: float):
+        """Attach the terrain of the planner envs (include/mocca.h mocca_set_heightfield): heights[rows][cols], x along the columns,
+        `scale` grid points per metre; copied into the handle, one grid for all envs."""
+        hf = np.ascontiguousarray(heights, np.float32)
+        if hf.ndim != 2:
+            raise ValueError("heights must be a [rows][cols] grid")
+        _lib.check(self.lib.mocca_set_heightfield(self.h, hf.ctypes.data_as(C.c_void_p), hf.shape[0], hf.shape[1], float(scale)), self.h)
+        self.height_field = (hf, float(scale))
 
     def set_param_v(self, pid: int, values, broadcast: bool = False):
         """Per-env curriculum / eval_mode / applied_gain (include/mocca.h mocca_set_param_v); values: [N] (or [1] with broadcast)."""

@@ -240,6 +240,10 @@ typedef struct {
   float *traj;
   int traj_n;
   double traj_tmax, traj_cstep;
+  /* planner envs: the height field (orc_set_heightfield), data[iy * cols + ix], `hf_scale` grid points per metre */
+  float *hf;
+  int hf_rows, hf_cols;
+  double hf_scale;
 } Oracle;
 
 static real draw_uniform(Oracle *o, int env, Task *tk) {
@@ -520,6 +524,82 @@ static void seg_seg(const real *p1, const real *q1, const real *p2, const real *
   for (int k = 0; k < 3; ++k) { c1[k] = p1[k] + d1[k] * s; c2[k] = p2[k] + d2[k] * t; }
 }
 
+/* ---- height field (bullet_objects.py:338-441: createCollisionShape(GEOM_HEIGHTFIELD, meshScale [1/scale, 1/scale, 1]), body placed at
+ * z = (max + min) / 2 so that world heights are the data values).  btHeightfieldTerrainShape centres the grid on the origin: grid point
+ * (ix, iy) sits at x = (ix - (cols - 1) / 2) / scale, y = (iy - (rows - 1) / 2) / scale, height data[iy * cols + ix]; every cell is two
+ * triangles split along the diagonal from (ix + 1, iy) to (ix, iy + 1) (no flipQuadEdges, no diamond subdivision)  [UNVERIFIED-BULLET].
+ * Outside the grid there is no terrain ("free falling off terrain", env_locomotion.py:1108). */
+static void closest_on_triangle(const real *p, const real *a, const real *b, const real *c, real *q) { /* Ericson, Real-Time Collision Detection 5.1.5 */
+  real ab[3], ac[3], ap[3], bp[3], cp[3];
+  for (int k = 0; k < 3; ++k) { ab[k] = b[k] - a[k]; ac[k] = c[k] - a[k]; ap[k] = p[k] - a[k]; }
+  real d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+  if (d1 <= 0 && d2 <= 0) { for (int k = 0; k < 3; ++k) q[k] = a[k]; return; }
+  for (int k = 0; k < 3; ++k) bp[k] = p[k] - b[k];
+  real d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+  if (d3 >= 0 && d4 <= d3) { for (int k = 0; k < 3; ++k) q[k] = b[k]; return; }
+  real vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { real v = d1 / (d1 - d3); for (int k = 0; k < 3; ++k) q[k] = a[k] + v * ab[k]; return; }
+  for (int k = 0; k < 3; ++k) cp[k] = p[k] - c[k];
+  real d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+  if (d6 >= 0 && d5 <= d6) { for (int k = 0; k < 3; ++k) q[k] = c[k]; return; }
+  real vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { real w = d2 / (d2 - d6); for (int k = 0; k < 3; ++k) q[k] = a[k] + w * ac[k]; return; }
+  real va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+    real w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    for (int k = 0; k < 3; ++k) q[k] = b[k] + w * (c[k] - b[k]);
+    return;
+  }
+  real den = 1 / (va + vb + vc), v = vb * den, w = vc * den;
+  for (int k = 0; k < 3; ++k) q[k] = a[k] + ab[k] * v + ac[k] * w;
+}
+/* signed gap and world normal of a sphere against the height field: the closest of the (up to) eight triangles of the 2 x 2 cells around
+ * the grid point nearest to the centre (exact while radius + margin <= half a cell).  A centre below a triangle's plane is inside the
+ * ground: the distance counts negative and the normal is the triangle's.  Returns 1e30 where there is no terrain. */
+static real sphere_heightfield(const Oracle *o, const real *C, real rad, real *n) {
+  const int cols = o->hf_cols, rows = o->hf_rows;
+  const real sc = (real)o->hf_scale, cell = 1 / sc;
+  real gap = 1e30;
+  n[0] = 0; n[1] = 0; n[2] = 1;
+  if (!o->hf) return gap;
+  real fx = C[0] * sc + (real)0.5 * (cols - 1), fy = C[1] * sc + (real)0.5 * (rows - 1);
+  if (!(fx >= -1 && fx <= cols && fy >= -1 && fy <= rows)) return gap;
+  int iv = (int)floor(fx + (real)0.5), jv = (int)floor(fy + (real)0.5);
+  for (int dj = -1; dj <= 0; ++dj)
+    for (int di = -1; di <= 0; ++di) {
+      int i = iv + di, j = jv + dj;
+      if (i < 0 || j < 0 || i > cols - 2 || j > rows - 2) continue;
+      real x0 = (i - (real)0.5 * (cols - 1)) * cell, y0 = (j - (real)0.5 * (rows - 1)) * cell;
+      real v00[3] = {x0, y0, o->hf[j * cols + i]}, v10[3] = {x0 + cell, y0, o->hf[j * cols + i + 1]};
+      real v01[3] = {x0, y0 + cell, o->hf[(j + 1) * cols + i]}, v11[3] = {x0 + cell, y0 + cell, o->hf[(j + 1) * cols + i + 1]};
+      for (int t = 0; t < 2; ++t) {
+        const real *a = t == 0 ? v00 : v10, *b = t == 0 ? v10 : v11, *c = v01;
+        real q[3], e1[3], e2[3], tn[3], d[3];
+        closest_on_triangle(C, a, b, c, q);
+        for (int k = 0; k < 3; ++k) { e1[k] = b[k] - a[k]; e2[k] = c[k] - a[k]; d[k] = C[k] - q[k]; }
+        cross3(e1, e2, tn); /* counter-clockwise seen from above: points up */
+        real il = 1 / sqrt(dot3(tn, tn));
+        for (int k = 0; k < 3; ++k) tn[k] *= il;
+        real side = (C[0] - a[0]) * tn[0] + (C[1] - a[1]) * tn[1] + (C[2] - a[2]) * tn[2];
+        real d2 = dot3(d, d), dist = sqrt(d2), nn[3];
+        if (side >= 0 && d2 > (real)1e-18) { for (int k = 0; k < 3; ++k) nn[k] = d[k] / dist; }
+        else { dist = -dist; for (int k = 0; k < 3; ++k) nn[k] = tn[k]; }
+        if (dist - rad < gap) { gap = dist - rad; n[0] = nn[0]; n[1] = nn[1]; n[2] = nn[2]; }
+      }
+    }
+  return gap;
+}
+/* HeightField.get_height_at (bullet_objects.py:348-353): ox, oy = data_size / scale / 2; data2d[int((y + oy) * scale), int((x + ox) * scale)]
+ * (indices clamped to the grid here; the reference would wrap negative ones and raise past the end) */
+static real hf_height_at(const Oracle *o, real x, real y) {
+  if (!o->hf) return 0;
+  real ox = (real)o->hf_rows / (real)o->hf_scale / 2, oy = (real)o->hf_cols / (real)o->hf_scale / 2;
+  int ix = (int)((x + ox) * (real)o->hf_scale), iy = (int)((y + oy) * (real)o->hf_scale);
+  ix = ix < 0 ? 0 : (ix > o->hf_cols - 1 ? o->hf_cols - 1 : ix);
+  iy = iy < 0 ? 0 : (iy > o->hf_rows - 1 ? o->hf_rows - 1 : iy);
+  return o->hf[iy * o->hf_cols + ix];
+}
+
 static void plank_frame(const Oracle *o, const Terrain *tr, int k, real *bc, real *Rb) {
   const MoccaModel *m = &o->m;
   const real *ti = tr->terrain[tr->plank_info[k]];
@@ -557,7 +637,13 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
       int is_target = 0;
       geom_point(m, w, g, e, C);
       for (int k = 0; k < 3; ++k) Cw[k] = C[k] + s->pos[k];
-      if (o->task_id != MOCCA_TASK_WALKER3D_STEPPER) {
+      if (o->task_id == MOCCA_TASK_WALKER3D_PLANNER) {
+        gap = sphere_heightfield(o, Cw, rad, n);
+        mu = (real)m->plank_friction * (real)m->g_friction[g]; /* HeightField.reload: lateralFriction 1.0, contactStiffness 30000, contactDamping 1000 */
+        real kk = m->plank_stiffness, cc = m->plank_damping, dt = m->dt;
+        erp = dt * kk / (dt * kk + cc);
+        cfm = 1 / (dt * kk + cc) / dt;
+      } else if (o->task_id != MOCCA_TASK_WALKER3D_STEPPER) {
         gap = Cw[2] - rad;
         mu = (real)m->ground_friction * (real)m->g_friction[g];
       } else {
@@ -585,7 +671,8 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
       }
       if (gap < margin) {
         slot_mask |= (uint64_t)1 << (m->g_slot[g] + e);
-        if (m->g_foot[g] >= 0) { w->foot_touch[m->g_foot[g]] = 1; if (is_target) w->foot_target[m->g_foot[g]] = 1; }
+        if (o->task_id == MOCCA_TASK_WALKER3D_PLANNER) { if (m->g_torso[g]) w->body_touch = 1; } /* the torso link touches the terrain, :1104-1110 */
+        else if (m->g_foot[g] >= 0) { w->foot_touch[m->g_foot[g]] = 1; if (is_target) w->foot_target[m->g_foot[g]] = 1; }
         else w->body_touch = 1; /* a non-foot link on the terrain (LaikagoCustomEnv, env_locomotion.py:880-890) */
         if (ncand < MOCCA_MAX_SLOTS) {
           TerrainCand *q = &cand[ncand++];
@@ -628,6 +715,8 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
       w->c_erp[i] = m->erp; w->c_cfm[i] = 0;
     }
     if (gap < margin && dist > (real)1e-9) ++n_self;
+    if (gap < margin && dist > (real)1e-9 && o->task_id == MOCCA_TASK_WALKER3D_PLANNER && (m->g_torso[ga] || m->g_torso[gb]))
+      w->body_touch = 1; /* getContactPoints(linkIndexA=torso) reports contacts with the robot's own links too */
     /* Walker3DStepperEnv.calc_feet_state counts ANY contact of a foot link (env_locomotion.py:645-647) */
     if (gap < margin && dist > (real)1e-9 && o->task_id == MOCCA_TASK_WALKER3D_STEPPER)
       for (int f = 0; f < m->n_feet; ++f)
@@ -1014,7 +1103,7 @@ static int obs_dim(const Oracle *o) {
   if (o->task_id == MOCCA_TASK_CASSIE) /* env_cassie.py:76-79,344-346; the phase envs: 40 + 2 (:574,633) */
     return o->m.cassie_mode == MOCCA_CASSIE_PLAIN ? 6 + 2 * o->m.n_ordered + 2 : 12 + 2 * o->m.n_ordered + 2;
   int base = 6 + 2 * o->m.n_joints + o->m.n_feet;
-  return o->task_id == MOCCA_TASK_WALKER3D_CUSTOM ? base + 2 : base + 5 * (o->m.lookbehind + 2);
+  return (o->task_id == MOCCA_TASK_WALKER3D_CUSTOM || o->task_id == MOCCA_TASK_WALKER3D_PLANNER) ? base + 2 : base + 5 * (o->m.lookbehind + 2);
 }
 
 /* ---------------- Cassie task layer, env_cassie.py:238-276,348-479; mocap / phase variants :481-660 ---------------- */
@@ -1233,6 +1322,8 @@ static void reset_env(Oracle *o, int env, float *obs) {
     tk->walk_target[0] = tk->dist * cos(tk->angle);
     tk->walk_target[1] = tk->dist * sin(tk->angle);
     tk->walk_target[2] = 1;
+  } else if (o->task_id == MOCCA_TASK_WALKER3D_PLANNER) {
+    /* the target is drawn AFTER robot.reset (env_locomotion.py:1052-1062): below */
   } else {
     tk->applied_gain = DEC(m->gain_cur[0]) + (DEC(m->gain_cur[1]) - DEC(m->gain_cur[0])) * tk->curriculum / 9; /* applied_gain_curriculum[curriculum], :369,489 */
   }
@@ -1268,7 +1359,16 @@ static void reset_env(Oracle *o, int env, float *obs) {
   int jal; float spd[MB];
   calc_robot_state(o, s, tk, obs, &jal, spd);
   int nb = 6 + 2 * nj + m->n_feet;
-  if (o->task_id == MOCCA_TASK_WALKER3D_CUSTOM) {
+  if (o->task_id == MOCCA_TASK_WALKER3D_PLANNER) { /* Walker3DPlannerEnv.reset, :1060-1073 */
+    real ux = draw_uniform(o, env, tk), uy = draw_uniform(o, env, tk), R = m->target_range;
+    tk->walk_target[0] = -R + 2 * R * ux;
+    tk->walk_target[1] = -R + 2 * R * uy;
+    tk->walk_target[2] = (real)(float)hf_height_at(o, tk->walk_target[0], tk->walk_target[1]);
+    for (int k = 0; k < 3; ++k) tk->walk_target[k] = (real)(float)tk->walk_target[k]; /* np.array(..., dtype=np.float32), :1062 */
+    real dist, ang;
+    calc_potential(o, s, tk, &dist, &ang);
+    softsign_tail(dist, ang, obs + nb);
+  } else if (o->task_id == MOCCA_TASK_WALKER3D_CUSTOM) {
     real dist, ang;
     calc_potential(o, s, tk, &dist, &ang);
     softsign_tail(dist, ang, obs + nb);
@@ -1317,7 +1417,22 @@ static void step_env(Oracle *o, int env, const float *act, float *obs, float *re
   kinematics(m, s, w);
   int jal; float spd[MB];
   real dist, ang, progress, posture = 0, energy, joints, tall, target_bonus = 0, step_bonus = 0;
-  if (o->task_id == MOCCA_TASK_WALKER3D_CUSTOM) {
+  if (o->task_id == MOCCA_TASK_WALKER3D_PLANNER) {
+    /* Walker3DPlannerEnv.step, env_locomotion.py:1075-1128.  calc_state() is called without contact ids: feet_contact keeps the
+     * zeros of robot.reset.  The reward's second term, log(max(1, base_value)) / 3, is the external base controller's value estimate:
+     * the caller adds it (mocca_envs_amd/envs.py); here reward = progress. */
+    for (int k = 0; k < m->n_feet; ++k) tk->feet_contact[k] = 0;
+    calc_robot_state(o, s, tk, obs, &jal, spd);
+    real old = tk->linear_potential;
+    calc_potential(o, s, tk, &dist, &ang);
+    progress = tk->linear_potential - old;
+    /* done = done or relative torso height < termination_height or z < -5 or the torso link touches anything (:1103-1111);
+     * NaN comparisons are False, as in the reference */
+    if (obs[0] < m->termination_height || s->pos[2] < (real)m->fall_z || body_touch) tk->done = 1;
+    *rew = (float)progress;
+    softsign_tail(dist, ang, obs + nb);
+    *info = 0;
+  } else if (o->task_id == MOCCA_TASK_WALKER3D_CUSTOM) {
     if (o->eval_mode) { tk->walk_target[0] = tk->prev_body_x + 4; tk->walk_target[1] = 0; tk->walk_target[2] = 1; } /* :115-116 */
     for (int k = 0; k < m->n_feet; ++k) tk->feet_contact[k] = touch[k]; /* robots.py:74-86 */
     calc_robot_state(o, s, tk, obs, &jal, spd);
@@ -1469,7 +1584,7 @@ API void *orc_create(const void *blob, int nbytes, int task_id, int n_envs) {
 API void orc_destroy(void *h) {
   Oracle *o = (Oracle *)h;
   if (!o) return;
-  free(o->dyn); free(o->task); free(o->ter); free(o->dbg); free(o->traj); free(o);
+  free(o->dyn); free(o->task); free(o->ter); free(o->dbg); free(o->traj); free(o->hf); free(o);
 }
 /* the reference motion of the Cassie mocap / phase envs (mocca_set_trajectory of include/mocca.h): copied */
 API int orc_set_trajectory(void *h, const float *table, int n_frames, double max_time, double control_step) {
@@ -1481,6 +1596,25 @@ API int orc_set_trajectory(void *h, const float *table, int n_frames, double max
   o->traj_n = n_frames; o->traj_tmax = max_time; o->traj_cstep = control_step;
   return 0;
 }
+/* the planner envs' terrain (mocca_set_heightfield of include/mocca.h): copied */
+API int orc_set_heightfield(void *h, const float *data, int rows, int cols, double scale) {
+  Oracle *o = (Oracle *)h;
+  if (!o || !data || rows < 2 || cols < 2 || !(scale > 0)) return -1;
+  free(o->hf);
+  o->hf = (float *)malloc((size_t)rows * cols * sizeof(float));
+  memcpy(o->hf, data, (size_t)rows * cols * sizeof(float));
+  o->hf_rows = rows; o->hf_cols = cols; o->hf_scale = scale;
+  return 0;
+}
+/* probe for the tests: gap and normal of a sphere (world centre, radius) against the attached height field; get_height_at */
+API double orc_heightfield_probe(void *h, const double *c, double rad, double *n_out) {
+  Oracle *o = (Oracle *)h;
+  real C[3] = {(real)c[0], (real)c[1], (real)c[2]}, n[3];
+  real g = sphere_heightfield(o, C, (real)rad, n);
+  for (int k = 0; k < 3; ++k) n_out[k] = n[k];
+  return g;
+}
+API double orc_height_at(void *h, double x, double y) { return hf_height_at((Oracle *)h, (real)x, (real)y); }
 API int orc_obs_dim(void *h) { return obs_dim((Oracle *)h); }
 API int orc_act_dim(void *h) { Oracle *o = (Oracle *)h; return o->task_id == MOCCA_TASK_CASSIE ? o->m.n_ctrl - 2 : o->m.n_joints; }
 API int orc_state_dim(void *h) { Oracle *o = (Oracle *)h; return MOCCA_STATE_DIM(o->m.n_joints, o->m.n_slots); }

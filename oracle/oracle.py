@@ -64,6 +64,12 @@ def _load(precision: str) -> C.CDLL:
     lib.orc_last_lambda.restype = C.c_int
     lib.orc_set_trajectory.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
     lib.orc_set_trajectory.restype = C.c_int
+    lib.orc_set_heightfield.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double]
+    lib.orc_set_heightfield.restype = C.c_int
+    lib.orc_heightfield_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+    lib.orc_heightfield_probe.restype = C.c_double
+    lib.orc_height_at.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    lib.orc_height_at.restype = C.c_double
     return lib
 
 
@@ -111,6 +117,21 @@ class Oracle:
         assert t.ndim == 2 and t.shape[1] == 32
         if self.lib.orc_set_trajectory(self.h, _p(t), t.shape[0], float(max_time), float(control_step)) != 0:
             raise ValueError("orc_set_trajectory rejected the table")
+
+    def set_heightfield(self, data: np.ndarray, scale: float):
+        """The planner envs' terrain: data[rows][cols] heights (x along the columns), `scale` grid points per metre (copied)."""
+        d = np.ascontiguousarray(data, np.float32)
+        assert d.ndim == 2
+        if self.lib.orc_set_heightfield(self.h, _p(d), d.shape[0], d.shape[1], float(scale)) != 0:
+            raise ValueError("orc_set_heightfield rejected the grid")
+
+    def heightfield_probe(self, centre, radius: float):
+        """(gap, normal) of a sphere against the attached height field."""
+        c, n = np.ascontiguousarray(centre, np.float64), np.zeros(3)
+        return self.lib.orc_heightfield_probe(self.h, _p(c), float(radius), _p(n)), n
+
+    def height_at(self, x: float, y: float) -> float:
+        return self.lib.orc_height_at(self.h, float(x), float(y))
 
     def reset(self, seed: int = 0, mask: Optional[np.ndarray] = None) -> np.ndarray:
         obs = np.zeros((self.n_envs, self.obs_dim), np.float32)

@@ -259,9 +259,56 @@ def _euler_mat(roll, pitch, yaw):
     return _rot_axis([0, 0, 1], yaw) @ _rot_axis([0, 1, 0], pitch) @ _rot_axis([1, 0, 0], roll)
 
 
-def detect_contacts(mdl: Model, st: State, planks=None):
-    """planks: None (flat ground z = 0) or list of (box centre, rotation, is_target) for the live planks.
-    Returns contacts in the oracle's priority order: terrain slots, then self pairs; capped at max_contacts."""
+def _closest_on_triangle(p, a, b, c):
+    """Closest point of triangle abc to p, NOT by Voronoi regions (the oracle's way): the unconstrained minimiser of
+    |a + s (b - a) + t (c - a) - p|^2 if it lies inside, else the best of the three edges by clamped projection."""
+    e1, e2, d = b - a, c - a, p - a
+    G = np.array([[e1 @ e1, e1 @ e2], [e1 @ e2, e2 @ e2]])
+    s, t = np.linalg.solve(G, [e1 @ d, e2 @ d])
+    if s >= 0 and t >= 0 and s + t <= 1:
+        return a + s * e1 + t * e2
+    best, bd = None, 1e300
+    for u, v in ((a, b), (b, c), (c, a)):
+        w = v - u
+        k = min(1.0, max(0.0, (p - u) @ w / (w @ w)))
+        q = u + k * w
+        if (p - q) @ (p - q) < bd:
+            best, bd = q, (p - q) @ (p - q)
+    return best
+
+
+def heightfield_gap(data, scale, C, radius, window=1):
+    """Signed gap and normal of a sphere against a height field (tests only; conventions in include/mocca.h mocca_set_heightfield):
+    explicit vertex coordinate arrays, every triangle of the cells within `window` cells of the nearest grid point."""
+    rows, cols = data.shape
+    X = (np.arange(cols) - (cols - 1) / 2) / scale
+    Y = (np.arange(rows) - (rows - 1) / 2) / scale
+    if C[0] < X[0] - 1 / scale or C[0] > X[-1] + 1 / scale or C[1] < Y[0] - 1 / scale or C[1] > Y[-1] + 1 / scale:
+        return 1e30, np.array([0.0, 0.0, 1.0])
+    iv, jv = int(np.floor((C[0] - X[0]) * scale + 0.5)), int(np.floor((C[1] - Y[0]) * scale + 0.5))
+    gap, n = 1e30, np.array([0.0, 0.0, 1.0])
+    for j in range(jv - window, jv + window):
+        for i in range(iv - window, iv + window):
+            if i < 0 or j < 0 or i > cols - 2 or j > rows - 2:
+                continue
+            V = lambda ii, jj: np.array([X[ii], Y[jj], data[jj, ii]])
+            for tri in ((V(i, j), V(i + 1, j), V(i, j + 1)), (V(i + 1, j), V(i + 1, j + 1), V(i, j + 1))):
+                q = _closest_on_triangle(C, *tri)
+                tn = np.cross(tri[1] - tri[0], tri[2] - tri[0]); tn /= np.linalg.norm(tn)
+                d = C - q
+                dist = np.linalg.norm(d)
+                if (C - tri[0]) @ tn >= 0 and dist > 1e-9:
+                    nn = d / dist
+                else:
+                    dist, nn = -dist, tn
+                if dist - radius < gap:
+                    gap, n = dist - radius, nn
+    return gap, n
+
+
+def detect_contacts(mdl: Model, st: State, planks=None, heightfield=None):
+    """planks: None (flat ground z = 0) or list of (box centre, rotation, is_target) for the live planks; heightfield: (data, scale) of
+    the planner envs.  Returns contacts in the oracle's priority order: terrain slots, then self pairs; capped at max_contacts."""
     R, o = fk(mdl, st.pos, _quat_mat(st.quat), st.q)
     out, slot_mask, n_self = [], 0, 0
     for g in mdl.geoms:
@@ -269,7 +316,11 @@ def detect_contacts(mdl: Model, st: State, planks=None):
             continue
         for e in range(2 if g["capsule"] else 1):
             C = o[g["body"]] + R[g["body"]] @ g["p"][e]
-            if planks is None:
+            if heightfield is not None:
+                gap, n = heightfield_gap(heightfield[0], heightfield[1], C, g["radius"])
+                kk, cc, dt = mdl.plank_stiffness, mdl.plank_damping, mdl.dt
+                mu, erp, cfm = mdl.plank_friction * g["friction"], dt * kk / (dt * kk + cc), 1 / (dt * kk + cc) / dt
+            elif planks is None:
                 gap, n = C[2] - g["radius"], np.array([0.0, 0.0, 1.0])
                 mu, erp, cfm = mdl.ground_friction * g["friction"], mdl.erp, 0.0
             else:
@@ -311,10 +362,10 @@ def detect_contacts(mdl: Model, st: State, planks=None):
     return out, R, o, slot_mask, n_self
 
 
-def substep(mdl: Model, st: State, tau, planks=None):
+def substep(mdl: Model, st: State, tau, planks=None, heightfield=None):
     """One physics substep.  Returns (new State, info dict with rows / impulses / contacts)."""
     dt = mdl.dt
-    contacts, R, o, slot_mask, n_self = detect_contacts(mdl, st, planks)
+    contacts, R, o, slot_mask, n_self = detect_contacts(mdl, st, planks, heightfield)
     nus, M = unconstrained_velocity(mdl, st, tau)
     # material points the rows act on
     pts = []

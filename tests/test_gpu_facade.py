@@ -237,3 +237,45 @@ def test_cassie2d_id_and_robot_params():
     w.set_robot_params({"applied_gain": 0.5})                                  # env_base.py:108-115, used by the next apply_action
     assert abs(task_to_float64(w._vec.get_task())[0][21] - 0.5) < 1e-7
     w.close()
+
+
+def test_planner_env_with_an_injected_base_controller():
+    """Walker3DPlannerEnv / MikePlannerEnv (env_locomotion.py:982-1133): 15-number plans in, the base controller -- injected, the
+    reference unpickles a policy class that is not in its tree -- turns [robot_state, plan * 2] into the 21 joint actions and a value."""
+    import mocca_envs_amd
+    from mocca_envs_amd import host_logic as H
+    seen = {}
+
+    def controller(o):
+        seen["obs"] = np.array(o)
+        return np.float32(7.5), 0.1 * np.tanh(o[:21])
+
+    for env_id, z0 in (("Walker3DPlannerEnv-v0", 1.32), ("MikePlannerEnv-v0", 1.05)):
+        env = mocca_envs_amd.make(env_id, base_controller=controller)
+        base = env.unwrapped
+        assert base.observation_space.shape == (52,) and base.action_space.shape == (15,)
+        base.seed(3)
+        obs = env.reset()
+        assert obs.shape == (52,) and abs(base.robot.body_xyz[2] - z0) < 1e-5 and abs(base.robot.body_xyz[0] + 15.5) < 1e-5
+        # the target lies on the height field: z = get_height_at(x, y) (float32, :1062)
+        assert abs(base.walk_target[2] - np.float32(base.terrain.get_height_at(base.walk_target[0], base.walk_target[1]))) < 1e-6
+        assert obs[48] == 0 and obs[49] == 0
+        plan = np.linspace(-1, 1, 15)
+        tot = 0.0
+        for t in range(30):
+            prev = obs
+            obs, rew, done, info = env.step(plan)
+            np.testing.assert_allclose(seen["obs"][:50], prev[:50], atol=1e-6)         # base_obs = [robot_state, plan * action_scale]
+            np.testing.assert_allclose(seen["obs"][50:], 2 * plan, atol=1e-6)
+            assert abs(rew - (base.progress + np.log(7.5) / 3)) < 1e-6                # reward = progress + log(max(1, value)) / 3
+            assert obs[48] == 0 and obs[49] == 0                                       # calc_state() without contact ids: feet_contact stays 0
+            tot += rew
+            if done:
+                break
+        assert np.isfinite(tot) and obs[0] > 0.4          # standing on the start platform (relative torso height)
+        env.close()
+    env = mocca_envs_amd.make("Walker3DPlannerEnv-v0")
+    env.reset()
+    with pytest.raises(RuntimeError):
+        env.step(np.zeros(15))
+    env.close()

@@ -378,3 +378,35 @@ def test_random_reward_episode_on_the_gpu(sg):
         rews[(mode, w)] = float(r[0])
     assert abs(rews[(2, 1.0)] - rews[(0, 1.0)]) < 1e-4 and abs(rews[(2, 2.0)] - 2 * rews[(0, 1.0)]) < 2e-4, rews
     env.close()
+
+
+@pytest.mark.parametrize("tag,env_id", [("planner", "Walker3DPlannerEnv-v0"), ("mikeplanner", "MikePlannerEnv-v0")])
+def test_planner_env_episodes_on_the_gpu(tag, env_id):
+    """Walker3DPlannerEnv / MikePlannerEnv (env_locomotion.py:982-1133) through the HIP task layer: reset (robot.reset draws, then the
+    target on the height field), progress reward, feet_contact pinned to 0, and the three ways an episode ends -- relative torso height
+    below 0.5, z < -5, the torso link touching something.  The controller's value term of the reward is the caller's (envs.py)."""
+    import torch
+    from mocca_envs_amd.vec_env import task_to_float64
+    pg = np.load(os.path.join(os.path.dirname(__file__), "golden", "planner_reference.npz"), allow_pickle=False)
+    ends = 0
+    for ep in range(int(pg[f"{tag}_n_episodes"])):
+        g = lambda k: pg[f"{tag}_ep{ep}_{k}"]
+        env = _env(env_id, g("tape"))
+        obs0 = env.reset().cpu().numpy()
+        st, tk = env.get_state().cpu().numpy(), task_to_float64(env.get_task())
+        np.testing.assert_allclose(st[0, 13:34], g("reset_q"), atol=TOL)
+        np.testing.assert_allclose(st[0, 0:3], g("reset_base_pos"), atol=TOL)
+        assert int(tk[0, 11]) == int(g("reset_mirrored"))
+        np.testing.assert_allclose(tk[0, 0:3], g("reset_walk_target"), atol=TOL)          # z = get_height_at on the device copy of the grid
+        np.testing.assert_allclose(obs0[0, 1:], g("reset_obs")[1:], atol=OBS_TOL)
+        for t in range(len(g("states"))):
+            _set_state(env, g("states")[t])
+            a = torch.from_numpy(np.tile(g("base_actions")[t][None].astype(np.float32), (REPL, 1)))
+            o, r, d, _ = env.task_step(a, np.ones((REPL, 2), np.int32), None, np.full(REPL, int(g("torso_touch")[t]), np.int32))
+            _same_in_every_replica(o, r, d)
+            np.testing.assert_allclose(o.cpu().numpy()[0], g("obs")[t], atol=OBS_TOL, err_msg=f"ep{ep} t{t} obs")
+            np.testing.assert_allclose(float(r[0]), g("progress")[t], atol=REW_TOL, err_msg=f"ep{ep} t{t} progress")
+            assert bool(int(d[0]) & 1) == bool(g("done")[t]), (ep, t)
+            ends += int(d[0]) & 1
+        env.close()
+    assert ends >= 3

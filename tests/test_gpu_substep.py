@@ -37,7 +37,10 @@ CASES = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("Walker3DStepper
          # the compiled model keeps massless -- mocca_create selects the TopoWalker3DMassive kernel instance for it
          ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_dump": "plain"}),
          ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_dump": "massive"}),
-         ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_dump": "massive"})]
+         ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_dump": "massive"}),
+         # the planner envs (env_locomotion.py:982-1133): spheres / capsule ends against the triangles of the height field; the envs are
+         # scattered over the field after reset (the episodes start on its flat corner platform)
+         ("Walker3DPlannerEnv-v0", M.TASK_WALKER3D_PLANNER, {}), ("MikePlannerEnv-v0", M.TASK_WALKER3D_PLANNER, {})]
 
 
 def _one_substep_blob(env_id, **kw):
@@ -85,8 +88,22 @@ def test_single_substep_parity_with_matching_active_sets(env_id, task, kw):
         env.set_param(pid, val); orc.set_param(pid, val); o64.set_param(pid, val)
     if task == M.TASK_WALKER3D_STEPPER:
         env.set_param(2, 9); orc.set_param(PARAM_CURRICULUM, 9); o64.set_param(PARAM_CURRICULUM, 9)
+    if task == M.TASK_WALKER3D_PLANNER:
+        orc.set_heightfield(*env.height_field); o64.set_heightfield(*env.height_field)
     env.reset(); orc.reset(seed=4); o64.reset(seed=4)
     rng = np.random.default_rng(2)
+
+    def scatter(mask=None):   # planner envs: move (the selected) robots from the flat start platform to random spots of the field
+        st = orc.get_state()
+        for e in range(n):
+            if mask is None or mask[e]:
+                xy = rng.uniform(-14, 14, 2)
+                st[e, 0:2] = xy
+                st[e, 2] = orc.height_at(*xy) + m.init_pos[2] + 0.02
+        orc.set_state(st)
+
+    if task == M.TASK_WALKER3D_PLANNER:
+        scatter()
     nd = 13 + 2 * m.n_joints
     n_same = n_diff = n_clamp_diff = 0
     e_gpu, e_f32, e_flip, rows_seen = [], [], [], []
@@ -123,6 +140,8 @@ def test_single_substep_parity_with_matching_active_sets(env_id, task, kw):
             fallen = (dc != 0).astype(np.uint8)
             if fallen.any():
                 orc.reset(seed=4, mask=fallen)
+                if task == M.TASK_WALKER3D_PLANNER:
+                    scatter(fallen)
     e_gpu, e_f32 = np.concatenate(e_gpu), np.concatenate(e_f32)
     rows = np.concatenate(rows_seen)
     total = max(1, n_same + n_diff + n_clamp_diff)

@@ -30,7 +30,7 @@ def _random_state(rng, m, z, spread=0.6, vel=1.0):
     return st
 
 
-def _compare(orc, m, mdl, row, tau, planks=None, tol=2e-8):
+def _compare(orc, m, mdl, row, tau, planks=None, tol=2e-8, heightfield=None):
     nj = m.n_joints
     full = row[None].copy()
     orc.set_state(full)
@@ -40,7 +40,7 @@ def _compare(orc, m, mdl, row, tau, planks=None, tol=2e-8):
     got = orc.get_state()[0]
     lam_o, kind_o = orc.last_lambda()
     st = D.State.from_row(mdl, row)
-    new, info = D.substep(mdl, st, np.concatenate([[0.0], tau]), planks)
+    new, info = D.substep(mdl, st, np.concatenate([[0.0], tau]), planks, heightfield)
     # unconstrained velocity: spatial -> classical acceleration of the base origin, as the oracle's substep does
     wxv = np.cross(row[10:13], row[7:10])
     nus_o = np.concatenate([row[10:13] + mdl.dt * a[0:3], row[7:10] + mdl.dt * (a[3:6] + wxv), row[13 + nj:13 + 2 * nj] + mdl.dt * a[6:]])
@@ -109,6 +109,42 @@ def test_substep_on_the_stepper_planks():
         info = _compare(orc, m, mdl, row, rng.uniform(-40, 40, 21), planks)
         rows.append(info["rows"])
     print("\nstepper rows per substep", rows)
+    assert max(rows) >= 12
+
+
+def test_substep_on_the_height_field():
+    """Planner envs (bullet_objects.py:338-441): spheres / capsule ends against the triangles of the height field, soft contact.  The
+    dense reference finds the closest triangle its own way (unconstrained minimiser + clamped edges, explicit vertex arrays)."""
+    from mocca_envs_amd.terrain import load_height_field
+    m = M.compile_walker3d(M.TASK_WALKER3D_PLANNER)
+    mdl = D.Model(m)
+    data, scale = load_height_field()
+    orc = Oracle(m.to_bytes(), M.TASK_WALKER3D_PLANNER, 1, "f64")
+    orc.set_heightfield(data, scale)
+    orc.reset(seed=3)
+    rng = np.random.default_rng(9)
+    # the probe alone, all over the field (ridges, valleys, the flat start platform, the rim and beyond): gap and normal
+    worst = 0.0
+    for k in range(600):
+        xy = rng.uniform(-16.5, 16.5, 2)
+        h = data[min(127, max(0, int((xy[1] + 16) * 4))), min(127, max(0, int((xy[0] + 16) * 4)))]
+        C = np.array([xy[0], xy[1], h + rng.uniform(-0.05, 0.2)])
+        rad = rng.choice([0.045, 0.055, 0.08, 0.1])
+        g_o, n_o = orc.heightfield_probe(C, rad)
+        g_d, n_d = D.heightfield_gap(data.astype(np.float64), scale, C, rad)
+        assert abs(g_o - g_d) < 1e-9 or (g_o > 1e29 and g_d > 1e29), (k, C, g_o, g_d)
+        if g_o < 0.02:
+            np.testing.assert_allclose(n_o, n_d, atol=1e-7)
+            worst = max(worst, 1 - n_o[2])
+    assert worst > 0.05                                               # slopes were really met
+    rows = []
+    for k in range(8):
+        row = _random_state(rng, m, 0.0, spread=0.5)
+        xy = rng.uniform(-14, 14, 2)
+        row[0:3] = [xy[0], xy[1], orc.height_at(*xy) + 0.3 + 0.3 * rng.random()]
+        info = _compare(orc, m, mdl, row, rng.uniform(-40, 40, 21), heightfield=(data.astype(np.float64), scale))
+        rows.append(info["rows"])
+    print("\nheight-field rows per substep", rows)
     assert max(rows) >= 12
 
 
