@@ -882,8 +882,9 @@ DI void closest_on_triangle(const float* p, const float* a, const float* b, cons
 #pragma unroll
   for (int k = 0; k < 3; ++k) q[k] = a[k] + ab[k] * v + ac[k] * w;
 }
-// signed gap and world normal of a sphere (world centre C) against the height field: the closest of the eight triangles of the 2 x 2 cells
-// around the grid point nearest to the centre; 1e30 where there is no terrain
+// signed gap and world normal of a sphere (world centre C) against the height field (see the oracle's sphere_heightfield): above the surface
+// the closest of the eight triangles of the 2 x 2 cells around the grid point nearest to the centre; below it the plane of the triangle the
+// centre is under; 1e30 where there is no terrain
 DI float sphere_heightfield(const float* __restrict__ hf, int rows, int cols, float sc, const float* C, float rad, float reach, float* n) {
   float gap = 1e30f;
   n[0] = 0; n[1] = 0; n[2] = 1;
@@ -891,6 +892,7 @@ DI float sphere_heightfield(const float* __restrict__ hf, int rows, int cols, fl
   const float fx = C[0] * sc + hx, fy = C[1] * sc + hy;
   if (!(fx >= -1.0f && fx <= (float)cols && fy >= -1.0f && fy <= (float)rows)) return gap;
   const int iv = (int)floorf(fx + 0.5f), jv = (int)floorf(fy + 0.5f);
+  const int ic = (int)floorf(fx), jc = (int)floorf(fy);   // the cell the centre is over
   // the nine grid points around it (clamped reads; cells outside the grid are skipped below)
   float hv[3][3];
   float hmax = -1e30f;
@@ -905,6 +907,7 @@ DI float sphere_heightfield(const float* __restrict__ hf, int rows, int cols, fl
       hmax = fmaxf(hmax, hv[dj][di]);
     }
   if (C[2] - reach > hmax) return gap;   // above everything nearby: no contact possible (exact: every triangle lies below hmax)
+  bool below = false;
 #pragma unroll
   for (int dj = 0; dj < 2; ++dj)
 #pragma unroll
@@ -914,23 +917,31 @@ DI float sphere_heightfield(const float* __restrict__ hf, int rows, int cols, fl
       const float x0 = ((float)i - hx) * cell, y0 = ((float)j - hy) * cell;
       const float v00[3] = {x0, y0, hv[dj][di]}, v10[3] = {x0 + cell, y0, hv[dj][di + 1]};
       const float v01[3] = {x0, y0 + cell, hv[dj + 1][di]}, v11[3] = {x0 + cell, y0 + cell, hv[dj + 1][di + 1]};
+      const float u = fx - (float)i, v = fy - (float)j;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const float* a = t == 0 ? v00 : v10;
         const float* b = t == 0 ? v10 : v11;
         const float* c = v01;
         float q[3], e1[3], e2[3], tn[3], d[3];
-        closest_on_triangle(C, a, b, c, q);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { e1[k] = b[k] - a[k]; e2[k] = c[k] - a[k]; d[k] = C[k] - q[k]; }
+        for (int k = 0; k < 3; ++k) { e1[k] = b[k] - a[k]; e2[k] = c[k] - a[k]; }
         cross3(e1, e2, tn);
         const float il = rsq(dot3(tn, tn));
-        const float side = ((C[0] - a[0]) * tn[0] + (C[1] - a[1]) * tn[1] + (C[2] - a[2]) * tn[2]) * il;
-        const float d2 = dot3(d, d), id = rsq(d2);
-        float dist = d2 * id, nn[3];
-        if (side >= 0 && d2 > 1e-18f) { nn[0] = d[0] * id; nn[1] = d[1] * id; nn[2] = d[2] * id; }
-        else { dist = d2 > 0 ? -dist : 0.0f; nn[0] = tn[0] * il; nn[1] = tn[1] * il; nn[2] = tn[2] * il; }
-        if (dist - rad < gap) { gap = dist - rad; n[0] = nn[0]; n[1] = nn[1]; n[2] = nn[2]; }
+        if (!below && i == ic && j == jc && (t == 0) == (u + v <= 1.0f)) {   // the triangle under the centre
+          const float side = ((C[0] - a[0]) * tn[0] + (C[1] - a[1]) * tn[1] + (C[2] - a[2]) * tn[2]) * il;
+          if (side < 0) { below = true; gap = side - rad; n[0] = tn[0] * il; n[1] = tn[1] * il; n[2] = tn[2] * il; }
+        }
+        if (below) continue;
+        closest_on_triangle(C, a, b, c, q);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[k] = C[k] - q[k];
+        const float d2 = dot3(d, d), id = rsq(d2), dist = d2 > 0 ? d2 * id : 0.0f;
+        if (dist - rad < gap) {
+          gap = dist - rad;
+          if (d2 > 1e-18f) { n[0] = d[0] * id; n[1] = d[1] * id; n[2] = d[2] * id; }
+          else { n[0] = tn[0] * il; n[1] = tn[1] * il; n[2] = tn[2] * il; }
+        }
       }
     }
   return gap;

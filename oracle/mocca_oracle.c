@@ -553,9 +553,11 @@ static void closest_on_triangle(const real *p, const real *a, const real *b, con
   real den = 1 / (va + vb + vc), v = vb * den, w = vc * den;
   for (int k = 0; k < 3; ++k) q[k] = a[k] + ab[k] * v + ac[k] * w;
 }
-/* signed gap and world normal of a sphere against the height field: the closest of the (up to) eight triangles of the 2 x 2 cells around
- * the grid point nearest to the centre (exact while radius + margin <= half a cell).  A centre below a triangle's plane is inside the
- * ground: the distance counts negative and the normal is the triangle's.  Returns 1e30 where there is no terrain. */
+/* signed gap and world normal of a sphere against the height field.  Centre ABOVE the surface (z >= the piecewise-linear height under it,
+ * or no surface under it): distance to the closest of the (up to) eight triangles of the 2 x 2 cells around the grid point nearest to the
+ * centre (exact while radius + margin <= half a cell), normal from the closest point to the centre.  Centre BELOW the surface (a sphere
+ * pushed more than its radius into the ground): signed distance to the plane of the triangle it is under, that triangle's normal.
+ * Returns 1e30 where there is no terrain. */
 static real sphere_heightfield(const Oracle *o, const real *C, real rad, real *n) {
   const int cols = o->hf_cols, rows = o->hf_rows;
   const real sc = (real)o->hf_scale, cell = 1 / sc;
@@ -565,6 +567,7 @@ static real sphere_heightfield(const Oracle *o, const real *C, real rad, real *n
   real fx = C[0] * sc + (real)0.5 * (cols - 1), fy = C[1] * sc + (real)0.5 * (rows - 1);
   if (!(fx >= -1 && fx <= cols && fy >= -1 && fy <= rows)) return gap;
   int iv = (int)floor(fx + (real)0.5), jv = (int)floor(fy + (real)0.5);
+  int ic = (int)floor(fx), jc = (int)floor(fy); /* the cell the centre is over */
   for (int dj = -1; dj <= 0; ++dj)
     for (int di = -1; di <= 0; ++di) {
       int i = iv + di, j = jv + dj;
@@ -572,19 +575,26 @@ static real sphere_heightfield(const Oracle *o, const real *C, real rad, real *n
       real x0 = (i - (real)0.5 * (cols - 1)) * cell, y0 = (j - (real)0.5 * (rows - 1)) * cell;
       real v00[3] = {x0, y0, o->hf[j * cols + i]}, v10[3] = {x0 + cell, y0, o->hf[j * cols + i + 1]};
       real v01[3] = {x0, y0 + cell, o->hf[(j + 1) * cols + i]}, v11[3] = {x0 + cell, y0 + cell, o->hf[(j + 1) * cols + i + 1]};
+      real u = fx - i, v = fy - j;
       for (int t = 0; t < 2; ++t) {
         const real *a = t == 0 ? v00 : v10, *b = t == 0 ? v10 : v11, *c = v01;
         real q[3], e1[3], e2[3], tn[3], d[3];
-        closest_on_triangle(C, a, b, c, q);
-        for (int k = 0; k < 3; ++k) { e1[k] = b[k] - a[k]; e2[k] = c[k] - a[k]; d[k] = C[k] - q[k]; }
+        for (int k = 0; k < 3; ++k) { e1[k] = b[k] - a[k]; e2[k] = c[k] - a[k]; }
         cross3(e1, e2, tn); /* counter-clockwise seen from above: points up */
         real il = 1 / sqrt(dot3(tn, tn));
         for (int k = 0; k < 3; ++k) tn[k] *= il;
-        real side = (C[0] - a[0]) * tn[0] + (C[1] - a[1]) * tn[1] + (C[2] - a[2]) * tn[2];
-        real d2 = dot3(d, d), dist = sqrt(d2), nn[3];
-        if (side >= 0 && d2 > (real)1e-18) { for (int k = 0; k < 3; ++k) nn[k] = d[k] / dist; }
-        else { dist = -dist; for (int k = 0; k < 3; ++k) nn[k] = tn[k]; }
-        if (dist - rad < gap) { gap = dist - rad; n[0] = nn[0]; n[1] = nn[1]; n[2] = nn[2]; }
+        if (i == ic && j == jc && (t == 0) == (u + v <= 1)) { /* the triangle under the centre */
+          real side = (C[0] - a[0]) * tn[0] + (C[1] - a[1]) * tn[1] + (C[2] - a[2]) * tn[2];
+          if (side < 0) { n[0] = tn[0]; n[1] = tn[1]; n[2] = tn[2]; return side - rad; }
+        }
+        closest_on_triangle(C, a, b, c, q);
+        for (int k = 0; k < 3; ++k) d[k] = C[k] - q[k];
+        real d2 = dot3(d, d), dist = sqrt(d2);
+        if (dist - rad < gap) {
+          gap = dist - rad;
+          if (d2 > (real)1e-18) { n[0] = d[0] / dist; n[1] = d[1] / dist; n[2] = d[2] / dist; }
+          else { n[0] = tn[0]; n[1] = tn[1]; n[2] = tn[2]; }
+        }
       }
     }
   return gap;

@@ -277,14 +277,34 @@ def _closest_on_triangle(p, a, b, c):
     return best
 
 
+def heightfield_surface(data, scale, x, y):
+    """(height of the piecewise-linear surface under (x, y), unit normal of the triangle there) or None outside the grid."""
+    rows, cols = data.shape
+    X = (np.arange(cols) - (cols - 1) / 2) / scale
+    Y = (np.arange(rows) - (rows - 1) / 2) / scale
+    i, j = int(np.searchsorted(X, x, side="right")) - 1, int(np.searchsorted(Y, y, side="right")) - 1
+    if i < 0 or j < 0 or i > cols - 2 or j > rows - 2:
+        return None
+    u, v = (x - X[i]) * scale, (y - Y[j]) * scale
+    P = lambda ii, jj: np.array([X[ii], Y[jj], data[jj, ii]])
+    tri = (P(i, j), P(i + 1, j), P(i, j + 1)) if u + v <= 1 else (P(i + 1, j), P(i + 1, j + 1), P(i, j + 1))
+    tn = np.cross(tri[1] - tri[0], tri[2] - tri[0]); tn /= np.linalg.norm(tn)
+    h = tri[0][2] - (tn[0] * (x - tri[0][0]) + tn[1] * (y - tri[0][1])) / tn[2]
+    return h, tn
+
+
 def heightfield_gap(data, scale, C, radius, window=1):
     """Signed gap and normal of a sphere against a height field (tests only; conventions in include/mocca.h mocca_set_heightfield):
-    explicit vertex coordinate arrays, every triangle of the cells within `window` cells of the nearest grid point."""
+    explicit vertex coordinate arrays; centre below the surface: distance to the plane of the triangle above it; otherwise every triangle
+    of the cells within `window` cells of the nearest grid point."""
     rows, cols = data.shape
     X = (np.arange(cols) - (cols - 1) / 2) / scale
     Y = (np.arange(rows) - (rows - 1) / 2) / scale
     if C[0] < X[0] - 1 / scale or C[0] > X[-1] + 1 / scale or C[1] < Y[0] - 1 / scale or C[1] > Y[-1] + 1 / scale:
         return 1e30, np.array([0.0, 0.0, 1.0])
+    under = heightfield_surface(data, scale, C[0], C[1])
+    if under is not None and C[2] < under[0]:
+        return (C[2] - under[0]) * under[1][2] - radius, under[1]       # distance to the plane = vertical distance x n_z
     iv, jv = int(np.floor((C[0] - X[0]) * scale + 0.5)), int(np.floor((C[1] - Y[0]) * scale + 0.5))
     gap, n = 1e30, np.array([0.0, 0.0, 1.0])
     for j in range(jv - window, jv + window):
@@ -294,15 +314,11 @@ def heightfield_gap(data, scale, C, radius, window=1):
             V = lambda ii, jj: np.array([X[ii], Y[jj], data[jj, ii]])
             for tri in ((V(i, j), V(i + 1, j), V(i, j + 1)), (V(i + 1, j), V(i + 1, j + 1), V(i, j + 1))):
                 q = _closest_on_triangle(C, *tri)
-                tn = np.cross(tri[1] - tri[0], tri[2] - tri[0]); tn /= np.linalg.norm(tn)
                 d = C - q
                 dist = np.linalg.norm(d)
-                if (C - tri[0]) @ tn >= 0 and dist > 1e-9:
-                    nn = d / dist
-                else:
-                    dist, nn = -dist, tn
                 if dist - radius < gap:
-                    gap, n = dist - radius, nn
+                    tn = np.cross(tri[1] - tri[0], tri[2] - tri[0])
+                    gap, n = dist - radius, (d / dist if dist > 1e-9 else tn / np.linalg.norm(tn))
     return gap, n
 
 
