@@ -344,6 +344,15 @@ DI float wave_sum(float v) {
   return (readlane(v, 0) + readlane(v, 16)) + (readlane(v, 32) + readlane(v, 48));
 }
 
+// max over the wave, result uniform (same DPP pattern as wave_sum: every step is a full permutation inside a row of 16)
+DI float wave_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  return fmaxf(fmaxf(readlane(v, 0), readlane(v, 16)), fmaxf(readlane(v, 32), readlane(v, 48)));
+}
+
 // Philox4x32-10; identical to oracle/mocca_oracle.c so device resets are reproducible on the host
 DI void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
 #pragma unroll
@@ -1093,6 +1102,39 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
       active = gap < margin;
 #pragma unroll
       for (int i = 0; i < 3; ++i) P[i] = C[i] - rad * n[i];
+    }
+  }
+  // Contact manifolds (MoccaModel.manifold_max): of the terrain slots of ONE link that are within the margin at most four survive -- the
+  // deepest, the one farthest from it, and the farthest on either side of the line through those two (signed area about the deepest
+  // point's normal) -- what a 4-point persistent manifold keeps of a convex hull lying on the ground.  Wave-uniform loop over the links
+  // that touch; only Cassie's blobs switch it on (twelve hull points per toe).
+  if (uni(M->manifold_max) > 0) {
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+      const int l0 = __builtin_ctzll(todo);
+      const int b0 = readlane_i(body, l0);
+      const bool inG = active && body == b0;
+      const unsigned long long G = __ballot(inG);
+      todo &= ~G;
+      if (__popcll(G) <= 4) continue;
+      const float dep = inG ? -gap : -1e30f;
+      const int l1 = __builtin_ctzll(__ballot(inG && dep == wave_max(dep)));
+      const float P1[3] = {readlane(P[0], l1), readlane(P[1], l1), readlane(P[2], l1)};
+      const float n1[3] = {readlane(n[0], l1), readlane(n[1], l1), readlane(n[2], l1)};
+      const float d[3] = {P[0] - P1[0], P[1] - P1[1], P[2] - P1[2]};
+      const bool c2 = inG && lane != l1;
+      const float dd = c2 ? d[0] * d[0] + d[1] * d[1] + d[2] * d[2] : -1e30f;
+      const int l2 = __builtin_ctzll(__ballot(c2 && dd == wave_max(dd)));
+      const float e[3] = {readlane(P[0], l2) - P1[0], readlane(P[1], l2) - P1[1], readlane(P[2], l2) - P1[2]};
+      float cx[3];
+      cross3(d, e, cx);
+      const float sg = n1[0] * cx[0] + n1[1] * cx[1] + n1[2] * cx[2];
+      const bool c3 = c2 && lane != l2;
+      const float sp = c3 ? sg : -1e30f, sm = c3 ? -sg : -1e30f;
+      const float mp = wave_max(sp), mm = wave_max(sm);
+      const int l3 = mp > 0.0f ? __builtin_ctzll(__ballot(c3 && sp == mp)) : -1;
+      const int l4 = mm > 0.0f ? __builtin_ctzll(__ballot(c3 && sm == mm)) : -1;
+      if (inG && lane != l1 && lane != l2 && lane != l3 && lane != l4) active = false;
     }
   }
   unsigned long long am = __ballot(active);

@@ -693,6 +693,44 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
       }
     }
   }
+  /* contact manifolds (MoccaModel.manifold_max): per link at most four of its terrain candidates survive -- the deepest (ties: lower slot),
+   * the one farthest from it, and the farthest on either side of the line through those two (signed area about the deepest point's normal) */
+  if (m->manifold_max > 0) {
+    int drop[MOCCA_MAX_SLOTS] = {0}, seen[MB] = {0};
+    for (int i0 = 0; i0 < ncand; ++i0) {
+      int b0 = cand[i0].body, cnt = 0;
+      if (seen[b0]) continue;
+      seen[b0] = 1;
+      for (int i = 0; i < ncand; ++i) cnt += cand[i].body == b0;
+      if (cnt <= 4) continue;
+      int l1 = -1, l2 = -1, l3 = -1, l4 = -1;
+      for (int i = 0; i < ncand; ++i) if (cand[i].body == b0 && (l1 < 0 || cand[i].depth > cand[l1].depth)) l1 = i;
+      real dd2 = -1e30;
+      for (int i = 0; i < ncand; ++i) {
+        if (cand[i].body != b0 || i == l1) continue;
+        real d[3] = {cand[i].P[0] - cand[l1].P[0], cand[i].P[1] - cand[l1].P[1], cand[i].P[2] - cand[l1].P[2]};
+        real dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        if (dd > dd2) { dd2 = dd; l2 = i; }
+      }
+      real e[3] = {cand[l2].P[0] - cand[l1].P[0], cand[l2].P[1] - cand[l1].P[1], cand[l2].P[2] - cand[l1].P[2]};
+      real mp = 0, mm = 0;
+      for (int i = 0; i < ncand; ++i) {
+        if (cand[i].body != b0 || i == l1 || i == l2) continue;
+        real d[3] = {cand[i].P[0] - cand[l1].P[0], cand[i].P[1] - cand[l1].P[1], cand[i].P[2] - cand[l1].P[2]}, cx[3];
+        cross3(d, e, cx);
+        real sg = cand[l1].n[0] * cx[0] + cand[l1].n[1] * cx[1] + cand[l1].n[2] * cx[2];
+        if (sg > mp) { mp = sg; l3 = i; }
+        if (-sg > mm) { mm = -sg; l4 = i; }
+      }
+      for (int i = 0; i < ncand; ++i)
+        if (cand[i].body == b0 && i != l1 && i != l2 && i != l3 && i != l4) drop[i] = 1;
+    }
+    int k = 0;
+    for (int i = 0; i < ncand; ++i)
+      if (!drop[i]) cand[k++] = cand[i];
+      else slot_mask &= ~((uint64_t)1 << cand[i].slot);
+    ncand = k;
+  }
   for (int i = 0; i < ncand; ++i) {
     int deeper = 0;
     for (int j = 0; j < ncand; ++j)

@@ -87,7 +87,7 @@ class Model:
         self.closures = [dict(a=m.cl_body_a[c], b=m.cl_body_b[c], pa=np.array(list(m.cl_point_a[c]), float),
                               pb=np.array(list(m.cl_point_b[c]), float)) for c in range(m.n_closures)]
         for k in ("gravity", "dt", "n_iters", "erp", "contact_margin", "lin_damp", "ang_damp", "max_qd", "warmstart", "ground_friction",
-                  "plank_friction", "plank_stiffness", "plank_damping", "limit_slack", "plank_com_z", "max_contacts", "max_rows", "n_slots"):
+                  "plank_friction", "plank_stiffness", "plank_damping", "limit_slack", "plank_com_z", "max_contacts", "max_rows", "n_slots", "manifold_max"):
             setattr(self, k, getattr(m, k))
         self.gravity, self.dt = float(np.float32(self.gravity)), float(np.float32(self.dt))
         self.plank_half = np.array(list(m.plank_half), float)
@@ -358,6 +358,29 @@ def detect_contacts(mdl: Model, st: State, planks=None, heightfield=None):
             if gap < mdl.contact_margin:
                 slot_mask |= 1 << (g["slot"] + e)
                 out.append(dict(a=g["body"], b=-1, slot=g["slot"] + e, P=C - g["radius"] * n, n=n, depth=-gap, mu=mu, erp=erp, cfm=cfm))
+    if getattr(mdl, "manifold_max", 0) > 0:   # 4-point manifold per link: deepest, farthest from it, farthest to either side of that line
+        keep = np.ones(len(out), bool)
+        for body in sorted({c["a"] for c in out}):
+            idx = [i for i, c in enumerate(out) if c["a"] == body]
+            if len(idx) <= 4:
+                continue
+            Pm = np.array([out[i]["P"] for i in idx]); dep = np.array([out[i]["depth"] for i in idx])
+            k1 = int(np.argmax(dep))                                    # (argmax returns the first of equals: the lower slot)
+            dist = np.linalg.norm(Pm - Pm[k1], axis=1); dist[k1] = -1
+            k2 = int(np.argmax(dist))
+            area = np.cross(Pm - Pm[k1], Pm[k2] - Pm[k1]) @ out[idx[k1]]["n"]
+            area[[k1, k2]] = 0
+            chosen = {k1, k2}
+            if area.max() > 0:
+                chosen.add(int(np.argmax(area)))
+            if area.min() < 0:
+                chosen.add(int(np.argmin(area)))
+            for k, i in enumerate(idx):
+                keep[i] = k in chosen
+        for i, c in enumerate(out):
+            if not keep[i]:
+                slot_mask &= ~(1 << c["slot"])
+        out = [c for i, c in enumerate(out) if keep[i]]
     if len(out) > mdl.max_contacts:      # more terrain contacts than the solver holds: the deepest stay (ties: lower slot), in slot order
         order = sorted(range(len(out)), key=lambda i: (-out[i]["depth"], i))[:mdl.max_contacts]
         out = [out[i] for i in sorted(order)]
