@@ -1117,14 +1117,18 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
       const unsigned long long G = __ballot(inG);
       todo &= ~G;
       if (__popcll(G) <= 4) continue;
+      // (the wave reductions are statements of their own: inside `inG && ...` they would run under the group's EXEC mask -- C++ short
+      // circuit -- and the DPP steps would read inactive lanes as 0)
       const float dep = inG ? -gap : -1e30f;
-      const int l1 = __builtin_ctzll(__ballot(inG && dep == wave_max(dep)));
+      const float dep_max = wave_max(dep);
+      const int l1 = __builtin_ctzll(__ballot(inG && dep == dep_max));
       const float P1[3] = {readlane(P[0], l1), readlane(P[1], l1), readlane(P[2], l1)};
       const float n1[3] = {readlane(n[0], l1), readlane(n[1], l1), readlane(n[2], l1)};
       const float d[3] = {P[0] - P1[0], P[1] - P1[1], P[2] - P1[2]};
       const bool c2 = inG && lane != l1;
       const float dd = c2 ? d[0] * d[0] + d[1] * d[1] + d[2] * d[2] : -1e30f;
-      const int l2 = __builtin_ctzll(__ballot(c2 && dd == wave_max(dd)));
+      const float dd_max = wave_max(dd);
+      const int l2 = __builtin_ctzll(__ballot(c2 && dd == dd_max));
       const float e[3] = {readlane(P[0], l2) - P1[0], readlane(P[1], l2) - P1[1], readlane(P[2], l2) - P1[2]};
       float cx[3];
       cross3(d, e, cx);

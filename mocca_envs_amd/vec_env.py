@@ -48,8 +48,8 @@ _DEFAULT_PARAMS = {"LaikagoCustomEnv-v0": {_lib.PARAM_RANDOM_POSE: 0},    # robo
 # tools/prio_sweep.sh on one MI355X (profiles/r02_prio_sweep.txt); ids not listed keep the library's default (14, 20, 28: the flat-ground
 # walker).  The stepping-stone walkers carry more rows as the curriculum rises: their thresholds grow with it (x 1.29 at curriculum 9).
 _ISSUE_PRIORITY = {"LaikagoCustomEnv-v0": (3, 6, 10), "LaikagoStepperEnv-v0": (4, 8, 12), "Child3DCustomEnv-v0": (20, 30, 42),
-                   "CassieEnv-v0": (36, 41, 45), "Cassie2DEnv-v0": (36, 41, 45), "CassiePhaseMocca2DEnv-v0": (36, 41, 45),
-                   "CassiePhaseMirror2DEnv-v0": (36, 41, 45)}
+                   "CassieEnv-v0": (24, 29, 33), "Cassie2DEnv-v0": (24, 29, 33), "CassiePhaseMocca2DEnv-v0": (24, 29, 33),
+                   "CassiePhaseMirror2DEnv-v0": (24, 29, 33)}
 _ISSUE_PRIORITY_CURRICULUM = {"Walker3DStepperEnv-v0": (14, 20, 28), "MikeStepperEnv-v0": (14, 20, 28)}
 
 
