@@ -122,7 +122,10 @@ enum : int {
   L_A = L_V,            // [MAXR][MAXR] Delassus matrix, row = updated row, column = lane
   L_J = L_V + 960,      // [MAXR][28] Jacobian rows (tail of the A region)
   L_XL = L_V,           // [MAXR][28] M^-1 J^T lambda, after the iterations
-  L_TOTAL = L_V + MAXR * MAXR + 28,  // + one dummy J row for lanes that own no row (A-row prefetches clamp to row MAXR - 1)
+#ifndef MOCCA_LDS_PAD
+#define MOCCA_LDS_PAD 0   // diagnostic builds only (tools/occupancy_probe.sh): extra floats of LDS per wave, to run the same code at fewer waves per SIMD
+#endif
+  L_TOTAL = L_V + MAXR * MAXR + 28 + MOCCA_LDS_PAD,  // + one dummy J row for lanes that own no row (A-row prefetches clamp to row MAXR - 1)
 };
 static_assert(L_ABA_END <= L_TOTAL, "ABA view must fit");
 static_assert(L_SV % 4 == 0 && SVS % 4 == 0 && SVS >= 16, "joint records live in the body records, 16-byte aligned");
@@ -130,7 +133,7 @@ static_assert(L_J + (MAXR + 1) * 28 <= L_TOTAL, "Jacobian rows (+ dummy) must fi
 static_assert(L_J % 4 == 0 && L_V % 4 == 0, "16-byte alignment of broadcast rows");
 static_assert(MAXR % 2 == 0 && 3 * MAXC <= MAXR, "friction rows sit on the top 2 MAXC lanes of the row range, odd lane = second tangent");
 static_assert(L_PLANK + 12 * MOCCA_MAX_PLANKS <= L_V && L_Q0 + 16 <= L_V, "persistent region overflows into the two-view region");
-static_assert(L_TOTAL * 4 <= 10240, "more than 10 KB of LDS per wave: fewer than 16 waves per CU, the 4096-env batch no longer fits one round");
+static_assert(L_TOTAL * 4 <= 10240 || MOCCA_LDS_PAD > 0, "more than 10 KB of LDS per wave: fewer than 16 waves per CU, the 4096-env batch no longer fits one round");
 static_assert(L_J >= L_RT, "J rows may be written while S, U, 1/D, the factor of IA0 and the contacts are still being read");
 
 // contact record fields

@@ -193,11 +193,17 @@ class VecEnv:
             raise ValueError("values must hold one float per env (or one float with broadcast=True)")
         _lib.check(self.lib.mocca_set_param_v(self.h, pid, C.c_void_p(v.data_ptr()), int(broadcast), self._stream()), self.h)
 
-    def seed(self, seed: int):
-        """Philox key of the in-kernel draws.  The (episode, draw) counters of the envs are NOT rewound: a re-seeded
-        VecEnv continues with new random numbers, it does not replay a fresh env's stream (create a new VecEnv for that)."""
+    def seed(self, seed: int, rewind: bool = True):
+        """Philox key of the in-kernel draws (gym's env.seed(s), env_base.py:164-166).  With rewind (default) the per-env episode
+        counters go back to "before the first episode", so that seed(s) followed by reset() replays exactly what a fresh VecEnv created
+        with seed=s produces -- the gym contract.  rewind=False only re-keys the stream: the envs continue with new random numbers."""
         self.seed_value = int(seed) & 0xFFFFFFFFFFFFFFFF
         _lib.check(self.lib.mocca_set_seed(self.h, self.seed_value), self.h)
+        if rewind:
+            tk = self.get_task()
+            tk[:, 9] = -1      # episode: the next reset is episode 0 (draws are keyed by (seed, global env id, episode, draw))
+            tk[:, 10] = 0      # draw counter
+            self.set_task(tk)
         return [seed]
 
     def set_draw_tape(self, tape) -> None:
