@@ -7,7 +7,8 @@ cd $R
 # 0. rocprofv3 on the headline config first: its PMC passes refresh profiles/traffic.json, which the bench lines below quote
 tools/profile_round.sh ${tag} Walker3DCustomEnv-v0 4096 > /dev/null 2>&1
 [ -s $O/${tag}_traffic.json ] && cp $O/${tag}_traffic.json profiles/traffic.json
-# 1. the driver's own default invocation + a long steady-state line (with the CPU baselines)
+# 1. the driver's own invocation (what BENCH_rNN.json records) + a long steady-state line (with the CPU baselines)
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${tag}_bench_driver_protocol.json 2> /dev/null
 python bench.py --steps 1000 --warmup 200 > $O/${tag}_bench_full.json 2> $O/${tag}_bench_full.err
 # 2. batch-size sweep of the headline env (1 / 2 / 4 waves per SIMD resident, then 2 and 4 rounds of waves)
 for n in 512 1024 2048 4096 8192 16384; do
@@ -19,7 +20,7 @@ python bench.py --envs 8192 --steps 400 --warmup 200 --no-cpu-baseline > $O/${ta
 python bench.py --env-id Walker3DStepperEnv-v0 --curriculum 0 --steps 400 --warmup 200 --no-cpu-baseline > $O/${tag}_stepper_c0_bench.json 2>/dev/null
 python bench.py --env-id Walker3DStepperEnv-v0 --curriculum 9 --steps 400 --warmup 200 --no-cpu-baseline > $O/${tag}_stepper_c9_bench.json 2>/dev/null
 python bench.py --env-id CassieEnv-v0 --envs 2048 --steps 100 --warmup 30 --no-cpu-baseline > $O/${tag}_cassie_bench.json 2>/dev/null
-for e in Child3DCustomEnv-v0 MikeStepperEnv-v0 Walker2DCustomEnv-v0 Crab2DCustomEnv-v0 LaikagoCustomEnv-v0 LaikagoStepperEnv-v0; do
+for e in Child3DCustomEnv-v0 MikeStepperEnv-v0 Walker2DCustomEnv-v0 Crab2DCustomEnv-v0 LaikagoCustomEnv-v0 LaikagoStepperEnv-v0 Walker3DPlannerEnv-v0 MikePlannerEnv-v0; do
   python bench.py --env-id $e --steps 300 --warmup 100 --no-cpu-baseline > $O/${tag}_$(echo $e | tr 'A-Z' 'a-z' | sed 's/env-v0//')_bench.json 2>/dev/null
 done
 python bench.py --env-id Cassie2DEnv-v0 --envs 2048 --steps 100 --warmup 30 --no-cpu-baseline > $O/${tag}_cassie2d_bench.json 2>/dev/null
@@ -29,6 +30,9 @@ python bench.py --env-id CassiePhaseMirror2DEnv-v0 --envs 2048 --steps 100 --war
 python tools/stamps.py Walker3DCustomEnv-v0 4096 > $O/${tag}_stamps_custom4096.txt 2>&1
 python tools/stamps.py Walker3DCustomEnv-v0 1024 > $O/${tag}_stamps_custom1024.txt 2>&1
 python tools/param_time.py 4096 > $O/${tag}_param_time_4096.txt 2>&1
+# 4b. cap pressure (how often the 12-contact / 48-row caps drop something) and the occupancy probe (throughput vs resident waves)
+python tools/cap_pressure.py 300 > $O/${tag}_cap_pressure.jsonl 2>/dev/null
+bash tools/occupancy_probe.sh 2>/dev/null | grep "^{" > $O/${tag}_occupancy_probe.jsonl
 # 5. record layouts
 hipcc --offload-arch=gfx950 -O3 -o /tmp/layout_bench tools/layout_bench.hip && /tmp/layout_bench 4096 > $O/${tag}_layout_bench.json && /tmp/layout_bench 65536 >> $O/${tag}_layout_bench.json
 # 5b. microbenchmarks behind DESIGN.md section 6: dependent-issue latencies, PGS visit forms, workgroup placement
