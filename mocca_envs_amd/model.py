@@ -689,6 +689,18 @@ WALKER3D_JOINT_NAMES = [
 ]
 
 
+# Bullet link that each of those joints carries: the last hinge of an MJCF body carries the body (and bears its name -- the reference
+# finds its parts by it: `parts["right_foot"]`, `parts["waist"]`, robots.py:232, env_locomotion.py:992); the hinges before it carry the
+# massless intermediate links of the multi-hinge joints  [UNVERIFIED-BULLET naming of the dummy links]
+WALKER3D_LINK_NAMES = [
+    "link_dummy_abdomen_z", "waist", "pelvis",
+    "link_dummy_right_hip_x", "link_dummy_right_hip_z", "right_thigh", "right_shin", "right_foot",
+    "link_dummy_left_hip_x", "link_dummy_left_hip_z", "left_thigh", "left_shin", "left_foot",
+    "link_dummy_right_shoulder_x", "link_dummy_right_shoulder_z", "right_upper_arm", "right_lower_arm",
+    "link_dummy_left_shoulder_x", "link_dummy_left_shoulder_z", "left_upper_arm", "left_lower_arm",
+]
+
+
 def walker3d_running_start() -> Dict[str, float]:
     """robots.py:296-302."""
     q = np.zeros(21)

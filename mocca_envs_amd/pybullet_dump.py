@@ -242,15 +242,21 @@ def warm_start_from_contacts(m: M.MoccaModel, bodies_of_links: np.ndarray, state
     return warm
 
 
-def synthetic_dump(m: M.MoccaModel, joint_names: Sequence[str], fixed_children: Dict[int, float] = None) -> Dict[str, np.ndarray]:
+def synthetic_dump(m: M.MoccaModel, joint_names: Sequence[str], fixed_children: Dict[int, float] = None,
+                   base_axes_aligned: bool = False, link_names: Optional[Sequence[str]] = None) -> Dict[str, np.ndarray]:
     """The record tools/dump_pybullet_trace.py WOULD write for a Bullet multibody equal to blob `m` (tests: loader round trip).
     Inertial frames are the principal-axes frames at the COM, as Bullet reports them.  `fixed_children`: {body: fraction}
-    splits that fraction of the body's mass off into an extra FIXED link (exercises the merge of fixed links)."""
+    splits that fraction of the body's mass off into an extra FIXED link (exercises the merge of fixed links).
+    `base_axes_aligned`: the base link's inertial frame keeps the link's axes (its inertia's off-diagonal terms are dropped), so that
+    resetting Bullet's base to the identity orientation stands the robot up -- what an MJCF import whose root body carries no inertial
+    rotation gives."""
     nb = m.n_bodies
     fr = _template_frames(m)
 
     def principal(b, mass_scale=1.0):
         xx, yy, zz, xy, xz, yz = m.inertia[b]
+        if b == 0 and base_axes_aligned:
+            return np.array([xx, yy, zz]) * mass_scale, np.eye(3)
         Im = np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]]) * mass_scale
         w, V = np.linalg.eigh(Im)
         if np.linalg.det(V) < 0:
@@ -276,12 +282,13 @@ def synthetic_dump(m: M.MoccaModel, joint_names: Sequence[str], fixed_children: 
     rows = []                                                      # (name, type, parent link, L frame (our base coords), body, mass frac)
     link_index = {0: -1}
     for b in range(1, nb):
-        rows.append(dict(name=joint_names[b - 1], type=JOINT_REVOLUTE, parent=link_index[m.parent[b]], L=fr[b], body=b, frac=1.0 - fixed_children.get(b, 0.0)))
+        rows.append(dict(name=joint_names[b - 1], type=JOINT_REVOLUTE, parent=link_index[m.parent[b]], L=fr[b], body=b, frac=1.0 - fixed_children.get(b, 0.0),
+                         link=link_names[b - 1] if link_names is not None else joint_names[b - 1] + "_link"))
         link_index[b] = len(rows) - 1
         if b in fixed_children:
-            rows.append(dict(name=f"jointfix_{b}", type=JOINT_FIXED, parent=link_index[b], L=fr[b], body=b, frac=fixed_children[b]))
+            rows.append(dict(name=f"jointfix_{b}", type=JOINT_FIXED, parent=link_index[b], L=fr[b], body=b, frac=fixed_children[b], link=f"fixed_part_{b}"))
     n = len(rows)
-    out = dict(joint_names=np.array([r["name"] for r in rows]), link_names=np.array([r["name"] + "_link" for r in rows]),
+    out = dict(joint_names=np.array([r["name"] for r in rows]), link_names=np.array([r["link"] for r in rows]),
                joint_type=np.array([r["type"] for r in rows]), parent_index=np.array([r["parent"] for r in rows]),
                joint_damping=np.zeros(n), joint_limits=np.zeros((n, 2)), joint_axis=np.zeros((n, 3)),
                parent_frame_pos=np.zeros((n, 3)), parent_frame_orn=np.zeros((n, 4)),

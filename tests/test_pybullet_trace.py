@@ -62,7 +62,9 @@ def one_step_errors_oracle(g, m, precision="f64"):
     errs = []
     for b, a, tq in zip(before, after, torques):
         o.set_state(b[None].copy())
-        o.step((tq / gains)[None].astype(np.float32))
+        # the recorded torques themselves, one stepSimulation = n_substeps physics substeps (env.step would round the action to float32:
+        # 1e-6 of joint speed, visible in f64)
+        o.physics_substeps(0, np.clip(tq, -gains, gains), int(m.n_substeps))
         errs.append(_joint_err(o.get_state()[0], a))
     return np.array(errs)
 
@@ -89,9 +91,10 @@ def free_run_errors_oracle(g, m, tag, precision="f64"):
     o.reset(seed=0)
     st = np.zeros((1, o.state_dim)); st[0, :ND] = states[0]
     o.set_state(st)
+    gains = np.array([m.gain[b] for b in range(1, NJ + 1)])
     errs = []
     for t, a in enumerate(actions):
-        o.step(a[None].astype(np.float32))
+        o.physics_substeps(0, gains * np.clip(a, -1, 1), int(m.n_substeps))      # robots.py:31-40 at applied_gain 1, in f64
         errs.append(_joint_err(o.get_state()[0], states[t + 1]))
     return np.array(errs)
 
@@ -220,3 +223,65 @@ def test_the_hip_harness_on_a_synthetic_trace(synth):
         assert worst[1] < max(2e-4, 3 * f32[0]), (tag, worst[1], f32[0])          # one step: rounding only
         assert worst[10] < max(2e-3, 10 * f32[:10].max()), (tag, worst[10])       # ten steps: no blow-up
         assert np.isfinite(errs).all()
+
+
+# ---------------------------------------------------------------------------------------------- the dump TOOL itself, run here
+@pytest.fixture(scope="module")
+def tool_file(tmp_path_factory):
+    """tools/dump_pybullet_trace.py executed against tests/fake_pybullet.py (PyBullet's API and conventions, the f64 oracle behind
+    stepSimulation): the file a maintainer would copy to tests/golden/, produced by the tool's own code."""
+    import importlib.util
+    import sys
+    from fake_pybullet import make_module
+    fake = make_module()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("dump_pybullet_trace", os.path.join(root, "tools", "dump_pybullet_trace.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    d = tmp_path_factory.mktemp("dump")
+    old_mod, old_cwd = sys.modules.get("pybullet"), os.getcwd()
+    sys.modules["pybullet"] = fake
+    os.chdir(d)
+    try:
+        tool.main("unused-data-dir", 60)
+    finally:
+        os.chdir(old_cwd)
+        if old_mod is None:
+            del sys.modules["pybullet"]
+        else:
+            sys.modules["pybullet"] = old_mod
+    return dict(np.load(os.path.join(d, "pybullet_walker3d.npz"))), fake
+
+
+def test_the_dump_tool_writes_a_file_the_harness_consumes(tool_file):
+    """The real-file branches, fed by the tool: the blob built from the tool's multibody record equals the one the fake simulated, the
+    teacher-forced replay (warm-started from the tool's contact points) and both free-running rollouts reproduce the fake's trajectory --
+    the tool's snapshots, torque -> action mapping, restart logic and contact bookkeeping line up with the harness."""
+    g, fake = tool_file
+    assert int(g["format_version"]) == 2 and int(g["n_links"]) == 22
+    for k in ("before", "after", "torques", "contact_points", "n_contact_points", "feet_contact", "free_states", "free_actions",
+              "free03_states", "free03_actions", "free_contact_points", "joint_names", "mass", "local_inertia_diag"):
+        assert k in g, k
+    assert g["before"].shape == (60, ND) and g["free_states"].shape == (61, ND) and g["contact_points"].shape == (60, 24, 9)
+    m = _blob(g)
+    assert m.to_bytes() == fake.fake_blob.to_bytes()
+    # the free-running rollouts start from the reference's reset pose: base at (0, 0, 1.32) at rest, "running_start" joint angles
+    np.testing.assert_allclose(g["free_states"][0][:3], [0, 0, 1.32], atol=1e-12)
+    np.testing.assert_allclose(g["free_states"][0][13:13 + NJ], [m.init_q[b] for b in range(1, NJ + 1)], atol=1e-6)
+    assert np.abs(g["free03_actions"]).max() <= 0.3 + 1e-12 < np.abs(g["free_actions"]).max()
+    assert (g["n_contact_points"] > 0).any() and (g["feet_contact"] == 1).any()
+    errs = one_step_errors_oracle(g, m)
+    assert errs.max() < 1e-9, errs.max()
+    for tag in ("free", "free03"):
+        assert free_run_errors_oracle(g, m, tag).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_the_dump_tools_file_on_the_hip_path(tool_file):
+    g, _ = tool_file
+    m = _blob(g)
+    e_hip, e_f32 = one_step_errors_hip(g, m), one_step_errors_oracle(g, m, "f32")
+    assert np.median(e_hip) < max(2e-5, 3 * np.median(e_f32)) and e_hip.max() < max(1e-3, 3 * e_f32.max()), (np.median(e_hip), e_hip.max())
+    for tag, errs in free_run_errors_hip(g, m).items():
+        worst = _report(f"HIP on the tool's rollout {tag!r}", errs)
+        assert worst[1] < 2e-4 and np.isfinite(errs).all()
