@@ -284,4 +284,5 @@ def test_the_dump_tools_file_on_the_hip_path(tool_file):
     assert np.median(e_hip) < max(2e-5, 3 * np.median(e_f32)) and e_hip.max() < max(1e-3, 3 * e_f32.max()), (np.median(e_hip), e_hip.max())
     for tag, errs in free_run_errors_hip(g, m).items():
         worst = _report(f"HIP on the tool's rollout {tag!r}", errs)
-        assert worst[1] < 2e-4 and np.isfinite(errs).all()
+        f32 = free_run_errors_oracle(g, m, tag, "f32")
+        assert worst[1] < max(2e-4, 3 * f32[0]) and np.isfinite(errs).all(), (tag, worst[1], f32[0])
