@@ -238,7 +238,7 @@ def test_per_env_parameters_through_the_abi():
 
 
 @pytest.mark.parametrize("env_id,n,steps", [("Walker3DStepperEnv-v0", 4096, 120), ("CassieEnv-v0", 2048, 12),
-                                            ("Walker3DCustomEnv-v0", 8192, 120)])
+                                            ("Walker3DCustomEnv-v0", 8192, 120), ("Walker3DPlannerEnv-v0", 4096, 120)])
 def test_properties_at_the_benchmark_sizes(env_id, n, steps):
     """BASELINE.json configs 2, 3 and 4's per-GPU shard at full size: bitwise determinism run to run, finite state, unit
     quaternions, joint limits honoured up to the solver's slack, speed clamp, done envs really restart."""
