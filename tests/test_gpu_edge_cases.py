@@ -300,3 +300,41 @@ def test_scalar_applied_gain_is_ordered_on_the_callers_stream():
         env.set_task(snap)
         np.testing.assert_array_equal(task_to_float64(env.get_task())[:, 21], 0.5)
         env.close(); ref.close()
+
+
+def test_planner_env_on_a_random_height_field():
+    """mocca_set_heightfield with another grid: a field drawn by host_logic.random_height_field (HeightField.reload(data=None),
+    bullet_objects.py:395-441; 64 x 64 points, 2 per metre) replaces the shipped one; HIP and oracle agree on it, robots scattered over it
+    stand on THEIR ground (the contact normals follow the slopes), and a grid of the wrong shape is refused."""
+    import torch
+    from mocca_envs_amd import host_logic as H
+    from mocca_envs_amd import lib as L
+    from mocca_envs_amd.vec_env import VecEnv, task_from_float64
+    from oracle.oracle import Oracle
+    n = 128
+    field = H.random_height_field(np.random.RandomState(5), (64, 64), 2).reshape(64, 64).astype(np.float32)
+    env = VecEnv("Walker3DPlannerEnv-v0", n, auto_reset=False, seed=3)
+    env.set_heightfield(field, 2)
+    orc = Oracle(env.model.to_bytes(), M.TASK_WALKER3D_PLANNER, n, "f32")
+    orc.set_heightfield(field, 2)
+    env.reset(); orc.reset(seed=3)
+    rng = np.random.default_rng(1)
+    st = orc.get_state()
+    for e in range(n):
+        xy = rng.uniform(-13, 13, 2)
+        st[e, 0:2], st[e, 2] = xy, orc.height_at(*xy) + 1.34
+    orc.set_state(st)
+    worst = 0.0
+    for t in range(40):
+        env.set_state(orc.get_state().astype(np.float32)); env.set_task(task_from_float64(orc.get_task()))
+        a = rng.uniform(-0.3, 0.3, (n, 21)).astype(np.float32)
+        og, rg, dg, _ = env.step(torch.from_numpy(a).cuda())
+        oc, rc, dc, _ = orc.step(a)
+        e = np.abs(env.get_state().cpu().numpy()[:, :55] - orc.get_state()[:, :55]) / (1e-3 + 1e-3 * np.abs(orc.get_state()[:, :55]))
+        worst = max(worst, float(np.median(e.max(axis=1))))
+    assert worst < 1.0, worst                                   # teacher-forced: fp32 rounding only
+    z = orc.get_state()[:, 2] - np.array([orc.height_at(x, y) for x, y in orc.get_state()[:, 0:2]])
+    assert (z > 0.5).mean() > 0.8                               # most robots still stand on the slopes they were put on
+    with pytest.raises(L.MoccaError):
+        env.set_heightfield(np.zeros((1, 64), np.float32), 2)
+    env.close()
