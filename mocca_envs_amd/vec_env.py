@@ -186,6 +186,40 @@ class VecEnv:
         _lib.check(self.lib.mocca_set_heightfield(self.h, hf.ctypes.data_as(C.c_void_p), hf.shape[0], hf.shape[1], float(scale)), self.h)
         self.height_field = (hf, float(scale))
 
+    # ---- the reference's env-level setters, batched (env_base.py:103-118, env_locomotion.py:76-77,224-282) ----
+    def set_env_params(self, params_dict):
+        """`set_env_params({"curriculum": k})`: one value for all envs or one per env (takes effect at each env's next reset; the
+        terminal height follows it at once, env_locomotion.py:628).  Unknown keys are ignored, like the reference's hasattr test."""
+        for k, v in params_dict.items():
+            if k == "curriculum":
+                if np.ndim(v) == 0:
+                    self.set_param(_lib.PARAM_CURRICULUM, float(v))
+                else:
+                    self.set_param_v(_lib.PARAM_CURRICULUM, v)
+
+    def set_robot_params(self, params_dict):
+        """`set_robot_params({"applied_gain": g})` (env_base.py:108-115): scalar or one value per env; acts on the next apply_action."""
+        if "applied_gain" in params_dict:
+            g = params_dict["applied_gain"]
+            if np.ndim(g) == 0:
+                self.set_param(_lib.PARAM_APPLIED_GAIN, float(g))
+            else:
+                self.set_param_v(_lib.PARAM_APPLIED_GAIN, g)
+
+    def evaluation_mode(self, on=True):
+        """Walker3DCustomEnv.evaluation_mode() (env_locomotion.py:76-77): fixed target 4 m ahead; scalar or one flag per env."""
+        if np.ndim(on) == 0:
+            self.set_param(_lib.PARAM_EVAL_MODE, 1.0 if on else 0.0)
+        else:
+            self.set_param_v(_lib.PARAM_EVAL_MODE, on)
+
+    def get_mirror_indices(self):
+        """The six index lists SymmetricRL consumes (env_locomotion.py:224-282 / :761-840); see symmetry.MirrorTransform."""
+        from . import host_logic as H
+        if self.task_id == M.TASK_CASSIE:
+            raise NotImplementedError("the Cassie envs publish their mirror indices through the gym classes (envs.py)")
+        return H.mirror_indices(self.model, stepper=self.task_id == M.TASK_WALKER3D_STEPPER)
+
     def set_param_v(self, pid: int, values, broadcast: bool = False):
         """Per-env curriculum / eval_mode / applied_gain (include/mocca.h mocca_set_param_v); values: [N] (or [1] with broadcast)."""
         v = torch.as_tensor(values, dtype=torch.float32).to(self.device).contiguous().reshape(-1)

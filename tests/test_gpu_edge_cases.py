@@ -338,3 +338,36 @@ def test_planner_env_on_a_random_height_field():
     with pytest.raises(L.MoccaError):
         env.set_heightfield(np.zeros((1, 64), np.float32), 2)
     env.close()
+
+
+def test_reference_named_setters_on_the_batched_env(golden):
+    """VecEnv.set_env_params / set_robot_params / evaluation_mode / get_mirror_indices: the reference's env-level calls (env_base.py:103-118,
+    env_locomotion.py:76-77,224-282), scalar or one value per env."""
+    from mocca_envs_amd.vec_env import VecEnv, task_to_float64
+    n = 32
+    env = VecEnv("Walker3DStepperEnv-v0", n, auto_reset=False, seed=2)
+    env.set_env_params({"curriculum": 7, "not_an_attribute": 1})
+    env.reset()
+    assert (task_to_float64(env.get_task())[:, 20] == 7).all()
+    cur = (np.arange(n) % 10).astype(np.float32)
+    env.set_env_params({"curriculum": cur})
+    env.reset()
+    np.testing.assert_array_equal(task_to_float64(env.get_task())[:, 20], cur)
+    for got, key in zip(env.get_mirror_indices(), ("neg_obs", "right_obs", "left_obs", "neg_act", "right_act", "left_act")):
+        np.testing.assert_array_equal(got, golden[f"mirror_stepper_{key}"])
+    env.close()
+    env = VecEnv("Walker3DCustomEnv-v0", n, auto_reset=False, seed=2)
+    env.set_robot_params({"applied_gain": np.linspace(0.8, 1.2, n).astype(np.float32)})
+    env.evaluation_mode((np.arange(n) % 2).astype(np.float32))
+    env.reset()
+    tk = task_to_float64(env.get_task())
+    np.testing.assert_allclose(tk[:, 21], np.linspace(0.8, 1.2, n), atol=1e-6)
+    assert (tk[1::2, 14] == 4.0).all() and (tk[0::2, 14] != 4.0).all()          # eval mode: dist 4, angle 0 (env_locomotion.py:69-70)
+    env.evaluation_mode(False)
+    env.set_robot_params({"applied_gain": 1.0})
+    env.reset()
+    tk = task_to_float64(env.get_task())
+    assert (tk[:, 21] == 1.0).all() and (tk[:, 14] != 4.0).all()
+    for got, key in zip(env.get_mirror_indices(), ("neg_obs", "right_obs", "left_obs", "neg_act", "right_act", "left_act")):
+        np.testing.assert_array_equal(got, golden[f"mirror_custom_{key}"])
+    env.close()
