@@ -123,6 +123,30 @@ __global__ __launch_bounds__(64) void k_e(float* o, long long* cyc, int iters) {
   o[blockIdx.x * 64 + threadIdx.x] = z + lam;
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
+// F: TWO ENVS PER WAVE (lanes 0..31 env A, 32..63 env B), the kernel's visit form A: row RR of both envs is visited at once.  Each half needs
+// ITS env's step: two v_readlane + one select on a constant half mask, and the commit takes a two-bit lane mask -- 7 VALU for two envs
+// instead of 5 for one ("Config 5").  32 visits per iteration (at most 32 rows per env).
+template <int RR> __device__ __forceinline__ void visit_f(float& y, float& lam, float as) {
+  if constexpr (RR < 32) {
+    const float nl = __builtin_amdgcn_fmed3f(y, 0.0f, 1e30f);
+    const float st = nl - lam;
+    const float da = readlane(st, RR), db = readlane(st, RR + 32);
+    float dl, nlam;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(dl) : "v"(da), "v"(db), "s"(0xFFFFFFFF00000000ull));
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(nlam) : "v"(lam), "v"(nl), "s"((1ull << RR) | (1ull << (RR + 32))));
+    lam = nlam;
+    y = fmaf(-as, dl, y);
+    visit_f<RR + 1>(y, lam, as);
+  }
+}
+__global__ __launch_bounds__(64) void k_f(float* o, long long* cyc, int iters) {
+  float y = 0.01f * threadIdx.x - 0.2f, lam = 0.0f, as = 0.001f * (threadIdx.x + 1);
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) visit_f<0>(y, lam, as);
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  o[blockIdx.x * 64 + threadIdx.x] = y + lam;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
 __global__ __launch_bounds__(64) void k_a(float* o, long long* cyc, int iters) {
   float y = 0.01f * threadIdx.x - 0.2f, lam = 0.0f, as = 0.001f * (threadIdx.x + 1);
   const long long t0 = __builtin_amdgcn_s_memtime();
@@ -159,6 +183,14 @@ int main() {
     (void)hipMemcpy(h, c, sizeof(long long) * 1024, hipMemcpyDeviceToHost);
     double s = 0; for (int i = 0; i < 1024; ++i) s += h[i];
     printf("{\"waves_per_simd\": %d, \"form\": \"E max-readlane-fma, bound and lambda off the chain\", \"cycles_per_visit\": %.1f}\n", waves, s / 1024 / (48.0 * iters));
+  }
+  for (int waves : {1, 2, 4}) {
+    const int blocks = 256 * 4 * waves, iters = 200;
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(k_f, dim3(blocks), dim3(64), 0, 0, d, c, iters);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h, c, sizeof(long long) * 1024, hipMemcpyDeviceToHost);
+    double s = 0; for (int i = 0; i < 1024; ++i) s += h[i];
+    printf("{\"waves_per_simd\": %d, \"form\": \"F two envs per wave: 2 readlane + select + 2-lane commit\", \"cycles_per_visit_serving_two_envs\": %.1f}\n", waves, s / 1024 / (32.0 * iters));
   }
   for (int waves : {1, 4}) {
     const int blocks = 256 * 4 * waves, iters = 200, nc = 12;
