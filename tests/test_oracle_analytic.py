@@ -6,6 +6,7 @@ these pin it to mechanics instead).  Tiny purpose-built models compiled with the
   * a hinge driven into its limit by a constant torque stops at the limit (no overshoot beyond the ERP slack)
   * a compound pendulum swings with the textbook period; a damped spinning link decays with c / I
   * two crossing capsules: contact point, normal, depth of the self-collision narrow phase; the impulse separates them
+  * a block on a height field of constant slope: plane normal, m g cos / (n k) sink, sticks below atan(mu), slides with g (sin - mu cos)
 CPU only.
 """
 import numpy as np
@@ -110,6 +111,48 @@ def test_coulomb_friction_on_an_incline(deg, sticks):
         a = G * (np.sin(th) - mu * np.cos(th))
         np.testing.assert_allclose(speed / t, a, rtol=0.03)
         assert abs((s[0:3] - p0) @ (Rb @ np.array([1.0, 0, 0]))) < 1e-3                          # and only down the slope
+
+
+@pytest.mark.parametrize("deg,sticks", [(12.0, True), (22.0, True), (32.0, False), (40.0, False)])
+def test_block_on_a_sloping_height_field(deg, sticks):
+    """The planner envs' terrain (bullet_objects.py:338-393): a height field whose heights rise linearly with y is a plane of slope
+    `deg` made of triangles.  The contact normal is the plane's, the block sinks m g cos(theta) / (n k) into the soft ground
+    (stiffness 30000, damping 1000), and Coulomb friction (field 1.0 x geom 0.5) holds it below atan(0.5) = 26.6 deg and lets it
+    slide with g (sin - mu cos) above -- whatever triangle of whatever cell each corner sphere happens to be over."""
+    mu, th = 0.5, np.deg2rad(deg)
+    m = _block(fric=mu)
+    o, st = _oracle(m, task=M.TASK_WALKER3D_PLANNER)
+    scale, npts = 4, 96
+    ys = (np.arange(npts) - (npts - 1) / 2) / scale
+    field = np.tile((np.tan(th) * ys)[:, None], (1, npts)).astype(np.float64)        # heights[iy][ix]
+    o.set_heightfield(field, scale)
+    nrm = np.array([0.0, -np.sin(th), np.cos(th)])
+    # a probe 5 cm above the surface (the 2 x 2-cell search is exact up to half a cell = 12.5 cm of reach)
+    g_probe, n_probe = o.heightfield_probe(np.array([0.3, 0.2, np.tan(th) * 0.2]) + 0.05 * nrm, 0.02)
+    np.testing.assert_allclose(n_probe, nrm, atol=1e-5)                               # (the grid is stored as float32)
+    np.testing.assert_allclose(g_probe, 0.05 - 0.02, atol=1e-5)
+    # the block, tilted with the slope, its corner spheres touching the surface
+    c, sn = np.cos(th / 2), np.sin(th / 2)
+    Rq = np.array([sn, 0, 0, c])                                                       # rotation by theta about x lifts +y
+    st[0, 0:3] = 0.12 * nrm + np.array([0.07, 0.11, np.tan(th) * 0.11])               # 0.12 = corner offset 0.1 + radius 0.02
+    st[0, 3:7] = Rq
+    o.set_state(st)
+    o.physics_substeps(0, np.zeros(0), 120)
+    p0, v0 = o.get_state()[0, 0:3].copy(), o.get_state()[0, 7:10].copy()
+    n_sub = 240
+    o.physics_substeps(0, np.zeros(0), n_sub)
+    s = o.get_state()[0]
+    down = np.array([0.0, -np.cos(th), -np.sin(th)])
+    travel, speed = (s[0:3] - p0) @ down, (s[7:10] - v0) @ down
+    if sticks:
+        assert abs(travel) < 1e-2 and abs(s[7:10] @ down) < 1e-2, (travel, s[7:10] @ down)
+        sink = 0.12 - (s[0:3] - np.array([s[0], s[1], np.tan(th) * s[1]])) @ nrm       # distance of the block centre to the plane
+        # (a 0.18 mm compression read off positions while the four corners still trade load: 8 %; the impulse sum below is exact)
+        np.testing.assert_allclose(sink, m.mass[0] * G * np.cos(th) / (4 * m.plank_stiffness), rtol=0.08)
+        np.testing.assert_allclose(s[13:].sum(), m.mass[0] * G * np.cos(th) * DT, rtol=1e-3)
+    else:
+        np.testing.assert_allclose(speed / (n_sub * DT), G * (np.sin(th) - mu * np.cos(th)), rtol=0.03)
+        assert abs(s[0] - p0[0]) < 1e-3                                                # and only down the slope
 
 
 def _base_with_arm(axis, lo, hi, arm_dir, damping=0.0, armature=0.0):
