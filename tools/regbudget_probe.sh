@@ -1,4 +1,7 @@
 #!/bin/bash
+# Timing of .ab/lib_dyn{4,5,6}.so -- the step kernel built with dynamic LDS (`extern __shared__`) and __launch_bounds__(64, W): the compiler then
+# sizes its register budget for W waves per SIMD (96 VGPRs at 5, 80 at 6) while the run-time occupancy stays at 4.  The 8-line source change is
+# described in profiles/r03_regbudget_probe.txt and was not kept (the dynamic form alone costs 28 %).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 for rep in 1 2; do
