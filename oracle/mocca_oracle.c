@@ -1809,7 +1809,7 @@ API void orc_physics_substeps(void *h, int e, const double *tau, int n) {
   real t[MB];
   t[0] = 0;
   for (int b = 1; b <= o->m.n_joints; ++b) t[b] = (real)tau[b - 1];
-  for (int k = 0; k < n; ++k) substep(o, &o->dyn[e], &o->task[e], &o->ter[e], t, &o->wk);
+  for (int k = 0; k < n; ++k) { substep(o, &o->dyn[e], &o->task[e], &o->ter[e], t, &o->wk); dbg_commit(o, e, &o->wk); }
 }
 /* forward dynamics at the current state: out = [a_base(6, spatial about base origin); qdd(nj)] */
 API void orc_forward_dynamics(void *h, int e, const double *tau, int with_bias, double *out) {

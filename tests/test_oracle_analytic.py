@@ -256,3 +256,43 @@ def test_two_crossing_capsules_self_contact():
     # whatever the base does moves both coincident points alike
     v_sep = -0.3 * qd_a - 0.3 * qd_b
     np.testing.assert_allclose(v_sep, 0.9 * 0.01 / DT, rtol=1e-6)
+
+
+def test_contact_manifold_keeps_the_corners_of_a_plate():
+    """MoccaModel.manifold_max (Cassie's toes): of nine support points in a 3 x 3 grid under one link, all within the
+    margin, the four-point manifold keeps the corners -- the deepest point, the one farthest from it and the farthest to either side of
+    the line through those two -- whichever corner is deepest; the plate then rests on them carrying m g, a quarter each when level."""
+    pts = [(sx * 0.1, sy * 0.1, -0.1) for sx in (-1, 0, 1) for sy in (-1, 0, 1)]
+    geoms = [Geom(f"p{i}", GEOM_SPHERE, 0.02, p, friction=0.5) for i, p in enumerate(pts)]
+    root = Body("plate", (0, 0, 0.5), geoms=geoms + [Geom("core", GEOM_SPHERE, 0.08, (0, 0, 0), group=0, mask=0)])
+    m = M.compile_model(root, [], {}, (0, 0, 0.5), [], [], [], self_collision=False)
+    m.lin_damp = m.ang_damp = 0.0
+    m.manifold_max = 4
+    corners = {0, 2, 6, 8}
+    rng = np.random.default_rng(0)
+    for trial in range(6):
+        o, st = _oracle(m)
+        tilt = rng.normal(0, 0.01, 2)                               # a random corner is the deepest
+        q = np.array([tilt[0] / 2, tilt[1] / 2, 0.0, 1.0]); q /= np.linalg.norm(q)
+        st[0, 2], st[0, 3:7] = 0.125, q                             # all nine within the 2 cm margin, none penetrating much
+        o.set_state(st)
+        o.physics_substeps(0, np.zeros(0), 1)
+        kept = {int(c[2]) for c in o.last_contacts()}
+        assert kept == corners, (trial, kept)
+        dbg = o.get_debug()[0]
+        assert dbg[2] == 4 and (int(dbg[3]) & 0x1FF) == sum(1 << k for k in corners)      # the slot mask is the manifold's, not all nine
+    o, st = _oracle(m)
+    st[0, 2] = 0.125
+    o.set_state(st)
+    o.physics_substeps(0, np.zeros(0), 480)
+    s = o.get_state()[0]
+    assert abs(s[2] - 0.12) < 2e-4 and np.abs(s[7:13]).max() < 1e-3
+    np.testing.assert_allclose(s[13:13 + 9].sum(), m.mass[0] * G * DT, rtol=1e-6)
+    np.testing.assert_allclose(s[13:13 + 9][sorted(corners)], m.mass[0] * G * DT / 4, rtol=0.03)
+    assert np.abs(s[13:13 + 9][[1, 3, 4, 5, 7]]).max() == 0.0       # the five inner / edge points carry nothing: they are not contacts
+    m.manifold_max = 0                                              # switched off: all nine are contacts again
+    o, st = _oracle(m)
+    st[0, 2] = 0.125
+    o.set_state(st)
+    o.physics_substeps(0, np.zeros(0), 1)
+    assert len(o.last_contacts()) == 9

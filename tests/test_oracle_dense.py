@@ -185,6 +185,45 @@ def _random_tree(rng, n_links):
     return bodies[0]
 
 
+def test_contact_manifolds_on_random_mechanisms():
+    """MoccaModel.manifold_max on mechanisms other than Cassie: random trees whose links carry six to nine support points each, dropped
+    flat onto the ground so that whole clusters are within the margin -- oracle and dense reference must keep the same four per link."""
+    from mocca_envs_amd.model import GEOM_SPHERE, Body, Geom, Hinge
+    rng = np.random.default_rng(21)
+    reduced = 0
+    for trial in range(8):
+        n = int(rng.integers(2, 4))
+        bodies = [Body("root", (0, 0, 1.0), geoms=[Geom(f"r{k}", GEOM_SPHERE, 0.0, tuple(rng.uniform(-0.12, 0.12, 3) * [1, 1, 0.15])) for k in range(7)])]
+        for k in range(1, n + 1):
+            parent = bodies[int(rng.integers(0, len(bodies)))]
+            axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+            npt = int(rng.integers(6, 9))            # <= 7 + 3 x 8 = 31 geoms (MOCCA_MAX_GEOMS 32)
+            geoms = [Geom(f"g{k}_{i}", GEOM_SPHERE, float(rng.choice([0.0, 0.01])), tuple(rng.uniform(-0.1, 0.1, 3) * [1, 1, 0.1])) for i in range(npt)]
+            b = Body(f"b{k}", tuple(rng.normal(0, 0.2, 3) * [1, 1, 0.05]), anchor=(0, 0, 0), hinges=[Hinge(f"j{k}", tuple(axis), -90, 90, 1.0)], geoms=geoms)
+            parent.children.append(b)
+            bodies.append(b)
+        m = M.compile_model(bodies[0], [], {}, (0, 0, 1.0), [], [], [], self_collision=False, joint_damping=0.1, joint_armature=0.01)
+        for b in range(m.n_bodies):      # point clouds carry no mass: give every link a plausible inertia
+            m.mass[b] = 1.0
+            for i in range(3):
+                m.inertia[b][i] = 0.01
+        m.manifold_max = 4
+        m.finalize_tables()
+        mdl = D.Model(m)
+        orc = Oracle(m.to_bytes(), 0, 1, "f64")
+        for k in range(3):
+            row = _random_state(rng, m, 0.0, spread=0.05, vel=0.3)
+            row[2] = 0.005 + 0.01 * rng.random()                    # lying flat, a centimetre up: most points within the margin
+            row[13:13 + m.n_joints] *= 0.1
+            info = _compare(orc, m, mdl, row, rng.uniform(-1, 1, m.n_joints), tol=5e-7)
+            per_link = {}
+            for c in info["contacts"]:
+                per_link[c["a"]] = per_link.get(c["a"], 0) + 1
+            assert per_link and max(per_link.values()) <= 4
+            reduced += sum(v == 4 for v in per_link.values())
+    assert reduced >= 10
+
+
 def test_substep_on_random_mechanisms():
     """Not only the five robots: random trees (3-9 links, random branching, axes, offsets, shapes) dropped onto the ground --
     the oracle's recursions must agree with the dense reference for ANY topology the blob can describe."""
