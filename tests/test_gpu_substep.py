@@ -40,13 +40,25 @@ CASES = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("Walker3DStepper
          ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_dump": "massive"}),
          # the planner envs (env_locomotion.py:982-1133): spheres / capsule ends against the triangles of the height field; the envs are
          # scattered over the field after reset (the episodes start on its flat corner platform)
-         ("Walker3DPlannerEnv-v0", M.TASK_WALKER3D_PLANNER, {}), ("MikePlannerEnv-v0", M.TASK_WALKER3D_PLANNER, {})]
+         ("Walker3DPlannerEnv-v0", M.TASK_WALKER3D_PLANNER, {}), ("MikePlannerEnv-v0", M.TASK_WALKER3D_PLANNER, {}),
+         # Cassie with mass on the two links its URDF leaves without inertia: the TopoCassieMassive kernel instance
+         ("CassieEnv-v0", M.TASK_CASSIE, {"_massive": True})]
 
 
 def _one_substep_blob(env_id, **kw):
     from mocca_envs_amd.vec_env import compile_model_for
-    dump = kw.pop("_dump", None)
+    dump, massive = kw.pop("_dump", None), kw.pop("_massive", False)
     m = compile_model_for(env_id, **kw)
+    if massive:
+        n = 0
+        for b in range(1, m.n_bodies):
+            if m.mass[b] == 0.0:
+                m.mass[b] = 0.05
+                for k in range(3):
+                    m.inertia[b][k] = 1e-4 * (1 + 0.5 * k)
+                n += 1
+        assert n >= 1
+        m.finalize_tables()
     if dump:
         from mocca_envs_amd.pybullet_dump import from_pybullet_dump, synthetic_dump
         src = m
