@@ -406,5 +406,6 @@ def test_abi_errors_of_the_planner_task_and_the_massive_instances():
     act, rew, done = torch.zeros(4, 21, device="cuda"), torch.zeros(4, device="cuda"), torch.zeros(4, dtype=torch.uint8, device="cuda")
     assert lib.mocca_step(h, C.c_void_p(act.data_ptr()), C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()), None, None) == 0
     torch.cuda.synchronize()
-    assert torch.isfinite(obs[:, :52]).all() and torch.isfinite(rew).all()
+    first = obs.flatten()[:4 * 52].reshape(4, 52)             # the library writes rows of obs_dim = 52 floats
+    assert torch.isfinite(first).all() and torch.isfinite(rew).all() and (first[:, 0] > 1.0).all()     # standing: relative height ~1.2
     lib.mocca_destroy(h)
