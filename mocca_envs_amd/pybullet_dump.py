@@ -216,8 +216,8 @@ def warm_start_from_contacts(m: M.MoccaModel, bodies_of_links: np.ndarray, state
     """[n_slots] warm-start normal impulses for the step that FOLLOWS `state_row`, from the contact points Bullet reported after the step
     that produced it (tools/dump_pybullet_trace.py `contact_points`: link, other link, position xyz, normal xyz, normal force).  Bullet
     warm-starts its solver with the impulses of the frame before; a teacher-forced state alone does not carry them.  A ground contact
-    on link l is credited to the terrain slot of l's body whose geom end point lies closest to the contact position; the impulse of
-    the last substep is force x dt.  Self contacts (other link >= 0) have no slot in this solver (they start from zero here too)."""
+    (or plank: other link < 0) contact on link l is credited to the terrain slot of l's body whose geom end point, moved one radius
+    against the reported normal, lies closest to the contact position; the impulse of the last substep is force x dt.  Self contacts (other link >= 0) have no slot in this solver (they start from zero here too)."""
     dt = float(m.dt) if dt is None else dt
     warm = np.zeros(m.n_slots)
     fr = None
@@ -234,7 +234,7 @@ def warm_start_from_contacts(m: M.MoccaModel, bodies_of_links: np.ndarray, state
             ends = [list(m.g_p1[g])] + ([list(m.g_p2[g])] if m.g_type[g] == M.GEOM_CAPSULE else [])
             for e, pl in enumerate(ends):
                 c = fr[body].apply(pl)
-                d = np.linalg.norm(c - np.array([0, 0, m.g_radius[g]]) - row[2:5])   # contact position = sphere centre - r e_z on flat ground
+                d = np.linalg.norm(c - m.g_radius[g] * row[5:8] - row[2:5])   # contact position on the robot = sphere centre - r n
                 if d < best_d:
                     best, best_d = m.g_slot[g] + e, d
         if best >= 0:

@@ -29,16 +29,54 @@ def make_module(fixed_children=None):
     for j in range(n_links):
         link_of_body.setdefault(int(bodies[1 + j]), j)
     hinge_links = {j: int(bodies[1 + j]) for j in range(n_links) if int(rec["joint_type"][j]) == PD.JOINT_REVOLUTE}
-    o = Oracle(blob.to_bytes(), 0, 1, "f64")
-    o.reset(seed=0)
-    st = {"forces": np.zeros(NJ), "force_links": list(hinge_links)}
+    box = {"o": Oracle(blob.to_bytes(), 0, 1, "f64")}
+    box["o"].reset(seed=0)
+    st = {"forces": np.zeros(NJ), "force_links": list(hinge_links), "planks": [], "terrain": np.zeros((1, 124)), "blob": blob}
     ROBOT, PLANE = 1, 0
+
+    class _O:       # the oracle currently behind the API: flat ground first, the stepping-stone world after removeBody(plane)
+        def __getattr__(self, k):
+            return getattr(box["o"], k)
+    o = _O()
 
     p = types.ModuleType("pybullet")
     p.DIRECT, p.GUI = 2, 1
     p.POSITION_CONTROL, p.VELOCITY_CONTROL, p.TORQUE_CONTROL = 2, 0, 1
     p.MJCF_COLORS_FROM_FILE, p.URDF_USE_SELF_COLLISION, p.URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS = 512, 8, 16
     p.fake_blob, p.fake_record = blob, rec
+    stepper_blob = PD.from_pybullet_dump(rec, M.compile_walker3d(M.TASK_WALKER3D_STEPPER), M.WALKER3D_JOINT_NAMES)
+    p.fake_stepper_blob = stepper_blob
+
+    def quat_from_euler(e):
+        r, pt, y = e
+        cr, sr, cp, sp, cy, sy = np.cos(r / 2), np.sin(r / 2), np.cos(pt / 2), np.sin(pt / 2), np.cos(y / 2), np.sin(y / 2)
+        return (sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy)
+
+    def euler_from_quat(q):
+        x, y, z, w = q
+        return (np.arctan2(2 * (y * z + w * x), w * w - x * x - y * y + z * z), np.arcsin(-2 * (x * z - w * y)),
+                np.arctan2(2 * (x * y + w * z), w * w + x * x - y * y - z * z))
+
+    p.getQuaternionFromEuler = quat_from_euler
+
+    def removeBody(body):
+        """The ground plane goes: from here on the world is the stepping-stone one (Oracle task 1 on the Stepper blob of the same record)."""
+        assert body == PLANE
+        old = box["o"].get_state()
+        box["o"] = Oracle(stepper_blob.to_bytes(), M.TASK_WALKER3D_STEPPER, 1, "f64")
+        box["o"].reset(seed=0)
+        box["o"].set_state(old)
+        st["terrain"][0, :120] = np.tile([100.0, 100.0, -50.0, 0, 0, 0], 20)       # no plank anywhere near until they are placed
+        st["terrain"][0, 120:124] = [0, 1, 2, 3]
+        box["o"].set_terrain(st["terrain"])
+        st["blob"] = stepper_blob
+
+    def loadURDF(f, basePosition=None, baseOrientation=None, useFixedBase=False, globalScaling=1.0):
+        assert f.endswith("plank_large.urdf") and abs(globalScaling - 0.5) < 1e-12 and not useFixedBase
+        st["planks"].append(10 + len(st["planks"]))
+        return st["planks"][-1]
+
+    p.removeBody, p.loadURDF = removeBody, loadURDF
 
     def state():
         return o.get_state()[0]
@@ -53,7 +91,7 @@ def make_module(fixed_children=None):
     p.changeDynamics = lambda *a, **k: None
     p.loadSDF = lambda f: (PLANE,)
     p.loadMJCF = lambda f, flags=0: (ROBOT,)
-    p.getNumJoints = lambda body: n_links
+    p.getNumJoints = lambda body: n_links if body == ROBOT else 1
     p.setJointMotorControl2 = lambda *a, **k: None
     p.getCollisionShapeData = lambda body, link: []
 
@@ -70,7 +108,12 @@ def make_module(fixed_children=None):
         return (float(rec["mass"][k]), 1.2, tuple(rec["local_inertia_diag"][k]), tuple(rec["inertial_pos"][k]), tuple(rec["inertial_orn"][k]), 0.0, 0.0, 0.0, -1, -1)
 
     p.getJointInfo, p.getDynamicsInfo = getJointInfo, getDynamicsInfo
-    p.getBasePositionAndOrientation = lambda body: (tuple(state()[0:3]), tuple(state()[3:7]))
+    def getBasePositionAndOrientation(body):
+        if body in st["planks"]:      # right after loadURDF at the origin: the base link's inertial frame, plank_large.urdf:8 x scale
+            return ((0.0, 0.0, float(stepper_blob.plank_com_z)), (0.0, 0.0, 0.0, 1.0))
+        return (tuple(state()[0:3]), tuple(state()[3:7]))
+
+    p.getBasePositionAndOrientation = getBasePositionAndOrientation
     p.getBaseVelocity = lambda body: (tuple(state()[7:10]), tuple(state()[10:13]))
 
     def getJointStates(body, ids):
@@ -81,7 +124,15 @@ def make_module(fixed_children=None):
             out.append((s[13 + b - 1], s[13 + NJ + b - 1], (0,) * 6, 0.0))
         return out
 
-    def resetBasePositionAndOrientation(body, pos, orn):
+    def resetBasePositionAndOrientation(body, pos=None, orn=None, posObj=None, ornObj=None):
+        pos, orn = (posObj if pos is None else pos), (ornObj if orn is None else orn)
+        if body in st["planks"]:      # BaseStep.set_position: pos = table xyz + _pos_offset (NOT rotated), orn = Euler(x_tilt, y_tilt, phi)
+            k = st["planks"].index(body)
+            xt, yt, phi = euler_from_quat(orn)
+            xyz = np.array(pos) - np.array([0.0, 0.0, float(stepper_blob.plank_com_z)])
+            st["terrain"][0, 6 * k:6 * k + 6] = [xyz[0], xyz[1], xyz[2], phi, xt, yt]
+            box["o"].set_terrain(st["terrain"])
+            return
         s = state().copy()
         s[0:3], s[3:7] = pos, orn
         s[13 + 2 * NJ:] = 0
@@ -105,7 +156,7 @@ def make_module(fixed_children=None):
                 st["forces"][hinge_links[j] - 1] = f
 
     def stepSimulation():
-        o.physics_substeps(0, st["forces"], int(blob.n_substeps))
+        o.physics_substeps(0, st["forces"], int(st["blob"].n_substeps))
         st["forces"] = np.zeros(NJ)      # Bullet clears applied torques after a step (TORQUE_CONTROL is per step)
 
     def getContactPoints(bodyA=None, linkIndexA=None):
@@ -117,7 +168,8 @@ def make_module(fixed_children=None):
             la = link_of_body[int(c[0])]
             if linkIndexA is not None and la != linkIndexA:
                 continue
-            bodyB, lb = (PLANE, -1) if int(c[1]) < 0 else (ROBOT, link_of_body[int(c[1])])
+            ground = st["planks"][0] if st["planks"] else PLANE         # (which plank it is does not matter to the tool)
+            bodyB, lb = (ground, -1) if int(c[1]) < 0 else (ROBOT, link_of_body[int(c[1])])
             force = normals[k] / blob.dt if k < len(normals) else 0.0
             out.append((0, ROBOT, bodyB, la, lb, tuple(c[3:6] + base), tuple(c[3:6] + base), tuple(c[6:9]), -float(c[9]), float(force)))
         return out

@@ -12,7 +12,14 @@ Writes pybullet_walker3d.npz with
     reference's reset pose (base at (0, 0, 1.32), "running_start" joint angles of robots.py:296-302, at rest, no noise, no
     mirror) N steps of U(-1, 1) actions from numpy.random.default_rng(0) WITHOUT any restart: free_actions [N][21],
     free_states [N + 1][55], free_contacts per step.  A second rollout with the actions scaled by 0.3 (the robot stays on
-    its feet longer, so more of the 1000 steps compare states rather than tumbling chaos): free03_*.
+    its feet longer, so more of the 1000 steps compare states rather than tumbling chaos): free03_*;
+  * a STEPPING-STONE trace (Walker3DStepperEnv, BASELINE config 2): the ground plane is removed and three LargePlank objects are loaded and
+    placed exactly as the reference does (bullet_objects.py:47-83,98-103, env_locomotion.py:443-465: loadURDF(plank_large.urdf,
+    globalScaling 0.5, useFixedBase=False), _pos_offset = the base position Bullet reports right after loading, changeDynamics(friction 1,
+    restitution 0.1, contactStiffness 30000, contactDamping 1000), resetBasePositionAndOrientation(pos + _pos_offset, quat of
+    Euler(x_tilt, y_tilt, phi))), flat, tilted and yawed; the robot starts above the first one and is teacher-forced like above:
+    stp_before / stp_after / stp_torques / stp_contact_points (other = -1: a plank) / stp_feet_contact, plus stp_terrain [3][6]
+    (x y z phi x_tilt y_tilt), stp_pos_offset, stp_plank_scale -- what pins the box contact, the un-rotated offset and the soft-contact rows.
 The loader side is mocca_envs_amd/pybullet_dump.py (from_pybullet_dump: model blob from this record, no importer
 assumptions left) and tests/test_pybullet_trace.py (the branches on the real file are skipped while it is absent): every
 "before" state goes through the f64 oracle and through the HIP stepper and the one-step error against Bullet's "after" is
@@ -38,6 +45,14 @@ def running_start():
     q[18] = np.pi / 6
     q[[16, 20]] = np.pi / 3
     return q
+
+
+# three live planks of the stepping-stone trace: x y z phi x_tilt y_tilt (env_locomotion.py:441); the first under the start pose, then one
+# tilted about x and yawed, one tilted about y and raised -- within the curriculum-9 ranges (+-20 deg yaw, +-15 deg tilt, :367-385)
+STEPPER_TERRAIN = np.array([[0.0, 0.0, 0.0, 0.0, 0.0, 0.0],
+                            [0.75, 0.0, 0.0, 0.2, 0.15, 0.0],
+                            [1.55, 0.15, 0.12, -0.25, 0.0, -0.2]])
+STEPPER_START = [0.3, 0.0, 1.32]      # Walker3DStepperEnv.robot_init_position, env_locomotion.py:339
 
 
 def main(data_dir, n_steps):
@@ -135,6 +150,50 @@ def main(data_dir, n_steps):
             fc.append([int(any(c[2] == plane for c in p.getContactPoints(bodyA=robot, linkIndexA=f))) for f in feet])
         out.update({f"{tag}_states": np.array(states), f"{tag}_actions": np.array(actions), f"{tag}_contact_points": np.array(cpts),
                     f"{tag}_feet_contact": np.array(fc)})
+    # ---- stepping stones: no ground plane, three planks placed like Walker3DStepperEnv.set_step_state
+    p.removeBody(plane)
+    scale = 2 * 0.25                                              # LargePlank(bc, step_radius): globalScaling = 2 * width
+    planks, offset = [], None
+    for k in range(3):
+        pid = p.loadURDF(f"{data_dir}/objects/steps/plank_large.urdf", basePosition=[0, 0, 0], baseOrientation=[0, 0, 0, 1],
+                         useFixedBase=False, globalScaling=scale)
+        offset = np.array(p.getBasePositionAndOrientation(pid)[0])
+        for link_id in range(-1, p.getNumJoints(pid)):
+            p.changeDynamics(pid, link_id, lateralFriction=1.0, restitution=0.1, contactStiffness=30000, contactDamping=1000)
+        x, y, z, phi, xt, yt = STEPPER_TERRAIN[k]
+        p.resetBasePositionAndOrientation(pid, posObj=list(np.array([x, y, z]) + offset), ornObj=p.getQuaternionFromEuler([xt, yt, phi]))
+        planks.append(pid)
+
+    def contact_points_planks():
+        rows = np.full((MAX_CP, 9), 0.0)
+        rows[:, 0] = -2
+        cps = p.getContactPoints(bodyA=robot)
+        for k, c in enumerate(cps[:MAX_CP]):
+            other = -1 if c[2] in planks else c[4]
+            rows[k] = [c[3], other, *c[5], *c[7], c[9]]
+        return rows, len(cps)
+
+    def place_stepper(q):
+        p.resetBasePositionAndOrientation(robot, STEPPER_START, [0, 0, 0, 1])
+        p.resetBaseVelocity(robot, [0, 0, 0], [0, 0, 0])
+        for k, j in enumerate(act):
+            p.resetJointState(robot, j, float(q[k]), 0.0)
+
+    rng = np.random.default_rng(1)
+    place_stepper(running_start())
+    before, after, torques, cpts, fc = [], [], [], [], []
+    for t in range(n_steps):
+        a = 0.5 * rng.uniform(-1, 1, 21)                          # gentler than U(-1, 1): the robot spends more steps on the planks
+        before.append(snap())
+        p.setJointMotorControlArray(robot, act, p.TORQUE_CONTROL, forces=list(GAINS * a))
+        p.stepSimulation()
+        after.append(snap()); torques.append(GAINS * a)
+        cpts.append(contact_points_planks()[0])
+        fc.append([int(any(c[2] in planks for c in p.getContactPoints(bodyA=robot, linkIndexA=f))) for f in feet])
+        if after[-1][2] < 0.5 or abs(after[-1][1]) > 2.0 or after[-1][0] > 2.2:     # fallen or walked off the planks: restart
+            place_stepper(running_start())
+    out.update(stp_before=np.array(before), stp_after=np.array(after), stp_torques=np.array(torques), stp_contact_points=np.array(cpts),
+               stp_feet_contact=np.array(fc), stp_terrain=STEPPER_TERRAIN, stp_pos_offset=offset, stp_plank_scale=np.array(scale))
     np.savez_compressed("pybullet_walker3d.npz", **out)
     print("wrote pybullet_walker3d.npz")
 
