@@ -55,6 +55,13 @@ def _oracle_rate(env_id, n_envs, seconds_target, max_steps=None):
     from oracle.oracle import Oracle, PARAM_AUTO_RESET
     from mocca_envs_amd.vec_env import TASKS, compile_model_for
     orc = Oracle(compile_model_for(env_id).to_bytes(), TASKS[env_id], n_envs, "f32")
+    if "Planner" in env_id:     # the planner envs stand on the height field
+        from mocca_envs_amd.terrain import load_height_field
+        orc.set_heightfield(*load_height_field())
+    if "Phase" in env_id:       # the Cassie mocap / phase envs read their reference motion
+        from mocca_envs_amd.trajectory import CassieTrajectory
+        tr = CassieTrajectory()
+        orc.set_trajectory(tr.table(), tr.max_time(), 0.03)
     orc.set_param(PARAM_AUTO_RESET, 1)
     orc.reset(seed=0)
     tape = np.random.default_rng(0).uniform(-1, 1, (64, n_envs, orc.act_dim)).astype(np.float32)
