@@ -29,7 +29,9 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: s
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     # -fno-slp-vectorize: the SLP vectoriser pairs scalar fp32 ops into v_pk_* but pays ~2 v_mov per pair to line
     # up register pairs; measured on this kernel it ADDS 12 % VALU instructions
-    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-I" + INCLUDE, "-I" + CSRC] + list(extra_flags)
+    # MOCCA_HIPCC_FLAGS: extra compiler flags for experiments (e.g. "-mllvm -amdgpu-sched-strategy=max-ilp"); never set for the product build
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-I" + INCLUDE, "-I" + CSRC] + list(extra_flags) \
+        + os.environ.get("MOCCA_HIPCC_FLAGS", "").split()
     if verbose:
         base.insert(1, "-Rpass-analysis=kernel-resource-usage")
     objdir = os.path.join(HERE, "build") if out is None else out + ".objs"
