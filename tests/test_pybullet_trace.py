@@ -11,7 +11,10 @@ file turns that statement into numbers:
     and through libmocca_hip.so (GPU, -m gpu), warm-started from the contact impulses Bullet reported for the frame before; the
     one-step joint-state error against Bullet is bounded by the north star's 1e-4;
   * free running (the north star's wording: "joint state within 1e-4 of PyBullet over 1000 steps"): the recorded action sequence
-    is replayed from the recorded initial state with no correction, and the joint-state error is reported at steps 1 / 10 / 100 / 1000."""
+    is replayed from the recorded initial state with no correction, and the joint-state error is reported at steps 1 / 10 / 100 / 1000;
+  * stepping stones (BASELINE config 2): the teacher-forced trace on three planks placed the way Walker3DStepperEnv places them.
+The dump tool itself is executed here too, against tests/fake_pybullet.py (PyBullet's API and conventions over the f64 oracle), and the
+file it writes goes through the same branches."""
 import os
 
 import numpy as np
