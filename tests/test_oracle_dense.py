@@ -137,6 +137,20 @@ def test_substep_on_the_height_field():
             np.testing.assert_allclose(n_o, n_d, atol=1e-7)
             worst = max(worst, 1 - n_o[2])
     assert worst > 0.05                                               # slopes were really met
+    # the 2 x 2-cell search against a 4 x 4-cell one (every triangle a sphere of up to 16 cm of reach can touch): on the shipped map the
+    # nearer window never misses the closest triangle, for any of the robots' sphere radii
+    n_contacts = 0
+    for k in range(2500):
+        xy = rng.uniform(-15.5, 15.5, 2)
+        h = data[min(127, max(0, int((xy[1] + 16) * 4))), min(127, max(0, int((xy[0] + 16) * 4)))]
+        rad = rng.choice([0.045, 0.09, 0.11, 0.14])
+        C = np.array([xy[0], xy[1], h + rad + rng.uniform(-0.03, 0.03)])
+        g1, _ = D.heightfield_gap(data.astype(np.float64), scale, C, rad, window=1)
+        if g1 < 0.02:
+            n_contacts += 1
+            g2, _ = D.heightfield_gap(data.astype(np.float64), scale, C, rad, window=2)
+            assert abs(g1 - g2) < 1e-9, (k, C, rad, g1, g2)
+    assert n_contacts > 1500
     rows = []
     for k in range(8):
         row = _random_state(rng, m, 0.0, spread=0.5)
