@@ -853,6 +853,13 @@ CASSIE_KP = np.array([100, 100, 88, 96, 50, 100, 100, 88, 96, 50, 400, 400]) / 1
 
 
 CASSIE_PLAIN, CASSIE_PHASE_MOCCA, CASSIE_PHASE_MIRROR = 0, 1, 2   # MoccaModel.cassie_mode (include/mocca_model.h)
+# Cassie2D (env_cassie.py:279-282) loads cassie_collide_2d.urdf.  The class's path (data/cassie/urdf/) does not exist in the reference's
+# tree; the file it means lies beside the 3-D one, data/robots/cassie/urdf/cassie_collide_2d.urdf.  It differs from cassie_collide.urdf in
+# two ways only: (1) a massless chain  world-fixed root -prismatic z-> -prismatic x-> -continuous y-> pelvis  (:449-468) in place of the
+# floating base -- the pelvis keeps x, z and pitch, which is what the three planar rows of this blob enforce (MoccaModel.planar); (2) the
+# limits of both hips' abduction and rotation joints shrink to +-0.01 rad (:479,486,535,542), which holds the legs in the sagittal plane.
+CASSIE_2D_LIMITS = {"hip_abduction_left": (-0.01, 0.01), "hip_rotation_left": (-0.01, 0.01),
+                    "hip_abduction_right": (-0.01, 0.01), "hip_rotation_right": (-0.01, 0.01)}
 
 
 def compile_cassie(planar: bool = False, power_coef: float = 1.0, residual_control: bool = True, mode: int = CASSIE_PLAIN,
@@ -892,6 +899,8 @@ def compile_cassie(planar: bool = False, power_coef: float = 1.0, residual_contr
             else:
                 lo = j["lower"] if j["lower"] is not None else -1e30
                 hi = j["upper"] if j["upper"] is not None else 1e30
+                if planar and j["name"] in CASSIE_2D_LIMITS:
+                    lo, hi = CASSIE_2D_LIMITS[j["name"]]
                 bodies.append(dict(name=j["name"], parent=body, jpos=tj, jrot=Rj, axis=np.asarray(j["axis"], float),
                                    lo=lo, hi=hi, parts=[], points=[], links={}))
                 visit(j["child"], len(bodies) - 1, np.eye(3), np.zeros(3))

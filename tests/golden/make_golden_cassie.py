@@ -72,6 +72,9 @@ class FakeBulletCassie:
         info = [None] * 17
         lo = jj["lower"] if jj["lower"] is not None else 0.0
         hi = jj["upper"] if jj["upper"] is not None else -1.0
+        if self.m.planar:                            # cassie_collide_2d.urdf: the four hip roll / yaw limits are +-0.01 rad
+            from mocca_envs_amd.model import CASSIE_2D_LIMITS
+            lo, hi = CASSIE_2D_LIMITS.get(jj["name"], (lo, hi))
         info[0], info[1], info[8], info[9], info[12] = j, jj["name"].encode(), lo, hi, jj["child"].encode()
         return tuple(info)
 

@@ -56,6 +56,33 @@ def test_pd_loop_and_closures_over_an_episode():
     assert o.last_rows() >= 6                        # 2 closures x 3 rows always present
 
 
+def test_planar_cassie_takes_the_2d_urdfs_hip_limits():
+    """Cassie2D (env_cassie.py:279-282) means data/robots/cassie/urdf/cassie_collide_2d.urdf: its planar root joints are this blob's three
+    planar rows, and the limits of hip abduction / rotation are +-0.01 rad on both sides (:479,486,535,542 of that file) -- everything else
+    equals the 3-D file.  The nominal pose (0.0356, -0.0135) starts outside them; the limit rows bring the joints back and hold them."""
+    m3, m2 = M.compile_cassie(), M.compile_cassie(planar=True)
+    names = M.CASSIE_ORDERED_JOINTS
+    for k, n in enumerate(names):
+        b = m2.ordered_body[k]
+        if n in M.CASSIE_2D_LIMITS:
+            assert (round(m2.jlo[b], 6), round(m2.jhi[b], 6)) == (-0.01, 0.01)
+            assert m3.jhi[b] - m3.jlo[b] > 0.6
+        else:
+            assert (m2.jlo[b], m2.jhi[b]) == (m3.jlo[b], m3.jhi[b])
+    assert sum(n in M.CASSIE_2D_LIMITS for n in names) == 4
+    o = Oracle(m2.to_bytes(), M.TASK_CASSIE, 1, "f64")
+    o.reset(seed=0)
+    roll_yaw = [k for k, n in enumerate(names) if n in M.CASSIE_2D_LIMITS]
+    for t in range(6):
+        obs, _, done, _ = o.step(np.zeros((1, 10), np.float32))
+        st = o.get_state()[0]
+        q = np.array([st[13 + m2.ordered_body[k] - 1] for k in roll_yaw])
+        assert np.abs(q).max() < 0.012, (t, q)       # one control step (50 substeps at erp 0.9) is enough to be inside
+        assert abs(st[1]) < 1e-6                     # and the pelvis stays in the y = 0 plane
+        if done[0]:
+            break
+
+
 def test_cassie_task_logic_matches_the_reference_code():
     """tests/golden/make_golden_cassie.py ran the reference's real Cassie / CassieEnv methods (with the missing
     imports supplied) over THIS oracle's physics; the oracle's own step must then reproduce them: PD loop, joint

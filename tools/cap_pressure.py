@@ -2,7 +2,7 @@
   Runs each env id with the debug record attached (MOCCA_DBG_CAP_*: cumulative per (env, substep)) after an
 untimed pre-roll, and prints one JSON line per env id: fraction of substeps in which contacts / rows were dropped, fraction of envs
 that ever hit a cap, the largest row count an uncapped solver would have held, and the row-count distribution of the last substeps.
-usage: python tools/cap_pressure.py [steps] > profiles/r03_cap_pressure.jsonl"""
+usage: python tools/cap_pressure.py [steps [env_id]] > profiles/r03_cap_pressure.jsonl"""
 import json
 import os
 import sys
@@ -18,7 +18,10 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 CASES = [("Walker3DCustomEnv-v0", 4096, None, 1.0), ("Walker3DStepperEnv-v0", 4096, 0, 1.0), ("Walker3DStepperEnv-v0", 4096, 9, 1.0),
          ("LaikagoCustomEnv-v0", 4096, None, 1.0), ("CassieEnv-v0", 2048, None, 0.1), ("CassieEnv-v0", 2048, None, 1.0),
          ("Cassie2DEnv-v0", 2048, None, 0.1)]
+only = sys.argv[2] if len(sys.argv) > 2 else None     # optional: one env id
 for env_id, n, cur, scale in CASES:
+    if only and env_id != only:
+        continue
     env = VecEnv(env_id, n, auto_reset=True, seed=1000)
     if cur is not None:
         env.set_param(2, cur)
