@@ -33,7 +33,9 @@ def build(force: bool = False) -> None:
 
 def _load(precision: str) -> C.CDLL:
     path = os.path.join(_HERE, f"liboracle_{precision}.so")
-    if not os.path.exists(path):
+    if os.environ.get("MOCCA_ORACLE_SANITIZED"):     # tools/sanitize_oracle.sh: the ASan / UBSan build of the same source
+        path = os.path.join(_HERE, "_san", f"liboracle_{precision}.so")
+    elif not os.path.exists(path):
         build()
     lib = C.CDLL(path)
     lib.orc_create.restype = C.c_void_p
