@@ -130,7 +130,7 @@ class EnvBase(gym.Env):
             self._vec.set_terrain(torch.from_numpy(np.asarray(terrain, np.float32)[None]))
 
     def _pull_robot(self):
-        st = self._vec.get_state()[0].cpu().numpy()
+        st = self._img["state"][0]      # the host image of the last step_host / observe_host / reset_host (one download per call)
         nj = self.model.n_joints
         self.robot.body_xyz = st[0:3].astype(np.float64)
         self.robot.joint_angles = st[13:13 + nj].copy()
@@ -140,10 +140,12 @@ class EnvBase(gym.Env):
         import torch
         action = np.asarray(action, dtype=np.float64)
         assert np.isfinite(action).all()  # robots.py:32
-        a = torch.from_numpy(action.astype(np.float32)[None])
-        obs, rew, done, info = self._vec.step(a)
-        return (obs[0].cpu().numpy().astype(np.float64), float(rew[0].item()), bool(int(done[0].item()) & 1),
-                int(info[0].item()))
+        img = self._img = self._vec.step_host(action.astype(np.float32)[None])
+        return img["obs"][0].astype(np.float64), float(img["rew"][0]), bool(int(img["done"][0]) & 1), int(img["info"][0])
+
+    def _observe(self):
+        self._img = self._vec.observe_host()
+        return self._img["obs"][0].astype(np.float64)
 
 
 class Walker3DCustomEnv(EnvBase):
@@ -180,7 +182,7 @@ class Walker3DCustomEnv(EnvBase):
         task = H.task_record(walk_target=self.walk_target, stop_frames=self.stop_frames, dist=self.dist, angle=self.angle,
                              mirrored=int(self.robot.mirrored), episode=self._episode)
         self._push(H.initial_state(self.model, q), task)
-        obs = self._vec.observe()[0].cpu().numpy().astype(np.float64)
+        obs = self._observe()
         self._pull_robot()
         return obs
 
@@ -188,13 +190,13 @@ class Walker3DCustomEnv(EnvBase):
         from .vec_env import task_to_float64, task_from_float64
         obs, rew, done, _ = self._step_device(action)
         self._pull_robot()
-        tk = task_to_float64(self._vec.get_task())[0]
+        tk = task_to_float64(self._img["task"])[0]
         self.walk_target, self.close_count = tk[0:3].copy(), int(tk[5])
         if self.close_count >= self.stop_frames:  # env_locomotion.py:214-222, host RandomState like the reference
             self.close_count = 0
             self.dist, self.angle, self.stop_frames = H.randomize_target(self.np_random, self.eval_mode)
             self.walk_target = self.walk_target + self.dist * np.array([np.cos(self.angle), np.sin(self.angle), 0.0])
-            st = self._vec.get_state()[0].cpu().numpy().astype(np.float64)
+            st = self._img["state"][0].astype(np.float64)
             yaw = H.yaw_from_quat(*st[3:7])
             dx, dy = self.walk_target[0] - st[0], self.walk_target[1] - st[1]
             ang, dist = np.arctan2(dy, dx) - yaw, np.hypot(dx, dy)
@@ -310,7 +312,7 @@ class Walker3DStepperEnv(EnvBase):
                              mirrored=int(self.robot.mirrored), episode=self._episode, draw=122)
         self._vec.set_param(2, cur)
         self._push(H.initial_state(self.model, q), task, terrain)
-        obs = self._vec.observe()[0].cpu().numpy().astype(np.float64)
+        obs = self._observe()
         self._pull_robot()
         return obs
 
@@ -318,7 +320,7 @@ class Walker3DStepperEnv(EnvBase):
         self.timestep += 1
         if self.random_reward:   # np_random.uniform(0.8, 1.2, 8), :533-535: drawn here, handed to the kernel in task words 30..37
             from .vec_env import task_to_float64, task_from_float64
-            tk = task_to_float64(self._vec.get_task())
+            tk = task_to_float64(self._img["task"])
             tk[0, 30:38] = self.np_random.uniform(0.8, 1.2, 8)
             self._vec.set_task(task_from_float64(tk))
         cur = min(int(self.curriculum), self.max_curriculum)
@@ -414,7 +416,7 @@ class Walker3DPlannerEnv(EnvBase):
         self._episode = getattr(self, "_episode", -1) + 1
         task = H.task_record(walk_target=self.walk_target.astype(np.float64), mirrored=int(self.robot.mirrored), episode=self._episode)
         self._push(H.initial_state(self.model, q), task)
-        obs = self._vec.observe()[0].cpu().numpy().astype(np.float64)
+        obs = self._observe()
         self.robot_state = obs[:self.robot_obs_dim].copy()
         self._pull_robot()
         return obs
@@ -475,18 +477,18 @@ class CassieEnv(EnvBase):
         import torch
         self.done = False
         self.walk_target = np.array([1000.0, 0.0, 0.0])
-        obs = self._vec.reset()[0].cpu().numpy().astype(np.float64)   # deterministic: nominal pose at rest
-        self.robot.body_xyz = self._vec.get_state()[0, 0:3].cpu().numpy().astype(np.float64)
-        return obs
+        img = self._img = self._vec.reset_host()                      # deterministic: nominal pose at rest
+        self.robot.body_xyz = img["state"][0, 0:3].astype(np.float64)
+        return img["obs"][0].astype(np.float64)
 
     def step(self, a):
         import torch
         a = np.asarray(a, dtype=np.float64)
         assert np.isfinite(a).all()  # env_cassie.py:226
-        obs, rew, done, _ = self._vec.step(torch.from_numpy(a.astype(np.float32)[None]))
-        self.robot.body_xyz = self._vec.get_state()[0, 0:3].cpu().numpy().astype(np.float64)
-        self.done = bool(int(done[0].item()) & 1)
-        return obs[0].cpu().numpy().astype(np.float64), float(rew[0].item()), self.done, {}
+        img = self._img = self._vec.step_host(a.astype(np.float32)[None])
+        self.robot.body_xyz = img["state"][0, 0:3].astype(np.float64)
+        self.done = bool(int(img["done"][0]) & 1)
+        return img["obs"][0].astype(np.float64), float(img["rew"][0]), self.done, {}
 
 
 class CassieMoccaEnv(CassieEnv):
@@ -538,10 +540,11 @@ class CassieMoccaEnv(CassieEnv):
         # the kernel's reset takes floor(10000 u) of the episode's first uniform as istep: hand it the one that gives `istep`
         tape = torch.tensor([[(int(istep) + 0.5) / 10000.0]], dtype=torch.float32)
         self._vec.set_draw_tape(tape)
-        obs = self._vec.reset()[0].cpu().numpy().astype(np.float64)
+        img = self._img = self._vec.reset_host()
+        obs = img["obs"][0].astype(np.float64)
         self._vec.set_draw_tape(None)
         self.istep = int(istep) if self.rsi else 0
-        self.robot.body_xyz = self._vec.get_state()[0, 0:3].cpu().numpy().astype(np.float64)
+        self.robot.body_xyz = img["state"][0, 0:3].astype(np.float64)
         return obs[: self._obs_dim]
 
     def step(self, a):

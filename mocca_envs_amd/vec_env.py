@@ -293,6 +293,63 @@ class VecEnv:
                                        C.c_void_p(self.info.data_ptr()), self._stream()), self.h)
         return self.obs, self.rew, self.done, self.info
 
+    # ---- host-side callers (the single-env gym classes; a trainer that lives on the host) ----
+    def host_mirror(self) -> dict:
+        """Lay obs / rew / info / state / task / done out in ONE device buffer with ONE pinned host image, so that a caller on the host
+        pays one upload, one download and one synchronize per step (`step_host`) instead of one blocking copy per quantity.  The
+        tensors `obs`, `rew`, `done`, `info` become views into that buffer.  Returns the numpy views of the host image."""
+        if getattr(self, "_host_np", None) is not None:
+            return self._host_np
+        n = self.n_envs
+        parts = [("obs", n * self.obs_dim, torch.float32, np.float32, (n, self.obs_dim)), ("rew", n, torch.float32, np.float32, (n,)),
+                 ("info", n, torch.int32, np.int32, (n,)), ("state", n * self.state_dim, torch.float32, np.float32, (n, self.state_dim)),
+                 ("task", n * M.TASK_WORDS, torch.int32, np.int32, (n, M.TASK_WORDS))]
+        words = sum(p[1] for p in parts)
+        total = 4 * words + ((n + 3) // 4) * 4
+        self._pack = torch.zeros(total, dtype=torch.uint8, device=self.device)
+        self._pack_host = torch.zeros(total, dtype=torch.uint8).pin_memory()
+        host = self._pack_host.numpy()
+        dev, hnp, off = {}, {}, 0
+        for name, cnt, tdt, ndt, shape in parts:
+            dev[name] = self._pack[off:off + 4 * cnt].view(tdt).view(*shape)
+            hnp[name] = host[off:off + 4 * cnt].view(ndt).reshape(shape)
+            off += 4 * cnt
+        dev["done"], hnp["done"] = self._pack[off:off + n], host[off:off + n]
+        dev["obs"].copy_(self.obs); dev["rew"].copy_(self.rew); dev["info"].copy_(self.info); dev["done"].copy_(self.done)
+        self.obs, self.rew, self.info, self.done = dev["obs"], dev["rew"], dev["info"], dev["done"]
+        self._dev_views = dev
+        self._act_host = torch.zeros(n, self.act_dim, dtype=torch.float32).pin_memory()
+        self._act_dev = torch.zeros(n, self.act_dim, dtype=torch.float32, device=self.device)
+        self._host_np = hnp
+        return hnp
+
+    def _download(self) -> dict:
+        d = self._dev_views
+        _lib.check(self.lib.mocca_get_state(self.h, C.c_void_p(d["state"].data_ptr()), self._stream()), self.h)
+        _lib.check(self.lib.mocca_get_task(self.h, C.c_void_p(d["task"].data_ptr()), self._stream()), self.h)
+        self._pack_host.copy_(self._pack, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return self._host_np
+
+    def step_host(self, actions_np) -> dict:
+        """step() for a caller on the host: float32 actions [n_envs, act_dim] in, the host image (obs, rew, done, info AND the state /
+        task records after the step) out -- valid until the next call.  One synchronize."""
+        hnp = self.host_mirror()
+        self._act_host.numpy()[...] = actions_np
+        self._act_dev.copy_(self._act_host, non_blocking=True)
+        self.step(self._act_dev)
+        return self._download()
+
+    def reset_host(self) -> dict:
+        self.host_mirror()
+        self.reset()
+        return self._download()
+
+    def observe_host(self) -> dict:
+        self.host_mirror()
+        self.observe()
+        return self._download()
+
     def observe(self) -> torch.Tensor:
         """calc_state() + observation tail of the current state, no stepping (include/mocca.h mocca_observe)."""
         _lib.check(self.lib.mocca_observe(self.h, C.c_void_p(self.obs.data_ptr()), self._stream()), self.h)
@@ -342,7 +399,7 @@ TASK_FLOAT_WORDS = (0, 1, 2, 3, 4, 6, 12, 13, 14, 15, 21, 22) + tuple(range(24, 
 
 def task_to_float64(t: torch.Tensor) -> np.ndarray:
     """int32 view of the device task record -> float64 array in the oracle's get_task() layout."""
-    a = t.cpu().numpy().astype(np.int32)
+    a = (t.cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)).astype(np.int32)
     out = a.astype(np.float64)
     fl = a.view(np.float32)
     for w in TASK_FLOAT_WORDS:

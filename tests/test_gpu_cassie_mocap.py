@@ -32,7 +32,9 @@ def test_recorded_episodes_replay_on_the_gpu(tag):
     from mocca_envs_amd.vec_env import VecEnv, task_to_float64, task_from_float64
     env = VecEnv(IDS[tag], REPL, auto_reset=False, seed=0)
     assert (env.obs_dim, env.act_dim) == (42, 10)
-    errs = []
+    o32 = _oracle_for(env, 1)                # the yardstick: the SAME teacher-forced step in fp32 on the CPU, against the f64 recording
+    o32.reset(seed=0)
+    errs, yard = [], []
     for ep in range(3):
         istep0 = int(G[f"{tag}_ep{ep}_istep0"])
         env.set_draw_tape(np.full((REPL, 1), (istep0 + 0.5) / 10000.0, np.float32))   # np_random.randint(0, 10000) of the recording
@@ -59,22 +61,29 @@ def test_recorded_episodes_replay_on_the_gpu(tag):
             assert (o == o[0]).all() and (r == r[0]).all() and (d == d[0]).all()       # every wave produces the same bits
             want = gobs[t + 1]
             errs.append(np.abs(o[0] - want) / (1e-3 + 1e-3 * np.abs(want)))
+            so = o32.get_state(); so[:] = 0; so[0, : len(G[f"{tag}_ep{ep}_state"][t])] = G[f"{tag}_ep{ep}_state"][t]; o32.set_state(so)
+            to = o32.get_task(); to[0, 24:38] = G[f"{tag}_ep{ep}_jvel"][t]; to[0, 39] = G[f"{tag}_ep{ep}_istep"][t]; to[0, 7] = 0
+            o32.set_task(to)
+            yard.append(np.abs(o32.step(a[None].astype(np.float32))[0][0] - want) / (1e-3 + 1e-3 * np.abs(want)))
             # exact entries: the two phases (f64 time arithmetic in the kernel) -- also proves the mirrored layout was chosen alike
             np.testing.assert_allclose(o[0, 40:42], want[40:42], atol=1e-6)
-            # 50 stiff fp32 iterations from an f64 state; the finite-difference joint speeds (26..39) divide by 0.03.  The bound is for the
-            # rare step in which fp32 rounding flips one clamp of one of the 50 solves (the f32 ORACLE has such a step too: 6.3e-3 at
-            # mocca ep1 t4, where the kernel has 6.4e-3; the kernel's own is 1.3e-2 on a knee speed of 3.85 at ep0 t9 --
-            # profiles/r03_mocap_step_probe.txt); the typical step is 4e-5 (the median bound below), and outliers are counted
-            np.testing.assert_allclose(o[0], want, atol=3e-3, rtol=3e-3, err_msg=f"{tag} ep{ep} t{t}")
+            # 50 stiff fp32 iterations from an f64 state; the finite-difference joint speeds (26..39) divide by 0.03: bounded below, against
+            # what the fp32 oracle loses on the same steps
             assert abs(float(r[0]) - G[f"{tag}_ep{ep}_rew"][t]) < 1e-3, (ep, t, float(r[0]), G[f"{tag}_ep{ep}_rew"][t])
             assert bool(int(d[0]) & 1) == bool(G[f"{tag}_ep{ep}_done"][t]), (ep, t)
             assert int(task_to_float64(env.get_task())[0, 39]) == G[f"{tag}_ep{ep}_istep"][t + 1]
     e = np.concatenate(errs)
     print(f"\n{tag}: GPU vs reference-code-over-f64-oracle, one env.step: median {np.median(e):.3g} p99 {np.percentile(e, 99):.3g} "
           f"max {e.max():.3g} units of 1e-3 (1 + |x|)")
-    assert np.median(e) < 0.05 and e.max() < 3.0
-    per_step = np.array([x.max() for x in errs])
-    assert (per_step > 0.5).sum() <= 2, per_step           # of ~42 steps: the flips named above, nothing systematic
+    # The typical step is 4e-5 absolute (0.04 units).  In a rare step fp32 rounding flips one clamp of one of the 50 solves, on EITHER
+    # implementation (profiles/r03_mocap_step_probe.txt: the f32 oracle is 6.3e-3 = 5.2 units from the recording at mocca ep1 t4, where the
+    # kernel is 6.4e-3; the kernel has one of its own, 1.3e-2 = 2.6 units on a knee speed of 3.85, at ep0 t9).  So: median and count of
+    # outlier steps bounded absolutely, the worst step against 3 x the fp32 yardstick's worst step.
+    per_step, y = np.array([x.max() for x in errs]), np.array([x.max() for x in yard])
+    print(f"   f32 oracle on the same steps: median {np.median(np.concatenate(yard)):.3g} worst step {y.max():.3g}; kernel worst step {per_step.max():.3g}")
+    assert np.median(e) < 0.05 and np.median(e) < 3 * max(np.median(np.concatenate(yard)), 0.01)
+    assert per_step.max() < max(3.0, 3 * y.max()), (per_step.max(), y.max())
+    assert (per_step > 0.5).sum() <= max(2, 2 * int((y > 0.5).sum())), per_step   # of ~42 steps: the flips, nothing systematic
     env.close()
 
 

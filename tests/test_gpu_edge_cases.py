@@ -409,3 +409,25 @@ def test_abi_errors_of_the_planner_task_and_the_massive_instances():
     first = obs.flatten()[:4 * 52].reshape(4, 52)             # the library writes rows of obs_dim = 52 floats
     assert torch.isfinite(first).all() and torch.isfinite(rew).all() and (first[:, 0] > 1.0).all()     # standing: relative height ~1.2
     lib.mocca_destroy(h)
+
+
+@pytest.mark.parametrize("env_id,n", [("Walker3DStepperEnv-v0", 37), ("CassieEnv-v0", 5)])
+def test_host_image_equals_the_separate_reads(env_id, n):
+    """VecEnv.step_host / reset_host / observe_host (one upload, one download, one synchronize per call -- what the single-env gym classes
+    and a host-side trainer use): the pinned host image holds the same bits as step() + get_state() + get_task() read one by one."""
+    import torch
+    from mocca_envs_amd.vec_env import VecEnv
+    a_env, b_env = VecEnv(env_id, n, auto_reset=True, seed=11), VecEnv(env_id, n, auto_reset=True, seed=11)
+    img = b_env.reset_host()
+    np.testing.assert_array_equal(a_env.reset().cpu().numpy(), img["obs"])
+    np.testing.assert_array_equal(a_env.get_state().cpu().numpy(), img["state"])
+    rng = np.random.default_rng(3)
+    for t in range(30):
+        a = rng.uniform(-1, 1, (n, a_env.act_dim)).astype(np.float32)
+        o, r, d, i = a_env.step(torch.from_numpy(a).cuda())
+        img = b_env.step_host(a)
+        for want, key in ((o, "obs"), (r, "rew"), (d, "done"), (i, "info"), (a_env.get_state(), "state"), (a_env.get_task(), "task")):
+            np.testing.assert_array_equal(want.cpu().numpy(), img[key], err_msg=f"{key} t{t}")
+        assert b_env.obs.data_ptr() == b_env._dev_views["obs"].data_ptr()          # the public tensors are views of the packed buffer
+    np.testing.assert_array_equal(a_env.observe().cpu().numpy(), b_env.observe_host()["obs"])
+    a_env.close(); b_env.close()
