@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define MOCCA_MODEL_MAGIC 0x41434F4Du /* "MOCA" */
-#define MOCCA_MODEL_VERSION 12u
+#define MOCCA_MODEL_VERSION 13u
 
 #define MOCCA_MAX_BODIES 24
 #define MOCCA_MAX_GEOMS 32
@@ -134,8 +134,8 @@ typedef struct MoccaModel {
   int32_t n_iters;      /* 5 */
   float erp;            /* 0.9  setDefaultContactERP */
   float contact_margin; /* contacts exist below this gap */
-  float lin_damp;       /* base linear damping  */
-  float ang_damp;       /* base angular damping */
+  float lin_damp;       /* link damping, btMultiBody m_linearDamping: every body (base and links) is dragged by m v (k + k |v|) through its COM */
+  float ang_damp;       /* ... and by the torque Ic w (k + k |w|), m_angularDamping (v13; up to v12: base only, k only)                       */
   float max_qd;         /* joint velocity clamp */
   float warmstart;      /* 0.85; 0 disables */
   float ground_friction;/* 0.8  bullet_utils.py:371 */

@@ -525,12 +525,20 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
       // gravity through the COM
       const float fz = -M->gravity * ms;
       p[0] -= cw[1] * fz; p[1] -= -cw[0] * fz; p[5] -= fz;
-      if (b == 0) {  // base damping [UNVERIFIED-BULLET], see oracle aba()
-        float om[3] = {v[0], v[1], v[2]}, Iom[3];
+      {  // link damping of btMultiBody, base and every link [UNVERIFIED-BULLET], see oracle aba(): force m vc (k + k |vc|) through the
+         // COM, torque Ic w (k + k |w|)
+        float om[3] = {v[0], v[1], v[2]}, Iom[3], wxc[3], F[3], cxF[3];
         float Iwf[9] = {Iw[0], Iw[1], Iw[2], Iw[1], Iw[4], Iw[5], Iw[2], Iw[5], Iw[8]};
         matvec3(Iwf, om, Iom);
+        cross3(om, cw, wxc);
+        float vc[3] = {v[3] + wxc[0], v[4] + wxc[1], v[5] + wxc[2]};
+        const float kl = unif(M->lin_damp) * ms * (1.0f + __builtin_sqrtf(dot3(vc, vc)));
+        const float ka = unif(M->ang_damp) * (1.0f + __builtin_sqrtf(dot3(om, om)));
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { p[i] += M->ang_damp * Iom[i]; p[3 + i] += M->lin_damp * ms * v[3 + i]; }
+        for (int i = 0; i < 3; ++i) F[i] = kl * vc[i];
+        cross3(cw, F, cxF);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { p[i] += ka * Iom[i] + cxF[i]; p[3 + i] += F[i]; }
       }
 #pragma unroll
       for (int i = 0; i < 6; ++i)

@@ -29,7 +29,7 @@ MAX_PAIRS = 192
 MAX_FEET = 4
 MAX_SLOTS = 40
 MAGIC = 0x41434F4D
-VERSION = 12
+VERSION = 13
 
 GEOM_SPHERE, GEOM_CAPSULE = 0, 1
 TASK_WALKER3D_CUSTOM, TASK_WALKER3D_STEPPER, TASK_CASSIE, TASK_WALKER3D_PLANNER = 0, 1, 2, 3
@@ -650,7 +650,7 @@ def compile_model(
     m.n_iters = 5                   # bullet_utils.py:340
     m.erp = 0.9                     # bullet_utils.py:345
     m.contact_margin = 0.02         # [UNVERIFIED-BULLET] contact breaking threshold
-    m.lin_damp = 0.04               # [UNVERIFIED-BULLET] btMultiBody default
+    m.lin_damp = 0.04               # [UNVERIFIED-BULLET] btMultiBody default; applies to the base and to every link, with the quadratic term
     m.ang_damp = 0.04
     m.max_qd = 100.0                # [UNVERIFIED-BULLET] maxCoordinateVelocity
     m.warmstart = 0.85              # [UNVERIFIED-BULLET] m_warmstartingFactor

@@ -349,19 +349,31 @@ static void aba(const MoccaModel *m, const Dyn *s, const real *tau, Work *w, int
     }
   }
   if (with_bias) {
-    /* base damping: force -k m v through the base origin, torque -k Ic w  [UNVERIFIED-BULLET] */
-    real Il[9] = {m->inertia[0][0], m->inertia[0][3], m->inertia[0][4],
-                  m->inertia[0][3], m->inertia[0][1], m->inertia[0][5],
-                  m->inertia[0][4], m->inertia[0][5], m->inertia[0][2]};
-    real T[9], Rt[9], Iw[9], Iom[3];
-    matmul3(w->R[0], Il, T);
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) Rt[3 * i + j] = w->R[0][3 * j + i];
-    matmul3(T, Rt, Iw);
-    matvec3(Iw, s->omg, Iom);
-    for (int k = 0; k < 3; ++k) {
-      w->pA[0][k] += (real)m->ang_damp * Iom[k];
-      w->pA[0][3 + k] += (real)m->lin_damp * (real)m->mass[0] * s->vel[k];
+    /* Link damping of btMultiBody (computeAccelerationsArticulatedBodyAlgorithmMultiDof, "adding damping terms (only)"): the base AND
+     * every link carry a drag force  m v (k1 + k2 |v|)  through their COM (v = the COM's velocity) and a torque  Ic w (k1 + k2 |w|),
+     * with k1 = k2 = m_linearDamping (resp. m_angularDamping), both 0.04 by default.  Restated from the published source as recalled;
+     * [UNVERIFIED-BULLET] until a dump pins it.  (Rounds 1-3 early: base only, k1 only, force through the base origin.) */
+    for (int b = 0; b < nb; ++b) {
+      real ms = (real)m->mass[b];
+      real Il[9] = {m->inertia[b][0], m->inertia[b][3], m->inertia[b][4],
+                    m->inertia[b][3], m->inertia[b][1], m->inertia[b][5],
+                    m->inertia[b][4], m->inertia[b][5], m->inertia[b][2]};
+      real T[9], Rt[9], Iw[9], Iom[3], wxc[3], vc[3], F[3], tq[3], cxF[3];
+      matmul3(w->R[b], Il, T);
+      for (int i = 0; i < 3; ++i)
+        for (int jj = 0; jj < 3; ++jj) Rt[3 * i + jj] = w->R[b][3 * jj + i];
+      matmul3(T, Rt, Iw);
+      const real *om = w->v[b];
+      matvec3(Iw, om, Iom);
+      cross3(om, w->comw[b], wxc);
+      for (int k = 0; k < 3; ++k) vc[k] = w->v[b][3 + k] + wxc[k];
+      real kl = (real)m->lin_damp * (1 + (real)sqrt(dot3(vc, vc))), ka = (real)m->ang_damp * (1 + (real)sqrt(dot3(om, om)));
+      for (int k = 0; k < 3; ++k) { F[k] = kl * ms * vc[k]; tq[k] = ka * Iom[k]; }
+      cross3(w->comw[b], F, cxF);
+      for (int k = 0; k < 3; ++k) {
+        w->pA[b][k] += tq[k] + cxF[k];
+        w->pA[b][3 + k] += F[k];
+      }
     }
   }
   /* pass 2 */

@@ -215,9 +215,12 @@ def unconstrained_velocity(mdl: Model, st: State, tau):
         Q += Jc[b].T @ np.array([0, 0, -mdl.gravity * mdl.mass[b]])
     for b in range(1, mdl.nb):
         Q[5 + b] += tau[b] - mdl.jdamp[b] * st.qd[b]
-    Iw0 = R[0] @ mdl.Il[0] @ R[0].T
-    Q[0:3] -= mdl.ang_damp * (Iw0 @ st.omg)          # pure torque on the base
-    Q[3:6] -= mdl.lin_damp * mdl.mass[0] * st.vel    # force through the base origin
+    # link damping (btMultiBody: base and every link): force m vc (k + k |vc|) through the COM, torque Ic w (k + k |w|)
+    for b in range(mdl.nb):
+        Iw = R[b] @ mdl.Il[b] @ R[b].T
+        vc, wb = Jc[b] @ nu, Jw[b] @ nu
+        Q -= Jc[b].T @ (mdl.lin_damp * (1 + np.linalg.norm(vc)) * mdl.mass[b] * vc)
+        Q -= Jw[b].T @ (mdl.ang_damp * (1 + np.linalg.norm(wb)) * (Iw @ wb))
     return nu + mdl.dt * np.linalg.solve(M, Q - h), M
 
 
