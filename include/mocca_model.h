@@ -137,7 +137,7 @@ typedef struct MoccaModel {
   float lin_damp;       /* link damping, btMultiBody m_linearDamping: every body (base and links) is dragged by m v (k + k |v|) through its COM */
   float ang_damp;       /* ... and by the torque Ic w (k + k |w|), m_angularDamping (v13; up to v12: base only, k only)                       */
   float max_qd;         /* joint velocity clamp */
-  float warmstart;      /* 0.85; 0 disables */
+  float warmstart;      /* fraction of last substep's normal impulse a terrain contact starts from; 0 disables (the compiled models: 0, see model.py) */
   float ground_friction;/* 0.8  bullet_utils.py:371 */
   float plank_friction; /* 1.0  bullet_objects.py:68 */
   float plank_stiffness;/* 30000 */
@@ -224,7 +224,11 @@ typedef struct MoccaModel {
                                        MANIFOLD_CACHE_SIZE 4) [UNVERIFIED-BULLET], so Cassie's twelve hull points per toe (one convex
                                        mesh in cassie_collide.urdf) give 4 contacts, not 12: the deepest, the one farthest from it,
                                        and the two farthest to either side of the line through those two                              */
-  int32_t reserved_[7];
+  float erp_noncontact;             /* v13: error reduction of the rows that are not contacts -- joint limits, Cassie's point-to-point closures,
+                                       the planar-base rows.  Bullet: infoGlobal.m_erp (0.2; pybullet's setDefaultContactERP only sets m_erp2,
+                                       which the contact rows use): btMultiBodyConstraint::fillMultiBodyConstraint ("split impulse is not
+                                       implemented yet for btMultiBody*": erp = m_erp) and btMultiBodyJointLimitConstraint  [UNVERIFIED-BULLET] */
+  int32_t reserved_[6];
 
   /* ---- derived lookup tables (model.py finalize_tables): one 16-byte load instead of chains of dependent loads ---- */
   float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | terrain<<24 | (foot + 1)<<25 | torso<<28), bits(anc_mask[body]) */

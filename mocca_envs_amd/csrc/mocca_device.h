@@ -1526,7 +1526,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
     const float q = L[L_Q + b];
     const float gap = side == 0 ? q - M->jlo[b] : M->jhi[b] - q;
     kind = 0; jl = b; ba = b; sgn = side == 0 ? 1.0f : -1.0f;
-    bias = gap < 0 ? M->erp * (-gap) * idt : -gap * idt;
+    bias = gap < 0 ? M->erp_noncontact * (-gap) * idt : -gap * idt;
   } else if (T::NCLOS > 0 && r < nl + NCL) {
     // loop closure c, world axis ax: dir . (v(pivot a) - v(pivot b)) = erp (Pb - Pa)/dt, unbounded impulse
     const int c = (r - nl) / 3, ax = (r - nl) % 3;
@@ -1548,7 +1548,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
 #pragma unroll
     for (int x = 0; x < 3; ++x) { F2[x] = pn[x]; F2[3 + x] = dir[x]; }
     const float e = ax == 0 ? Pb[0] - Pa[0] : (ax == 1 ? Pb[1] - Pa[1] : Pb[2] - Pa[2]);
-    bias = M->erp * e * idt;
+    bias = M->erp_noncontact * e * idt;
   } else if (T::NCLOS > 0 && r < nl + NFIX) {
     // planar base: the base's y axis stays the world's (R e_y = e_y <=> omega_x = omega_z = 0) and y stays where it started;
     // small-angle error of R e_y = (u_x, u_y, u_z): delta_x = u_z, delta_z = -u_x
@@ -1558,7 +1558,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
 #pragma unroll
     for (int x = 0; x < 6; ++x) F[x] = x == comp ? 1.0f : 0.0f;
     const float err = k == 0 ? L[L_RT + 9] /* R[2][1] */ : (k == 1 ? -L[L_RT + 1] /* R[0][1] */ : L[L_BASE + 1] - M->init_pos[1]);
-    bias = -M->erp * err * idt;
+    bias = -M->erp_noncontact * err * idt;
   } else if (has_row) {
     const float* ct = L + L_CT + 16 * ci;
     float n[3] = {ct[C_N], ct[C_N + 1], ct[C_N + 2]}, P[3] = {ct[C_P], ct[C_P + 1], ct[C_P + 2]}, dir[3];

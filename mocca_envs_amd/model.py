@@ -158,7 +158,8 @@ class MoccaModel(C.Structure):
         ("target_range", C.c_float),
         ("fall_z", C.c_float),
         ("manifold_max", C.c_int32),
-        ("reserved_", C.c_int32 * 7),
+        ("erp_noncontact", C.c_float),
+        ("reserved_", C.c_int32 * 6),
         ("slot_tab", (C.c_float * 4) * MAX_SLOTS),
         ("gp_tab", (C.c_float * 4) * (2 * MAX_GEOMS)),
         ("pair_tab", (C.c_float * 4) * MAX_PAIRS),
@@ -648,12 +649,13 @@ def compile_model(
     m.dt = 1.0 / 240.0              # env_base.py:81 with env_locomotion.py:39-41
     m.n_substeps = 4                # env_locomotion.py:41
     m.n_iters = 5                   # bullet_utils.py:340
-    m.erp = 0.9                     # bullet_utils.py:345
+    m.erp = 0.9                     # bullet_utils.py:345: setDefaultContactERP = infoGlobal.m_erp2, the contact rows' ERP
+    m.erp_noncontact = ERP_NONCONTACT
     m.contact_margin = 0.02         # [UNVERIFIED-BULLET] contact breaking threshold
     m.lin_damp = 0.04               # [UNVERIFIED-BULLET] btMultiBody default; applies to the base and to every link, with the quadratic term
     m.ang_damp = 0.04
     m.max_qd = 100.0                # [UNVERIFIED-BULLET] maxCoordinateVelocity
-    m.warmstart = 0.85              # [UNVERIFIED-BULLET] m_warmstartingFactor
+    m.warmstart = WARMSTART
     m.ground_friction = 0.8         # bullet_utils.py:371
     set_stepper_params(m, plank_class=plank_class)   # plank geometry, terrain ranges, curricula (LargePlank: 0.5 x 10 x 0.25 m slab)
     m.limit_slack = 0.05
@@ -852,6 +854,17 @@ CASSIE_SPRINGS = [4, 11]                                                        
 CASSIE_KP = np.array([100, 100, 88, 96, 50, 100, 100, 88, 96, 50, 400, 400]) / 1.9  # env_cassie.py:292-317
 
 
+# Bullet defaults the reference never touches (bullet_utils.py:338-350 sets the time step, 5 iterations, 4 substeps and the CONTACT erp only),
+# restated from the published source as recalled  [UNVERIFIED-BULLET]:
+#  * rows that are not contacts (joint limits, point-to-point closures) take infoGlobal.m_erp = 0.2, not the contact ERP (m_erp2) that
+#    setDefaultContactERP(0.9) sets: btMultiBodyConstraint::fillMultiBodyConstraint ("split impulse is not implemented yet for
+#    btMultiBody*": erp = infoGlobal.m_erp), btMultiBodyJointLimitConstraint::createConstraintRows;
+#  * multibody contact rows do NOT warm start: btMultiBodyConstraintSolver::setupMultiBodyContactConstraint, "disable warmstarting for
+#    btMultiBody, it has issues gaining energy (==explosion)", `if (0)`; later versions gate it behind SOLVER_USE_ARTICULATED_WARMSTARTING,
+#    which pybullet's default solver mode does not contain.  (Rounds 1-3 early used 0.85, btContactSolverInfo's rigid-body factor.)
+ERP_NONCONTACT = 0.2
+WARMSTART = 0.0
+
 CASSIE_PLAIN, CASSIE_PHASE_MOCCA, CASSIE_PHASE_MIRROR = 0, 1, 2   # MoccaModel.cassie_mode (include/mocca_model.h)
 # Cassie2D (env_cassie.py:279-282) loads cassie_collide_2d.urdf.  The class's path (data/cassie/urdf/) does not exist in the reference's
 # tree; the file it means lies beside the 3-D one, data/robots/cassie/urdf/cassie_collide_2d.urdf.  It differs from cassie_collide.urdf in
@@ -979,8 +992,9 @@ def compile_cassie(planar: bool = False, power_coef: float = 1.0, residual_contr
             m.cl_point_b[k][i] = cb[i] + v
     # physics: env_cassie.py:287-289 control_step 0.03 / llc 50 / sim_frame_skip 1
     m.gravity, m.dt, m.n_substeps, m.n_iters, m.erp = 9.8, 0.03 / 50, 1, 5, 0.9
+    m.erp_noncontact = ERP_NONCONTACT   # the two point-to-point closures (btMultiBodyPoint2Point -> fillMultiBodyConstraint) and the limits
     m.n_llc = 50
-    m.contact_margin, m.lin_damp, m.ang_damp, m.max_qd, m.warmstart = 0.02, 0.04, 0.04, 100.0, 0.85
+    m.contact_margin, m.lin_damp, m.ang_damp, m.max_qd, m.warmstart = 0.02, 0.04, 0.04, 100.0, WARMSTART
     m.ground_friction = 0.8
     m.limit_slack, m.max_contacts, m.max_rows = 0.05, 12, 48
     # each toe is ONE convex mesh in cassie_collide.urdf: Bullet keeps at most 4 contact points per pair of collision objects
@@ -1108,7 +1122,8 @@ def compile_laikago(stepper: bool = False, plank_class: str = "LargePlank") -> M
     m.n_pairs = 0
     # physics: control_step 1/60, sim_frame_skip 8 (env_locomotion.py:856-858) -> 8 substeps of 1/480 s
     m.gravity, m.dt, m.n_substeps, m.n_iters, m.erp = 9.8, 1.0 / 480.0, 8, 5, 0.9
-    m.contact_margin, m.lin_damp, m.ang_damp, m.max_qd, m.warmstart = 0.02, 0.04, 0.04, 100.0, 0.85
+    m.erp_noncontact = ERP_NONCONTACT
+    m.contact_margin, m.lin_damp, m.ang_damp, m.max_qd, m.warmstart = 0.02, 0.04, 0.04, 100.0, WARMSTART
     m.ground_friction = 0.8
     m.limit_slack, m.max_contacts, m.max_rows = 0.05, 12, 48
     m.init_pos[0], m.init_pos[1], m.init_pos[2] = 0.0, 0.0, 0.56                      # env_locomotion.py:864

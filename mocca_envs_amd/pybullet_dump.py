@@ -114,6 +114,16 @@ def from_pybullet_dump(dump: Mapping[str, np.ndarray], template: M.MoccaModel, j
             raise ValueError(f"tree mismatch at {names[j]!r}: dump parent body {owner(parent[j])}, template {template.parent[b]}")
 
     out = M.MoccaModel.from_bytes(template.to_bytes())
+    # solver parameters of the recorded session (format >= 2 files written after round 3 carry getPhysicsEngineParameters())
+    if "engine_erp" in dump:
+        out.erp_noncontact = float(dump["engine_erp"])              # infoGlobal.m_erp: joint limits, point-to-point closures
+    if "engine_contactERP" in dump:
+        out.erp = float(dump["engine_contactERP"])                  # infoGlobal.m_erp2: contact rows (setDefaultContactERP)
+    if "engine_numSolverIterations" in dump:
+        out.n_iters = int(dump["engine_numSolverIterations"])
+    for key in ("rolling_friction", "spinning_friction", "restitution"):
+        if key in dump and np.abs(np.asarray(dump[key], float)).max() > 0:
+            raise ValueError(f"the dump reports non-zero {key} on a robot link: not modelled by this stepper (DESIGN.md section 9)")
     frame = {0: _T()}
     frame.update({b: L[j] for b, j in link_of.items()})
     # the template's base frame is the robot file's root BODY frame (DESIGN.md "Model assumptions"); Bullet's base frame is the

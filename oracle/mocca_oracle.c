@@ -830,7 +830,7 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
       for (int k = 0; k < nd; ++k) w->J[r][k] = 0;
       w->J[r][5 + b] = sgn;
       w->row_kind[r] = 0; w->row_normal[r] = -1; w->row_mu[r] = 0; w->row_slot[r] = -1;
-      w->bias[r] = gap < 0 ? (real)m->erp * (-gap) * idt : -gap * idt;
+      w->bias[r] = gap < 0 ? (real)m->erp_noncontact * (-gap) * idt : -gap * idt;
       w->cfm[r] = 0; w->lam[r] = 0;
     }
   }
@@ -846,7 +846,7 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
       int r = nr++;
       pair_jacobian(m, w, ba, Pa, bb, Pb, dir, w->J[r]);
       w->row_kind[r] = 3; w->row_normal[r] = -1; w->row_mu[r] = 0; w->row_slot[r] = -1;
-      w->bias[r] = (real)m->erp * (Pb[ax] - Pa[ax]) * idt; /* pull pivot a onto pivot b */
+      w->bias[r] = (real)m->erp_noncontact * (Pb[ax] - Pa[ax]) * idt; /* pull pivot a onto pivot b */
       w->cfm[r] = 0; w->lam[r] = 0;
     }
   }
@@ -862,7 +862,7 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
       for (int c = 0; c < nd; ++c) w->J[r][c] = 0;
       w->J[r][comp[k]] = 1;
       w->row_kind[r] = 3; w->row_normal[r] = -1; w->row_mu[r] = 0; w->row_slot[r] = -1;
-      w->bias[r] = -(real)m->erp * err[k] * idt;
+      w->bias[r] = -(real)m->erp_noncontact * err[k] * idt;
       w->cfm[r] = 0; w->lam[r] = 0;
       ++n_planar;
     }

@@ -88,6 +88,9 @@ def make_module(fixed_children=None):
     p.setGravity = lambda *a: None
     p.setDefaultContactERP = lambda v: None
     p.setPhysicsEngineParameter = lambda **k: None
+    p.getPhysicsEngineParameters = lambda: {"fixedTimeStep": float(blob.dt) * int(blob.n_substeps), "numSubSteps": int(blob.n_substeps),
+                                            "numSolverIterations": int(blob.n_iters), "erp": float(blob.erp_noncontact),
+                                            "contactERP": float(blob.erp), "frictionERP": 0.2, "useRealTimeSimulation": 0}
     p.changeDynamics = lambda *a, **k: None
     p.loadSDF = lambda f: (PLANE,)
     p.loadMJCF = lambda f, flags=0: (ROBOT,)

@@ -42,13 +42,18 @@ CASES = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("Walker3DStepper
          # scattered over the field after reset (the episodes start on its flat corner platform)
          ("Walker3DPlannerEnv-v0", M.TASK_WALKER3D_PLANNER, {}), ("MikePlannerEnv-v0", M.TASK_WALKER3D_PLANNER, {}),
          # Cassie with mass on the two links its URDF leaves without inertia: the TopoCassieMassive kernel instance
-         ("CassieEnv-v0", M.TASK_CASSIE, {"_massive": True})]
+         ("CassieEnv-v0", M.TASK_CASSIE, {"_massive": True}),
+         # the solver's warm-start path (the compiled blobs start from zero, as Bullet's multibody contacts do; a record may say otherwise)
+         ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_warm": 0.85}), ("CassieEnv-v0", M.TASK_CASSIE, {"_warm": 0.85})]
 
 
 def _one_substep_blob(env_id, **kw):
     from mocca_envs_amd.vec_env import compile_model_for
-    dump, massive = kw.pop("_dump", None), kw.pop("_massive", False)
+    dump, massive, warm = kw.pop("_dump", None), kw.pop("_massive", False), kw.pop("_warm", None)
     m = compile_model_for(env_id, **kw)
+    assert m.warmstart == 0.0
+    if warm is not None:
+        m.warmstart = warm
     if massive:
         n = 0
         for b in range(1, m.n_bodies):

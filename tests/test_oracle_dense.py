@@ -71,10 +71,16 @@ def _compare(orc, m, mdl, row, tau, planks=None, tol=2e-8, heightfield=None):
 
 
 @pytest.mark.parametrize("name,compile_fn,task,z", [("walker3d", M.compile_walker3d, 0, 0.25), ("laikago", M.compile_laikago, 0, 0.2),
-                                                    ("crab2d", M.compile_crab2d, 0, 0.3)])
+                                                    ("crab2d", M.compile_crab2d, 0, 0.3), ("walker3d-warm", M.compile_walker3d, 0, 0.25)])
 def test_substep_on_random_contact_states(name, compile_fn, task, z):
-    """Tumbling robots close to the ground: 3-12 contacts (terrain + self), limit rows, stale warm starts, the row cap."""
+    """Tumbling robots close to the ground: 3-12 contacts (terrain + self), limit rows, stale warm starts, the row cap.
+    "-warm": the compiled blobs start every impulse from zero (Bullet's multibody contacts do not warm start); the warm-start path of
+    the solver -- kept for a record that says otherwise -- is pinned with a blob that asks for 0.85 of last substep's normal impulse."""
     m = compile_fn()
+    if name.endswith("-warm"):
+        m.warmstart = 0.85
+    else:
+        assert m.warmstart == 0.0
     mdl = D.Model(m)
     orc = Oracle(m.to_bytes(), task, 1, "f64")
     orc.reset(seed=0)
@@ -87,7 +93,7 @@ def test_substep_on_random_contact_states(name, compile_fn, task, z):
         seen_rows.append(info["rows"]); seen_self += info["n_self"]; seen_cap += info["rows"] >= m.max_rows - 2
     print(f"\n{name}: rows per substep {seen_rows}, self contacts {seen_self}")
     assert max(seen_rows) >= 20
-    if name == "walker3d":
+    if name.startswith("walker3d"):
         assert seen_self > 0
 
 

@@ -61,9 +61,9 @@ def test_loader_reproduces_the_mechanism_in_bullets_frames():
         Ta, Tb = 0.5 * sa.nu() @ Ma @ sa.nu(), 0.5 * sb.nu() @ Mb @ sb.nu()
         assert abs(Ta - Tb) < 1e-5 * Ta
     # and the same dynamics through the oracle: ONE substep from contact-rich states (tumbling close to the ground: terrain and
-    # self contacts, limit rows), and a free-flight trajectory.  Base damping off: it acts at the base point, which moved.
-    for mm in (tmpl, m):
-        mm.lin_damp = mm.ang_damp = 0.0
+    # self contacts, limit rows), and a free-flight trajectory.  Link damping stays ON: btMultiBody's law acts on every link's COM velocity
+    # and angular velocity, which do not depend on where a blob puts its link frames (the base-point damping of blob <= v12 did).
+    assert tmpl.lin_damp > 0 and abs(m.lin_damp - tmpl.lin_damp) < 1e-9 and abs(m.erp_noncontact - tmpl.erp_noncontact) < 1e-9
     oa_, ob_ = Oracle(tmpl.to_bytes(), 0, 1, "f64"), Oracle(m.to_bytes(), 0, 1, "f64")
     oa_.reset(seed=1); ob_.reset(seed=1)
     from test_oracle_dense import _random_state
@@ -87,11 +87,18 @@ def test_loader_reproduces_the_mechanism_in_bullets_frames():
         w2 = qb[10:13] @ qb[10:13]
         np.testing.assert_allclose(mapped[7:10], qb[7:10], atol=1e-3 + 2.0 * tmpl.dt * w2 * np.linalg.norm(C0t))
     assert max(rows) >= 20
+    # free flight over 60 substeps, drag off: the two blobs carry different base POINTS through a first-order integrator (above), and
+    # drag would feed that O(dt) difference of the absolute velocities into the joints (1e-3 after 60 substeps)
+    for mm in (tmpl, m):
+        mm.lin_damp = mm.ang_damp = 0.0
+    oa_, ob_ = Oracle(tmpl.to_bytes(), 0, 1, "f64"), Oracle(m.to_bytes(), 0, 1, "f64")
+    oa_.reset(seed=1); ob_.reset(seed=1)
     s0 = _random_state(rng, tmpl, 3.0)
     oa_.set_state(s0[None].copy()); ob_.set_state(_map_state(s0, C0t, C0R, nj)[None].copy())
     for k in range(60):
         oa_.physics_substeps(0, tau, 1); ob_.physics_substeps(0, tau, 1)
-    np.testing.assert_allclose(oa_.get_state()[0][13:13 + 2 * nj], ob_.get_state()[0][13:13 + 2 * nj], atol=2e-5)
+    # 60 driven substeps: the fp32 rounding of the two blobs' numbers (1e-7 relative, different frames) grows along the trajectory
+    np.testing.assert_allclose(oa_.get_state()[0][13:13 + 2 * nj], ob_.get_state()[0][13:13 + 2 * nj], atol=1e-4)
 
 
 def test_loader_rejects_a_different_tree():

@@ -292,10 +292,22 @@ def test_the_harness_runs_on_a_synthetic_trace(synth):
 
 def test_warm_start_recovery_matters(synth):
     """Dropping the contact points (format 1 records had none) leaves the teacher-forced replay without Bullet's carried impulses:
-    the replay of the oracle's own trace is then no longer exact -- the reason the trace format records them."""
+    the replay of the oracle's own trace is then no longer exact -- the reason the trace format records them.
+    The compiled models no longer warm start (btMultiBody contact rows do not, model.py WARMSTART): for them the carried impulses are
+    inert.  A Bullet build that does warm start its multibody contacts (SOLVER_USE_ARTICULATED_WARMSTARTING) is the case the recovery
+    exists for: exercised here with a template whose blob says 0.85."""
     g, m = synth
+    assert m.warmstart == 0.0
     g1 = {k: v for k, v in g.items() if k != "contact_points"}
-    assert one_step_errors_oracle(g1, m).max() > 1e-6
+    assert one_step_errors_oracle(g1, m).max() < 1e-9          # nothing to carry
+    from pybullet_synth import synthetic_record
+    from mocca_envs_amd import model as M
+    tm = M.compile_walker3d()
+    tm.warmstart = 0.85
+    gw, mw = synthetic_record(template=tm, n_trace=40, n_free=2)
+    assert abs(mw.warmstart - 0.85) < 1e-6 and one_step_errors_oracle(gw, mw).max() < 1e-9
+    g2 = {k: v for k, v in gw.items() if k != "contact_points"}
+    assert one_step_errors_oracle(g2, mw).max() > 1e-6
 
 
 @pytest.mark.gpu
@@ -357,6 +369,13 @@ def test_the_dump_tool_writes_a_file_the_harness_consumes(tool_file):
     assert g["before"].shape == (60, ND) and g["free_states"].shape == (61, ND) and g["contact_points"].shape == (60, 24, 9)
     m = _blob(g)
     assert m.to_bytes() == fake.fake_blob.to_bytes()
+    # the session's solver parameters travel with the file (getPhysicsEngineParameters) and replace the blob's assumptions when loaded
+    assert abs(float(g["engine_erp"]) - 0.2) < 1e-6 and abs(float(g["engine_contactERP"]) - 0.9) < 1e-6 and int(g["engine_numSolverIterations"]) == 5
+    g35 = dict(g, engine_erp=np.array(0.35), engine_numSolverIterations=np.array(7.0))
+    m35 = _blob(g35)
+    assert abs(m35.erp_noncontact - 0.35) < 1e-6 and m35.n_iters == 7 and abs(m35.erp - 0.9) < 1e-6
+    with pytest.raises(ValueError):
+        _blob(dict(g, rolling_friction=np.full(len(g["mass"]), 0.1)))
     # the free-running rollouts start from the reference's reset pose: base at (0, 0, 1.32) at rest, "running_start" joint angles
     np.testing.assert_allclose(g["free_states"][0][:3], [0, 0, 1.32], atol=1e-12)
     np.testing.assert_allclose(g["free_states"][0][13:13 + NJ], [m.init_q[b] for b in range(1, NJ + 1)], atol=1e-6)

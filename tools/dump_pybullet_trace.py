@@ -83,6 +83,16 @@ def main(data_dir, n_steps):
     out["local_inertia_diag"] = np.array([d[2] for d in dyn])
     out["inertial_pos"] = np.array([d[3] for d in dyn])
     out["inertial_orn"] = np.array([d[4] for d in dyn])
+    if all(len(d) >= 8 for d in dyn):     # restitution, rolling and spinning friction: the stepper models none of the three on robot links
+        out["restitution"] = np.array([d[5] for d in dyn])
+        out["rolling_friction"] = np.array([d[6] for d in dyn])
+        out["spinning_friction"] = np.array([d[7] for d in dyn])
+    # the solver parameters this session ran with (the reference sets fixedTimeStep / numSolverIterations / numSubSteps and the contact
+    # ERP only, bullet_utils.py:338-350; `erp` -- joint limits, point-to-point constraints -- stays at Bullet's default)
+    if hasattr(p, "getPhysicsEngineParameters"):
+        for k, v in p.getPhysicsEngineParameters().items():
+            if isinstance(v, (int, float)):
+                out["engine_" + k] = np.array(float(v))
     shapes = []
     for l in range(-1, nj):
         for s in p.getCollisionShapeData(robot, l):
