@@ -228,7 +228,11 @@ typedef struct MoccaModel {
                                        the planar-base rows.  Bullet: infoGlobal.m_erp (0.2; pybullet's setDefaultContactERP only sets m_erp2,
                                        which the contact rows use): btMultiBodyConstraint::fillMultiBodyConstraint ("split impulse is not
                                        implemented yet for btMultiBody*": erp = m_erp) and btMultiBodyJointLimitConstraint  [UNVERIFIED-BULLET] */
-  int32_t reserved_[6];
+  int32_t friction_cone;            /* v13: 1 = the two friction rows of a contact are solved together and clipped to the CIRCLE of radius
+                                       mu * lambda_n (Bullet >= 2.87 "implicit cone friction", btMultiBodyConstraintSolver::
+                                       resolveConeFrictionConstraintRows; pybullet's enableConeFriction, "cone is default");
+                                       0 = one after the other, each clipped to +-mu * lambda_n (pyramid)          [UNVERIFIED-BULLET] */
+  int32_t reserved_[5];
 
   /* ---- derived lookup tables (model.py finalize_tables): one 16-byte load instead of chains of dependent loads ---- */
   float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | terrain<<24 | (foot + 1)<<25 | torso<<28), bits(anc_mask[body]) */

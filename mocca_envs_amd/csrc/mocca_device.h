@@ -1366,6 +1366,23 @@ DI void pgs_visit_friction(float as, float& y, float& lam, float lm) {
   lam = commit_lane<RR>(nl_, lam);
   y = fmaf(-as, dl, y);
 }
+// Implicit cone friction (MoccaModel.friction_cone; btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows): the two friction rows of
+// contact I take their candidates from the SAME state (y of lanes A and B as they stand), the pair is clipped to the circle of radius
+// lm = mu * lambda_n, then both deltas go out.  Five v_readlane instead of two for the pair, one v_rsq; the chain is about as long as the two
+// dependent pyramid visits it replaces.
+template <int A, int B>
+DI void pgs_visit_cone(float asA, float asB, float& y, float& lam, float lm) {
+  const float sa = readlane(y, A), sb = readlane(y, B), lim = readlane(lm, A);   // wave-uniform
+  const float r2 = fmaf(sa, sa, sb * sb);
+  const float sc = r2 > lim * lim ? lim * rsq(r2) : 1.0f;
+  const float nl_ = y * sc;                                                      // meaningful on lanes A and B
+  const float dl = nl_ - lam;
+  const float dA = readlane(dl, A), dB = readlane(dl, B);
+  lam = commit_lane<A>(nl_, lam);
+  lam = commit_lane<B>(nl_, lam);
+  y = fmaf(-asA, dA, y);
+  y = fmaf(-asB, dB, y);
+}
 // Friction rows live on STATIC lanes at the top of the row range: contact i owns lanes MAXR - 2 - 2i (first tangent) and
 // MAXR - 1 - 2i (second), whatever the number of limit / normal rows below them.  With the lane an immediate a friction visit is
 // the fixed-bound visit (readlane / writelane immediates, LDS offsets immediates, A entries requested two contacts ahead): ~30
@@ -1384,7 +1401,7 @@ template <class T> struct PgsWin { static constexpr int ROWS = MOCCA_PGS_REG_ROW
 #else
 template <class T> struct PgsWin { static constexpr int ROWS = T::NCLOS > 0 ? 24 : 16, CONTACTS = T::NCLOS > 0 ? 12 : 4; };
 #endif
-template <int PGS_REG_ROWS, int PGS_REG_CONTACTS, int I>
+template <int PGS_REG_ROWS, int PGS_REG_CONTACTS, int I, bool CONE>
 DI void pgs_friction_rows(const float* Acol, const float* af, float a0, float a1, float b0, float b1, int nc, float& y, float& lam, float invdiag, float lm) {
   if constexpr (I < MAXC) {
     if (I >= nc) return;
@@ -1393,10 +1410,16 @@ DI void pgs_friction_rows(const float* Acol, const float* af, float a0, float a1
     if constexpr (I + 2 >= PGS_REG_CONTACTS) {
       if (I + 2 < nc) { n0 = Acol[MAXR * fric_lane(IN, 0)]; n1 = Acol[MAXR * fric_lane(IN, 1)]; }  // wave-uniform: rows of existing contacts only
     }
-    pgs_visit_friction<fric_lane(I, 0)>(I < PGS_REG_CONTACTS ? af[2 * (I < PGS_REG_CONTACTS ? I : 0)] : a0 * invdiag, y, lam, lm);
-    pgs_visit_friction<fric_lane(I, 1)>(I < PGS_REG_CONTACTS ? af[2 * (I < PGS_REG_CONTACTS ? I : 0) + 1] : a1 * invdiag, y, lam, lm);
+    const float gA = I < PGS_REG_CONTACTS ? af[2 * (I < PGS_REG_CONTACTS ? I : 0)] : a0 * invdiag;
+    const float gB = I < PGS_REG_CONTACTS ? af[2 * (I < PGS_REG_CONTACTS ? I : 0) + 1] : a1 * invdiag;
+    if constexpr (CONE) {
+      pgs_visit_cone<fric_lane(I, 0), fric_lane(I, 1)>(gA, gB, y, lam, lm);
+    } else {
+      pgs_visit_friction<fric_lane(I, 0)>(gA, y, lam, lm);
+      pgs_visit_friction<fric_lane(I, 1)>(gB, y, lam, lm);
+    }
     if constexpr (I + 2 >= PGS_REG_CONTACTS) { pin1(n0); pin1(n1); }
-    pgs_friction_rows<PGS_REG_ROWS, PGS_REG_CONTACTS, I + 1>(Acol, af, b0, b1, n0, n1, nc, y, lam, invdiag, lm);
+    pgs_friction_rows<PGS_REG_ROWS, PGS_REG_CONTACTS, I + 1, CONE>(Acol, af, b0, b1, n0, n1, nc, y, lam, invdiag, lm);
   }
 }
 // fewer than four fixed-bound rows left: one uniform exit test per visit
@@ -1759,6 +1782,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
   // friction lane fetches its contact's normal impulse once per iteration, after the normal rows were visited (they do not change
   // again before the next iteration).  A visit is ~30 cycles of dependent issue: med3, sub, readlane, fma (pgs_visit*).
   const int iters = uni(M->n_iters);
+  const bool cone = uni(M->friction_cone) != 0;
   const float lo0 = kind == 3 ? -1e30f : 0.0f;
   const float* Acol = L + L_A + lc;
   const float* Acol_fr = Acol - MAXR * row_gap;   // friction visits name their rows by LANE (static): lane l holds dense row l - row_gap
@@ -1789,10 +1813,13 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
       if (PGS_REG_CONTACTS < 1) { f0 = Acol_fr[MAXR * fric_lane(0, 0)]; f1 = Acol_fr[MAXR * fric_lane(0, 1)]; }
       if (PGS_REG_CONTACTS < 2 && ncc > 1) { g0 = Acol_fr[MAXR * fric_lane(1, 0)]; g1 = Acol_fr[MAXR * fric_lane(1, 1)]; }
       lm = mu * __shfl(lam, nrow_lane, 64);
-      pgs_friction_rows<PGS_REG_ROWS, PGS_REG_CONTACTS, 0>(Acol_fr, af, f0, f1, g0, g1, ncc, y, lam, invdiag, lm);
+      if (cone) pgs_friction_rows<PGS_REG_ROWS, PGS_REG_CONTACTS, 0, true>(Acol_fr, af, f0, f1, g0, g1, ncc, y, lam, invdiag, lm);   // wave-uniform
+      else pgs_friction_rows<PGS_REG_ROWS, PGS_REG_CONTACTS, 0, false>(Acol_fr, af, f0, f1, g0, g1, ncc, y, lam, invdiag, lm);
     }
     if (dbg) {  // wave-uniform, off the product path: which rows this iteration left ON a bound (the solver's discrete decisions)
-      const bool clamped = has_row && (kind == 2 ? fabsf(lam) == lm : (kind != 3 && lam == 0.0f));
+      const float lpart = __shfl_xor(lam, 1, 64);   // a friction lane's partner: the contact's other friction row (lanes 2k, 2k + 1)
+      const bool on_circle = lam * lam + lpart * lpart >= lm * lm * (1.0f - 1e-5f);   // cone: the pair sits on the circle (the oracle's expression)
+      const bool clamped = has_row && (kind == 2 ? (cone ? on_circle : fabsf(lam) == lm) : (kind != 3 && lam == 0.0f));
       clamp_last = __ballot(clamped);
       clamp_sig = ((clamp_sig << 7) | (clamp_sig >> 57)) ^ clamp_last;
     }

@@ -924,6 +924,39 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
   for (int it = 0; it < m->n_iters; ++it) {
     clamp_last = 0;
     for (int r = 0; r < nr; ++r) {
+      if (m->friction_cone && w->row_kind[r] == 2) {
+        /* Implicit cone friction (btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows): the contact's two friction rows r, r + 1
+         * take their candidate impulses from the SAME velocity state, the pair is clipped to the circle of radius mu * lambda_n (Bullet:
+         * angle = atan2(sumA, sumB), |sumA| <= lim |sin|, |sumB| <= lim |cos| -- the radial projection), then both deltas are applied. */
+        int rb = r + 1;
+        real lim = w->row_mu[r] * w->lam[w->row_normal[r]];
+        real s2[2];
+        for (int k = 0; k < 2; ++k) {
+          int q = r + k;
+          real den = w->A[q][q] + w->cfm[q];
+          s2[k] = w->lam[q] + (den > (real)1e-12 ? (w->bias[q] - w->w[q] - w->cfm[q] * w->lam[q]) / den : 0);
+        }
+        real r2 = s2[0] * s2[0] + s2[1] * s2[1];
+        real sc = r2 > lim * lim ? lim / (real)sqrt(r2) : 1;
+        for (int k = 0; k < 2; ++k) {
+          int q = r + k;
+          real nl = s2[k] * sc, dl = nl - w->lam[q];
+          w->lam[q] = nl;
+          if (dl != 0)
+            for (int c = 0; c < nr; ++c) w->w[c] += w->A[q][c] * dl;
+        }
+        {
+          /* "on the bound": the pair sits on the circle (1e-5 relative; the HIP solver evaluates the same expression after the sweep) */
+          real l2 = w->lam[r] * w->lam[r] + w->lam[rb] * w->lam[rb];
+          int clamped = l2 >= lim * lim * (real)(1 - 1e-5);
+          for (int k = 0; k < 2; ++k) {
+            int q = r + k, lane = KERNEL_MAXR - 2 - 2 * ((q - first_fric) / 2) + ((q - first_fric) & 1);
+            if (clamped) clamp_last |= (uint64_t)1 << lane;
+          }
+        }
+        ++r;
+        continue;
+      }
       real lo = 0, hi = (real)1e30;
       if (w->row_kind[r] == 3) lo = (real)-1e30;
       if (w->row_kind[r] == 2) {

@@ -86,7 +86,7 @@ class Model:
         self.pairs = [(m.pair_a[k], m.pair_b[k]) for k in range(m.n_pairs)]
         self.closures = [dict(a=m.cl_body_a[c], b=m.cl_body_b[c], pa=np.array(list(m.cl_point_a[c]), float),
                               pb=np.array(list(m.cl_point_b[c]), float)) for c in range(m.n_closures)]
-        for k in ("gravity", "dt", "n_iters", "erp", "erp_noncontact", "contact_margin", "lin_damp", "ang_damp", "max_qd", "warmstart", "ground_friction",
+        for k in ("gravity", "dt", "n_iters", "erp", "erp_noncontact", "friction_cone", "contact_margin", "lin_damp", "ang_damp", "max_qd", "warmstart", "ground_friction",
                   "plank_friction", "plank_stiffness", "plank_damping", "limit_slack", "plank_com_z", "max_contacts", "max_rows", "n_slots", "manifold_max"):
             setattr(self, k, getattr(m, k))
         self.gravity, self.dt = float(np.float32(self.gravity)), float(np.float32(self.dt))
@@ -461,8 +461,26 @@ def substep(mdl: Model, st: State, tau, planks=None, heightfield=None):
         A = J @ Mi
         w = J @ nus + A @ lam                      # warm-start impulses act before the first iteration
         for _ in range(mdl.n_iters):
+            skip = False
             for r in range(nr):
+                if skip:
+                    skip = False
+                    continue
                 row = rows[r]
+                if mdl.friction_cone and row["kind"] == 2:      # implicit cone friction: the pair from one velocity state, clipped to the circle
+                    lim = row["mu"] * lam[row["normal"]]
+                    cand = []
+                    for q in (r, r + 1):
+                        den = A[q, q] + rows[q]["cfm"]
+                        cand.append(lam[q] + ((rows[q]["bias"] - w[q] - rows[q]["cfm"] * lam[q]) / den if den > 1e-12 else 0.0))
+                    rad = np.hypot(*cand)
+                    sc = lim / rad if rad > lim else 1.0
+                    for q, sq in zip((r, r + 1), cand):
+                        new = sq * sc
+                        w += A[:, q] * (new - lam[q])
+                        lam[q] = new
+                    skip = True
+                    continue
                 lo, hi = (row["lo"], row["hi"]) if row["kind"] != 2 else (-row["mu"] * lam[row["normal"]], row["mu"] * lam[row["normal"]])
                 den = A[r, r] + row["cfm"]
                 dl = (row["bias"] - w[r] - row["cfm"] * lam[r]) / den if den > 1e-12 else 0.0

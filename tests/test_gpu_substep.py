@@ -44,16 +44,20 @@ CASES = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("Walker3DStepper
          # Cassie with mass on the two links its URDF leaves without inertia: the TopoCassieMassive kernel instance
          ("CassieEnv-v0", M.TASK_CASSIE, {"_massive": True}),
          # the solver's warm-start path (the compiled blobs start from zero, as Bullet's multibody contacts do; a record may say otherwise)
-         ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_warm": 0.85}), ("CassieEnv-v0", M.TASK_CASSIE, {"_warm": 0.85})]
+         ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_warm": 0.85}), ("CassieEnv-v0", M.TASK_CASSIE, {"_warm": 0.85}),
+         # the pyramid friction path (pybullet's enableConeFriction = 0; the compiled blobs use Bullet's implicit cone)
+         ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_cone": 0}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_cone": 0})]
 
 
 def _one_substep_blob(env_id, **kw):
     from mocca_envs_amd.vec_env import compile_model_for
-    dump, massive, warm = kw.pop("_dump", None), kw.pop("_massive", False), kw.pop("_warm", None)
+    dump, massive, warm, cone = kw.pop("_dump", None), kw.pop("_massive", False), kw.pop("_warm", None), kw.pop("_cone", None)
     m = compile_model_for(env_id, **kw)
-    assert m.warmstart == 0.0
+    assert m.warmstart == 0.0 and m.friction_cone == 1
     if warm is not None:
         m.warmstart = warm
+    if cone is not None:
+        m.friction_cone = cone
     if massive:
         n = 0
         for b in range(1, m.n_bodies):

@@ -27,6 +27,10 @@ def _block(fric=0.5):
     root = Body("block", (0, 0, 0.5), geoms=c + [Geom("core", GEOM_SPHERE, 0.08, (0, 0, 0), friction=fric)])
     m = M.compile_model(root, [], {}, (0, 0, 0.5), [], [], [], self_collision=False)
     m.lin_damp = m.ang_damp = 0.0
+    # the closed forms below are those of the CONVERGED contact solve.  The envs' 5 Gauss-Seidel sweeps from zero (no warm start) leave a
+    # resting block a steady creep of 1e-3 rad/s (pyramid) / 2.6e-3 (cone) about the vertical and shift a soft-contact equilibrium by
+    # 10 %; with 50 sweeps both vanish -- the tests pin the rows' physics, not the truncation
+    m.n_iters = 50
     return m
 
 
@@ -75,8 +79,7 @@ def test_block_sinks_mg_over_k_into_a_soft_plank():
     """Plank contacts are springs: stiffness 30000, damping 1000 (bullet_objects.py:70-71) -> erp / cfm of the normal rows.
     At rest each of the n = 4 corner contacts carries m g / 4 and is compressed by m g / (4 k)."""
     m = _block()
-    m.n_iters = 50      # the closed form is the converged solve: four rows coupled through one rigid body (A_ij = 1/m = 0.44 against
-                        # cfm 0.21) take more than the envs' 5 Gauss-Seidel sweeps from zero (there is no warm start) to share the load
+    assert m.n_iters == 50   # four rows coupled through one rigid body (A_ij = 1/m = 0.44 against cfm 0.21) take more than the envs' 5 sweeps
     o, st, bc, Rb, mdl = _plank_world(m, 0.0)
     o.set_state(_put_on_plank(st, bc, Rb, mdl, 0.0))
     o.physics_substeps(0, np.zeros(0), 1200)
@@ -270,6 +273,7 @@ def test_contact_manifold_keeps_the_corners_of_a_plate():
     m = M.compile_model(root, [], {}, (0, 0, 0.5), [], [], [], self_collision=False)
     m.lin_damp = m.ang_damp = 0.0
     m.manifold_max = 4
+    m.n_iters = 50                                                  # the resting state below is the converged solve's (see _block)
     corners = {0, 2, 6, 8}
     rng = np.random.default_rng(0)
     for trial in range(6):
@@ -335,3 +339,29 @@ def test_link_damping_is_btmultibodys_law_on_every_link():
     s1 = o.get_state()[0]
     np.testing.assert_allclose(s1[12], 3.0 * (1 - float(b.dt) * float(b.ang_damp) * (1 + 3.0)), rtol=0, atol=1e-12)
     assert np.abs(s1[7:12]).max() < 1e-12
+
+
+@pytest.mark.parametrize("cone", [1, 0])
+def test_sliding_friction_is_a_cone_or_a_pyramid(cone):
+    """A block sliding along the diagonal of the two friction directions (btPlaneSpace1 of a vertical normal: -y and x).  With Bullet's
+    implicit cone friction (the blobs' default, `friction_cone`) the pair of friction impulses is clipped to the circle: the block
+    decelerates by mu g along its velocity.  With the pyramid (`enableConeFriction = 0`) each direction is clipped on its own: sqrt(2) mu g."""
+    m = _block()
+    assert m.friction_cone == 1
+    m.friction_cone = cone
+    mu = float(m.ground_friction) * 0.5
+    o, st = _oracle(m)
+    st[0, 2] = 0.12
+    o.set_state(st)
+    o.physics_substeps(0, np.zeros(0), 60)                  # settle
+    st = o.get_state()
+    v0 = np.array([1.5, 1.5, 0.0])
+    st[0, 7:10] = v0
+    o.set_state(st)
+    n = 48
+    o.physics_substeps(0, np.zeros(0), n)
+    v1 = o.get_state()[0, 7:10]
+    decel = (np.linalg.norm(v0) - np.linalg.norm(v1[:2])) / (n * DT)
+    want = mu * G * (1.0 if cone else np.sqrt(2.0))
+    np.testing.assert_allclose(decel, want, rtol=0.02)
+    assert abs(v1[0] - v1[1]) < 1e-3 * np.linalg.norm(v1)   # still along the diagonal
