@@ -1368,18 +1368,28 @@ DI void pgs_visit_friction(float as, float& y, float& lam, float lm) {
 }
 // Implicit cone friction (MoccaModel.friction_cone; btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows): the two friction rows of
 // contact I take their candidates from the SAME state (y of lanes A and B as they stand), the pair is clipped to the circle of radius
-// lm = mu * lambda_n, then both deltas go out.  Five v_readlane instead of two for the pair, one v_rsq; the chain is about as long as the two
-// dependent pyramid visits it replaces.
+// lm = mu * lambda_n, then both deltas go out.  The clip is evaluated per LANE -- the partner's candidate arrives by one DPP quad swap (the
+// pair sits on lanes 2k, 2k + 1), every friction lane holds its own contact's lm -- so only the two deltas cross to the scalar side:
+// 12 VALU for the pair against 10 for the two pyramid visits it replaces (the first form, with the candidates and the bound read into
+// SGPRs, took 18 and cost the launch 4 %).  min(1, lm rsq(r2)): r2 = 0 gives inf -> 1, and 0 x inf = NaN -> 1 too (v_min returns the number).
+template <int A>
+DI float commit_pair(float v, float old) {   // old with lanes A and A + 1 replaced by those lanes' v
+  float r;
+  unsigned long long m;
+  asm("s_mov_b64 %1, 0\n\ts_bitset1_b64 %1, %4\n\ts_bitset1_b64 %1, %5\n\tv_cndmask_b32 %0, %2, %3, %1"
+      : "=v"(r), "=&s"(m) : "v"(old), "v"(v), "n"(A), "n"(A + 1));
+  return r;
+}
 template <int A, int B>
 DI void pgs_visit_cone(float asA, float asB, float& y, float& lam, float lm) {
-  const float sa = readlane(y, A), sb = readlane(y, B), lim = readlane(lm, A);   // wave-uniform
-  const float r2 = fmaf(sa, sa, sb * sb);
-  const float sc = r2 > lim * lim ? lim * rsq(r2) : 1.0f;
-  const float nl_ = y * sc;                                                      // meaningful on lanes A and B
+  static_assert(B == A + 1 && A % 2 == 0, "the pair must share a DPP quad");
+  const float yp = dpp_mov<0xB1>(y);              // quad_perm [1,0,3,2]: the partner row's candidate
+  const float r2 = fmaf(yp, yp, y * y);
+  const float sc = fminf(1.0f, lm * rsq(r2));
+  const float nl_ = y * sc;                       // meaningful on the friction lanes
   const float dl = nl_ - lam;
   const float dA = readlane(dl, A), dB = readlane(dl, B);
-  lam = commit_lane<A>(nl_, lam);
-  lam = commit_lane<B>(nl_, lam);
+  lam = commit_pair<A>(nl_, lam);
   y = fmaf(-asA, dA, y);
   y = fmaf(-asB, dB, y);
 }
