@@ -1383,8 +1383,8 @@ DI float commit_pair(float v, float old) {   // old with lanes A and A + 1 repla
 template <int A, int B>
 DI void pgs_visit_cone(float asA, float asB, float& y, float& lam, float lm) {
   static_assert(B == A + 1 && A % 2 == 0, "the pair must share a DPP quad");
-  const float yp = dpp_mov<0xB1>(y);              // quad_perm [1,0,3,2]: the partner row's candidate
-  const float r2 = fmaf(yp, yp, y * y);
+  const float y2 = y * y;
+  const float r2 = y2 + dpp_mov<0xB1>(y2);        // quad_perm [1,0,3,2]: + the partner row's candidate squared (one v_add_f32_dpp)
   const float sc = fminf(1.0f, lm * rsq(r2));
   const float nl_ = y * sc;                       // meaningful on the friction lanes
   const float dl = nl_ - lam;
