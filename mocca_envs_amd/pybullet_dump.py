@@ -121,6 +121,8 @@ def from_pybullet_dump(dump: Mapping[str, np.ndarray], template: M.MoccaModel, j
         out.erp = float(dump["engine_contactERP"])                  # infoGlobal.m_erp2: contact rows (setDefaultContactERP)
     if "engine_numSolverIterations" in dump:
         out.n_iters = int(dump["engine_numSolverIterations"])
+    if "engine_enableConeFriction" in dump:
+        out.friction_cone = int(dump["engine_enableConeFriction"])   # 0: pyramid (SOLVER_DISABLE_IMPLICIT_CONE_FRICTION)
     for key in ("rolling_friction", "spinning_friction", "restitution"):
         if key in dump and np.abs(np.asarray(dump[key], float)).max() > 0:
             raise ValueError(f"the dump reports non-zero {key} on a robot link: not modelled by this stepper (DESIGN.md section 9)")

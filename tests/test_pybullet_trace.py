@@ -371,9 +371,10 @@ def test_the_dump_tool_writes_a_file_the_harness_consumes(tool_file):
     assert m.to_bytes() == fake.fake_blob.to_bytes()
     # the session's solver parameters travel with the file (getPhysicsEngineParameters) and replace the blob's assumptions when loaded
     assert abs(float(g["engine_erp"]) - 0.2) < 1e-6 and abs(float(g["engine_contactERP"]) - 0.9) < 1e-6 and int(g["engine_numSolverIterations"]) == 5
-    g35 = dict(g, engine_erp=np.array(0.35), engine_numSolverIterations=np.array(7.0))
+    assert int(g["engine_enableConeFriction"]) == 1
+    g35 = dict(g, engine_erp=np.array(0.35), engine_numSolverIterations=np.array(7.0), engine_enableConeFriction=np.array(0.0))
     m35 = _blob(g35)
-    assert abs(m35.erp_noncontact - 0.35) < 1e-6 and m35.n_iters == 7 and abs(m35.erp - 0.9) < 1e-6
+    assert abs(m35.erp_noncontact - 0.35) < 1e-6 and m35.n_iters == 7 and abs(m35.erp - 0.9) < 1e-6 and m35.friction_cone == 0
     with pytest.raises(ValueError):
         _blob(dict(g, rolling_friction=np.full(len(g["mass"]), 0.1)))
     # the free-running rollouts start from the reference's reset pose: base at (0, 0, 1.32) at rest, "running_start" joint angles
