@@ -1411,8 +1411,12 @@ template <class T> struct PgsWin { static constexpr int ROWS = MOCCA_PGS_REG_ROW
 #else
 template <class T> struct PgsWin { static constexpr int ROWS = T::NCLOS > 0 ? 24 : 16, CONTACTS = T::NCLOS > 0 ? 12 : 4; };
 #endif
+// `fpos`: bit l set iff lane l's friction bound is positive.  Bullet solves a contact's friction rows only while its normal row carries an
+// impulse (`if (totalImpulse > 0)` in btMultiBodyConstraintSolver::solveSingleIteration) and leaves them as they are otherwise -- a contact
+// that is only within the margin (a gap row without impulse: every other contact of a walking robot) costs a scalar bit test, no visit.
 template <int PGS_REG_ROWS, int PGS_REG_CONTACTS, int I, bool CONE>
-DI void pgs_friction_rows(const float* Acol, const float* af, float a0, float a1, float b0, float b1, int nc, float& y, float& lam, float invdiag, float lm) {
+DI void pgs_friction_rows(const float* Acol, const float* af, float a0, float a1, float b0, float b1, int nc, float& y, float& lam, float invdiag, float lm,
+                          unsigned long long fpos) {
   if constexpr (I < MAXC) {
     if (I >= nc) return;
     constexpr int IN = I + 2 < MAXC ? I + 2 : MAXC - 1;
@@ -1422,14 +1426,16 @@ DI void pgs_friction_rows(const float* Acol, const float* af, float a0, float a1
     }
     const float gA = I < PGS_REG_CONTACTS ? af[2 * (I < PGS_REG_CONTACTS ? I : 0)] : a0 * invdiag;
     const float gB = I < PGS_REG_CONTACTS ? af[2 * (I < PGS_REG_CONTACTS ? I : 0) + 1] : a1 * invdiag;
-    if constexpr (CONE) {
-      pgs_visit_cone<fric_lane(I, 0), fric_lane(I, 1)>(gA, gB, y, lam, lm);
-    } else {
-      pgs_visit_friction<fric_lane(I, 0)>(gA, y, lam, lm);
-      pgs_visit_friction<fric_lane(I, 1)>(gB, y, lam, lm);
+    if ((fpos >> fric_lane(I, 0)) & 1ull) {   // wave-uniform
+      if constexpr (CONE) {
+        pgs_visit_cone<fric_lane(I, 0), fric_lane(I, 1)>(gA, gB, y, lam, lm);
+      } else {
+        pgs_visit_friction<fric_lane(I, 0)>(gA, y, lam, lm);
+        pgs_visit_friction<fric_lane(I, 1)>(gB, y, lam, lm);
+      }
     }
     if constexpr (I + 2 >= PGS_REG_CONTACTS) { pin1(n0); pin1(n1); }
-    pgs_friction_rows<PGS_REG_ROWS, PGS_REG_CONTACTS, I + 1, CONE>(Acol, af, b0, b1, n0, n1, nc, y, lam, invdiag, lm);
+    pgs_friction_rows<PGS_REG_ROWS, PGS_REG_CONTACTS, I + 1, CONE>(Acol, af, b0, b1, n0, n1, nc, y, lam, invdiag, lm, fpos);
   }
 }
 // fewer than four fixed-bound rows left: one uniform exit test per visit
@@ -1822,9 +1828,11 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
       float f0 = 0.0f, f1 = 0.0f, g0 = 0.0f, g1 = 0.0f;
       if (PGS_REG_CONTACTS < 1) { f0 = Acol_fr[MAXR * fric_lane(0, 0)]; f1 = Acol_fr[MAXR * fric_lane(0, 1)]; }
       if (PGS_REG_CONTACTS < 2 && ncc > 1) { g0 = Acol_fr[MAXR * fric_lane(1, 0)]; g1 = Acol_fr[MAXR * fric_lane(1, 1)]; }
-      lm = mu * __shfl(lam, nrow_lane, 64);
-      if (cone) pgs_friction_rows<PGS_REG_ROWS, PGS_REG_CONTACTS, 0, true>(Acol_fr, af, f0, f1, g0, g1, ncc, y, lam, invdiag, lm);   // wave-uniform
-      else pgs_friction_rows<PGS_REG_ROWS, PGS_REG_CONTACTS, 0, false>(Acol_fr, af, f0, f1, g0, g1, ncc, y, lam, invdiag, lm);
+      const float ln_ = __shfl(lam, nrow_lane, 64);
+      lm = mu * ln_;
+      const unsigned long long fpos = __ballot(ln_ > 0.0f);
+      if (cone) pgs_friction_rows<PGS_REG_ROWS, PGS_REG_CONTACTS, 0, true>(Acol_fr, af, f0, f1, g0, g1, ncc, y, lam, invdiag, lm, fpos);   // wave-uniform
+      else pgs_friction_rows<PGS_REG_ROWS, PGS_REG_CONTACTS, 0, false>(Acol_fr, af, f0, f1, g0, g1, ncc, y, lam, invdiag, lm, fpos);
     }
     if (dbg) {  // wave-uniform, off the product path: which rows this iteration left ON a bound (the solver's discrete decisions)
       const float lpart = __shfl_xor(lam, 1, 64);   // a friction lane's partner: the contact's other friction row (lanes 2k, 2k + 1)

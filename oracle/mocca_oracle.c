@@ -929,21 +929,23 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
          * take their candidate impulses from the SAME velocity state, the pair is clipped to the circle of radius mu * lambda_n (Bullet:
          * angle = atan2(sumA, sumB), |sumA| <= lim |sin|, |sumB| <= lim |cos| -- the radial projection), then both deltas are applied. */
         int rb = r + 1;
-        real lim = w->row_mu[r] * w->lam[w->row_normal[r]];
-        real s2[2];
-        for (int k = 0; k < 2; ++k) {
-          int q = r + k;
-          real den = w->A[q][q] + w->cfm[q];
-          s2[k] = w->lam[q] + (den > (real)1e-12 ? (w->bias[q] - w->w[q] - w->cfm[q] * w->lam[q]) / den : 0);
-        }
-        real r2 = s2[0] * s2[0] + s2[1] * s2[1];
-        real sc = r2 > lim * lim ? lim / (real)sqrt(r2) : 1;
-        for (int k = 0; k < 2; ++k) {
-          int q = r + k;
-          real nl = s2[k] * sc, dl = nl - w->lam[q];
-          w->lam[q] = nl;
-          if (dl != 0)
-            for (int c = 0; c < nr; ++c) w->w[c] += w->A[q][c] * dl;
+        real lam_n = w->lam[w->row_normal[r]], lim = w->row_mu[r] * lam_n;
+        if (lam_n > 0) { /* Bullet: `if (totalImpulse > btScalar(0))` -- without a normal impulse the friction rows are left as they are */
+          real s2[2];
+          for (int k = 0; k < 2; ++k) {
+            int q = r + k;
+            real den = w->A[q][q] + w->cfm[q];
+            s2[k] = w->lam[q] + (den > (real)1e-12 ? (w->bias[q] - w->w[q] - w->cfm[q] * w->lam[q]) / den : 0);
+          }
+          real r2 = s2[0] * s2[0] + s2[1] * s2[1];
+          real sc = r2 > lim * lim ? lim / (real)sqrt(r2) : 1;
+          for (int k = 0; k < 2; ++k) {
+            int q = r + k;
+            real nl = s2[k] * sc, dl = nl - w->lam[q];
+            w->lam[q] = nl;
+            if (dl != 0)
+              for (int c = 0; c < nr; ++c) w->w[c] += w->A[q][c] * dl;
+          }
         }
         {
           /* "on the bound": the pair sits on the circle (1e-5 relative; the HIP solver evaluates the same expression after the sweep) */
@@ -968,6 +970,7 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
        * SIMD_EPSILON) instead of dividing */
       real den = w->A[r][r] + w->cfm[r];
       real dl = den > (real)1e-12 ? (w->bias[r] - w->w[r] - w->cfm[r] * w->lam[r]) / den : 0;
+      if (w->row_kind[r] == 2 && !(w->lam[w->row_normal[r]] > 0)) { dl = 0; lo = (real)-1e30; hi = (real)1e30; } /* pyramid: the same `if (totalImpulse > 0)` */
       real nl = w->lam[r] + dl;
       nl = nl < lo ? lo : (nl > hi ? hi : nl);
       dl = nl - w->lam[r];
@@ -975,7 +978,8 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
       if (dl != 0)
         for (int c = 0; c < nr; ++c) w->w[c] += w->A[r][c] * dl;
       {
-        int clamped = w->row_kind[r] == 2 ? fabs(nl) == hi : (w->row_kind[r] != 3 && nl == 0);
+        real hi_f = w->row_kind[r] == 2 ? w->row_mu[r] * w->lam[w->row_normal[r]] : 0;
+        int clamped = w->row_kind[r] == 2 ? fabs(nl) == hi_f : (w->row_kind[r] != 3 && nl == 0);
         int lane = r < first_fric ? r : KERNEL_MAXR - 2 - 2 * ((r - first_fric) / 2) + ((r - first_fric) & 1);
         if (clamped) clamp_last |= (uint64_t)1 << lane;
       }

@@ -469,6 +469,9 @@ def substep(mdl: Model, st: State, tau, planks=None, heightfield=None):
                 row = rows[r]
                 if mdl.friction_cone and row["kind"] == 2:      # implicit cone friction: the pair from one velocity state, clipped to the circle
                     lim = row["mu"] * lam[row["normal"]]
+                    skip = True
+                    if not lam[row["normal"]] > 0:               # Bullet: `if (totalImpulse > 0)`, else the pair is left as it is
+                        continue
                     cand = []
                     for q in (r, r + 1):
                         den = A[q, q] + rows[q]["cfm"]
@@ -482,6 +485,8 @@ def substep(mdl: Model, st: State, tau, planks=None, heightfield=None):
                     skip = True
                     continue
                 lo, hi = (row["lo"], row["hi"]) if row["kind"] != 2 else (-row["mu"] * lam[row["normal"]], row["mu"] * lam[row["normal"]])
+                if row["kind"] == 2 and not lam[row["normal"]] > 0:   # pyramid: the same test
+                    continue
                 den = A[r, r] + row["cfm"]
                 dl = (row["bias"] - w[r] - row["cfm"] * lam[r]) / den if den > 1e-12 else 0.0
                 new = min(hi, max(lo, lam[r] + dl))

@@ -79,7 +79,9 @@ def test_episode_matches_the_reference_code(tag, ep):
     for t, a in enumerate(G[f"{tag}_ep{ep}_actions"]):
         obs, rew, done, _ = o.step(a.astype(np.float32)[None])
         # (entries 26..39 are finite-difference joint speeds, (q' - q) / 0.03 of float32 angles: one ulp of an angle is 2e-6 of speed)
-        np.testing.assert_allclose(obs[0], gobs[t + 1], rtol=0, atol=1e-5, err_msg=f"step {t}")
+        # ... and the episode runs free: 50 solves per step whose `if (normal impulse > 0)` friction switch turns last-bit differences of the
+        # two drivers (the reference's Python PD loop in float64 here, the oracle's C loop there) into 1e-5 now and then
+        np.testing.assert_allclose(obs[0], gobs[t + 1], rtol=0, atol=3e-5, err_msg=f"step {t}")
         assert abs(float(rew[0]) - grew[t]) < 5e-6, (t, rew, grew[t])
         assert (int(done[0]) & 1) == gdone[t]
         assert o.get_task()[0, 39] == G[f"{tag}_ep{ep}_istep"][t + 1]
