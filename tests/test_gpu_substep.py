@@ -127,7 +127,7 @@ def test_single_substep_parity_with_matching_active_sets(env_id, task, kw):
         scatter()
     nd = 13 + 2 * m.n_joints
     n_same = n_diff = n_clamp_diff = 0
-    e_gpu, e_f32, e_flip, rows_seen = [], [], [], []
+    e_gpu, e_f32, e_flip, e_f32_flip, rows_seen = [], [], [], [], []
     units = lambda a, b: np.abs(a - b) / (1e-5 * (1.0 + np.abs(b)))
     for t in range(steps):
         env.set_state(orc.get_state().astype(np.float32))
@@ -156,6 +156,9 @@ def test_single_substep_parity_with_matching_active_sets(env_id, task, kw):
         same64 = (d6_[:, :12] == dc_[:, :12]).all(axis=1) & ok
         if same64.any():
             e_f32.append(units(sc[same64][:, :nd], s6[same64][:, :nd]).max(axis=1))
+        flip64 = (d6_[:, :8] == dc_[:, :8]).all(axis=1) & ok & ~same64      # the yardstick's own flips: f32 vs f64 oracle, same rows, another pattern
+        if flip64.any():
+            e_f32_flip.append(units(sc[flip64][:, :nd], s6[flip64][:, :nd]).max(axis=1))
         # restart fallen envs so the sample keeps standing / stepping / falling robots
         if t % 8 == 7:
             fallen = (dc != 0).astype(np.uint8)
@@ -178,10 +181,18 @@ def test_single_substep_parity_with_matching_active_sets(env_id, task, kw):
     if e_flip:
         e_flip = np.concatenate(e_flip)
         print(f"  same rows, another clamp pattern ({len(e_flip)} samples): state error median {q(e_flip, 50):.3g} p99 {q(e_flip, 99):.3g} max {e_flip.max():.3g}")
-        # a flipped clamp is ANOTHER linear system: on a contact set where fp32 arithmetic alone (same clamps) is e_f32.max() from the exact
-        # solve -- 766 units on the height field's worst sample -- the flip costs a multiple of that (4.1e3 on one of five such samples,
-        # round 3); bounded at 10 x the yardstick's worst, the bucket's median at 100 units, its size by frac_clamp above
-        assert q(e_flip, 50) < max(100.0, 5 * q(e_f32, 50)) and e_flip.max() < max(1000.0, 10 * e_f32.max()), (q(e_flip, 50), e_flip.max())
+        # A flipped clamp is ANOTHER linear system -- and since the friction rows follow Bullet's `if (normal impulse > 0)` switch, a normal
+        # impulse that is 0 on one side and 1e-9 on the other turns a whole friction pair on or off for a sweep: what a flip costs is a
+        # property of the solver, not of the arithmetic that triggered it (1e-2 relative on single samples).  What is bounded is how OFTEN it
+        # happens -- against the fp32 oracle's own flip rate relative to the f64 oracle on the same substeps (same rows, another pattern) --
+        # and, for buckets large enough to have one, the median; single samples only get a sanity bound (10 % of 1 + |x|).
+        yf = np.concatenate(e_f32_flip) if e_f32_flip else np.zeros(0)
+        rate_y = len(yf) / total
+        print(f"  the f32 oracle's own flips against the f64 oracle: {len(yf)} samples ({100 * rate_y:.3f} %)" + (f", median {q(yf, 50):.3g} max {yf.max():.3g}" if len(yf) else ""))
+        assert frac_clamp <= 3 * rate_y + 1e-3, (frac_clamp, rate_y)
+        assert e_flip.max() < 1e4, e_flip.max()
+        if len(e_flip) >= 20:
+            assert q(e_flip, 50) < max(100.0, 5 * q(e_f32, 50), 3 * (q(yf, 50) if len(yf) else 0.0)), (q(e_flip, 50), len(yf))
     # Same rows, same arithmetic, another association order.  The fp32 tolerance of ONE substep is what fp32 arithmetic itself
     # costs on this substep: the f32 oracle's distance from the f64 oracle (stiff rows divide position errors of 1e-7 by dt:
     # Cassie's closure rows at dt = 0.6 ms turn them into 1e-4 of velocity).  The kernel may be no further from the f32 oracle
