@@ -232,7 +232,11 @@ typedef struct MoccaModel {
                                        mu * lambda_n (Bullet >= 2.87 "implicit cone friction", btMultiBodyConstraintSolver::
                                        resolveConeFrictionConstraintRows; pybullet's enableConeFriction, "cone is default");
                                        0 = one after the other, each clipped to +-mu * lambda_n (pyramid)          [UNVERIFIED-BULLET] */
-  int32_t reserved_[5];
+  int32_t limit_at_violation;       /* v13: 1 = a joint-limit row exists only while the joint is AT or PAST its limit (btMultiBodyJointLimitConstraint::
+                                       createConstraintRows: "if (penetration > 0) continue"), pushed back with erp_noncontact; 0 = a row exists from a
+                                       predicted gap of limit_slack on and stops the joint at the limit within the step (the file's older form,
+                                       whose positive-gap branch is still in the source)                                   [UNVERIFIED-BULLET] */
+  int32_t reserved_[4];
 
   /* ---- derived lookup tables (model.py finalize_tables): one 16-byte load instead of chains of dependent loads ---- */
   float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | terrain<<24 | (foot + 1)<<25 | torso<<28), bits(anc_mask[body]) */

@@ -1506,7 +1506,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
       const float q = L[L_Q + b];
       const float gap = side == 0 ? q - M->jlo[b] : M->jhi[b] - q;
       const float vel = (side == 0 ? 1.0f : -1.0f) * L[L_NU + 5 + b];
-      act = gap + dt * vel < M->limit_slack;
+      act = M->limit_at_violation ? !(gap > 0.0f) : gap + dt * vel < M->limit_slack;
     }
     const unsigned long long lm = __ballot(act);
     const int rk = lane_rank(lm);

@@ -160,7 +160,8 @@ class MoccaModel(C.Structure):
         ("manifold_max", C.c_int32),
         ("erp_noncontact", C.c_float),
         ("friction_cone", C.c_int32),
-        ("reserved_", C.c_int32 * 5),
+        ("limit_at_violation", C.c_int32),
+        ("reserved_", C.c_int32 * 4),
         ("slot_tab", (C.c_float * 4) * MAX_SLOTS),
         ("gp_tab", (C.c_float * 4) * (2 * MAX_GEOMS)),
         ("pair_tab", (C.c_float * 4) * MAX_PAIRS),
@@ -653,6 +654,7 @@ def compile_model(
     m.erp = 0.9                     # bullet_utils.py:345: setDefaultContactERP = infoGlobal.m_erp2, the contact rows' ERP
     m.erp_noncontact = ERP_NONCONTACT
     m.friction_cone = FRICTION_CONE
+    m.limit_at_violation = LIMIT_AT_VIOLATION
     m.contact_margin = 0.02         # [UNVERIFIED-BULLET] contact breaking threshold
     m.lin_damp = 0.04               # [UNVERIFIED-BULLET] btMultiBody default; applies to the base and to every link, with the quadratic term
     m.ang_damp = 0.04
@@ -867,9 +869,14 @@ CASSIE_KP = np.array([100, 100, 88, 96, 50, 100, 100, 88, 96, 50, 400, 400]) / 1
 #  * the two friction rows of a contact are coupled ("implicit cone friction", Bullet >= 2.87): both candidate impulses from the same
 #    velocity state, the pair clipped to the circle of radius mu * lambda_n (btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows);
 #    pybullet: setPhysicsEngineParameter(enableConeFriction=0) selects the pyramid, "cone is default".  (Pyramid until round 3 late.)
+#  * a joint-limit row exists only while the joint is at or past its limit: btMultiBodyJointLimitConstraint::createConstraintRows,
+#    "//todo: consider adding some safety threshold here / if (penetration > 0) continue;" -- the joint crosses the limit by up to
+#    speed x dt and is pushed back with the non-contact ERP.  (Until round 3 late: a row from a predicted gap of 0.05 rad on, which stops the
+#    joint AT the limit -- the older form of that file, whose positive-gap branch `velocityError = -penetration / dt` is still in the source.)
 ERP_NONCONTACT = 0.2
 WARMSTART = 0.0
 FRICTION_CONE = 1
+LIMIT_AT_VIOLATION = 1
 
 CASSIE_PLAIN, CASSIE_PHASE_MOCCA, CASSIE_PHASE_MIRROR = 0, 1, 2   # MoccaModel.cassie_mode (include/mocca_model.h)
 # Cassie2D (env_cassie.py:279-282) loads cassie_collide_2d.urdf.  The class's path (data/cassie/urdf/) does not exist in the reference's
@@ -1000,6 +1007,7 @@ def compile_cassie(planar: bool = False, power_coef: float = 1.0, residual_contr
     m.gravity, m.dt, m.n_substeps, m.n_iters, m.erp = 9.8, 0.03 / 50, 1, 5, 0.9
     m.erp_noncontact = ERP_NONCONTACT   # the two point-to-point closures (btMultiBodyPoint2Point -> fillMultiBodyConstraint) and the limits
     m.friction_cone = FRICTION_CONE
+    m.limit_at_violation = LIMIT_AT_VIOLATION
     m.n_llc = 50
     m.contact_margin, m.lin_damp, m.ang_damp, m.max_qd, m.warmstart = 0.02, 0.04, 0.04, 100.0, WARMSTART
     m.ground_friction = 0.8
@@ -1131,6 +1139,7 @@ def compile_laikago(stepper: bool = False, plank_class: str = "LargePlank") -> M
     m.gravity, m.dt, m.n_substeps, m.n_iters, m.erp = 9.8, 1.0 / 480.0, 8, 5, 0.9
     m.erp_noncontact = ERP_NONCONTACT
     m.friction_cone = FRICTION_CONE
+    m.limit_at_violation = LIMIT_AT_VIOLATION
     m.contact_margin, m.lin_damp, m.ang_damp, m.max_qd, m.warmstart = 0.02, 0.04, 0.04, 100.0, WARMSTART
     m.ground_friction = 0.8
     m.limit_slack, m.max_contacts, m.max_rows = 0.05, 12, 48

@@ -823,7 +823,7 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
       real sgn = side == 0 ? 1 : -1;
       real gap = side == 0 ? s->q[b] - (real)m->jlo[b] : (real)m->jhi[b] - s->q[b];
       real vel = sgn * nu[5 + b];
-      if (gap + dt * vel >= (real)m->limit_slack) continue;
+      if (m->limit_at_violation ? gap > 0 : gap + dt * vel >= (real)m->limit_slack) continue;
       limit_mask |= (uint64_t)1 << (2 * (b - 1) + side);
       if (nr >= m->max_rows) continue;
       int r = nr++;

@@ -86,7 +86,7 @@ class Model:
         self.pairs = [(m.pair_a[k], m.pair_b[k]) for k in range(m.n_pairs)]
         self.closures = [dict(a=m.cl_body_a[c], b=m.cl_body_b[c], pa=np.array(list(m.cl_point_a[c]), float),
                               pb=np.array(list(m.cl_point_b[c]), float)) for c in range(m.n_closures)]
-        for k in ("gravity", "dt", "n_iters", "erp", "erp_noncontact", "friction_cone", "contact_margin", "lin_damp", "ang_damp", "max_qd", "warmstart", "ground_friction",
+        for k in ("gravity", "dt", "n_iters", "erp", "erp_noncontact", "friction_cone", "limit_at_violation", "contact_margin", "lin_damp", "ang_damp", "max_qd", "warmstart", "ground_friction",
                   "plank_friction", "plank_stiffness", "plank_damping", "limit_slack", "plank_com_z", "max_contacts", "max_rows", "n_slots", "manifold_max"):
             setattr(self, k, getattr(m, k))
         self.gravity, self.dt = float(np.float32(self.gravity)), float(np.float32(self.dt))
@@ -422,7 +422,7 @@ def substep(mdl: Model, st: State, tau, planks=None, heightfield=None):
     for b in range(1, mdl.nb):
         for side, sgn in ((0, 1.0), (1, -1.0)):
             gap = st.q[b] - mdl.jlo[b] if side == 0 else mdl.jhi[b] - st.q[b]
-            if gap + dt * sgn * nus[5 + b] >= mdl.limit_slack or len(rows) >= mdl.max_rows:
+            if (gap > 0 if mdl.limit_at_violation else gap + dt * sgn * nus[5 + b] >= mdl.limit_slack) or len(rows) >= mdl.max_rows:
                 continue
             J = np.zeros(mdl.nd); J[5 + b] = sgn
             rows.append(dict(J=J, bias=mdl.erp_noncontact * (-gap) / dt if gap < 0 else -gap / dt, cfm=0.0, lo=0.0, hi=1e30, lam=0.0, kind=0, slot=-1))

@@ -46,14 +46,19 @@ CASES = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("Walker3DStepper
          # the solver's warm-start path (the compiled blobs start from zero, as Bullet's multibody contacts do; a record may say otherwise)
          ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_warm": 0.85}), ("CassieEnv-v0", M.TASK_CASSIE, {"_warm": 0.85}),
          # the pyramid friction path (pybullet's enableConeFriction = 0; the compiled blobs use Bullet's implicit cone)
-         ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_cone": 0}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_cone": 0})]
+         ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_cone": 0}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_cone": 0}),
+         # limit rows from a predicted gap on (limit_at_violation = 0; the compiled blobs build them at / past the limit only)
+         ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_predict": True}), ("CassieEnv-v0", M.TASK_CASSIE, {"_predict": True})]
 
 
 def _one_substep_blob(env_id, **kw):
     from mocca_envs_amd.vec_env import compile_model_for
     dump, massive, warm, cone = kw.pop("_dump", None), kw.pop("_massive", False), kw.pop("_warm", None), kw.pop("_cone", None)
+    predict = kw.pop("_predict", False)
     m = compile_model_for(env_id, **kw)
-    assert m.warmstart == 0.0 and m.friction_cone == 1
+    assert m.warmstart == 0.0 and m.friction_cone == 1 and m.limit_at_violation == 1
+    if predict:
+        m.limit_at_violation = 0
     if warm is not None:
         m.warmstart = warm
     if cone is not None:

@@ -182,8 +182,14 @@ def _arm_inertia_about_hinge(m):
     return ax @ Ic @ ax + m.mass[1] * d2, m.mass[1], c
 
 
-def test_hinge_driven_into_its_limit_stops_there():
+@pytest.mark.parametrize("at_violation", [1, 0])
+def test_hinge_driven_into_its_limit_stops_there(at_violation):
+    """`limit_at_violation = 1` (the blobs' default, Bullet's `if (penetration > 0) continue`): no row before the joint is at the limit, so it
+    crosses by speed x dt, is pushed back with the non-contact ERP and settles on the stop.  0: a row from a predicted gap of limit_slack
+    on stops it AT the limit."""
     m = _base_with_arm((0, 0, 1), -30, 30, (1, 0, 0))     # vertical axis: gravity does not load the joint
+    assert m.limit_at_violation == 1
+    m.limit_at_violation = at_violation
     o, st = _oracle(m)
     st[0, 2] = 0.52
     o.set_state(st)
@@ -195,8 +201,13 @@ def test_hinge_driven_into_its_limit_stops_there():
         qs.append(s[13]); qds.append(s[14])
     qs, qds = np.array(qs), np.array(qds)
     assert qds.max() > 4.0                                # it did arrive at speed
-    assert qs.max() < hi + 1e-3, qs.max() - hi            # no overshoot beyond a milliradian
-    assert abs(qs[-1] - hi) < 1e-3 and np.abs(qds[-100:]).max() < 0.05      # and rests against the stop under the torque
+    if at_violation:
+        k = int(np.argmax(qs > hi))                       # the substep that crossed: by at most its speed x dt, and it did cross
+        assert 0 < qs.max() - hi <= qds[k] * DT * 1.001 + 1e-9, (qs.max() - hi, qds[k] * DT)
+        assert (qs[k + 1:] < qs[k] + 1e-9).all()          # the row that exists from then on lets it go no further
+    else:
+        assert qs.max() < hi + 1e-3, qs.max() - hi        # no overshoot beyond a milliradian
+    assert abs(qs[-1] - hi) < 1e-3 and np.abs(qds[-100:]).max() < (0.2 if at_violation else 0.05)   # and rests against the stop under the torque
 
 
 def test_compound_pendulum_period_and_joint_damping():
