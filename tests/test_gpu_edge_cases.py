@@ -114,7 +114,10 @@ def test_stepper_standing_on_planks(cur):
     orc = Oracle(env.model.to_bytes(), 1, 32, "f32")
     env.set_param(2, cur); orc.set_param(PARAM_CURRICULUM, cur)
     env.reset(); orc.reset(seed=4)
-    st = orc.get_state(); st[:, 13:13 + NJ] = 0; st[:, 2] = 1.27; orc.set_state(st)   # T-pose, feet on the plank
+    st = orc.get_state(); st[:, 13:13 + NJ] = 0; st[:, 2] = 1.27                      # T-pose, feet on the plank ...
+    lo, hi = M.joint_limits(env.model)
+    st[:, 13:13 + NJ] += 0.05 * (lo > -1e-6) - 0.05 * (hi < 1e-6)   # ... with knees and elbows 0.05 rad inside their stops: a joint exactly AT its
+    orc.set_state(st)                                              # limit switches its row on or off with the last bit (limit_at_violation)
     rng = np.random.default_rng(3)
     touched = 0
     for t in range(12):

@@ -216,7 +216,11 @@ def test_properties_at_full_size():
     m = M.compile_walker3d()
     lo, hi = M.joint_limits(m)
     q = sa[:, 13:34].cpu().numpy()
-    assert (q > lo - 0.35).all() and (q < hi + 0.35).all()  # ERP 0.9 + 100 rad/s impacts: bounded overshoot
+    # limit rows exist only at / past the limit (limit_at_violation): a joint crosses by at most its speed x dt -- 100 rad/s / 240 = 0.42 rad for
+    # the flailing limbs of a fallen robot under U(-1, 1) actions -- and is then held and pushed back (non-contact ERP 0.2)
+    over = max(float((lo - q).max()), float((q - hi).max()))
+    print(f"largest limit overshoot {over:.3f} rad")
+    assert over < float(m.max_qd) * float(m.dt) + 0.15
     assert (sa[:, 34:55].abs() <= 100.0 + 1e-3).all()      # max_qd clamp
 
 

@@ -311,7 +311,10 @@ def test_properties_at_the_benchmark_sizes(env_id, n, steps):
     lo, hi = M.joint_limits(m)
     q = s1[:, 13:13 + nj].cpu().numpy()
     fin = (hi > lo) & (hi - lo < 1e20)          # Cassie's continuous rod joints carry +-1e30
-    assert (q[:, fin] > lo[fin] - 0.35).all() and (q[:, fin] < hi[fin] + 0.35).all()
+    # limit rows exist only at / past the limit: a joint crosses by at most speed x dt (100 rad/s x dt), then it is held and pushed back
+    over = max(float((lo[fin] - q[:, fin]).max()), float((q[:, fin] - hi[fin]).max()))
+    print(f"largest limit overshoot {over:.3f} rad")
+    assert over < float(m.max_qd) * float(m.dt) + 0.15
     assert (s1[:, 13 + nj:13 + 2 * nj].abs() <= m.max_qd + 1e-3).all()
     ep = t1[:, 9].cpu().numpy()
     assert (ep >= 0).all() and (nd1 == 0 or ep.max() >= 1)          # episode counters advanced where envs finished
