@@ -239,10 +239,20 @@ typedef struct MoccaModel {
   int32_t reserved_[4];
 
   /* ---- derived lookup tables (model.py finalize_tables): one 16-byte load instead of chains of dependent loads ---- */
-  float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | terrain<<24 | (foot + 1)<<25 | torso<<28), bits(anc_mask[body]) */
+  float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | margin_code<<17 (7 bits, x 2^-13 m) | terrain<<24 | (foot + 1)<<25 | torso<<28), bits(anc_mask[body]) */
   float gp_tab[2 * MOCCA_MAX_GEOMS][4];     /* geom end point in its body frame (x, y, z), bits(body) */
   float pair_tab[MOCCA_MAX_PAIRS][4];       /* bits(geom_a | geom_b<<8 | body_a<<16 | body_b<<24), radius_a, radius_b,
-                                               broad-phase reach = half_len_a + half_len_b + radius_a + radius_b (padded; + contact_margin at run time) */
+                                               broad-phase reach = half_len_a + half_len_b + radius_a + radius_b (padded; + the pair's margin at run time) */
+  float slot_margin[MOCCA_MAX_SLOTS];       /* g_margin of the slot's geom (or contact_margin), quantised to 2^-13 m like the code in slot_tab */
+  float pair_margin[MOCCA_MAX_PAIRS];       /* min of the two geoms' margins */
+  /* (the new arrays sit at the END of the record: the kernels' loads of the older fields keep their immediate offsets) */
+  float g_margin[MOCCA_MAX_GEOMS];  /* v13: contact breaking threshold of the geom's Bullet link.  btCollisionDispatcher::getNewManifold uses the RELATIVE
+                                       threshold (CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD, on by default): min over the two collision objects of
+                                       shape->getContactBreakingThreshold(gContactBreakingThreshold) = contact_margin x getAngularMotionDisc(), the disc
+                                       being the half diagonal of the link shape's AABB + the distance of its centre from the link's inertial frame --
+                                       3 to 6 mm for a walker's links, not 20 mm.  The ground plane, planks and the height field have larger discs: the
+                                       robot link's value decides; a self pair takes the smaller of its two links'.  <= 0: contact_margin itself (absolute).
+                                       [UNVERIFIED-BULLET] */
 } MoccaModel;
 
 /* ------------------------------------------------------------------------

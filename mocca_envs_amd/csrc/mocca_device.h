@@ -1046,7 +1046,10 @@ template <class T, int TASK>
 DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next_step_index,
                         int* nc_out, int32_t* dbg, int* nc_wanted, const HeightFieldArgs& hfa) {
   STAMP_BEGIN;
-  const float margin = unif(M->contact_margin);
+  // contacts open within the geom's margin (Bullet's relative breaking threshold of its link, a few mm; decoded from the slot record where
+  // it is compared: a separate load spilled).  `mreach`: gContactBreakingThreshold itself, 20 mm -- an upper bound of every relative
+  // threshold (discs below 1 m), used where a reach only prunes
+  const float mreach = unif(M->contact_margin);
   ContactFlags fl = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int maxc = uni(M->max_contacts);
   // ---- terrain: lane -> (geom, end)
@@ -1057,7 +1060,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
   if (lane < T::NSLOT) {
     const f4_t st = *(CF4P)(M->slot_tab[lane]);  // radius, friction, ids, ancestor mask
     const int ids = __float_as_int(st.z);
-    const int g = (ids >> 8) & 0xFF, e = (ids >> 16) & 0xFF;
+    const int g = (ids >> 8) & 0xFF, e = (ids >> 16) & 1;
     bmask = __float_as_uint(st.w);
     if ((ids >> 24) & 1) {  // flags: bit 24 terrain, bits 25.. foot index + 1
       gfoot = ((ids >> 25) & 7) - 1;
@@ -1069,7 +1072,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
       body = ids & 0xFF;
       if (TASK == MOCCA_TASK_WALKER3D_PLANNER) {
         // height field (HeightField.reload: lateralFriction 1.0, contactStiffness 30000, contactDamping 1000, bullet_objects.py:386-393)
-        gap = sphere_heightfield(hfa.data, hfa.rows, hfa.cols, hfa.scale, Cw, rad, rad + margin, n);
+        gap = sphere_heightfield(hfa.data, hfa.rows, hfa.cols, hfa.scale, Cw, rad, rad + mreach, n);
         mu = M->plank_friction * gfric;
         const float kk = M->plank_stiffness, cc = M->plank_damping, dt = M->dt;
         const float ikc = rcp(dt * kk + cc);
@@ -1093,7 +1096,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
           box_local(Cw, bc, Rb, lb);
           // wave-uniform skip: no contact point of this env is within reach of plank k (exact: such a plank can neither
           // activate a slot nor win the minimum against one that does)
-          const float reach = rad + margin;
+          const float reach = rad + mreach;
           if (__ballot(fabsf(lb[0]) < h[0] + reach && fabsf(lb[1]) < h[1] + reach && fabsf(lb[2]) < h[2] + reach) == 0ull) continue;
           const float gk = cyl ? sphere_cylinder(lb, rad, Rb, h, nn) : sphere_box(lb, rad, Rb, h, nn);  // uniform branch
           if (gk < gap) {
@@ -1110,7 +1113,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
         erp = dt * kk * ikc;
         cfm = ikc * rcp(dt);
       }
-      active = gap < margin;
+      active = gap < (float)((ids >> 17) & 0x7F) * (1.0f / 8192.0f);   // the link's margin, a 7-bit multiple of 2^-13 m in the slot record (= slot_margin)
 #pragma unroll
       for (int i = 0; i < 3; ++i) P[i] = C[i] - rad * n[i];
     }
@@ -1217,7 +1220,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
 #pragma unroll
       for (int i = 0; i < 3; ++i)
         dm[i] = (L[L_GP + 6 * ga + i] + L[L_GP + 6 * ga + 3 + i]) - (L[L_GP + 6 * gb + i] + L[L_GP + 6 * gb + 3 + i]);
-      const float reach = 2.0f * (pt.w + margin);
+      const float reach = 2.0f * (pt.w + M->pair_margin[k]);
       near = dot3(dm, dm) < reach * reach;
     }
     const unsigned long long nm = __ballot(near);
@@ -1247,7 +1250,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
       float d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
       const float d2 = dot3(d, d), id = rsq(d2), dist = d2 * id, ra = pt.y, rb = pt.z;  // v_rsq_f32 (1 ulp)
       g2 = dist - ra - rb;
-      hit = g2 < margin && d2 > 1e-18f;
+      hit = g2 < M->pair_margin[k] && d2 > 1e-18f;
       if (hit) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {

@@ -165,6 +165,9 @@ class MoccaModel(C.Structure):
         ("slot_tab", (C.c_float * 4) * MAX_SLOTS),
         ("gp_tab", (C.c_float * 4) * (2 * MAX_GEOMS)),
         ("pair_tab", (C.c_float * 4) * MAX_PAIRS),
+        ("slot_margin", C.c_float * MAX_SLOTS),
+        ("pair_margin", C.c_float * MAX_PAIRS),
+        ("g_margin", C.c_float * MAX_GEOMS),
     ]
 
     def to_bytes(self) -> bytes:
@@ -178,6 +181,12 @@ class MoccaModel(C.Structure):
         if m.magic != MAGIC or m.version != VERSION:
             raise ValueError("bad model blob magic/version")
         return m
+
+    def margin_code(self, g: int) -> int:
+        """The geom's contact margin in units of 2^-13 m (0.122 mm), 7 bits: what the kernels decode from the slot record (the tables
+        slot_margin / pair_margin hold the same, decoded -- every implementation compares against the quantised value)."""
+        gm = self.g_margin[g] if self.g_margin[g] > 0 else self.contact_margin
+        return int(min(127, max(1, round(gm / MARGIN_UNIT))))
 
     def finalize_tables(self) -> "MoccaModel":
         """Fill the derived lookup tables from the primary fields (call after any edit of geoms / pairs)."""
@@ -197,12 +206,14 @@ class MoccaModel(C.Structure):
                 for k in range(3):
                     self.gp_tab[2 * g + e][k] = p[k]
                 self.gp_tab[2 * g + e][3] = bits(b)
+            mq = self.margin_code(g)
             for e in range(ne):
                 sl = self.g_slot[g] + e
+                self.slot_margin[sl] = mq * MARGIN_UNIT
                 self.slot_tab[sl][0] = self.g_radius[g]
                 self.slot_tab[sl][1] = self.g_friction[g]
-                self.slot_tab[sl][2] = bits(b | (g << 8) | (e << 16) | ((1 if self.g_terrain[g] else 0) << 24) | ((self.g_foot[g] + 1) << 25) |
-                                               ((1 if self.g_torso[g] else 0) << 28))
+                self.slot_tab[sl][2] = bits(b | (g << 8) | (e << 16) | (mq << 17) | ((1 if self.g_terrain[g] else 0) << 24) |
+                                            ((self.g_foot[g] + 1) << 25) | ((1 if self.g_torso[g] else 0) << 28))
                 self.slot_tab[sl][3] = bits(self.anc_mask[b])
         for k in range(self.n_pairs):
             ga, gb = self.pair_a[k], self.pair_b[k]
@@ -213,11 +224,31 @@ class MoccaModel(C.Structure):
             # time), padded by 1e-6 relative + 1e-6 m so that fp32 rounding can only widen the conservative test
             half = lambda g: 0.5 * math.sqrt(sum((float(self.g_p2[g][i]) - float(self.g_p1[g][i])) ** 2 for i in range(3)))
             self.pair_tab[k][3] = (half(ga) + half(gb) + self.g_radius[ga] + self.g_radius[gb]) * (1.0 + 1e-6) + 1e-6
+            self.pair_margin[k] = min(self.margin_code(ga), self.margin_code(gb)) * MARGIN_UNIT
         return self
 
     @property
     def state_dim(self) -> int:
         return STATE_BASE + 2 * self.n_joints + self.n_slots
+
+
+def relative_margins(factor: float, groups) -> dict:
+    """Bullet's relative contact breaking threshold per collision object: `groups` maps a link id to a list of
+    (kind, radius, p1, p2, mass, com) geoms given in ONE frame whose axes are the link's; returns {link id: factor x getAngularMotionDisc()},
+    the disc = half diagonal of the AABB of the link's shapes + distance of the AABB's centre from the link's COM (the inertial frame
+    Bullet hangs the shapes on)."""
+    out = {}
+    for lid, gs in groups.items():
+        lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+        mass, mom = 0.0, np.zeros(3)
+        for kind, r, p1, p2, gm, gc in gs:
+            for p in (np.asarray(p1, float), np.asarray(p2, float)):
+                lo, hi = np.minimum(lo, p - r), np.maximum(hi, p + r)
+            mass += gm
+            mom += gm * np.asarray(gc, float)
+        com = mom / mass if mass > 0 else 0.5 * (lo + hi)
+        out[lid] = factor * (0.5 * float(np.linalg.norm(hi - lo)) + float(np.linalg.norm(0.5 * (lo + hi) - com)))
+    return out
 
 
 # --------------------------------------------------------------------------
@@ -596,6 +627,14 @@ def compile_model(
         m.g_terrain[gi] = int(filters_collide(g.group, g.mask, TERRAIN_GROUP, TERRAIN_MASK))
     assert slot <= MAX_SLOTS
     m.n_slots = slot
+    # Bullet's relative contact breaking threshold, per Bullet link (a hinge-less child body is a link of its own there)
+    groups = {}
+    for gi, (b, g, bl) in enumerate(geoms):
+        gm, gc, _ = _geom_inertial(g)
+        groups.setdefault((b, bl), []).append((g.kind, g.radius, g.p1, g.p2, gm, gc))
+    rel = relative_margins(CONTACT_BREAKING_THRESHOLD, groups)
+    for gi, (b, g, bl) in enumerate(geoms):
+        m.g_margin[gi] = rel[(b, bl)]
 
     # self-collision candidate pairs: URDF_USE_SELF_COLLISION |
     # URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS (robots.py:259-264) + group/mask filter
@@ -655,7 +694,7 @@ def compile_model(
     m.erp_noncontact = ERP_NONCONTACT
     m.friction_cone = FRICTION_CONE
     m.limit_at_violation = LIMIT_AT_VIOLATION
-    m.contact_margin = 0.02         # [UNVERIFIED-BULLET] contact breaking threshold
+    m.contact_margin = CONTACT_BREAKING_THRESHOLD   # gContactBreakingThreshold: the FACTOR of the relative thresholds in g_margin (above)
     m.lin_damp = 0.04               # [UNVERIFIED-BULLET] btMultiBody default; applies to the base and to every link, with the quadratic term
     m.ang_damp = 0.04
     m.max_qd = 100.0                # [UNVERIFIED-BULLET] maxCoordinateVelocity
@@ -873,6 +912,11 @@ CASSIE_KP = np.array([100, 100, 88, 96, 50, 100, 100, 88, 96, 50, 400, 400]) / 1
 #    "//todo: consider adding some safety threshold here / if (penetration > 0) continue;" -- the joint crosses the limit by up to
 #    speed x dt and is pushed back with the non-contact ERP.  (Until round 3 late: a row from a predicted gap of 0.05 rad on, which stops the
 #    joint AT the limit -- the older form of that file, whose positive-gap branch `velocityError = -penetration / dt` is still in the source.)
+#  * contacts open within the RELATIVE breaking threshold 0.02 x getAngularMotionDisc() of the smaller of the two collision objects
+#    (btCollisionDispatcher::getNewManifold, CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD on by default; MoccaModel.g_margin): 3 - 6 mm for a
+#    walker's links.  (Until round 3 late: 20 mm for every pair.)
+CONTACT_BREAKING_THRESHOLD = 0.02
+MARGIN_UNIT = 2.0 ** -13      # slot_tab carries a geom's margin as a 7-bit multiple of this (0.122 mm; up to 15.5 mm)
 ERP_NONCONTACT = 0.2
 WARMSTART = 0.0
 FRICTION_CONE = 1
@@ -969,6 +1013,14 @@ def compile_cassie(planar: bool = False, power_coef: float = 1.0, residual_contr
     m.n_geoms = m.n_slots = g
     m.n_pairs = 0
     m.n_feet = 2
+    # relative contact breaking threshold of each toe (one convex mesh = one collision object): from the AABB of its hull points
+    groups = {}
+    for gi in range(m.n_geoms):
+        bb = m.g_body[gi]
+        groups.setdefault(bb, []).append((GEOM_SPHERE, 0.0, list(m.g_p1[gi]), list(m.g_p1[gi]), 1.0, list(m.com[bb])))
+    rel = relative_margins(CONTACT_BREAKING_THRESHOLD, groups)
+    for gi in range(m.n_geoms):
+        m.g_margin[gi] = rel[m.g_body[gi]]
     m.foot_body[0], m.foot_body[1] = names.index("toe_joint_right"), names.index("toe_joint_left")  # env_cassie.py:72
     for gi in range(m.n_geoms):
         m.g_foot[gi] = next((k for k in range(2) if m.foot_body[k] == m.g_body[gi]), -1)
@@ -1009,7 +1061,7 @@ def compile_cassie(planar: bool = False, power_coef: float = 1.0, residual_contr
     m.friction_cone = FRICTION_CONE
     m.limit_at_violation = LIMIT_AT_VIOLATION
     m.n_llc = 50
-    m.contact_margin, m.lin_damp, m.ang_damp, m.max_qd, m.warmstart = 0.02, 0.04, 0.04, 100.0, WARMSTART
+    m.contact_margin, m.lin_damp, m.ang_damp, m.max_qd, m.warmstart = CONTACT_BREAKING_THRESHOLD, 0.04, 0.04, 100.0, WARMSTART
     m.ground_friction = 0.8
     m.limit_slack, m.max_contacts, m.max_rows = 0.05, 12, 48
     # each toe is ONE convex mesh in cassie_collide.urdf: Bullet keeps at most 4 contact points per pair of collision objects
@@ -1135,12 +1187,22 @@ def compile_laikago(stepper: bool = False, plank_class: str = "LargePlank") -> M
     assert g <= MAX_GEOMS
     m.n_geoms = m.n_slots = g
     m.n_pairs = 0
+    # relative contact breaking thresholds: a toe sphere is a collision object of its own (fixed child link); the hull points of the
+    # mesh links are grouped by the body they move with
+    groups = {}
+    for gi in range(m.n_geoms):
+        bb, rr, pp = m.g_body[gi], m.g_radius[gi], list(m.g_p1[gi])
+        key = ("toe", gi) if m.g_foot[gi] >= 0 else ("body", bb)
+        groups.setdefault(key, []).append((GEOM_SPHERE, rr, pp, pp, 1.0, pp if m.g_foot[gi] >= 0 else list(m.com[bb])))
+    rel = relative_margins(CONTACT_BREAKING_THRESHOLD, groups)
+    for gi in range(m.n_geoms):
+        m.g_margin[gi] = rel[("toe", gi) if m.g_foot[gi] >= 0 else ("body", m.g_body[gi])]
     # physics: control_step 1/60, sim_frame_skip 8 (env_locomotion.py:856-858) -> 8 substeps of 1/480 s
     m.gravity, m.dt, m.n_substeps, m.n_iters, m.erp = 9.8, 1.0 / 480.0, 8, 5, 0.9
     m.erp_noncontact = ERP_NONCONTACT
     m.friction_cone = FRICTION_CONE
     m.limit_at_violation = LIMIT_AT_VIOLATION
-    m.contact_margin, m.lin_damp, m.ang_damp, m.max_qd, m.warmstart = 0.02, 0.04, 0.04, 100.0, WARMSTART
+    m.contact_margin, m.lin_damp, m.ang_damp, m.max_qd, m.warmstart = CONTACT_BREAKING_THRESHOLD, 0.04, 0.04, 100.0, WARMSTART
     m.ground_friction = 0.8
     m.limit_slack, m.max_contacts, m.max_rows = 0.05, 12, 48
     m.init_pos[0], m.init_pos[1], m.init_pos[2] = 0.0, 0.0, 0.56                      # env_locomotion.py:864

@@ -644,7 +644,7 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
   w->body_touch = 0;
   uint64_t slot_mask = 0;
   int n_self = 0;
-  real margin = m->contact_margin;
+  /* margins: Bullet's relative contact breaking threshold of the geom's link (MoccaModel.slot_margin / pair_margin, include/mocca_model.h) */
   /* terrain: every slot within the margin is a candidate; when there are more than the solver holds (a robot lying on the
    * ground) the max_contacts DEEPEST are kept (ties: lower slot first) and solved in slot order */
   typedef struct { int body, slot; real n[3], P[3], depth, mu, erp, cfm; } TerrainCand;
@@ -691,7 +691,7 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
         erp = dt * kk / (dt * kk + cc);
         cfm = 1 / (dt * kk + cc) / dt;
       }
-      if (gap < margin) {
+      if (gap < (real)m->slot_margin[m->g_slot[g] + e]) {
         slot_mask |= (uint64_t)1 << (m->g_slot[g] + e);
         if (o->task_id == MOCCA_TASK_WALKER3D_PLANNER) { if (m->g_torso[g]) w->body_touch = 1; } /* the torso link touches the terrain, :1104-1110 */
         else if (m->g_foot[g] >= 0) { w->foot_touch[m->g_foot[g]] = 1; if (is_target) w->foot_target[m->g_foot[g]] = 1; }
@@ -762,7 +762,7 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
     seg_seg(a1, a2, b1, b2, ca, cb);
     real d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
     real dist = sqrt(dot3(d, d)), ra = m->g_radius[ga], rb = m->g_radius[gb];
-    real gap = dist - ra - rb;
+    real gap = dist - ra - rb, margin = m->pair_margin[k];
     if (gap < margin && w->nc < m->max_contacts && dist > (real)1e-9) {
       int i = w->nc++;
       w->c_a[i] = m->g_body[ga]; w->c_b[i] = m->g_body[gb]; w->c_slot[i] = -1;

@@ -82,7 +82,8 @@ class Model:
             self.anc[b] = self.anc[self.parent[b]] + [b]
         self.geoms = [dict(body=m.g_body[g], capsule=m.g_type[g] == 1, slot=m.g_slot[g], terrain=bool(m.g_terrain[g]),
                            radius=float(m.g_radius[g]), p=[np.array(list(m.g_p1[g]), float), np.array(list(m.g_p2[g]), float)],
-                           friction=float(m.g_friction[g])) for g in range(m.n_geoms)]
+                           friction=float(m.g_friction[g]),
+                           margin=float(m.slot_margin[m.g_slot[g]])) for g in range(m.n_geoms)]   # the link's relative threshold, as quantised in the blob
         self.pairs = [(m.pair_a[k], m.pair_b[k]) for k in range(m.n_pairs)]
         self.closures = [dict(a=m.cl_body_a[c], b=m.cl_body_b[c], pa=np.array(list(m.cl_point_a[c]), float),
                               pb=np.array(list(m.cl_point_b[c]), float)) for c in range(m.n_closures)]
@@ -358,7 +359,7 @@ def detect_contacts(mdl: Model, st: State, planks=None, heightfield=None):
                         gap, n = dist - g["radius"], Rb @ nl
                 kk, cc, dt = mdl.plank_stiffness, mdl.plank_damping, mdl.dt
                 mu, erp, cfm = mdl.plank_friction * g["friction"], dt * kk / (dt * kk + cc), 1 / (dt * kk + cc) / dt
-            if gap < mdl.contact_margin:
+            if gap < g["margin"]:              # the link's relative contact breaking threshold
                 slot_mask |= 1 << (g["slot"] + e)
                 out.append(dict(a=g["body"], b=-1, slot=g["slot"] + e, P=C - g["radius"] * n, n=n, depth=-gap, mu=mu, erp=erp, cfm=cfm))
     if getattr(mdl, "manifold_max", 0) > 0:   # 4-point manifold per link: deepest, farthest from it, farthest to either side of that line
@@ -395,7 +396,7 @@ def detect_contacts(mdl: Model, st: State, planks=None, heightfield=None):
         d = ca - cb
         dist = np.linalg.norm(d)
         gap = dist - A["radius"] - B["radius"]
-        if gap < mdl.contact_margin and dist > 1e-9:
+        if gap < min(A["margin"], B["margin"]) and dist > 1e-9:
             n_self += 1
             if len(out) < mdl.max_contacts:
                 n = d / dist
