@@ -32,14 +32,14 @@ def _close(a, b, tol=5.0):
 
 
 def test_contact_and_row_caps_are_applied_identically():
-    """A robot lying 5-8 cm above the plane touches with ~30 points: both sides keep the same max_contacts = 12
+    """A robot lying 2-4 cm above the plane touches with > 12 points: both sides keep the same max_contacts = 12
     (terrain slot order) and stay inside the 48-row budget (12 contacts + limit rows) in the first substeps."""
     import torch
     env, orc = _pair("Walker3DCustomEnv-v0", 0, 16)
     rng = np.random.default_rng(0)
     st = np.zeros_like(orc.get_state())
     for e in range(16):
-        st[e, 2] = 0.05 + 0.03 * rng.random()
+        st[e, 2] = 0.02 + 0.02 * rng.random()      # (contacts open within millimetres: the body has to be IN the ground to touch everywhere)
         pitch = np.pi / 2 * (1 if e % 2 else -1) + rng.normal(0, 0.02)  # face down / face up
         st[e, 3:7] = [0, np.sin(pitch / 2), 0, np.cos(pitch / 2)]
         st[e, 13:13 + NJ] = rng.uniform(-0.05, 0.05, NJ)
