@@ -241,7 +241,7 @@ typedef struct MoccaModel {
   /* ---- derived lookup tables (model.py finalize_tables): one 16-byte load instead of chains of dependent loads ---- */
   float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | margin_code<<17 (7 bits, x 2^-13 m) | terrain<<24 | (foot + 1)<<25 | torso<<28), bits(anc_mask[body]) */
   float gp_tab[2 * MOCCA_MAX_GEOMS][4];     /* geom end point in its body frame (x, y, z), bits(body) */
-  float pair_tab[MOCCA_MAX_PAIRS][4];       /* bits(geom_a | geom_b<<8 | body_a<<16 | body_b<<24), radius_a, radius_b,
+  float pair_tab[MOCCA_MAX_PAIRS][4];       /* bits(geom_a | geom_b<<5 | body_a<<10 | body_b<<15 | margin_code<<20), radius_a, radius_b,
                                                broad-phase reach = half_len_a + half_len_b + radius_a + radius_b (padded; + the pair's margin at run time) */
   float slot_margin[MOCCA_MAX_SLOTS];       /* g_margin of the slot's geom (or contact_margin), quantised to 2^-13 m like the code in slot_tab */
   float pair_margin[MOCCA_MAX_PAIRS];       /* min of the two geoms' margins */

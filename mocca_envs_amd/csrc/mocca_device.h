@@ -1214,13 +1214,13 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
     bool near = false;
     if (k < npairs) {
       const f4_t pt = *(CF4P)(M->pair_tab[k]);  // geoms, bodies, radii, reach: one load
-      const int ids = __float_as_int(pt.x);
-      const int ga = ids & 0xFF, gb = (ids >> 8) & 0xFF;
+      const int ids = __float_as_int(pt.x);   // geom_a | geom_b << 5 | body_a << 10 | body_b << 15 | margin code << 20
+      const int ga = ids & 31, gb = (ids >> 5) & 31;
       float dm[3];  // distance of the two segment midpoints (x2); the segments' half lengths and radii are constants of the pair (pt.w)
 #pragma unroll
       for (int i = 0; i < 3; ++i)
         dm[i] = (L[L_GP + 6 * ga + i] + L[L_GP + 6 * ga + 3 + i]) - (L[L_GP + 6 * gb + i] + L[L_GP + 6 * gb + 3 + i]);
-      const float reach = 2.0f * (pt.w + M->pair_margin[k]);
+      const float reach = 2.0f * (pt.w + (float)((ids >> 20) & 0x7F) * (1.0f / 8192.0f));   // + the pair's margin (= pair_margin[k])
       near = dot3(dm, dm) < reach * reach;
     }
     const unsigned long long nm = __ballot(near);
@@ -1238,7 +1238,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
       const int k = cand[base + lane];
       const f4_t pt = *(CF4P)(M->pair_tab[k]);
       const int ids = __float_as_int(pt.x);
-      const int ga = ids & 0xFF, gb = (ids >> 8) & 0xFF;
+      const int ga = ids & 31, gb = (ids >> 5) & 31;
       float a1[3], a2[3], b1[3], b2[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -1250,21 +1250,21 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
       float d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
       const float d2 = dot3(d, d), id = rsq(d2), dist = d2 * id, ra = pt.y, rb = pt.z;  // v_rsq_f32 (1 ulp)
       g2 = dist - ra - rb;
-      hit = g2 < M->pair_margin[k] && d2 > 1e-18f;
+      hit = g2 < (float)((ids >> 20) & 0x7F) * (1.0f / 8192.0f) && d2 > 1e-18f;   // the smaller of the two links' relative thresholds
       if (hit) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           nn[i] = d[i] * id;
           PP[i] = 0.5f * ((ca[i] - ra * d[i] * id) + (cb[i] + rb * d[i] * id));
         }
-        ba = (ids >> 16) & 0xFF; bb = (ids >> 24) & 0xFF;
+        ba = (ids >> 10) & 31; bb = (ids >> 15) & 31;
         mu2 = M->g_friction[ga] * M->g_friction[gb];  // rare path (a self contact): two cached loads
       }
     }
     const unsigned long long hm = __ballot(hit);
     if (TASK == MOCCA_TASK_WALKER3D_PLANNER && hm != 0ull) {   // rare: a self contact; does it involve a geom of the torso link?
       int tor = 0;
-      if (hit) { const int ids2 = __float_as_int((*(CF4P)(M->pair_tab[cand[base + lane]])).x); tor = M->g_torso[ids2 & 0xFF] | M->g_torso[(ids2 >> 8) & 0xFF]; }
+      if (hit) { const int ids2 = __float_as_int((*(CF4P)(M->pair_tab[cand[base + lane]])).x); tor = M->g_torso[ids2 & 31] | M->g_torso[(ids2 >> 5) & 31]; }
       if (__ballot(hit && tor) != 0ull) fl.body_touch = 1;
     }
     if (TASK == MOCCA_TASK_WALKER3D_STEPPER) {  // calc_feet_state counts any contact of a foot link
@@ -1412,7 +1412,9 @@ constexpr int fric_lane(int i, int s) { return MAXR - 2 - 2 * i + s; }
 #ifdef MOCCA_PGS_REG_ROWS   // override for sweeps
 template <class T> struct PgsWin { static constexpr int ROWS = MOCCA_PGS_REG_ROWS, CONTACTS = MOCCA_PGS_REG_CONTACTS; };
 #else
-template <class T> struct PgsWin { static constexpr int ROWS = T::NCLOS > 0 ? 24 : 16, CONTACTS = T::NCLOS > 0 ? 12 : 4; };
+// (round 3 late: limit rows exist only at the stops and contacts open within millimetres -- a walker's substep holds ~11 rows, Cassie's at
+// most 8 contacts, two 4-point toe manifolds: 12 + 4 and 24 + 8 cover them, and the 128-VGPR budget holds without scratch again)
+template <class T> struct PgsWin { static constexpr int ROWS = T::NCLOS > 0 ? 24 : 12, CONTACTS = T::NCLOS > 0 ? 8 : 4; };
 #endif
 // `fpos`: bit l set iff lane l's friction bound is positive.  Bullet solves a contact's friction rows only while its normal row carries an
 // impulse (`if (totalImpulse > 0)` in btMultiBodyConstraintSolver::solveSingleIteration) and leaves them as they are otherwise -- a contact

@@ -217,7 +217,9 @@ class MoccaModel(C.Structure):
                 self.slot_tab[sl][3] = bits(self.anc_mask[b])
         for k in range(self.n_pairs):
             ga, gb = self.pair_a[k], self.pair_b[k]
-            self.pair_tab[k][0] = bits(ga | (gb << 8) | (self.g_body[ga] << 16) | (self.g_body[gb] << 24))
+            assert MAX_GEOMS <= 32 and MAX_BODIES <= 32
+            pm = min(self.margin_code(ga), self.margin_code(gb))
+            self.pair_tab[k][0] = bits(ga | (gb << 5) | (self.g_body[ga] << 10) | (self.g_body[gb] << 15) | (pm << 20))
             self.pair_tab[k][1] = self.g_radius[ga]
             self.pair_tab[k][2] = self.g_radius[gb]
             # broad-phase reach of the pair: half lengths + radii (constants of the two geoms; the contact margin is added at run
