@@ -67,7 +67,7 @@ enum {
   MOCCA_PARAM_ISSUE_PRIORITY = 9, /* TIMING ONLY (no reference counterpart, results do not depend on it): constraint-row counts above which a
                                      wave runs at issue priority 1 / 2 / 3 in the step kernel, packed t1 + 64 t2 + 4096 t3 (each 0..63).
                                      A launch lasts as long as its slowest wave and an env's cost grows with its rows, so the best
-                                     thresholds follow the batch's row distribution; default 14 / 20 / 28 (flat-ground walker) */
+                                     thresholds follow the batch's row distribution; default 4 / 7 / 12 (flat-ground walker, blob v13 physics) */
 };
 
 /* words of the per-env debug record (mocca_set_debug_buffer): words 0..11 the active set of the LAST physics substep, words 12..15

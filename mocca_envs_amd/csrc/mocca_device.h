@@ -64,9 +64,9 @@ typedef float f4_t __attribute__((ext_vector_type(4)));  // native vector: loada
 typedef const MOCCA_AS_CONST f4_t* CF4P;
 
 #ifndef MOCCA_PRIO_T3  // default row-count thresholds of the issue priorities 3 / 2 / 1 (solve_constraints; MOCCA_PARAM_ISSUE_PRIORITY)
-#define MOCCA_PRIO_T3 28   // re-tuned on the 116 us kernel (36 / 26 / 18 before: +0.7 %; no priorities at all: +13 %)
-#define MOCCA_PRIO_T2 20
-#define MOCCA_PRIO_T1 14
+#define MOCCA_PRIO_T3 12   // re-tuned for the blob v13 physics (5.7 rows per substep, p99 17): 28 / 20 / 14 of the 12.7-row days had stopped
+#define MOCCA_PRIO_T2 7    // selecting anything -- 110.0 -> 104.3 us (profiles/r03_prio_sweep_v13.txt); no priorities at all: +13 % in round 2
+#define MOCCA_PRIO_T1 4
 #endif
 constexpr int MAXR = 48;  // rows held by one wave (MoccaModel.max_rows must be <= MAXR)
 constexpr int MAXC = 12;  // contacts            (MoccaModel.max_contacts <= MAXC)

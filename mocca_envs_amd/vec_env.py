@@ -45,12 +45,15 @@ _DEFAULT_PARAMS = {"LaikagoCustomEnv-v0": {_lib.PARAM_RANDOM_POSE: 0},    # robo
 
 # Issue-priority thresholds of the step kernel (PARAM_ISSUE_PRIORITY; timing only, results do not depend on them): constraint-row counts
 # above which a wave runs at priority 1 / 2 / 3.  The best set follows the batch's row distribution -- measured per env id with
-# tools/prio_sweep.sh on one MI355X (profiles/r02_prio_sweep.txt); ids not listed keep the library's default (14, 20, 28: the flat-ground
-# walker).  The stepping-stone walkers carry more rows as the curriculum rises: their thresholds grow with it (x 1.29 at curriculum 9).
-_ISSUE_PRIORITY = {"LaikagoCustomEnv-v0": (3, 6, 10), "LaikagoStepperEnv-v0": (4, 8, 12), "Child3DCustomEnv-v0": (20, 30, 42),
-                   "CassieEnv-v0": (24, 29, 33), "Cassie2DEnv-v0": (24, 29, 33), "CassiePhaseMocca2DEnv-v0": (24, 29, 33),
-                   "CassiePhaseMirror2DEnv-v0": (24, 29, 33)}
-_ISSUE_PRIORITY_CURRICULUM = {"Walker3DStepperEnv-v0": (14, 20, 28), "MikeStepperEnv-v0": (14, 20, 28)}
+# tools/prio_sweep.sh on one MI355X (profiles/r03_prio_sweep_v13.txt: the blob v13 physics hold 5.7 rows per substep on the flat-ground walker
+# instead of 12.7, and the thresholds of round 2 had stopped selecting anything: -5.5 % on the launch for re-reading them off the new
+# distribution); ids not listed keep the library's default (4, 7, 12: the flat-ground walker).  The stepping-stone walkers carry more rows as
+# the curriculum rises: their thresholds grow with it (x 1.7 at curriculum 9).
+_ISSUE_PRIORITY = {"LaikagoCustomEnv-v0": (3, 6, 10), "LaikagoStepperEnv-v0": (4, 8, 12), "Child3DCustomEnv-v0": (6, 11, 18),
+                   "CassieEnv-v0": (18, 23, 27), "Cassie2DEnv-v0": (18, 23, 27), "CassiePhaseMocca2DEnv-v0": (18, 23, 27),
+                   "CassiePhaseMirror2DEnv-v0": (18, 23, 27)}
+_ISSUE_PRIORITY_CURRICULUM = {"Walker3DStepperEnv-v0": (7, 11, 17), "MikeStepperEnv-v0": (7, 11, 17)}
+_ISSUE_PRIORITY_CURRICULUM_GAIN = 0.7   # thresholds x (1 + gain * curriculum / 9)
 
 
 def _pack_prio(t):
@@ -165,7 +168,7 @@ class VecEnv:
     def set_param(self, pid: int, value: float):
         _lib.check(self.lib.mocca_set_param(self.h, pid, float(value)), self.h)
         if pid == _lib.PARAM_CURRICULUM and self.env_id in _ISSUE_PRIORITY_CURRICULUM:   # timing only, see _ISSUE_PRIORITY
-            k = 1.0 + 0.29 * min(9.0, max(0.0, float(value))) / 9.0
+            k = 1.0 + _ISSUE_PRIORITY_CURRICULUM_GAIN * min(9.0, max(0.0, float(value))) / 9.0
             base = _ISSUE_PRIORITY_CURRICULUM[self.env_id]
             _lib.check(self.lib.mocca_set_param(self.h, _lib.PARAM_ISSUE_PRIORITY, float(_pack_prio([min(63, round(k * t)) for t in base]))), self.h)
 
