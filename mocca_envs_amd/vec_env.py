@@ -49,9 +49,10 @@ _DEFAULT_PARAMS = {"LaikagoCustomEnv-v0": {_lib.PARAM_RANDOM_POSE: 0},    # robo
 # instead of 12.7, and the thresholds of round 2 had stopped selecting anything: -5.5 % on the launch for re-reading them off the new
 # distribution); ids not listed keep the library's default (4, 7, 12: the flat-ground walker).  The stepping-stone walkers carry more rows as
 # the curriculum rises: their thresholds grow with it (x 1.7 at curriculum 9).
-_ISSUE_PRIORITY = {"LaikagoCustomEnv-v0": (3, 6, 10), "LaikagoStepperEnv-v0": (4, 8, 12), "Child3DCustomEnv-v0": (6, 11, 18),
-                   "CassieEnv-v0": (18, 23, 27), "Cassie2DEnv-v0": (18, 23, 27), "CassiePhaseMocca2DEnv-v0": (18, 23, 27),
-                   "CassiePhaseMirror2DEnv-v0": (18, 23, 27)}
+_ISSUE_PRIORITY = {"LaikagoCustomEnv-v0": (2, 4, 7), "LaikagoStepperEnv-v0": (2, 4, 7), "Child3DCustomEnv-v0": (6, 11, 18),
+                   "CassieEnv-v0": (18, 23, 27), "Cassie2DEnv-v0": (24, 29, 33), "CassiePhaseMocca2DEnv-v0": (24, 29, 33),
+                   "CassiePhaseMirror2DEnv-v0": (24, 29, 33), "Walker3DPlannerEnv-v0": (10, 16, 24), "MikePlannerEnv-v0": (10, 16, 24),
+                   "Walker2DCustomEnv-v0": (6, 9, 14), "Crab2DCustomEnv-v0": (8, 12, 18)}
 _ISSUE_PRIORITY_CURRICULUM = {"Walker3DStepperEnv-v0": (7, 11, 17), "MikeStepperEnv-v0": (7, 11, 17)}
 _ISSUE_PRIORITY_CURRICULUM_GAIN = 0.7   # thresholds x (1 + gain * curriculum / 9)
 
