@@ -80,13 +80,13 @@ def test_bench_launches_its_own_ranks():
     whole-job rate over the SLOWEST rank's time (the dry run makes rank r take (r + 1) ms per step)."""
     out = _bench("--gpus", "2", "--steps", "40", "--warmup", "1", "--dry-run")
     assert out["n_gpus"] == 2 and out["dry_run"] and out["scaling"] == "weak"
-    assert 2.0 <= out["ms_per_step"] < 2.3                                # rank 1's time (a 80 ms sleep), not rank 0's
+    assert 2.0 <= out["ms_per_step"] < 6.0                                # rank 1's time (a 80 ms sleep; a loaded host oversleeps), not rank 0's
     assert abs(out["value"] - 2 * 4096 / (1e-3 * out["ms_per_step"])) < 1e-3 * out["value"]
     assert "x2" in out["config"]["parallelism"]
     # every rank's own numbers travel in the line; ms_per_step is the max of the per-rank list
     pr = out["per_rank"]
     assert len(pr["ms_per_step"]) == 2 and len(pr["kernel_ms"]) == 2 and pr["kernel_ms"] == [1.0, 2.0]
-    assert 1.0 <= pr["ms_per_step"][0] < 1.3 and out["ms_per_step"] == max(pr["ms_per_step"])
+    assert 1.0 <= pr["ms_per_step"][0] < 3.0 and out["ms_per_step"] == max(pr["ms_per_step"])
     out = _bench("--gpus", "1", "--steps", "2", "--dry-run", "--envs", "8192")
     assert out["n_gpus"] == 1 and out["config"]["envs_per_gpu"] == 8192
     # the contract's fields, and the untimed pre-roll is declared in the line (it is data preparation, not part of W or K)
@@ -101,8 +101,8 @@ def test_a_slow_barrier_stays_outside_the_timed_window():
     """The start / stop rendezvous is a gloo barrier over TCP: every rank's clock stops at its own synchronize, BEFORE the stop
     barrier.  A barrier that takes 0.25 s (25 x the 10 ms window of this run) must not show up in ms_per_step or value."""
     out = _bench("--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run", "--test-barrier-delay", "0.25")
-    assert 2.0 <= out["ms_per_step"] < 3.0, out["ms_per_step"]           # 5 steps x 2 ms on rank 1; with the barrier inside: > 50 ms
-    assert out["value"] > 2 * 4096 / 3e-3
+    assert 2.0 <= out["ms_per_step"] < 10.0, out["ms_per_step"]          # 5 steps x 2 ms on rank 1 (more on a loaded host); with the barrier inside: > 50 ms
+    assert out["value"] > 2 * 4096 / 10e-3
 
 
 def test_the_launcher_counts_gpus_without_a_hip_runtime():
