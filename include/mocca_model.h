@@ -239,7 +239,7 @@ typedef struct MoccaModel {
   int32_t reserved_[4];
 
   /* ---- derived lookup tables (model.py finalize_tables): one 16-byte load instead of chains of dependent loads ---- */
-  float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | margin_code<<17 (7 bits, x 2^-13 m) | terrain<<24 | (foot + 1)<<25 | torso<<28), bits(anc_mask[body]) */
+  float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | margin_code<<17 (8 bits, x 2^-13 m) | terrain<<25 | (foot + 1)<<26 | torso<<29), bits(anc_mask[body]) */
   float gp_tab[2 * MOCCA_MAX_GEOMS][4];     /* geom end point in its body frame (x, y, z), bits(body) */
   float pair_tab[MOCCA_MAX_PAIRS][4];       /* bits(geom_a | geom_b<<5 | body_a<<10 | body_b<<15 | margin_code<<20), radius_a, radius_b,
                                                broad-phase reach = half_len_a + half_len_b + radius_a + radius_b (padded; + the pair's margin at run time) */

@@ -1062,9 +1062,9 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
     const int ids = __float_as_int(st.z);
     const int g = (ids >> 8) & 0xFF, e = (ids >> 16) & 1;
     bmask = __float_as_uint(st.w);
-    if ((ids >> 24) & 1) {  // flags: bit 24 terrain, bits 25.. foot index + 1
-      gfoot = ((ids >> 25) & 7) - 1;
-      gtorso = (ids >> 28) & 1;
+    if ((ids >> 25) & 1) {  // flags: bits 17..24 margin code, bit 25 terrain, bits 26..28 foot index + 1, bit 29 torso
+      gfoot = ((ids >> 26) & 7) - 1;
+      gtorso = (ids >> 29) & 1;
       float C[3], Cw[3];
       const float rad = st.x, gfric = st.y;
 #pragma unroll
@@ -1113,7 +1113,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
         erp = dt * kk * ikc;
         cfm = ikc * rcp(dt);
       }
-      active = gap < (float)((ids >> 17) & 0x7F) * (1.0f / 8192.0f);   // the link's margin, a 7-bit multiple of 2^-13 m in the slot record (= slot_margin)
+      active = gap < (float)((ids >> 17) & 0xFF) * (1.0f / 8192.0f);   // the link's margin, an 8-bit multiple of 2^-13 m in the slot record (= slot_margin)
 #pragma unroll
       for (int i = 0; i < 3; ++i) P[i] = C[i] - rad * n[i];
     }
@@ -1220,7 +1220,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
 #pragma unroll
       for (int i = 0; i < 3; ++i)
         dm[i] = (L[L_GP + 6 * ga + i] + L[L_GP + 6 * ga + 3 + i]) - (L[L_GP + 6 * gb + i] + L[L_GP + 6 * gb + 3 + i]);
-      const float reach = 2.0f * (pt.w + (float)((ids >> 20) & 0x7F) * (1.0f / 8192.0f));   // + the pair's margin (= pair_margin[k])
+      const float reach = 2.0f * (pt.w + (float)((ids >> 20) & 0xFF) * (1.0f / 8192.0f));   // + the pair's margin (= pair_margin[k])
       near = dot3(dm, dm) < reach * reach;
     }
     const unsigned long long nm = __ballot(near);
@@ -1250,7 +1250,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
       float d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
       const float d2 = dot3(d, d), id = rsq(d2), dist = d2 * id, ra = pt.y, rb = pt.z;  // v_rsq_f32 (1 ulp)
       g2 = dist - ra - rb;
-      hit = g2 < (float)((ids >> 20) & 0x7F) * (1.0f / 8192.0f) && d2 > 1e-18f;   // the smaller of the two links' relative thresholds
+      hit = g2 < (float)((ids >> 20) & 0xFF) * (1.0f / 8192.0f) && d2 > 1e-18f;   // the smaller of the two links' relative thresholds
       if (hit) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {

@@ -183,10 +183,10 @@ class MoccaModel(C.Structure):
         return m
 
     def margin_code(self, g: int) -> int:
-        """The geom's contact margin in units of 2^-13 m (0.122 mm), 7 bits: what the kernels decode from the slot record (the tables
+        """The geom's contact margin in units of 2^-13 m (0.122 mm), 8 bits: what the kernels decode from the slot record (the tables
         slot_margin / pair_margin hold the same, decoded -- every implementation compares against the quantised value)."""
         gm = self.g_margin[g] if self.g_margin[g] > 0 else self.contact_margin
-        return int(min(127, max(1, round(gm / MARGIN_UNIT))))
+        return int(min(255, max(1, round(gm / MARGIN_UNIT))))
 
     def finalize_tables(self) -> "MoccaModel":
         """Fill the derived lookup tables from the primary fields (call after any edit of geoms / pairs)."""
@@ -212,8 +212,8 @@ class MoccaModel(C.Structure):
                 self.slot_margin[sl] = mq * MARGIN_UNIT
                 self.slot_tab[sl][0] = self.g_radius[g]
                 self.slot_tab[sl][1] = self.g_friction[g]
-                self.slot_tab[sl][2] = bits(b | (g << 8) | (e << 16) | (mq << 17) | ((1 if self.g_terrain[g] else 0) << 24) |
-                                            ((self.g_foot[g] + 1) << 25) | ((1 if self.g_torso[g] else 0) << 28))
+                self.slot_tab[sl][2] = bits(b | (g << 8) | (e << 16) | (mq << 17) | ((1 if self.g_terrain[g] else 0) << 25) |
+                                            ((self.g_foot[g] + 1) << 26) | ((1 if self.g_torso[g] else 0) << 29))
                 self.slot_tab[sl][3] = bits(self.anc_mask[b])
         for k in range(self.n_pairs):
             ga, gb = self.pair_a[k], self.pair_b[k]
@@ -918,7 +918,7 @@ CASSIE_KP = np.array([100, 100, 88, 96, 50, 100, 100, 88, 96, 50, 400, 400]) / 1
 #    (btCollisionDispatcher::getNewManifold, CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD on by default; MoccaModel.g_margin): 3 - 6 mm for a
 #    walker's links.  (Until round 3 late: 20 mm for every pair.)
 CONTACT_BREAKING_THRESHOLD = 0.02
-MARGIN_UNIT = 2.0 ** -13      # slot_tab carries a geom's margin as a 7-bit multiple of this (0.122 mm; up to 15.5 mm)
+MARGIN_UNIT = 2.0 ** -13      # slot_tab carries a geom's margin as an 8-bit multiple of this (0.122 mm; up to 31 mm)
 ERP_NONCONTACT = 0.2
 WARMSTART = 0.0
 FRICTION_CONE = 1

@@ -48,17 +48,25 @@ CASES = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("Walker3DStepper
          # the pyramid friction path (pybullet's enableConeFriction = 0; the compiled blobs use Bullet's implicit cone)
          ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_cone": 0}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_cone": 0}),
          # limit rows from a predicted gap on (limit_at_violation = 0; the compiled blobs build them at / past the limit only)
-         ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_predict": True}), ("CassieEnv-v0", M.TASK_CASSIE, {"_predict": True})]
+         ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_predict": True}), ("CassieEnv-v0", M.TASK_CASSIE, {"_predict": True}),
+         # one absolute contact margin of 2 cm for every pair (g_margin <= 0; the compiled blobs carry Bullet's relative thresholds, millimetres)
+         ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_abs_margin": True}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_abs_margin": True})]
 
 
 def _one_substep_blob(env_id, **kw):
     from mocca_envs_amd.vec_env import compile_model_for
     dump, massive, warm, cone = kw.pop("_dump", None), kw.pop("_massive", False), kw.pop("_warm", None), kw.pop("_cone", None)
-    predict = kw.pop("_predict", False)
+    predict, abs_margin = kw.pop("_predict", False), kw.pop("_abs_margin", False)
     m = compile_model_for(env_id, **kw)
     assert m.warmstart == 0.0 and m.friction_cone == 1 and m.limit_at_violation == 1
     if predict:
         m.limit_at_violation = 0
+    assert 0.001 < m.slot_margin[0] < 0.01
+    if abs_margin:
+        for g in range(m.n_geoms):
+            m.g_margin[g] = 0.0
+        m.finalize_tables()
+        assert abs(m.slot_margin[0] - 0.02) < 1e-4 and (m.n_pairs == 0 or abs(m.pair_margin[0] - 0.02) < 1e-4)
     if warm is not None:
         m.warmstart = warm
     if cone is not None:

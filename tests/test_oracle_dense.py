@@ -73,7 +73,8 @@ def _compare(orc, m, mdl, row, tau, planks=None, tol=2e-8, heightfield=None):
 @pytest.mark.parametrize("name,compile_fn,task,z", [("walker3d", M.compile_walker3d, 0, 0.25), ("laikago", M.compile_laikago, 0, 0.2),
                                                     ("crab2d", M.compile_crab2d, 0, 0.3), ("walker3d-warm", M.compile_walker3d, 0, 0.25),
                                                     ("walker3d-pyramid", M.compile_walker3d, 0, 0.25),
-                                                    ("walker3d-predicted-limits", M.compile_walker3d, 0, 0.25)])
+                                                    ("walker3d-predicted-limits", M.compile_walker3d, 0, 0.25),
+                                                    ("walker3d-absolute-margin", M.compile_walker3d, 0, 0.25)])
 def test_substep_on_random_contact_states(name, compile_fn, task, z):
     """Tumbling robots close to the ground: 3-12 contacts (terrain + self), limit rows, stale warm starts, the row cap.
     "-warm": the compiled blobs start every impulse from zero (Bullet's multibody contacts do not warm start); the warm-start path of
@@ -83,6 +84,11 @@ def test_substep_on_random_contact_states(name, compile_fn, task, z):
         m.warmstart = 0.85
     else:
         assert m.warmstart == 0.0
+    if name.endswith("-absolute-margin"):    # 2 cm for every pair (g_margin <= 0); the compiled blobs: Bullet's relative thresholds, millimetres
+        for g in range(m.n_geoms):
+            m.g_margin[g] = 0.0
+        m.finalize_tables()
+        assert abs(m.slot_margin[0] - 0.02) < 1e-4
     if name.endswith("-predicted-limits"):   # limit rows from a predicted gap of limit_slack on (the compiled blobs: only at / past the limit)
         m.limit_at_violation = 0
     else:
