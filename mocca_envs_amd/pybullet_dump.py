@@ -121,6 +121,11 @@ def from_pybullet_dump(dump: Mapping[str, np.ndarray], template: M.MoccaModel, j
         out.erp = float(dump["engine_contactERP"])                  # infoGlobal.m_erp2: contact rows (setDefaultContactERP)
     if "engine_numSolverIterations" in dump:
         out.n_iters = int(dump["engine_numSolverIterations"])
+    if "engine_contactBreakingThreshold" in dump:                   # gContactBreakingThreshold: the factor of the links' relative margins
+        f = float(dump["engine_contactBreakingThreshold"]) / float(template.contact_margin)
+        out.contact_margin = float(dump["engine_contactBreakingThreshold"])
+        for g in range(out.n_geoms):
+            out.g_margin[g] = template.g_margin[g] * f
     if "engine_enableConeFriction" in dump:
         out.friction_cone = int(dump["engine_enableConeFriction"])   # 0: pyramid (SOLVER_DISABLE_IMPLICIT_CONE_FRICTION)
     for key in ("rolling_friction", "spinning_friction", "restitution"):

@@ -91,7 +91,7 @@ def make_module(fixed_children=None):
     p.getPhysicsEngineParameters = lambda: {"fixedTimeStep": float(blob.dt) * int(blob.n_substeps), "numSubSteps": int(blob.n_substeps),
                                             "numSolverIterations": int(blob.n_iters), "erp": float(blob.erp_noncontact),
                                             "contactERP": float(blob.erp), "frictionERP": 0.2, "useRealTimeSimulation": 0,
-                                            "enableConeFriction": int(blob.friction_cone)}
+                                            "enableConeFriction": int(blob.friction_cone), "contactBreakingThreshold": float(blob.contact_margin)}
     p.changeDynamics = lambda *a, **k: None
     p.loadSDF = lambda f: (PLANE,)
     p.loadMJCF = lambda f, flags=0: (ROBOT,)

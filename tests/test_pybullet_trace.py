@@ -375,6 +375,8 @@ def test_the_dump_tool_writes_a_file_the_harness_consumes(tool_file):
     g35 = dict(g, engine_erp=np.array(0.35), engine_numSolverIterations=np.array(7.0), engine_enableConeFriction=np.array(0.0))
     m35 = _blob(g35)
     assert abs(m35.erp_noncontact - 0.35) < 1e-6 and m35.n_iters == 7 and abs(m35.erp - 0.9) < 1e-6 and m35.friction_cone == 0
+    m01 = _blob(dict(g, engine_contactBreakingThreshold=np.array(0.01)))          # half the factor: half the relative margins
+    assert abs(m01.slot_margin[0] - 0.5 * m.slot_margin[0]) < 1.3e-4 and abs(m01.contact_margin - 0.01) < 1e-7
     with pytest.raises(ValueError):
         _blob(dict(g, rolling_friction=np.full(len(g["mass"]), 0.1)))
     # the free-running rollouts start from the reference's reset pose: base at (0, 0, 1.32) at rest, "running_start" joint angles
