@@ -33,12 +33,25 @@ sys.path.insert(0, ROOT)
 ENVS_PER_GPU = 4096
 ENV_ID = "Walker3DCustomEnv-v0"
 # algorithmic HBM bytes of one env-step (state + task + action in, state + task + obs + reward +
-# done out) for Walker3DCustomEnv, contact warm-start impulses persisted (34 slots)
-ALGO_BYTES_PER_ENV_STEP = 836 + 2 * 34 * 4
+# done out) for Walker3DCustomEnv: 352 read + 484 written.  A blob that warm-starts its contact rows (warmstart != 0; the compiled blobs do
+# not) also reads and writes one impulse per terrain contact slot: algo_bytes_per_env_step() adds them only then.
+ALGO_BYTES_PER_ENV_STEP = 836
+
+
+def algo_bytes_per_env_step(env_id, model, obs_dim, act_dim, persist_impulses=False) -> int:
+    nj, ns = int(model.n_joints), int(model.n_slots)
+    warm_in = 4 * ns if model.warmstart != 0.0 else 0
+    warm_out = 4 * ns if (model.warmstart != 0.0 or persist_impulses) else 0
+    if env_id == ENV_ID:
+        return ALGO_BYTES_PER_ENV_STEP + warm_in + warm_out   # the figure quoted in DESIGN.md (24-word task record of the metric env)
+    sd, td = (13 + 2 * nj) * 4, 40 * 4                          # state (pose, velocity, q, qd) + task record
+    return (sd + td + act_dim * 4 + warm_in) + (sd + td + obs_dim * 4 + 5 + warm_out)
+
+
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3   # same guide: peak FP32 vector rate
 KERNEL_SOURCES = ["mocca_envs_amd/csrc/mocca_device.h", "mocca_envs_amd/csrc/mocca_kernels.h", "mocca_envs_amd/csrc/mocca_api.hip",
-                  "mocca_envs_amd/csrc/topo_walker3d.h", "include/mocca_model.h"]
+                  "mocca_envs_amd/csrc/mocca_r32.hip", "mocca_envs_amd/csrc/topo_walker3d.h", "include/mocca_model.h"]
 
 
 def kernel_source_hash() -> str:
@@ -112,6 +125,13 @@ def parse_args(argv=None):
     ap.add_argument("--prio", default=None,
                     help="TUNING ONLY: t1,t2,t3 row-count thresholds of the step kernel's issue priorities (MOCCA_PARAM_ISSUE_PRIORITY) in place of "
                          "the env id's default; timing only, results do not depend on it")
+    ap.add_argument("--max-rows", type=int, default=None,
+                    help="solver cap of the batch (MoccaModel.max_rows; default: the compiled blob's 48).  <= 32 selects the compact step-kernel "
+                         "instance (less LDS per env, five resident waves per SIMD instead of four); reported in config.max_rows")
+    ap.add_argument("--kernel-variant", type=int, default=0, help="TIMING ONLY: 1 forces the 48-row kernel instance for a blob that fits the compact one (A/B)")
+    ap.add_argument("--action-scale", type=float, default=1.0,
+                    help="actions are action_scale x U(-1,1) (SURVEY 8d config 4 asks for 0.1 on Cassie: a robot that stays up instead of one that "
+                         "falls every ~17 steps); reported in config.workload")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise launch / rendezvous / reporting only (CPU tests)")
     ap.add_argument("--test-barrier-delay", type=float, default=0.0,
                     help="TEST ONLY: every rank sleeps this many seconds inside each barrier (a slow rendezvous); the timed window must not see it")
@@ -218,7 +238,9 @@ def main():
         dev = torch.device("cuda", local_rank)
         from mocca_envs_amd.vec_env import VecEnv
         # same seed on every rank, draws keyed by the GLOBAL env id: the job's result does not depend on how many GPUs share it
-        env = VecEnv(args.env_id, args.envs, device=local_rank, auto_reset=True, seed=1000, env_offset=lo)
+        env = VecEnv(args.env_id, args.envs, device=local_rank, auto_reset=True, seed=1000, env_offset=lo, max_rows=args.max_rows)
+        if args.kernel_variant:
+            env.set_param(11, args.kernel_variant)  # MOCCA_PARAM_KERNEL_VARIANT
         if args.curriculum is not None:
             env.set_param(2, args.curriculum)  # MOCCA_PARAM_CURRICULUM: takes effect at reset
         if args.prio:
@@ -227,7 +249,7 @@ def main():
         env.reset()
         g = torch.Generator(device=dev)
         g.manual_seed(1 + rank)
-        tape = torch.rand(64, args.envs, env.act_dim, device=dev, generator=g) * 2 - 1  # U(-1,1) action tape, looped
+        tape = (torch.rand(64, args.envs, env.act_dim, device=dev, generator=g) * 2 - 1) * args.action_scale  # action_scale x U(-1,1) action tape, looped
 
         # the synthetic input of this metric is a batch of envs in mid-episode, not 4096 identical first frames: age it
         for i in range(args.preroll):
@@ -287,22 +309,18 @@ def main():
             else:
                 pmc_note = "profiles/traffic.json was measured on other kernel sources (stale): traffic not reported"
         value = sharding.aggregate_throughput(args.envs, world, args.steps, elapsed)
-        if args.env_id == ENV_ID:
-            algo = ALGO_BYTES_PER_ENV_STEP  # the figure quoted in DESIGN.md (24-word task record of the metric env)
-        elif env is not None:
-            # per env-step: state + task + action read, state + task + obs + reward + done written
-            sd, td = env.state_dim * 4, 40 * 4
-            algo = (sd + td + env.act_dim * 4) + (sd + td + env.obs_dim * 4 + 5)
-        else:
-            algo = 0
+        # per env-step: state + task + action read, state + task + obs + reward + done written, derived from the blob
+        algo = algo_bytes_per_env_step(args.env_id, env.model, env.obs_dim, env.act_dim) if env is not None else 0
         achieved = algo * args.envs / (kern_ms * 1e-3) / 1e9
-        terrain = "20 stepping planks" if "Stepper" in args.env_id else "flat ground"
+        terrain = "20 stepping planks" if "Stepper" in args.env_id else ("height field" if "Planner" in args.env_id else "flat ground")
+        scale_txt = "" if args.action_scale == 1.0 else f"{args.action_scale:g} x "
         out = {
             "metric": "env-steps/sec, Walker3DCustomEnv-v0 @ 4096 envs, 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.env_id}, {args.envs} envs/GPU, {terrain}, U(-1,1) action tape, auto-reset",
+            "config": {"workload": f"{args.env_id}, {args.envs} envs/GPU, {terrain}, {scale_txt}U(-1,1) action tape, auto-reset",
+                       "max_rows": int(env.model.max_rows) if env is not None else None, "max_contacts": int(env.model.max_contacts) if env is not None else None,
                        "envs_per_gpu": args.envs, "parallelism": f"independent env shards x{world}, no collective",
                        "reset_fraction_per_step": reset_frac, "preroll_steps": args.preroll},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

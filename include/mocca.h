@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MOCCA_ABI_VERSION 4
+#define MOCCA_ABI_VERSION 5
 
 typedef struct mocca_ctx *mocca_handle;
 
@@ -68,6 +68,17 @@ enum {
                                      wave runs at issue priority 1 / 2 / 3 in the step kernel, packed t1 + 64 t2 + 4096 t3 (each 0..63).
                                      A launch lasts as long as its slowest wave and an env's cost grows with its rows, so the best
                                      thresholds follow the batch's row distribution; default 4 / 7 / 12 (flat-ground walker, blob v13 physics) */
+  MOCCA_PARAM_PERSIST_IMPULSES = 10, /* no reference counterpart.  Words 13 + 2 n_joints .. of the state record (mocca_get_state) hold the normal
+                                        impulse of every terrain contact slot in the LAST substep.  A blob that warm-starts its contact rows
+                                        (MoccaModel.warmstart != 0) reads and writes them every step; the compiled blobs do not (Bullet does not
+                                        warm start multibody contacts), and then mocca_step neither loads nor stores them -- 272 B per env-step of
+                                        dead traffic until ABI 4 -- unless this parameter is 1 (tests and tools that want the impulses as a
+                                        diagnostic).  Results do not depend on it. */
+  MOCCA_PARAM_KERNEL_VARIANT = 11,   /* TIMING ONLY.  mocca_create picks the step-kernel instance from the blob: max_rows <= 32 and
+                                        max_contacts <= 10 on a tree without loop closures run the COMPACT instance (32 x 32 Delassus matrix,
+                                        the articulated-body view aliased under it: less LDS per env, more resident waves per CU); every other
+                                        blob the 48-row instance.  1 forces the 48-row instance for such a blob (A/B runs), 0 = automatic.
+                                        Both instances execute the same arithmetic in the same order: results are bit-identical. */
 };
 
 /* words of the per-env debug record (mocca_set_debug_buffer): words 0..11 the active set of the LAST physics substep, words 12..15

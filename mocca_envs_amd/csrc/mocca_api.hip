@@ -12,6 +12,13 @@
 
 using namespace mocca;
 
+// the compact instance of the step kernel (mocca_r32.hip)
+extern "C" size_t mocca_r32_args_sizeof(void);
+extern "C" int mocca_r32_max_rows(void);
+extern "C" int mocca_r32_max_contacts(void);
+extern "C" void mocca_r32_launch_step(int topo, int task_id, int n, hipStream_t s, const void* args);
+extern "C" void mocca_r32_kernel_info(int topo, int task_id, hipFuncAttributes* fa, int* nb, hipError_t* e);
+
 // --------------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------------
@@ -34,6 +41,9 @@ struct mocca_ctx {
   float* d_terrain = nullptr;
   int auto_reset = 0, eval_mode = 0, random_pose = 1, curriculum = 0, host_retarget = 0, env_offset = 0, random_reward = 0;
   float gain = 1.0f;
+  bool compact = false;        // the blob fits the compact step-kernel instance (compact_ok); MOCCA_PARAM_KERNEL_VARIANT = 1 overrides
+  int force_full = 0;
+  int persist_warm = 0;        // MOCCA_PARAM_PERSIST_IMPULSES
   bool gain_pending = false;   // a scalar MOCCA_PARAM_APPLIED_GAIN not yet written into the task records (flush_pending)
   float* final_obs = nullptr;  // caller-owned (mocca_set_terminal_obs_buffer)
   float* d_pvec[3] = {nullptr, nullptr, nullptr};  // per-env curriculum / eval_mode / applied_gain (mocca_set_param_v), lazily allocated
@@ -89,7 +99,7 @@ static int check_topology_t(const MoccaModel& m, const char* name, std::string& 
     err = std::string("model blob gives mass to a link the compiled topology treats as massless (") + name + ")";   // (check_topology picks the
     return MOCCA_E_TOPOLOGY;                                                                                      // ...Massive instance first)
   }
-  if (m.n_pairs > 0 && 6 * T::NG > L_CT - L_GP) {
+  if (m.n_pairs > 0 && 6 * T::NG > GP_FLOATS) {
     err = std::string("this topology's geom points overlap the contact records: blobs with self-collision pairs are not supported (") + name + ")";
     return MOCCA_E_ARG;
   }
@@ -129,6 +139,12 @@ static int check_topology(const MoccaModel& m, int task_id, int* topo, std::stri
   return check_topology_t<TopoWalker3D>(m, "TopoWalker3D", err);
 }
 
+// A blob whose caps fit 32 rows / 10 contacts on a tree without loop closures runs the compact instance of the step kernel (less LDS per
+// env: more resident waves).  Same arithmetic, same order: which instance runs is not observable in the results.
+static bool compact_ok(const MoccaModel& m, int topo) {
+  return topo != TOPO_CASSIE && topo != TOPO_CASSIE_MASSIVE && m.n_closures == 0 && m.max_rows <= mocca_r32_max_rows() &&
+         m.max_contacts <= mocca_r32_max_contacts() && mocca_r32_args_sizeof() == sizeof(StepArgs);
+}
 template <class T, int TASK> struct LaunchStep {
   static void run(int n, hipStream_t s, StepArgs a) { hipLaunchKernelGGL((mocca_step_kernel<T, TASK>), dim3(n), dim3(64), 0, s, a); }
 };
@@ -186,6 +202,7 @@ int mocca_create(const void* model_blob, size_t nbytes, int task_id, int n_envs,
     g_err = "no such HIP device"; delete h; return MOCCA_E_NODEVICE;
   }
   h->task_id = task_id; h->n_envs = n_envs; h->device = device;
+  h->compact = compact_ok(h->model, h->topo);
   h->obs_dim = task_id == MOCCA_TASK_CASSIE
                    ? (h->model.cassie_mode == MOCCA_CASSIE_PLAIN ? 6 + 2 * h->model.n_ordered + 2 : 12 + 2 * h->model.n_ordered + 2)  // env_cassie.py:344-346 / :633
                    : 6 + 2 * h->model.n_joints + h->model.n_feet + (task_id == MOCCA_TASK_WALKER3D_STEPPER ? 5 * (h->model.lookbehind + 2) : 2);
@@ -275,6 +292,7 @@ static StepArgs make_args(mocca_handle h) {
   a.prio = h->prio;
   a.traj = h->d_traj; a.traj_n = h->traj_n; a.traj_tmax = h->traj_tmax; a.traj_cstep = h->traj_cstep;
   a.final_obs = h->final_obs;
+  a.persist_warm = h->persist_warm;
   a.hf = h->d_hf; a.hf_rows = h->hf_rows; a.hf_cols = h->hf_cols; a.hf_scale = h->hf_scale;
   return a;
 }
@@ -328,7 +346,8 @@ int mocca_step(mocca_handle h, const float* act_dev, float* obs_dev, float* rew_
   a.act = act_dev; a.obs = obs_dev; a.rew = rew_dev; a.done = done_dev; a.info = info_dev;
   hipStream_t s = (hipStream_t)stream;
   if (int rc = flush_pending(h, s)) return rc;
-  dispatch<LaunchStep>(h->topo, h->task_id, h->n_envs, s, a);
+  if (h->compact && !h->force_full) mocca_r32_launch_step(h->topo, h->task_id, h->n_envs, s, &a);
+  else dispatch<LaunchStep>(h->topo, h->task_id, h->n_envs, s, a);
   HIP_TRY(h, hipGetLastError());
   return MOCCA_OK;
 }
@@ -489,6 +508,10 @@ int mocca_set_param(mocca_handle h, int param_id, double value) {
     case MOCCA_PARAM_RANDOM_REWARD:
       if (value != 0 && value != 1 && value != 2) { h->err = "MOCCA_PARAM_RANDOM_REWARD is 0, 1 or 2"; return MOCCA_E_ARG; }
       h->random_reward = (int)value; break;
+    case MOCCA_PARAM_PERSIST_IMPULSES: h->persist_warm = value != 0; break;
+    case MOCCA_PARAM_KERNEL_VARIANT:
+      if (value != 0 && value != 1) { h->err = "MOCCA_PARAM_KERNEL_VARIANT is 0 (automatic) or 1 (force the 48-row instance)"; return MOCCA_E_ARG; }
+      h->force_full = (int)value; break;
     default: h->err = "unknown parameter id"; return MOCCA_E_ARG;
   }
   return MOCCA_OK;
@@ -504,6 +527,9 @@ int mocca_set_param_v(mocca_handle h, int param_id, const float* values_dev, int
   hipLaunchKernelGGL(copy_param_kernel, dim3((h->n_envs + 255) / 256), dim3(256), 0, s, h->d_pvec[slot], values_dev, broadcast != 0, h->n_envs);
   HIP_TRY(h, hipGetLastError());
   if (slot == 2) {  // applied_gain acts at once (robots.py:33)
+    // the per-env values supersede a scalar mocca_set_param(APPLIED_GAIN) that was not flushed yet: left pending, the next call with a
+    // stream would overwrite every env's word with the stale scalar (call order must win, as it did when the scalar write was synchronous)
+    h->gain_pending = false;
     hipLaunchKernelGGL(set_task_word_kernel, dim3((h->n_envs + 255) / 256), dim3(256), 0, s, h->d_task, (int)T_GAIN, (const float*)h->d_pvec[slot], 0.0f, 0, h->n_envs);
     HIP_TRY(h, hipGetLastError());
   }
@@ -525,7 +551,8 @@ int mocca_kernel_info(mocca_handle h, int* vgprs, int* sgprs, int* lds_bytes, in
   hipFuncAttributes fa;
   int nb = 0;
   hipError_t e = hipSuccess;
-  dispatch<KernelInfo>(h->topo, h->task_id, &fa, &nb, &e);
+  if (h->compact && !h->force_full) mocca_r32_kernel_info(h->topo, h->task_id, &fa, &nb, &e);
+  else dispatch<KernelInfo>(h->topo, h->task_id, &fa, &nb, &e);
   HIP_TRY(h, e);
   if (vgprs) *vgprs = fa.numRegs;
   if (sgprs) *sgprs = 0;

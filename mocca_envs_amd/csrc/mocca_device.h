@@ -35,7 +35,20 @@
 
 #define DI __device__ __forceinline__
 
-namespace mocca {
+// The device code is compiled into the library TWICE: namespace mocca (48 rows per env: every blob) and namespace mocca_r32
+// (mocca_r32.hip: MOCCA_MAXR = 32, MOCCA_COMPACT = 1 -- the compact LDS layout below; blobs with max_rows <= 32, max_contacts <= 10 and no
+// loop closures, picked by mocca_create).  Same source, same arithmetic in the same order: the two instances are bit-identical.
+#ifndef MOCCA_NS
+#define MOCCA_NS mocca
+#endif
+#ifndef MOCCA_MAXR
+#define MOCCA_MAXR 48
+#endif
+#ifndef MOCCA_COMPACT
+#define MOCCA_COMPACT 0
+#endif
+
+namespace MOCCA_NS {
 
 // The same trees with NO link treated as massless: mocca_create() selects these instances for a blob that gives mass or inertia to the
 // intermediate links of the multi-hinge joints (what a PyBullet dump may report, pybullet_dump.from_pybullet_dump) -- the ABA inward pass
@@ -68,11 +81,15 @@ typedef const MOCCA_AS_CONST f4_t* CF4P;
 #define MOCCA_PRIO_T2 7    // selecting anything -- 110.0 -> 104.3 us (profiles/r03_prio_sweep_v13.txt); no priorities at all: +13 % in round 2
 #define MOCCA_PRIO_T1 4
 #endif
-constexpr int MAXR = 48;  // rows held by one wave (MoccaModel.max_rows must be <= MAXR)
-constexpr int MAXC = 12;  // contacts            (MoccaModel.max_contacts <= MAXC)
+constexpr int MAXR = MOCCA_MAXR;                  // rows held by one wave (MoccaModel.max_rows must be <= MAXR)
+constexpr int MAXC = MAXR >= 36 ? 12 : MAXR / 3;  // contacts            (MoccaModel.max_contacts <= MAXC)
+constexpr bool COMPACT = MOCCA_COMPACT != 0;
 constexpr int DYN_STRIDE = 96;      // floats per env in the dynamic-state buffer
 constexpr int TERRAIN_STRIDE = 128; // floats per env in the terrain buffer
 
+#ifndef MOCCA_LDS_PAD
+#define MOCCA_LDS_PAD 0   // diagnostic builds only (tools/occupancy_probe.sh): extra floats of LDS per wave, to run the same code at fewer waves per SIMD
+#endif
 // ---- LDS layout, float offsets (one wave = one env) ----
 // [0, L_V)      survives the whole step (state, torques, new velocity, warm-start impulses)
 // [L_V, end)    one region with two views: the ABA view (joint vectors, articulated inertias, geom points,
@@ -91,21 +108,51 @@ enum : int {
   L_JVEL = 168,   // [16] Cassie: filtered joint speeds of the low-level PD loop (env_cassie.py:451-453)
   L_Q0 = 184,     // [16] Cassie: joint angles at the start of the env.step (finite-difference jvel, :467-468)
   L_V = 216,
-  // ---- ABA view
-  L_B0 = L_V + 0,       // [6][8] base: rows of its articulated inertia + bias component (ABA base solve)
   // One 80-byte record per body with everything the passes over the tree read together (an LDS instruction costs the CU's pipe
   // ~3.5 cycles whatever its width, and that pipe is the busiest unit of the kernel):
   //   S (6) joint motion vector about the base origin, world axes | V (6) = IA S / D | c (6) velocity-product acceleration |
   //   u / D (u = tau - S.pA; before the ABA: the net joint torque) | 1 / D, D = S.(IA S) + armature (before the ABA: the armature)
   // Row sweeps read floats 0..11 (three 16-byte reads), the ABA outward walk 0..18 (five), the inward pass S and c (four).
   SVS = 20, SV_V = 6, SV_C = 12, SV_UU = 18, SV_INVD = 19,
+  // per-joint walk records, 16 floats each: [jrot * Rot(axis, q)](9) jpos(3) axis(3) qd(1), rebuilt by stage_joints() before every
+  // walk IN THE BODY RECORDS (L_SV + SVS j: what those hold is dead by then, and the walk writes S only after its last record read).
+  // Record 0 is the identity (the blob's joint 0), which a packed path names past its end: the walk composes a fixed number of
+  // records without a branch.  At the 20-float stride the joints visited at one path position by the lanes of a wave (up to MAXW of
+  // them) start in different LDS banks (16 j mod 64 put joints 9, 17 and 21 of the walker on the same banks: a 3-way conflict).
+  L_B0 = L_V + 0,       // [6][8] base: rows of its articulated inertia + bias component (ABA base solve)
   L_SV = L_V + 48,      // [22][SVS]
+#if MOCCA_COMPACT
+  // ---- ABA view, compact (mocca_r32): what is live together is what takes space.  A substep runs  stage joints -> walk phase 1 (body
+  // frames) -> geom points -> collision -> walk phase 2 (S, c, link inertias, bias forces) -> ABA -> rows -> solver: the geom points, the
+  // self-collision candidate list and the body frames are dead before the first link inertia is written, and live UNDER them (phase 2
+  // reads its frame into registers, then a wave barrier, then writes); the limit-row candidates are compacted after the base solve, into
+  // its 6 x 8 block; the Jacobian rows start right behind the body records (the contact records they overwrite were read while the rows
+  // were built -- program order of one wave).  No closure topologies here: their rows read the body frames after the ABA.
+  L_ROWD = L_B0,                      // [<= 48] compacted limit-row candidates (int)
+  L_CT = L_V + 488,                   // [MAXC][16] contact records
+  L_P = L_CT + 16 * MAXC,             // [NB][6]  bias forces
+  L_M = L_P + 132,                    // [NB][36] link / articulated inertias, full 6x6 rows (lane = row in the inward pass)
+  L_RT = L_M,                         // [NB][3][4] body frames (264)
+  L_GP = L_M + 264,                   // [NG][2][3] geom end points rel. base origin (<= 192: Laikago's 32 geoms)
+  GP_FLOATS = 192,
+  L_OBS = L_GP,
+  L_CAND = L_GP + GP_FLOATS,          // [MAX_PAIRS] u16 self-collision candidates
+  L_ABA_END = L_M + 792,
+  // ---- solver view
+  L_A = L_V,                          // [MAXR][MAXR] Delassus matrix, row = updated row, column = lane
+  L_J = L_V + 488,                    // [MAXR + 1][28] Jacobian rows (+ one dummy row for lanes that own no row)
+  L_XL = L_V,                         // [MAXR][28] M^-1 J^T lambda, after the iterations
+  L_SOLVER_END = (L_J + 28 * (MAXR + 1) > L_A + MAXR * MAXR ? L_J + 28 * (MAXR + 1) : L_A + MAXR * MAXR),
+  L_TOTAL = (L_ABA_END > L_SOLVER_END ? L_ABA_END : L_SOLVER_END) + MOCCA_LDS_PAD,
+#else
+  // ---- ABA view
   L_A0 = L_V + 488,     // [32] free (the Cholesky factor of IA0 and the base acceleration travel in registers: aba_passes -> solve_constraints)
   L_GP = L_V + 520,     // [NG][2][3] geom end points rel. base origin (136)
   L_OBS = L_V + 520,    // [<= 136] task layer (after the substeps: the geom points are dead): the observation is assembled here and leaves
                         //          in one coalesced store -- twice for an env that ends under auto-reset (terminal observation, then the
                         //          first observation of the next episode)
   L_CT = L_V + 656,     // [MAXC][16] contact records (192)
+  GP_FLOATS = L_CT - L_GP,
   L_ROWD = L_V + 848,   // [48] compacted limit-row candidates (int)
   L_RT = L_V + 896,     // [NB][3][4] body frames: row i of the rotation (3) + component i of the origin rel. the base origin: one 16-byte
                         //            write per (body, row) lane of the walk, three 16-byte reads per consumer
@@ -113,28 +160,27 @@ enum : int {
   L_P = L_V + 1952,     // [NB][6]  bias forces
   L_ABA_END = L_V + 2084,
   L_CAND = L_ABA_END,   // [MAX_PAIRS] u16 self-collision candidates (collide only: the slack the joint records 9.. used during the walk)
-  // per-joint walk records, 16 floats each: [jrot * Rot(axis, q)](9) jpos(3) axis(3) qd(1), rebuilt by stage_joints() before every
-  // walk IN THE BODY RECORDS (L_SV + SVS j: what those hold is dead by then, and the walk writes S only after its last record read).
-  // Record 0 is the identity (the blob's joint 0), which a packed path names past its end: the walk composes a fixed number of
-  // records without a branch.  At the 20-float stride the joints visited at one path position by the lanes of a wave (up to MAXW of
-  // them) start in different LDS banks (16 j mod 64 put joints 9, 17 and 21 of the walker on the same banks: a 3-way conflict).
   // ---- solver view
   L_A = L_V,            // [MAXR][MAXR] Delassus matrix, row = updated row, column = lane
   L_J = L_V + 960,      // [MAXR][28] Jacobian rows (tail of the A region)
   L_XL = L_V,           // [MAXR][28] M^-1 J^T lambda, after the iterations
-#ifndef MOCCA_LDS_PAD
-#define MOCCA_LDS_PAD 0   // diagnostic builds only (tools/occupancy_probe.sh): extra floats of LDS per wave, to run the same code at fewer waves per SIMD
-#endif
   L_TOTAL = L_V + MAXR * MAXR + 28 + MOCCA_LDS_PAD,  // + one dummy J row for lanes that own no row (A-row prefetches clamp to row MAXR - 1)
+#endif
 };
 static_assert(L_ABA_END <= L_TOTAL, "ABA view must fit");
 static_assert(L_SV % 4 == 0 && SVS % 4 == 0 && SVS >= 16, "joint records live in the body records, 16-byte aligned");
 static_assert(L_J + (MAXR + 1) * 28 <= L_TOTAL, "Jacobian rows (+ dummy) must fit the tail of the A region");
-static_assert(L_J % 4 == 0 && L_V % 4 == 0, "16-byte alignment of broadcast rows");
+static_assert(L_J % 4 == 0 && L_V % 4 == 0 && L_RT % 4 == 0 && L_CT % 4 == 0, "16-byte alignment of broadcast rows");
 static_assert(MAXR % 2 == 0 && 3 * MAXC <= MAXR, "friction rows sit on the top 2 MAXC lanes of the row range, odd lane = second tangent");
 static_assert(L_PLANK + 12 * MOCCA_MAX_PLANKS <= L_V && L_Q0 + 16 <= L_V, "persistent region overflows into the two-view region");
+#if MOCCA_COMPACT
+static_assert(L_TOTAL * 4 <= 8192 || MOCCA_LDS_PAD > 0, "more than 8 KB of LDS per wave: fewer than 20 waves per CU (5 per SIMD)");
+static_assert(L_J >= L_SV + 22 * SVS, "J rows are written while S, V, 1/D are still being read");
+static_assert(L_CAND + (MOCCA_MAX_PAIRS + 1) / 2 <= L_ABA_END && L_RT + 264 <= L_GP, "frames, geom points and the candidate list live under the link inertias");
+#else
 static_assert(L_TOTAL * 4 <= 10240 || MOCCA_LDS_PAD > 0, "more than 10 KB of LDS per wave: fewer than 16 waves per CU, the 4096-env batch no longer fits one round");
 static_assert(L_J >= L_RT, "J rows may be written while S, U, 1/D, the factor of IA0 and the contacts are still being read");
+#endif
 
 // contact record fields
 enum : int { C_BA = 0, C_BB = 1, C_SLOT = 2, C_P = 3, C_N = 6, C_DEPTH = 9, C_MU = 10, C_ERP = 11, C_CFM = 12, C_MA = 13, C_MB = 14 };
@@ -193,6 +239,9 @@ struct StepArgs {
   // optional (mocca_set_terminal_obs_buffer): [N][obs_dim]; the row of an env that ends under auto-reset receives the observation of
   // its final state (what the reference's step() returns with done, env_locomotion.py:128-141) before `obs` gets the next episode's first
   float* final_obs;
+  // the last substep's normal impulses per terrain slot (state words 13 + 2 NJ ..) are stored although the blob does not warm-start
+  // (MOCCA_PARAM_PERSIST_IMPULSES); a blob with warmstart != 0 always loads and stores them
+  int persist_warm;
 };
 
 // ------------------------------------------------------------------ helpers
@@ -393,20 +442,25 @@ DI float draw_u(const StepArgs& a, int env, int episode, int d) {  // env = glob
 //  2. lane = body: joint motion vector S = (a, r x a), then -- FULL only -- the spatial velocity as a plain sum of
 //     S_j qd_j along the path (no rotation chain any more), the velocity-product acceleration, link inertia, bias force.
 // One lane per body for everything cost ~90 VALU per path step; this costs ~20 + ~12.
-template <class T, bool FULL>
-DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
-  asm volatile("" : "+v"(lane));  // lane-derived indices are recomputed per walk: CSE across walks kept them live from kernel entry (spilled)
-  static_assert(3 * (T::NB - 1) <= 63, "three lanes per body must fit the wave (lane 63 writes the base)");
-  const int b = lane < T::NB ? lane : 0;
-  // the body's own constants are fetched before the walk so that their latency hides behind it
-  const float cl[3] = {M->com[b][0], M->com[b][1], M->com[b][2]};
-  float inl[6] = {0, 0, 0, 0, 0, 0}, ms = 0, jarm = 0, jdamp = 0;
+// the body's own constants of the walk's second phase
+struct WalkConsts { float cl[3], inl[6], ms, jarm, jdamp; };
+template <bool FULL>
+DI void walk_consts(ModelP M, int b, WalkConsts& k) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) k.cl[i] = M->com[b][i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) k.inl[i] = 0.0f;
+  k.ms = 0; k.jarm = 0; k.jdamp = 0;
   if (FULL) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) inl[i] = M->inertia[b][i];
-    ms = M->mass[b]; jarm = M->jarm[b]; jdamp = M->jdamp[b];
+    for (int i = 0; i < 6; ++i) k.inl[i] = M->inertia[b][i];
+    k.ms = M->mass[b]; k.jarm = M->jarm[b]; k.jdamp = M->jdamp[b];
   }
-  // ---- phase 1
+}
+// ---- phase 1: body frames (L_RT) and world joint axes (L_SV + SVS b + 0..2)
+template <class T>
+DI void walk_phase1(float* L, int lane, unsigned long long ppk) {
+  static_assert(3 * (T::NB - 1) <= 63, "three lanes per body must fit the wave (lane 63 writes the base)");
   {
     const int g = (lane * 43) >> 7;          // lane / 3 for lane < 64
     const int ri = lane - 3 * g;             // row of the rotation this lane owns
@@ -443,8 +497,14 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
       for (int i = 0; i < 3; ++i) *reinterpret_cast<float4*>(L + L_RT + 4 * i) = make_float4(Rb[3 * i], Rb[3 * i + 1], Rb[3 * i + 2], 0.0f);
     }
   }
-  wsync();
-  // ---- phase 2
+}
+// ---- phase 2: lane = body (see above); in the compact layout the link inertias it writes overlay the body frames, the geom points and
+// the candidate list: every lane holds its frame in registers before the first store (wave barrier inside `if (FULL)`)
+template <class T, bool FULL>
+DI void walk_phase2(ModelP M, float* L, int lane, int b, unsigned long long ppk, const WalkConsts& wk) {
+  const float cl[3] = {wk.cl[0], wk.cl[1], wk.cl[2]};
+  const float inl[6] = {wk.inl[0], wk.inl[1], wk.inl[2], wk.inl[3], wk.inl[4], wk.inl[5]};
+  const float ms = wk.ms, jarm = wk.jarm, jdamp = wk.jdamp;
   float R[9], r[3], v[6], S[6] = {0, 0, 0, 0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -552,6 +612,17 @@ DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
       L[L_SV + SVS * b + SV_UU] = L[L_TAU + b] - jdamp * L[L_QD + b];
     }
   }
+}
+
+template <class T, bool FULL>
+DI void walk_kinematics(ModelP M, float* L, int lane, unsigned long long ppk) {
+  asm volatile("" : "+v"(lane));  // lane-derived indices are recomputed per walk: CSE across walks kept them live from kernel entry (spilled)
+  const int b = lane < T::NB ? lane : 0;
+  WalkConsts wk;
+  walk_consts<FULL>(M, b, wk);   // fetched before the walk so that their latency hides behind it
+  walk_phase1<T>(L, lane, ppk);
+  wsync();
+  walk_phase2<T, FULL>(M, L, lane, b, ppk, wk);
 }
 
 // 6x6 SPD system through its Cholesky factor, symmetric storage, all indices static: F[sym(i, j)] = L_ij (i > j),
@@ -1006,7 +1077,7 @@ DI void geom_points(ModelP M, float* L, int lane) {
   // L_GP holds L_CT - L_GP floats; a topology with more geoms spills into the contact records, which is harmless only
   // while nothing reads L_GP after the terrain contacts are written, i.e. without self-collision pairs
   // (check_topology_t rejects blobs with pairs for such topologies)
-  static_assert(6 * T::NG <= L_CT - L_GP || T::NPAIR == 0, "geom points would overlap the contact records read by the self-collision pass");
+  static_assert(6 * T::NG <= GP_FLOATS || (T::NPAIR == 0 && !COMPACT), "geom points would overlap the contact records read by the self-collision pass");
   if (lane < 2 * T::NG) {
     const f4_t t = *(CF4P)(M->gp_tab[lane]);  // point (body frame) + body id, one load
     const int b = __float_as_int(t.w);
@@ -1206,7 +1277,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
   // pass 2: narrow phase over the survivors only -- typically one batch of 64 instead of ceil(n_pairs / 64).
   const int npairs = uni(M->n_pairs);
   unsigned short* cand = reinterpret_cast<unsigned short*>(L + L_CAND);
-  static_assert(2 * (L_TOTAL - L_CAND) >= MOCCA_MAX_PAIRS, "candidate list must hold every pair");
+  static_assert(2 * ((COMPACT ? L_ABA_END : L_TOTAL) - L_CAND) >= MOCCA_MAX_PAIRS, "candidate list must hold every pair");
   int ncand = 0;
 #pragma unroll 1
   for (int base = 0; base < npairs; base += 64) {
@@ -1498,7 +1569,8 @@ DI void set_issue_priority(int nr, int prio) {
   else __builtin_amdgcn_s_setprio(0);
 }
 template <class T>
-DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wanted, unsigned long long ppk, int32_t* dbg, const float* Afac, int prio, int& rows_out) {
+DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wanted, unsigned long long ppk, int32_t* dbg, const float* Afac, int prio, int& rows_out,
+                          bool keep_warm) {   // keep_warm (wave-uniform): the slots' normal impulses are wanted after the substep (warm start / diagnostic)
   STAMP_BEGIN;
   // wave-uniform scalars live in SGPRs: loop control becomes s_cmp/s_cbranch instead of exec-mask bookkeeping
   const float dt = unif(M->dt), idt = rcp(dt);
@@ -1549,7 +1621,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
   STAMP(16);
   if (nr == 0) {  // nothing touches, no limit near: nothing to solve (uniform branch)
     if (dbg && lane == 0) { dbg[8] = 0; dbg[9] = 0; dbg[10] = 0; dbg[11] = 0; }
-    if (lane < T::NSLOT) L[L_WARM + lane] = 0.0f;
+    if (keep_warm && lane < T::NSLOT) L[L_WARM + lane] = 0.0f;
     wsync();
     return;
   }
@@ -1614,7 +1686,8 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
       bias = depth > 0 ? ct[C_ERP] * depth * idt : depth * idt;
       cfm = ct[C_CFM];
       slot = __float_as_int(ct[C_SLOT]);
-      lam = slot >= 0 ? M->warmstart * L[L_WARM + slot] : 0.0f;
+      const float wsf = unif(M->warmstart);
+      lam = (wsf != 0.0f && slot >= 0) ? wsf * L[L_WARM + slot] : 0.0f;   // (compiled blobs: 0 -- Bullet does not warm start multibody contacts)
     } else {
       kind = 2;
       float t1[3], t2[3];
@@ -1858,9 +1931,9 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
 #pragma unroll
     for (int d = 0; d < T::ND; ++d) L[L_XL + 28 * dense + d] = X[d] * lam;
   }
-  if (lane < T::NSLOT) L[L_WARM + lane] = 0.0f;
+  if (keep_warm && lane < T::NSLOT) L[L_WARM + lane] = 0.0f;
   wsync();
-  if (kind == 1 && slot >= 0) L[L_WARM + slot] = lam;
+  if (keep_warm && kind == 1 && slot >= 0) L[L_WARM + slot] = lam;
   if (lane < T::ND) {
     // dense row order: fixed-bound rows, then the friction rows by lane.  Four reads in flight per round trip, summed in the same order:
     // one read per trip made this loop an LDS-latency chain as long as the row count, on exactly the waves the launch waits for
@@ -1970,30 +2043,53 @@ DI void stage_joints(ModelP M, float* L, int lane) {
 // one physics substep (what stepSimulation does numSubSteps times, bullet_utils.py:346-353)
 template <class T, int TASK>
 DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next_step_index,
-                        unsigned long long ppk, int32_t* dbg, int prio, int& rows_out, const HeightFieldArgs& hfa = HeightFieldArgs{nullptr, 0, 0, 0.0f}) {
+                        unsigned long long ppk, int32_t* dbg, int prio, int& rows_out, bool keep_warm,
+                        const HeightFieldArgs& hfa = HeightFieldArgs{nullptr, 0, 0, 0.0f}) {
   STAMP(30);
   stage_joints<T>(M, L, lane);
   STAMP(29);
-  walk_kinematics<T, true>(M, L, lane, ppk);
-  wsync();
-  STAMP(0);
-  geom_points<T>(M, L, lane);
-  wsync();
-  STAMP(15);
   int nc = 0, nc_wanted = 0;
   float Afac[21] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // Cholesky factor of the base's articulated inertia (aba_passes -> solve_constraints)
-#ifdef MOCCA_SKIP_COLLIDE  // profiling builds only (tools/ablate.sh): results are wrong by construction
-  ContactFlags fl = {0, 0, 0, 0, 0, 0, 0};
-#else
-  ContactFlags fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc, dbg, &nc_wanted, hfa);
+  ContactFlags fl = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (COMPACT) {
+    // compact layout: collision detection sits BETWEEN the two phases of the walk -- it needs the body frames only, and the link
+    // inertias of phase 2 overwrite the frames, the geom points and the candidate list (same arithmetic, another order of the phases)
+    static_assert(!COMPACT || T::NCLOS == 0, "closure rows read the body frames after the ABA: not in the compact layout");
+    int wl = lane;
+    asm volatile("" : "+v"(wl));
+    walk_phase1<T>(L, wl, ppk);
+    wsync();
+    STAMP(0);
+    geom_points<T>(M, L, lane);
+    wsync();
+    STAMP(15);
+#ifndef MOCCA_SKIP_COLLIDE
+    fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc, dbg, &nc_wanted, hfa);
 #endif
+    wsync();   // (a compiler fence: phase 2 stores over what the collision pass read)
+    const int wb = wl < T::NB ? wl : 0;
+    WalkConsts wk;
+    walk_consts<true>(M, wb, wk);
+    walk_phase2<T, true>(M, L, wl, wb, ppk, wk);
+    wsync();
+  } else {
+    walk_kinematics<T, true>(M, L, lane, ppk);
+    wsync();
+    STAMP(0);
+    geom_points<T>(M, L, lane);
+    wsync();
+    STAMP(15);
+#ifndef MOCCA_SKIP_COLLIDE  // profiling builds only (tools/ablate.sh): results are wrong by construction
+    fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc, dbg, &nc_wanted, hfa);
+#endif
+  }
   STAMP(1);
 #ifndef MOCCA_SKIP_ABA
   aba_passes<T>(M, L, lane, ppk, Afac);
 #endif
   STAMP(2);
 #ifndef MOCCA_SKIP_SOLVE
-  solve_constraints<T>(M, L, lane, nc, nc_wanted, ppk, dbg, Afac, prio, rows_out);
+  solve_constraints<T>(M, L, lane, nc, nc_wanted, ppk, dbg, Afac, prio, rows_out, keep_warm);
 #endif
   STAMP(3);
 #ifdef MOCCA_DUMMY_VALU  // experiment: is the kernel VALU-issue-bound?  (tools/ab.sh variants)
@@ -2488,15 +2584,19 @@ DI void cassie_reset_env(const StepArgs& a, ModelP M, float* L, int env, int lan
   t.linpot = cassie_potential(M, L);
 }
 
-DI void load_dyn(const float* st, float* L, int lane, int nj, int nslots) {
+// `warm` (wave-uniform): the per-slot normal impulses travel with the record.  A blob that does not warm-start its contact rows never reads
+// them (they start every step as zeros in LDS) and writes them only on request (StepArgs.persist_warm): 2 x 136 B per env-step of dead
+// traffic otherwise.
+DI void load_dyn(const float* st, float* L, int lane, int nj, int nslots, bool warm = true) {
   if (lane < 13) L[L_BASE + lane] = st[lane];
   if (lane < nj) { L[L_Q + 1 + lane] = st[13 + lane]; L[L_QD + 1 + lane] = st[13 + nj + lane]; }
-  if (lane < nslots) L[L_WARM + lane] = st[13 + 2 * nj + lane];
+  if (warm) { if (lane < nslots) L[L_WARM + lane] = st[13 + 2 * nj + lane]; }
+  else if (lane < MOCCA_MAX_SLOTS) L[L_WARM + lane] = 0.0f;
 }
-DI void store_dyn(float* st, const float* L, int lane, int nj, int nslots) {
+DI void store_dyn(float* st, const float* L, int lane, int nj, int nslots, bool warm = true) {
   if (lane < 13) st[lane] = L[L_BASE + lane];
   if (lane < nj) { st[13 + lane] = L[L_Q + 1 + lane]; st[13 + nj + lane] = L[L_QD + 1 + lane]; }
-  if (lane < nslots) st[13 + 2 * nj + lane] = L[L_WARM + lane];
+  if (warm && lane < nslots) st[13 + 2 * nj + lane] = L[L_WARM + lane];
 }
 
-}  // namespace mocca
+}  // namespace MOCCA_NS

@@ -7,7 +7,7 @@
 #include "mocca.h"
 #include "mocca_device.h"
 
-namespace mocca {
+namespace MOCCA_NS {
 
 #ifndef MOCCA_WAVES_PER_EU
 #define MOCCA_WAVES_PER_EU 4
@@ -45,7 +45,9 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   float* obs = L + L_OBS;   // assembled in LDS, stored once at the end (flush_obs)
   int32_t* dbg = a.dbg ? a.dbg + (size_t)env * MOCCA_DEBUG_WORDS : nullptr;
 
-  load_dyn(st, L, lane, T::NJ, T::NSLOT);
+  // the slots' normal impulses: loaded iff the blob warm-starts, stored iff it does or the caller wants them (INJECT: no physics, the record passes through)
+  const bool warm_ld = INJECT || uni(__float_as_int(M->warmstart)) != 0, warm_st = warm_ld || a.persist_warm != 0;
+  load_dyn(st, L, lane, T::NJ, T::NSLOT, warm_ld);
   // the lane's root->body path, packed 5 bits per step; the only lane-derived value kept across the substeps
   const unsigned long long ppk = T::path_packed(lane < T::NB ? lane : 0);
   if constexpr (TASK == MOCCA_TASK_CASSIE) {
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
         L[L_TAU + b] = tq < -lim ? -lim : (tq > lim ? lim : tq);
       }
       wsync();
-      substep<T, TASK>(Ms, L, ln, nullptr, 0, pk, dbg, a.prio, last_rows);
+      substep<T, TASK>(Ms, L, ln, nullptr, 0, pk, dbg, a.prio, last_rows, warm_st);
     }
     if (!INJECT && lane == 0) tk[T_RES23] = (uint32_t)last_rows;
     TaskRegs t;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     }
     wsync();
     flush_obs(L, obs_out, lane, a.obs_dim);
-    store_dyn(st, L, lane, T::NJ, T::NSLOT);
+    store_dyn(st, L, lane, T::NJ, T::NSLOT, warm_st);
     if (lane == 0) store_task(tk, t);
     return;
   }
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     int ln = lane;  // same for lane-derived offsets and predicates (recomputing them costs a few instructions)
     unsigned long long pk = ppk;  // laundered too: otherwise every (ppk >> 5k) & 31 and the addresses derived from it
     asm volatile("" : "+s"(Ms), "+v"(ln), "+v"(pk));  // are hoisted out of the loop and spilled
-    fl = substep<T, TASK>(Ms, L, ln, ter, nsi0, pk, dbg, a.prio, last_rows, HeightFieldArgs{a.hf, a.hf_rows, a.hf_cols, a.hf_scale});
+    fl = substep<T, TASK>(Ms, L, ln, ter, nsi0, pk, dbg, a.prio, last_rows, warm_st, HeightFieldArgs{a.hf, a.hf_rows, a.hf_cols, a.hf_scale});
   }
   if constexpr (INJECT) {  // getContactPoints results handed in by the caller (robots.py:74-86, env_locomotion.py:634-650, :880-890)
     const int32_t* tc = a.inj_touch + (size_t)env * T::NFEET;
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   }
   wsync();
   flush_obs(L, obs_out, lane, a.obs_dim);
-  store_dyn(st, L, lane, T::NJ, T::NSLOT);
+  store_dyn(st, L, lane, T::NJ, T::NSLOT, warm_st);
   if (lane == 0) store_task(tk, t, T::NFEET > 2);
   STAMP(25);  // reset (if any) + write-back done
 #ifdef MOCCA_STAMPS
@@ -454,8 +456,12 @@ enum { TOPO_WALKER3D = 0, TOPO_CASSIE = 1, TOPO_WALKER2D = 2, TOPO_CRAB2D = 3, T
 // kernel selection by (topology, task id)
 template <template <class, int> class Launcher, class... Args>
 static void dispatch(int topo, int task_id, Args... args) {
-  if (topo == TOPO_CASSIE) Launcher<TopoCassie, MOCCA_TASK_CASSIE>::run(args...);
-  else if (topo == TOPO_CASSIE_MASSIVE) Launcher<TopoCassieMassive, MOCCA_TASK_CASSIE>::run(args...);
+  if (topo == TOPO_CASSIE || topo == TOPO_CASSIE_MASSIVE) {
+    if constexpr (!COMPACT) {   // (closure rows read the body frames after the ABA: Cassie runs the 48-row instance only)
+      if (topo == TOPO_CASSIE) Launcher<TopoCassie, MOCCA_TASK_CASSIE>::run(args...);
+      else Launcher<TopoCassieMassive, MOCCA_TASK_CASSIE>::run(args...);
+    }
+  }
   else if (topo == TOPO_WALKER3D_MASSIVE && task_id == MOCCA_TASK_WALKER3D_PLANNER) Launcher<TopoWalker3DMassive, MOCCA_TASK_WALKER3D_PLANNER>::run(args...);
   else if (topo == TOPO_WALKER3D && task_id == MOCCA_TASK_WALKER3D_PLANNER) Launcher<TopoWalker3D, MOCCA_TASK_WALKER3D_PLANNER>::run(args...);
   else if (topo == TOPO_WALKER3D_MASSIVE && task_id == MOCCA_TASK_WALKER3D_CUSTOM) Launcher<TopoWalker3DMassive, MOCCA_TASK_WALKER3D_CUSTOM>::run(args...);
@@ -468,8 +474,10 @@ static void dispatch(int topo, int task_id, Args... args) {
   else Launcher<TopoWalker3D, MOCCA_TASK_WALKER3D_STEPPER>::run(args...);
 }
 
+#if !MOCCA_COMPACT
 // defined in mocca_task.hip (INJECT = true instances)
 void launch_task_step(int topo, int task_id, int n, hipStream_t s, StepArgs a);
 void launch_taped_reset(int topo, int task_id, int n, hipStream_t s, StepArgs a);
+#endif
 
-}  // namespace mocca
+}  // namespace MOCCA_NS

@@ -12,9 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # MOCCA_LIB_PATH selects another build of the same HIP library (A/B kernel experiments); never a CPU fallback
 LIB_PATH = os.environ.get("MOCCA_LIB_PATH") or os.path.join(HERE, "libmocca_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 PARAM_AUTO_RESET, PARAM_EVAL_MODE, PARAM_CURRICULUM, PARAM_RANDOM_POSE, PARAM_HOST_RETARGET, PARAM_SEED, PARAM_ENV_OFFSET, PARAM_APPLIED_GAIN, PARAM_RANDOM_REWARD = 0, 1, 2, 3, 4, 5, 6, 7, 8
 PARAM_ISSUE_PRIORITY = 9   # timing only: row-count thresholds of the step kernel's issue priorities, t1 + 64 t2 + 4096 t3
+PARAM_PERSIST_IMPULSES = 10  # keep the last substep's normal impulses in the state record although the blob does not warm-start (diagnostic)
+PARAM_KERNEL_VARIANT = 11    # timing only: 1 forces the 48-row step-kernel instance for a blob that would run the compact one
 DEBUG_WORDS = 16
 
 # every symbol include/mocca.h declares: (name, restype, argtypes)

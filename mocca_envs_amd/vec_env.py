@@ -102,7 +102,7 @@ class VecEnv:
 
     def __init__(self, env_id: str = "Walker3DCustomEnv-v0", n_envs: int = 1, device: Optional[int] = None,
                  auto_reset: bool = True, seed: int = 0, model_blob: Optional[bytes] = None, env_offset: int = 0,
-                 terminal_obs: bool = False, **model_kw):
+                 terminal_obs: bool = False, max_rows: Optional[int] = None, max_contacts: Optional[int] = None, **model_kw):
         if env_id not in TASKS:
             raise KeyError(f"{env_id!r} has no GPU stepper yet; available: {sorted(TASKS)}")
         if not torch.cuda.is_available():
@@ -116,6 +116,15 @@ class VecEnv:
             model_blob = self.model.to_bytes()
         else:
             self.model = M.MoccaModel.from_bytes(model_blob)
+        if max_rows is not None or max_contacts is not None:
+            # Solver caps of this batch (MoccaModel.max_rows / max_contacts; Bullet has neither).  A tree without loop closures whose caps are
+            # <= 32 rows / <= 10 contacts runs the COMPACT instance of the step kernel (include/mocca.h MOCCA_PARAM_KERNEL_VARIANT: less LDS
+            # per env, more resident waves -- what batches beyond one residency round, > 4096 envs per GPU, want); an env that asks for
+            # more in a substep keeps its deepest contacts, exactly as under the default 48 / 12 caps (how often: tools/cap_pressure.py).
+            if max_rows is not None:
+                self.model.max_rows = int(max_rows)
+            self.model.max_contacts = int(max_contacts) if max_contacts is not None else min(int(self.model.max_contacts), int(self.model.max_rows) // 3)
+            model_blob = self.model.to_bytes()
         if self.lib.mocca_model_sizeof() != len(model_blob):
             raise _lib.MoccaError("MoccaModel layout mismatch between model.py and libmocca_hip.so")
         self._blob = C.create_string_buffer(model_blob, len(model_blob))

@@ -1,0 +1,92 @@
+"""The two instances of the step kernel are the same program: mocca_r32.hip (32 rows / 10 contacts per env, compact LDS layout, picked by
+mocca_create from the blob's caps) against the 48-row instance forced onto the SAME blob (MOCCA_PARAM_KERNEL_VARIANT = 1) -- observations,
+rewards, done flags, state, task and terrain records must agree BIT FOR BIT over free-running rollouts with in-kernel auto-resets, for
+every topology the compact instance is built for; plus the traffic switch of the slots' normal impulses (MOCCA_PARAM_PERSIST_IMPULSES).
+Needs a real MI355X: -m gpu."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+IDS = ["Walker3DCustomEnv-v0", "Walker3DStepperEnv-v0", "Walker3DPlannerEnv-v0", "MikePlannerEnv-v0", "Child3DCustomEnv-v0", "MikeStepperEnv-v0",
+       "Walker2DCustomEnv-v0", "Crab2DCustomEnv-v0", "LaikagoCustomEnv-v0", "LaikagoStepperEnv-v0"]
+
+
+@pytest.mark.parametrize("env_id", IDS)
+def test_compact_and_full_instances_agree_bit_for_bit(env_id):
+    import torch
+    from mocca_envs_amd import lib as L
+    from mocca_envs_amd.vec_env import VecEnv
+    n, steps = 512, 300
+    a_env = VecEnv(env_id, n, auto_reset=True, seed=21, max_rows=32)
+    b_env = VecEnv(env_id, n, auto_reset=True, seed=21, max_rows=32)
+    b_env.set_param(L.PARAM_KERNEL_VARIANT, 1)
+    ka, kb = a_env.kernel_info(), b_env.kernel_info()
+    assert ka["lds_bytes"] <= 8192 and kb["lds_bytes"] > 8192, (ka, kb)          # two different kernels ...
+    assert ka["max_blocks_per_cu"] >= 20 and ka["scratch_bytes"] <= 128, ka      # ... the compact one at >= 5 waves per SIMD
+    if "Stepper" in env_id:
+        a_env.set_param(L.PARAM_CURRICULUM, 9); b_env.set_param(L.PARAM_CURRICULUM, 9)
+    dbg_a, dbg_b = a_env.set_debug(True), b_env.set_debug(True)
+    oa, ob = a_env.reset(), b_env.reset()
+    assert torch.equal(oa, ob)
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    n_done = 0
+    for t in range(steps):
+        act = (torch.rand(n, a_env.act_dim, device="cuda", generator=g) * 2 - 1) * (1.0 if t % 3 else 0.3)
+        ra, rb = a_env.step(act), b_env.step(act)
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), (env_id, t)
+        n_done += int((ra[2] != 0).sum())
+    assert torch.equal(a_env.get_state()[:, :13 + 2 * a_env.model.n_joints], b_env.get_state()[:, :13 + 2 * a_env.model.n_joints])
+    assert torch.equal(a_env.get_task(), b_env.get_task())
+    # same active sets and cap-pressure counters (words 8..11, the solver's clamp masks, name friction rows by LANE: 46 - 2i there, 30 - 2i here)
+    assert torch.equal(dbg_a[:, :8], dbg_b[:, :8]) and torch.equal(dbg_a[:, 12:], dbg_b[:, 12:])
+    nfix = (dbg_a[:, 0] - 2 * dbg_a[:, 2]).clamp(max=30)        # lanes 0 .. r_fr - 1 hold the limit + normal rows in both instances: same clamp bits
+    low = ((torch.ones_like(nfix, dtype=torch.int64) << nfix.to(torch.int64)) - 1).to(torch.int32)
+    assert torch.equal(dbg_a[:, 8] & low, dbg_b[:, 8] & low)
+    if "Stepper" in env_id:
+        assert torch.equal(a_env.get_terrain(), b_env.get_terrain())
+    assert n_done > n // 4, "the rollout must cross in-kernel resets"
+    assert int(dbg_a[:, 15].max()) >= 20, "the sample must contain contact-rich substeps"
+    a_env.close(); b_env.close()
+
+
+def test_caps_above_the_compact_instance_run_the_full_one():
+    from mocca_envs_amd.vec_env import VecEnv
+    for kw, compact in (({}, False), ({"max_rows": 33}, False), ({"max_rows": 32, "max_contacts": 11}, False), ({"max_rows": 32}, True), ({"max_rows": 16}, True)):
+        env = VecEnv("Walker3DCustomEnv-v0", 4, **kw)
+        assert (env.kernel_info()["lds_bytes"] <= 8192) == compact, kw
+        env.close()
+    env = VecEnv("CassieEnv-v0", 4)                       # loop closures: 48-row instance whatever the caps
+    assert env.kernel_info()["lds_bytes"] > 8192
+    env.close()
+
+
+@pytest.mark.parametrize("max_rows", [None, 32])
+def test_impulses_are_persisted_on_request_only(max_rows):
+    """A blob that does not warm-start neither loads nor stores the slots' normal impulses (state words 13 + 2 NJ ..): what set_state put
+    there survives a step untouched; with MOCCA_PARAM_PERSIST_IMPULSES they are the last substep's impulses (standing robots: positive on the
+    feet), and the dynamic state does not depend on the switch."""
+    import torch
+    from mocca_envs_amd import lib as L
+    from mocca_envs_amd.vec_env import VecEnv
+    n = 64
+    envs = [VecEnv("Walker3DCustomEnv-v0", n, auto_reset=False, seed=5, max_rows=max_rows) for _ in range(2)]
+    assert envs[0].model.warmstart == 0.0
+    envs[1].set_param(L.PARAM_PERSIST_IMPULSES, 1)
+    nd = 13 + 2 * envs[0].model.n_joints
+    for e in envs:
+        e.reset()
+        st = e.get_state()
+        st[:, nd:] = 7.0
+        e.set_state(st)
+    act = torch.zeros(n, 21, device="cuda")
+    for _ in range(30):
+        for e in envs:
+            e.step(act)
+    s0, s1 = envs[0].get_state(), envs[1].get_state()
+    assert torch.equal(s0[:, :nd], s1[:, :nd])
+    assert (s0[:, nd:] == 7.0).all()
+    assert (s1[:, nd:] != 7.0).all() and (s1[:, nd:] >= 0).all() and (s1[:, nd:].sum(dim=1) > 0).float().mean() > 0.5
+    for e in envs:
+        e.close()

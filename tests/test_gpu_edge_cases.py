@@ -13,6 +13,7 @@ def _pair(env_id, task, n, seed=2, **kw):
     from mocca_envs_amd.vec_env import VecEnv
     from oracle.oracle import Oracle
     env = VecEnv(env_id, n, auto_reset=False, seed=seed, **kw)
+    env.set_param(10, 1)   # MOCCA_PARAM_PERSIST_IMPULSES: the last substep's normal impulses stay readable through get_state (the oracle always keeps them)
     orc = Oracle(env.model.to_bytes(), task, n, "f32")
     env.reset(); orc.reset(seed=seed)
     return env, orc
@@ -302,6 +303,19 @@ def test_scalar_applied_gain_is_ordered_on_the_callers_stream():
         env.set_param(L.PARAM_APPLIED_GAIN, 0.9)
         env.set_task(snap)
         np.testing.assert_array_equal(task_to_float64(env.get_task())[:, 21], 0.5)
+        # call order wins: scalar, THEN one value per env (VecEnv.set_robot_params reaches this) -- the scalar was still pending when
+        # the per-env write went out and the next step's flush overwrote every env with it
+        vec = np.linspace(0.7, 1.3, n).astype(np.float32)
+        env.set_param(L.PARAM_APPLIED_GAIN, 0.25)
+        env.set_param_v(L.PARAM_APPLIED_GAIN, vec)
+        env.step(act)
+        s.synchronize()
+        np.testing.assert_array_equal(task_to_float64(env.get_task())[:, 21].astype(np.float32), vec)
+        # ... and per-env, THEN scalar: the scalar wins
+        env.set_param(L.PARAM_APPLIED_GAIN, 0.75)
+        env.step(act)
+        s.synchronize()
+        np.testing.assert_array_equal(task_to_float64(env.get_task())[:, 21], 0.75)
         env.close(); ref.close()
 
 

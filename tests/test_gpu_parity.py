@@ -33,6 +33,7 @@ def _mk(env_id, task, n, seed, auto_reset=False, curriculum=None):
     from mocca_envs_amd.vec_env import VecEnv
     from oracle.oracle import Oracle, PARAM_CURRICULUM, PARAM_AUTO_RESET
     env = VecEnv(env_id, n, auto_reset=auto_reset, seed=seed)
+    env.set_param(10, 1)   # MOCCA_PARAM_PERSIST_IMPULSES: the slots' normal impulses are compared below (a blob that does not warm-start drops them otherwise)
     o32 = Oracle(env.model.to_bytes(), task, n, "f32")
     o64 = Oracle(env.model.to_bytes(), task, n, "f64")
     from mocca_envs_amd.vec_env import _DEFAULT_PARAMS

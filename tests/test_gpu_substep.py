@@ -49,6 +49,11 @@ CASES = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("Walker3DStepper
          ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_cone": 0}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_cone": 0}),
          # limit rows from a predicted gap on (limit_at_violation = 0; the compiled blobs build them at / past the limit only)
          ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_predict": True}), ("CassieEnv-v0", M.TASK_CASSIE, {"_predict": True}),
+         # the COMPACT instance of the step kernel (mocca_r32.hip: 32 rows / 10 contacts per env, the articulated-body view aliased under a
+         # 32 x 32 Delassus matrix; mocca_create picks it from the blob's caps) against the oracle with the same caps
+         ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_caps": (32, 10)}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_caps": (32, 10)}),
+         ("LaikagoStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_caps": (32, 10)}), ("Crab2DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_caps": (32, 10)}),
+         ("Walker3DPlannerEnv-v0", M.TASK_WALKER3D_PLANNER, {"_caps": (32, 10)}), ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_caps": (24, 6), "_warm": 0.85}),
          # one absolute contact margin of 2 cm for every pair (g_margin <= 0; the compiled blobs carry Bullet's relative thresholds, millimetres)
          ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_abs_margin": True}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_abs_margin": True})]
 
@@ -56,8 +61,10 @@ CASES = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("Walker3DStepper
 def _one_substep_blob(env_id, **kw):
     from mocca_envs_amd.vec_env import compile_model_for
     dump, massive, warm, cone = kw.pop("_dump", None), kw.pop("_massive", False), kw.pop("_warm", None), kw.pop("_cone", None)
-    predict, abs_margin = kw.pop("_predict", False), kw.pop("_abs_margin", False)
+    predict, abs_margin, caps = kw.pop("_predict", False), kw.pop("_abs_margin", False), kw.pop("_caps", None)
     m = compile_model_for(env_id, **kw)
+    if caps:
+        m.max_rows, m.max_contacts = caps
     assert m.warmstart == 0.0 and m.friction_cone == 1 and m.limit_at_violation == 1
     if predict:
         m.limit_at_violation = 0
