@@ -129,6 +129,8 @@ def parse_args(argv=None):
                     help="solver cap of the batch (MoccaModel.max_rows; default: the compiled blob's 48).  <= 32 selects the compact step-kernel "
                          "instance (less LDS per env, five resident waves per SIMD instead of four); reported in config.max_rows")
     ap.add_argument("--kernel-variant", type=int, default=0, help="TIMING ONLY: 1 forces the 48-row kernel instance for a blob that fits the compact one (A/B)")
+    ap.add_argument("--order-every", type=int, default=None, help="TIMING ONLY: MOCCA_PARAM_ORDER_EVERY (heaviest envs first, re-sorted every K steps; 0 off; default: VecEnv's choice)")
+    ap.add_argument("--pace", type=int, default=None, help="TIMING ONLY: MOCCA_PARAM_PACE_TICKS (pace priorities; 0 off)")
     ap.add_argument("--action-scale", type=float, default=1.0,
                     help="actions are action_scale x U(-1,1) (SURVEY 8d config 4 asks for 0.1 on Cassie: a robot that stays up instead of one that "
                          "falls every ~17 steps); reported in config.workload")
@@ -239,6 +241,10 @@ def main():
         from mocca_envs_amd.vec_env import VecEnv
         # same seed on every rank, draws keyed by the GLOBAL env id: the job's result does not depend on how many GPUs share it
         env = VecEnv(args.env_id, args.envs, device=local_rank, auto_reset=True, seed=1000, env_offset=lo, max_rows=args.max_rows)
+        if args.order_every is not None:
+            env.set_param(12, args.order_every)  # MOCCA_PARAM_ORDER_EVERY
+        if args.pace is not None:
+            env.set_param(13, args.pace)  # MOCCA_PARAM_PACE_TICKS
         if args.kernel_variant:
             env.set_param(11, args.kernel_variant)  # MOCCA_PARAM_KERNEL_VARIANT
         if args.curriculum is not None:

@@ -79,6 +79,18 @@ enum {
                                         the articulated-body view aliased under it: less LDS per env, more resident waves per CU); every other
                                         blob the 48-row instance.  1 forces the 48-row instance for such a blob (A/B runs), 0 = automatic.
                                         Both instances execute the same arithmetic in the same order: results are bit-identical. */
+  MOCCA_PARAM_ORDER_EVERY = 12,      /* TIMING ONLY.  K > 0: every K-th mocca_step first sorts the envs by the constraint-row count their last step
+                                        ended with and the step kernel starts the heaviest first (a launch of more envs than the chip holds at
+                                        once ends with the waves it started last: they should be the light ones); 0: index order.  Envs never
+                                        interact, so the order changes when an env runs, not what it computes. */
+  MOCCA_PARAM_PACE_TICKS = 13,       /* TIMING ONLY.  PACE priorities instead of the row-count priorities above.  The hardware serves equal-priority
+                                        waves of a SIMD oldest-first, so its four resident waves finish one after the other and the launch waits
+                                        for the last, which runs alone.  With a pace P a wave compares the shader-clock ticks it has used with
+                                        the share of the env.step it has done (64 units per substep + 2 per constraint row) and runs at issue
+                                        priority 3 / 2 / 1 / 0 as its estimated finish lies beyond 17/16 of, beyond, within 1/16 below, or
+                                        further below P: the waves of a SIMD finish together.  value > 0: P in ticks; value = -k (1 <= k <= 64):
+                                        self-calibrating, P = k/16 of the mean wave time of the previous launch (every 61st wave adds a sample;
+                                        the first launch of a handle falls back to the row-count priorities); 0: off.  Default -18. */
 };
 
 /* words of the per-env debug record (mocca_set_debug_buffer): words 0..11 the active set of the LAST physics substep, words 12..15

@@ -31,6 +31,30 @@ __global__ void set_task_word_kernel(uint32_t* task, int word, const float* vals
   if (i < n) task[(size_t)i * MOCCA_TASK_WORDS + word] = __float_as_uint(use_scalar ? scalar : vals[i]);
 }
 
+// Launch order of the step kernel (MOCCA_PARAM_ORDER_EVERY): a counting sort of the envs by the constraint-row count their last step ended
+// with (task word 23, 0 .. 63), most rows first.  One workgroup; the order inside a bucket is whatever the atomics make it -- it only
+// decides when an env's wave starts.  ~6 us for 8192 envs, every K-th step.
+__global__ __launch_bounds__(1024) void order_by_rows_kernel(const uint32_t* task, int32_t* order, int n) {
+  __shared__ int hist[64], start[64];
+  const int t = threadIdx.x;
+  if (t < 64) hist[t] = 0;
+  __syncthreads();
+  for (int e = t; e < n; e += 1024) {
+    const uint32_t r = task[(size_t)e * MOCCA_TASK_WORDS + 23];
+    atomicAdd(&hist[63 - (r > 63u ? 63u : r)], 1);   // bucket 0 = heaviest
+  }
+  __syncthreads();
+  if (t == 0) {
+    int acc = 0;
+    for (int k = 0; k < 64; ++k) { start[k] = acc; acc += hist[k]; }
+  }
+  __syncthreads();
+  for (int e = t; e < n; e += 1024) {
+    const uint32_t r = task[(size_t)e * MOCCA_TASK_WORDS + 23];
+    order[atomicAdd(&start[63 - (r > 63u ? 63u : r)], 1)] = e;
+  }
+}
+
 struct mocca_ctx {
   MoccaModel model;
   int task_id = 0, n_envs = 0, device = 0, obs_dim = 0;
@@ -44,6 +68,12 @@ struct mocca_ctx {
   bool compact = false;        // the blob fits the compact step-kernel instance (compact_ok); MOCCA_PARAM_KERNEL_VARIANT = 1 overrides
   int force_full = 0;
   int persist_warm = 0;        // MOCCA_PARAM_PERSIST_IMPULSES
+  int pace = -18;              // MOCCA_PARAM_PACE_TICKS: self-calibrating pace priorities, 18/16 of the previous launch's mean wave time (profiles/r04_pace_*.jsonl)
+  unsigned* d_pace_acc = nullptr;  // [3][2] self-calibration samples of the pace (StepArgs.pace_acc), owned by the handle
+  unsigned pace_step = 0;
+  int order_every = 0;         // MOCCA_PARAM_ORDER_EVERY: re-sort the launch order every K steps (0: envs run in index order)
+  int order_age = 0;           // steps since the last sort
+  int32_t* d_order = nullptr;  // [N] the permutation, owned by the handle
   bool gain_pending = false;   // a scalar MOCCA_PARAM_APPLIED_GAIN not yet written into the task records (flush_pending)
   float* final_obs = nullptr;  // caller-owned (mocca_set_terminal_obs_buffer)
   float* d_pvec[3] = {nullptr, nullptr, nullptr};  // per-env curriculum / eval_mode / applied_gain (mocca_set_param_v), lazily allocated
@@ -264,6 +294,8 @@ int mocca_destroy(mocca_handle h) {
   if (h->d_terrain) (void)hipFree(h->d_terrain);
   if (h->d_traj) (void)hipFree(h->d_traj);
   if (h->d_hf) (void)hipFree(h->d_hf);
+  if (h->d_order) (void)hipFree(h->d_order);
+  if (h->d_pace_acc) (void)hipFree(h->d_pace_acc);
   for (float* p : h->d_pvec) if (p) (void)hipFree(p);
   delete h;
   return MOCCA_OK;
@@ -293,6 +325,7 @@ static StepArgs make_args(mocca_handle h) {
   a.traj = h->d_traj; a.traj_n = h->traj_n; a.traj_tmax = h->traj_tmax; a.traj_cstep = h->traj_cstep;
   a.final_obs = h->final_obs;
   a.persist_warm = h->persist_warm;
+  a.pace = h->pace;
   a.hf = h->d_hf; a.hf_rows = h->hf_rows; a.hf_cols = h->hf_cols; a.hf_scale = h->hf_scale;
   return a;
 }
@@ -346,6 +379,26 @@ int mocca_step(mocca_handle h, const float* act_dev, float* obs_dev, float* rew_
   a.act = act_dev; a.obs = obs_dev; a.rew = rew_dev; a.done = done_dev; a.info = info_dev;
   hipStream_t s = (hipStream_t)stream;
   if (int rc = flush_pending(h, s)) return rc;
+  if (h->pace < 0) {   // self-calibrating pace priorities: three sample slots, rotated per launch (StepArgs.pace_acc)
+    if (!h->d_pace_acc) {
+      HIP_TRY(h, hipMalloc(&h->d_pace_acc, 6 * sizeof(unsigned)));
+      HIP_TRY(h, hipMemsetAsync(h->d_pace_acc, 0, 6 * sizeof(unsigned), s));
+      h->pace_step = 0;
+    }
+    a.pace_acc = h->d_pace_acc;
+    a.pace_slot_w = (int)(h->pace_step % 3u); a.pace_slot_r = (int)((h->pace_step + 2u) % 3u); a.pace_slot_c = (int)((h->pace_step + 1u) % 3u);
+    ++h->pace_step;
+  }
+  if (h->order_every > 0) {   // heaviest envs first: the permutation is rebuilt on the caller's stream, ahead of the step that reads it
+    if (!h->d_order) { HIP_TRY(h, hipMalloc(&h->d_order, (size_t)h->n_envs * sizeof(int32_t))); h->order_age = h->order_every; }
+    if (h->order_age >= h->order_every) {
+      hipLaunchKernelGGL(order_by_rows_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)h->d_task, h->d_order, h->n_envs);
+      HIP_TRY(h, hipGetLastError());
+      h->order_age = 0;
+    }
+    ++h->order_age;
+    a.order = h->d_order;
+  }
   if (h->compact && !h->force_full) mocca_r32_launch_step(h->topo, h->task_id, h->n_envs, s, &a);
   else dispatch<LaunchStep>(h->topo, h->task_id, h->n_envs, s, a);
   HIP_TRY(h, hipGetLastError());
@@ -509,6 +562,12 @@ int mocca_set_param(mocca_handle h, int param_id, double value) {
       if (value != 0 && value != 1 && value != 2) { h->err = "MOCCA_PARAM_RANDOM_REWARD is 0, 1 or 2"; return MOCCA_E_ARG; }
       h->random_reward = (int)value; break;
     case MOCCA_PARAM_PERSIST_IMPULSES: h->persist_warm = value != 0; break;
+    case MOCCA_PARAM_PACE_TICKS:
+      if (value < -64 || value > 1e9) { h->err = "MOCCA_PARAM_PACE_TICKS is a tick count > 0, 0 (off) or -k (self-calibrating, k / 16 of the mean wave time, k <= 64)"; return MOCCA_E_ARG; }
+      h->pace = (int)value; break;
+    case MOCCA_PARAM_ORDER_EVERY:
+      if (value < 0 || value > 1e6) { h->err = "MOCCA_PARAM_ORDER_EVERY is a step count >= 0"; return MOCCA_E_ARG; }
+      h->order_every = (int)value; h->order_age = h->order_every; break;
     case MOCCA_PARAM_KERNEL_VARIANT:
       if (value != 0 && value != 1) { h->err = "MOCCA_PARAM_KERNEL_VARIANT is 0 (automatic) or 1 (force the 48-row instance)"; return MOCCA_E_ARG; }
       h->force_full = (int)value; break;

@@ -242,6 +242,18 @@ struct StepArgs {
   // the last substep's normal impulses per terrain slot (state words 13 + 2 NJ ..) are stored although the blob does not warm-start
   // (MOCCA_PARAM_PERSIST_IMPULSES); a blob with warmstart != 0 always loads and stores them
   int persist_warm;
+  // optional (MOCCA_PARAM_ORDER_EVERY): workgroup b advances env order[b] -- a permutation of 0 .. n_envs - 1, heaviest envs (most constraint
+  // rows at the end of the step before) first; null = identity.  Envs never interact: the order decides WHEN an env runs, not what it computes
+  const int32_t* order;
+  // MOCCA_PARAM_PACE_TICKS (timing only): > 0 replaces the row-count issue priorities by PACE priorities -- a wave that is behind the pace
+  // of `pace` shader-clock ticks per env.step (its own elapsed time against the fraction of the step it has done) raises its issue
+  // priority, one that is ahead lowers it, so that the waves of a SIMD finish together instead of oldest-first
+  int pace;
+  // pace < 0: self-calibrating pace = (-pace / 16) x the mean wave time of the PREVIOUS launch.  Every 64th wave adds its elapsed ticks to
+  // pace_acc[slot_w] = {sum of ticks / 16, samples}; this launch reads slot_r (written by the launch before), and its workgroup 0 clears
+  // slot_c for the launch after (three slots, rotated by the host: no launch reads or clears what another one in flight is adding to)
+  unsigned* pace_acc;
+  int pace_slot_r, pace_slot_w, pace_slot_c;
 };
 
 // ------------------------------------------------------------------ helpers
@@ -1115,7 +1127,7 @@ struct ContactFlags { int touch0, touch1, target0, target1, touch2, touch3, body
 // Contacts are compacted in slot order, then pair order (the oracle's priority), up to max_contacts.
 template <class T, int TASK>
 DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next_step_index,
-                        int* nc_out, int32_t* dbg, int* nc_wanted, const HeightFieldArgs& hfa) {
+                        int* nc_out, int32_t* dbg, int* nc_wanted, const HeightFieldArgs hfa) {
   STAMP_BEGIN;
   // contacts open within the geom's margin (Bullet's relative breaking threshold of its link, a few mm; decoded from the slot record where
   // it is compared: a separate load spilled).  `mreach`: gContactBreakingThreshold itself, 20 mm -- an upper bound of every relative
@@ -1568,9 +1580,54 @@ DI void set_issue_priority(int nr, int prio) {
   else if (nr > (prio & 63)) __builtin_amdgcn_s_setprio(1);
   else __builtin_amdgcn_s_setprio(0);
 }
+// Pace priority (StepArgs.pace > 0): the hardware arbitrates equal-priority waves of a SIMD oldest-first, so the four resident waves finish
+// one after the other and the last one runs alone -- latency-bound, three quarters of the SIMD's issue slots idle -- while the launch waits
+// for it.  Each wave therefore compares the time it has used (s_memtime since its start, kept in the spare word of the base record)
+// with the share of the step it has done (`done` of `total` units): estimated finish = elapsed * total / done, against the pace +- 1/8.
+// All scalar: one s_memtime, one LDS word, three multiplies, three compares.
+// (The pace travels in LDS next to the start time, not in scalar registers: the kernel holds all 102 of them already, and one more value
+// that lives across the substeps is spilled to a VGPR lane, which in turn is spilled to scratch.)
+#ifndef MOCCA_PACE_ROWUNIT
+#define MOCCA_PACE_ROWUNIT 2   // pace units per constraint row (a substep without rows: 64); 0 .. 4 measured: profiles/r04_pace_probe_ru*.jsonl
+#endif
+#ifndef MOCCA_PACE_SHIFT
+#define MOCCA_PACE_SHIFT 4   // width of the priority bands around the pace: 2^-4
+#endif
+enum : int { L_T0 = L_BASE + 13, L_PACE = L_BASE + 14, L_KEEPWARM = L_BASE + 15 /* StepArgs.persist_warm or a warm-starting blob: same reason */ };
+DI void pace_start(const StepArgs& a, float* L, int lane, int pace) {
+  if (lane == 0) {
+    int p16 = pace >> 4;
+    if (pace < 0) {   // self-calibrating: the previous launch's mean wave time (ticks / 16) x (-pace) / 16; no sample yet: row-count priorities
+      const unsigned sum = a.pace_acc[2 * a.pace_slot_r], cnt = a.pace_acc[2 * a.pace_slot_r + 1];
+      p16 = cnt > 0u ? (int)((float)sum / (float)cnt * (float)(-pace) * 0.0625f) : 0;
+      if (blockIdx.x == 0) { a.pace_acc[2 * a.pace_slot_c] = 0u; a.pace_acc[2 * a.pace_slot_c + 1] = 0u; }
+    }
+    L[L_PACE] = __int_as_float(p16);
+    if (pace != 0) L[L_T0] = __uint_as_float((unsigned)__builtin_amdgcn_s_memtime());
+  }
+}
+DI void pace_finish(const StepArgs& a, const float* L, int lane, int pace) {   // (after a barrier: lane 0's words are visible to itself anyway)
+  if (pace < 0 && lane == 0 && (blockIdx.x % 61u) == 0u) {   // one wave in 61: a sample spread over the XCDs and CUs
+    const unsigned el = (unsigned)__builtin_amdgcn_s_memtime() - __float_as_uint(L[L_T0]);
+    atomicAdd(&a.pace_acc[2 * a.pace_slot_w], el >> 4);
+    atomicAdd(&a.pace_acc[2 * a.pace_slot_w + 1], 1u);
+  }
+}
+DI bool pace_on(const float* L) { return uni(__float_as_int(L[L_PACE])) > 0; }
+DI void pace_checkpoint(const float* L, int done, int total) {
+  const unsigned p16 = (unsigned)uni(__float_as_int(L[L_PACE]));   // pace / 16; 0 = off (wave-uniform branch)
+  if (p16 == 0u) return;
+  const unsigned el = (unsigned)__builtin_amdgcn_s_memtime() - (unsigned)uni(__float_as_int(L[L_T0]));
+  const unsigned lhs = (el >> 4) * (unsigned)total, r = p16 * (unsigned)done;   // ticks / 16: the products stay below 2^32
+  if (lhs > r + (r >> MOCCA_PACE_SHIFT)) __builtin_amdgcn_s_setprio(3);
+  else if (lhs > r) __builtin_amdgcn_s_setprio(2);
+  else if (lhs > r - (r >> MOCCA_PACE_SHIFT)) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
 template <class T>
 DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wanted, unsigned long long ppk, int32_t* dbg, const float* Afac, int prio, int& rows_out,
-                          bool keep_warm) {   // keep_warm (wave-uniform): the slots' normal impulses are wanted after the substep (warm start / diagnostic)
+                          bool keep_warm_unused) {
+  const bool keep_warm = uni(__float_as_int(L[L_KEEPWARM])) != 0;   // (wave-uniform) the slots' normal impulses are wanted after the substep (warm start / diagnostic)
   STAMP_BEGIN;
   // wave-uniform scalars live in SGPRs: loop control becomes s_cmp/s_cbranch instead of exec-mask bookkeeping
   const float dt = unif(M->dt), idt = rcp(dt);
@@ -1615,7 +1672,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
   // its row count (an env lying on the ground has 48 rows, a standing one ~20).  Issue priority follows the row count,
   // so heavy waves run at nearly their stand-alone speed while light ones -- which have slack -- yield.  nr is in an
   // SGPR: each branch is s_cmp / s_cbranch around one s_setprio (which ignores EXEC).
-  set_issue_priority(nr, prio);
+  if (!pace_on(L)) set_issue_priority(nr, prio);   // (pace priorities replace the row-count ones, substep())
   rows_out = nr;
   wsync();
   STAMP(16);
@@ -1917,6 +1974,10 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
       const bool on_circle = lam * lam + lpart * lpart >= lm * lm * (1.0f - 1e-5f);   // cone: the pair sits on the circle (the oracle's expression)
       const bool clamped = has_row && (kind == 2 ? (cone ? on_circle : fabsf(lam) == lm) : (kind != 3 && lam == 0.0f));
       clamp_last = __ballot(clamped);
+      if constexpr (MAXR != 48) {   // the record names friction rows by the lanes of the 48-row instance (46 - 2i, 47 - 2i; include/mocca.h): move this instance's up
+        const int lo = MAXR - 2 * nc;
+        clamp_last = (clamp_last & ((1ull << lo) - 1ull)) | ((clamp_last >> lo) << (48 - 2 * nc));
+      }
       clamp_sig = ((clamp_sig << 7) | (clamp_sig >> 57)) ^ clamp_last;
     }
   }
@@ -2044,7 +2105,11 @@ DI void stage_joints(ModelP M, float* L, int lane) {
 template <class T, int TASK>
 DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next_step_index,
                         unsigned long long ppk, int32_t* dbg, int prio, int& rows_out, bool keep_warm,
-                        const HeightFieldArgs& hfa = HeightFieldArgs{nullptr, 0, 0, 0.0f}) {
+                        const HeightFieldArgs hfa = HeightFieldArgs{nullptr, 0, 0, 0.0f}, int sidx = 0, int nsub = 1) {
+  // pace checkpoints: a substep counts 64 units + MOCCA_PACE_ROWUNIT per constraint row (the row count of the substep before stands in until
+  // this one's is known) -- 20 after the collision pass, 36 after the ABA, all at its end: an env with many rows has more of its step
+  // ahead of it at the same point of the program, and is given priority BEFORE it falls behind
+  const int per0 = 64 + MOCCA_PACE_ROWUNIT * rows_out, done0 = sidx * per0, total = nsub * per0;
   STAMP(30);
   stage_joints<T>(M, L, lane);
   STAMP(29);
@@ -2084,10 +2149,12 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
 #endif
   }
   STAMP(1);
+  pace_checkpoint(L, done0 + 20, total);
 #ifndef MOCCA_SKIP_ABA
   aba_passes<T>(M, L, lane, ppk, Afac);
 #endif
   STAMP(2);
+  pace_checkpoint(L, done0 + 36, total);
 #ifndef MOCCA_SKIP_SOLVE
   solve_constraints<T>(M, L, lane, nc, nc_wanted, ppk, dbg, Afac, prio, rows_out, keep_warm);
 #endif
@@ -2102,6 +2169,7 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
 #endif
   integrate<T>(M, L, lane);
   STAMP(4);
+  pace_checkpoint(L, (sidx + 1) * (64 + MOCCA_PACE_ROWUNIT * rows_out), nsub * (64 + MOCCA_PACE_ROWUNIT * rows_out));
   return fl;
 }
 

@@ -35,8 +35,11 @@ DI void keep_terminal_obs(const StepArgs& a, const float* L, int env, int lane) 
 template <class T, int TASK, bool INJECT = false>
 __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(StepArgs a) {
   __shared__ float L[L_TOTAL];
-  const int env = blockIdx.x, lane = threadIdx.x;
-  if (env >= a.n_envs) return;
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= a.n_envs) return;
+  // heaviest envs first (StepArgs.order): a launch of more envs than the chip holds at once ends with its last-started waves, which
+  // should be the light ones (longest-processing-time-first); one scalar load, wave-uniform
+  const int env = a.order ? uni(a.order[blockIdx.x]) : (int)blockIdx.x;
   ModelP M = (ModelP)a.model;
   float* st = a.dyn + (size_t)env * DYN_STRIDE;
   uint32_t* tk = a.task + (size_t)env * MOCCA_TASK_WORDS;
@@ -48,6 +51,8 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   // the slots' normal impulses: loaded iff the blob warm-starts, stored iff it does or the caller wants them (INJECT: no physics, the record passes through)
   const bool warm_ld = INJECT || uni(__float_as_int(M->warmstart)) != 0, warm_st = warm_ld || a.persist_warm != 0;
   load_dyn(st, L, lane, T::NJ, T::NSLOT, warm_ld);
+  pace_start(a, L, lane, INJECT ? 0 : a.pace);
+  if (lane == 0) L[L_KEEPWARM] = __int_as_float(warm_st ? 1 : 0);
   // the lane's root->body path, packed 5 bits per step; the only lane-derived value kept across the substeps
   const unsigned long long ppk = T::path_packed(lane < T::NB ? lane : 0);
   if constexpr (TASK == MOCCA_TASK_CASSIE) {
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     wsync();
     const int nllc = INJECT ? 0 : M->n_llc;
     int last_rows = uni((int)tk[T_RES23]);
-    if (!INJECT) set_issue_priority(last_rows, a.prio);
+    if (!INJECT && a.pace == 0) set_issue_priority(last_rows, a.prio);
 #pragma unroll 1
     for (int it = 0; it < nllc; ++it) {
       ModelP Ms = M;
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
         L[L_TAU + b] = tq < -lim ? -lim : (tq > lim ? lim : tq);
       }
       wsync();
-      substep<T, TASK>(Ms, L, ln, nullptr, 0, pk, dbg, a.prio, last_rows, warm_st);
+      substep<T, TASK>(Ms, L, ln, nullptr, 0, pk, dbg, a.prio, last_rows, false, HeightFieldArgs{nullptr, 0, 0, 0.0f}, it, nllc);
     }
     if (!INJECT && lane == 0) tk[T_RES23] = (uint32_t)last_rows;
     TaskRegs t;
@@ -135,8 +140,9 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     }
     wsync();
     flush_obs(L, obs_out, lane, a.obs_dim);
-    store_dyn(st, L, lane, T::NJ, T::NSLOT, warm_st);
+    store_dyn(st, L, lane, T::NJ, T::NSLOT, uni(__float_as_int(L[L_KEEPWARM])) != 0);
     if (lane == 0) store_task(tk, t);
+    if (!INJECT) pace_finish(a, L, lane, a.pace);
     return;
   }
   // apply_action, robots.py:31-40.  Only the two task words the physics needs are read before the substeps;
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   // the env's row count at the end of the step before (task word 23) sets the issue priority until the first substep knows better:
   // a heavy env is almost always still heavy, and more than half of a substep runs before its own count is known
   int last_rows = uni((int)tk[T_RES23]);
-  if (!INJECT) set_issue_priority(last_rows, a.prio);
+  if (!INJECT && a.pace == 0) set_issue_priority(last_rows, a.prio);
 #pragma unroll 1
   for (int s = 0; s < nsub; ++s) {
     // launder the model pointer: keeps LICM from hoisting dozens of loop-invariant model loads out of the
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     int ln = lane;  // same for lane-derived offsets and predicates (recomputing them costs a few instructions)
     unsigned long long pk = ppk;  // laundered too: otherwise every (ppk >> 5k) & 31 and the addresses derived from it
     asm volatile("" : "+s"(Ms), "+v"(ln), "+v"(pk));  // are hoisted out of the loop and spilled
-    fl = substep<T, TASK>(Ms, L, ln, ter, nsi0, pk, dbg, a.prio, last_rows, warm_st, HeightFieldArgs{a.hf, a.hf_rows, a.hf_cols, a.hf_scale});
+    fl = substep<T, TASK>(Ms, L, ln, ter, nsi0, pk, dbg, a.prio, last_rows, false, HeightFieldArgs{a.hf, a.hf_rows, a.hf_cols, a.hf_scale}, s, nsub);
   }
   if constexpr (INJECT) {  // getContactPoints results handed in by the caller (robots.py:74-86, env_locomotion.py:634-650, :880-890)
     const int32_t* tc = a.inj_touch + (size_t)env * T::NFEET;
@@ -369,8 +375,9 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   }
   wsync();
   flush_obs(L, obs_out, lane, a.obs_dim);
-  store_dyn(st, L, lane, T::NJ, T::NSLOT, warm_st);
+  store_dyn(st, L, lane, T::NJ, T::NSLOT, uni(__float_as_int(L[L_KEEPWARM])) != 0);
   if (lane == 0) store_task(tk, t, T::NFEET > 2);
+  if (!INJECT) pace_finish(a, L, lane, a.pace);
   STAMP(25);  // reset (if any) + write-back done
 #ifdef MOCCA_STAMPS
   if (lane == 0 && blockIdx.x < STAMP_WAVES) g_stamps[blockIdx.x * STAMP_SLOTS + 24] = (unsigned long long)(a.auto_reset && dflag);

@@ -43,6 +43,9 @@ TASKS = {
 _DEFAULT_PARAMS = {"LaikagoCustomEnv-v0": {_lib.PARAM_RANDOM_POSE: 0},    # robot_random_start = False, env_locomotion.py:863
                    "LaikagoStepperEnv-v0": {_lib.PARAM_RANDOM_POSE: 0}}   # :899
 
+# Since round 4 the step kernel sets its issue priorities from each wave's PACE (PARAM_PACE_TICKS, default: self-calibrating -- 2.6 % to 8.7 %
+# faster than the tables below on every env id, profiles/r04_pace_envs.jsonl); the row-count thresholds only serve a handle's first launch
+# (no pace sample yet) and handles that switch the pace off.
 # Issue-priority thresholds of the step kernel (PARAM_ISSUE_PRIORITY; timing only, results do not depend on them): constraint-row counts
 # above which a wave runs at priority 1 / 2 / 3.  The best set follows the batch's row distribution -- measured per env id with
 # tools/prio_sweep.sh on one MI355X (profiles/r03_prio_sweep_v13.txt: the blob v13 physics hold 5.7 rows per substep on the flat-ground walker

@@ -39,15 +39,12 @@ def test_compact_and_full_instances_agree_bit_for_bit(env_id):
         n_done += int((ra[2] != 0).sum())
     assert torch.equal(a_env.get_state()[:, :13 + 2 * a_env.model.n_joints], b_env.get_state()[:, :13 + 2 * a_env.model.n_joints])
     assert torch.equal(a_env.get_task(), b_env.get_task())
-    # same active sets and cap-pressure counters (words 8..11, the solver's clamp masks, name friction rows by LANE: 46 - 2i there, 30 - 2i here)
-    assert torch.equal(dbg_a[:, :8], dbg_b[:, :8]) and torch.equal(dbg_a[:, 12:], dbg_b[:, 12:])
-    nfix = (dbg_a[:, 0] - 2 * dbg_a[:, 2]).clamp(max=30)        # lanes 0 .. r_fr - 1 hold the limit + normal rows in both instances: same clamp bits
-    low = ((torch.ones_like(nfix, dtype=torch.int64) << nfix.to(torch.int64)) - 1).to(torch.int32)
-    assert torch.equal(dbg_a[:, 8] & low, dbg_b[:, 8] & low)
+    assert torch.equal(dbg_a, dbg_b)                      # same active sets, same clamp masks and signatures (48-row lane numbering), same cap-pressure counters
     if "Stepper" in env_id:
         assert torch.equal(a_env.get_terrain(), b_env.get_terrain())
-    assert n_done > n // 4, "the rollout must cross in-kernel resets"
-    assert int(dbg_a[:, 15].max()) >= 20, "the sample must contain contact-rich substeps"
+    if "2D" not in env_id:        # (Walker2DCustomEnv never sets done, env_locomotion.py:302-309: only the TimeLimit ends its episodes)
+        assert n_done > n // 4, "the rollout must cross in-kernel resets"
+    assert int(dbg_a[:, 15].max()) >= 12, "the sample must contain contact-rich substeps"
     a_env.close(); b_env.close()
 
 
@@ -90,3 +87,30 @@ def test_impulses_are_persisted_on_request_only(max_rows):
     assert (s1[:, nd:] != 7.0).all() and (s1[:, nd:] >= 0).all() and (s1[:, nd:].sum(dim=1) > 0).float().mean() > 0.5
     for e in envs:
         e.close()
+
+
+@pytest.mark.parametrize("env_id,kw", [("Walker3DCustomEnv-v0", {}), ("Walker3DStepperEnv-v0", {"max_rows": 32}), ("CassieEnv-v0", {})])
+def test_launch_order_does_not_change_results(env_id, kw):
+    """MOCCA_PARAM_ORDER_EVERY: the step kernel starts the heaviest envs first (a permutation rebuilt every K steps from the row counts of
+    the step before); every env's results are bit-identical to index order, and the permutation really is one."""
+    import torch
+    from mocca_envs_amd import lib as L
+    from mocca_envs_amd.vec_env import VecEnv
+    n, steps = 777, 60 if env_id.startswith("Cassie") else 200     # odd batch size: the last workgroups must not run off the permutation
+    a_env = VecEnv(env_id, n, auto_reset=True, seed=8, **kw)
+    b_env = VecEnv(env_id, n, auto_reset=True, seed=8, **kw)
+    b_env.set_param(L.PARAM_ORDER_EVERY, 3)
+    b_env.set_param(L.PARAM_PACE_TICKS, 180000)                    # ... and with pace priorities instead of row-count priorities (timing only)
+    a_env.reset(); b_env.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(4)
+    for t in range(steps):
+        act = (torch.rand(n, a_env.act_dim, device="cuda", generator=g) * 2 - 1) * (0.1 if env_id.startswith("Cassie") else 1.0)
+        for x, y in zip(a_env.step(act), b_env.step(act)):
+            assert torch.equal(x, y), (env_id, t)
+    nd = 13 + 2 * a_env.model.n_joints
+    assert torch.equal(a_env.get_state()[:, :nd], b_env.get_state()[:, :nd]) and torch.equal(a_env.get_task(), b_env.get_task())
+    b_env.set_param(L.PARAM_ORDER_EVERY, 0)                        # back to index order
+    act = torch.zeros(n, a_env.act_dim, device="cuda")
+    for x, y in zip(a_env.step(act), b_env.step(act)):
+        assert torch.equal(x, y)
+    a_env.close(); b_env.close()
