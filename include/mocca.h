@@ -208,8 +208,11 @@ int mocca_set_trajectory(mocca_handle h, const float *table_host, int n_frames, 
  * (env_locomotion.py:1011-1021, bullet_objects.py:338-393: createCollisionShape(GEOM_HEIGHTFIELD, meshScale [1/scale, 1/scale, 1]), body at
  * z = (max + min) / 2, lateralFriction 1, contactStiffness 30000, contactDamping 1000 -- the last three are blob numbers).
  * heights_host [rows][cols] f32 (HOST memory, copied into the handle; x runs along the columns), `scale` grid points per metre.  The grid is
- * centred on the origin, every cell two triangles split from (ix + 1, iy) to (ix, iy + 1); spheres / capsule ends collide with the closest
- * of the eight triangles around the nearest grid point; outside the grid there is no ground.  One grid shared by all envs of the handle
+ * centred on the origin, every cell two triangles split from (ix + 1, iy) to (ix, iy + 1); a sphere / capsule end collides with the closest
+ * triangle among the 2 W x 2 W cells around the grid point nearest to its centre, W = ceil((radius + contact margin) x scale + 1/2) -- every
+ * cell it can reach (W = 1 for feet and limbs at 4 points per metre, 2 for the walker's 14 cm pelvis and Mike's 23 cm waist sphere, mike.xml:20,
+ * whose contact ends MikePlannerEnv's episode; a grid on which a sphere would span more than 4 cells each way is refused);
+ * outside the grid there is no ground.  One grid shared by all envs of the handle
  * (the reference loads the same file for every env).  Required before reset / step / observe with MOCCA_TASK_WALKER3D_PLANNER. */
 int mocca_set_heightfield(mocca_handle h, const float *heights_host, int rows, int cols, double scale);
 

@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC (see mocca_envs_amd/build.py).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -472,13 +473,49 @@ int mocca_set_trajectory(mocca_handle h, const float* table_host, int n_frames, 
 int mocca_set_heightfield(mocca_handle h, const float* heights_host, int rows, int cols, double scale) {
   if (!h) return MOCCA_E_ARG;
   if (!heights_host || rows < 2 || cols < 2 || !(scale > 0.0)) { h->err = "mocca_set_heightfield: needs at least 2 x 2 heights and a positive scale"; return MOCCA_E_ARG; }
+  // Search window of every terrain contact slot: a sphere of reach rho = radius + margin around a centre that is at most half a cell from
+  // its nearest grid point touches only cells within W = ceil(rho scale + 1/2) of that point (1e-6: a reach of exactly half a cell is W = 1).
+  // W - 1 travels in bits 30..31 of the slot record; a grid so fine that a sphere spans more than 4 cells each way is refused.
+  int wmax = 1;
+  uint32_t wbits[MOCCA_MAX_SLOTS];
+  for (int sl = 0; sl < h->model.n_slots; ++sl) {
+    uint32_t ids; std::memcpy(&ids, &h->model.slot_tab[sl][2], 4);
+    const double reach = (double)h->model.slot_tab[sl][0] + (double)((ids >> 17) & 0xFFu) / 8192.0;
+    int w = (int)std::ceil(reach * scale + 0.5 - 1e-6);
+    if (w < 1) w = 1;
+    if (w > 4 && ((ids >> 25) & 1u)) { h->err = "mocca_set_heightfield: the grid is too fine for this robot (a contact sphere would span more than 4 cells each way)"; return MOCCA_E_ARG; }
+    if (w > 4) w = 4;
+    wbits[sl] = (ids & 0x3FFFFFFFu) | ((uint32_t)(w - 1) << 30);
+    if (((ids >> 25) & 1u) && w > wmax) wmax = w;
+  }
   DeviceGuard guard(h->device);
-  const size_t bytes = (size_t)rows * cols * sizeof(float);
+  // the heights, followed by one max-pooled copy per window 2 .. wmax (copy k: the highest point within k + 1 cells of each grid point): what a
+  // wide sphere's search is pruned by with one load
+  const size_t cells = (size_t)rows * cols, bytes = cells * wmax * sizeof(float);
+  float* host = new (std::nothrow) float[cells * wmax];
+  if (!host) { h->err = "mocca_set_heightfield: out of host memory"; return MOCCA_E_ARG; }
+  std::memcpy(host, heights_host, cells * sizeof(float));
+  for (int w = 2; w <= wmax; ++w) {
+    float* out = host + cells * (w - 1);
+    for (int j = 0; j < rows; ++j)
+      for (int i = 0; i < cols; ++i) {
+        float m = -1e30f;
+        for (int jj = (j - w < 0 ? 0 : j - w); jj <= (j + w > rows - 1 ? rows - 1 : j + w); ++jj)
+          for (int ii = (i - w < 0 ? 0 : i - w); ii <= (i + w > cols - 1 ? cols - 1 : i + w); ++ii)
+            m = heights_host[(size_t)jj * cols + ii] > m ? heights_host[(size_t)jj * cols + ii] : m;
+        out[(size_t)j * cols + i] = m;
+      }
+  }
   float* d = nullptr;
-  HIP_TRY(h, hipMalloc(&d, bytes));
-  hipError_t e = hipMemcpy(d, heights_host, bytes, hipMemcpyHostToDevice);   // synchronous
-  if (e != hipSuccess) { (void)hipFree(d); h->err = std::string("hipMemcpy(heightfield): ") + hipGetErrorString(e); return MOCCA_E_HIP; }
-  if (h->d_hf) { (void)hipDeviceSynchronize(); (void)hipFree(h->d_hf); }   // no kernel in flight still reads the old grid
+  hipError_t e = hipMalloc(&d, bytes);
+  if (e == hipSuccess) e = hipMemcpy(d, host, bytes, hipMemcpyHostToDevice);   // synchronous: no kernel in flight still reads the old grid
+  delete[] host;
+  if (e != hipSuccess) { if (d) (void)hipFree(d); h->err = std::string("mocca_set_heightfield: ") + hipGetErrorString(e); return MOCCA_E_HIP; }
+  (void)hipDeviceSynchronize();   // ... nor the old slot records
+  for (int sl = 0; sl < h->model.n_slots; ++sl) std::memcpy(&h->model.slot_tab[sl][2], &wbits[sl], 4);
+  e = hipMemcpy(h->d_model, &h->model, sizeof(MoccaModel), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(d); h->err = std::string("hipMemcpy(model): ") + hipGetErrorString(e); return MOCCA_E_HIP; }
+  if (h->d_hf) (void)hipFree(h->d_hf);
   h->d_hf = d; h->hf_rows = rows; h->hf_cols = cols; h->hf_scale = (float)scale;
   return MOCCA_OK;
 }

@@ -985,10 +985,27 @@ DI void closest_on_triangle(const float* p, const float* a, const float* b, cons
 #pragma unroll
   for (int k = 0; k < 3; ++k) q[k] = a[k] + ab[k] * v + ac[k] * w;
 }
+// one triangle (a, b, c) of the height field against the sphere centre C: keeps the smaller gap and its normal (tn: the triangle's normal, unnormalised; il = 1 / |tn|)
+DI void hf_triangle(const float* C, float rad, const float* a, const float* b, const float* c, const float* tn, float il, float& gap, float* n) {
+  float q[3], d[3];
+  closest_on_triangle(C, a, b, c, q);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d[k] = C[k] - q[k];
+  const float d2 = dot3(d, d), id = rsq(d2), dist = d2 > 0 ? d2 * id : 0.0f;
+  if (dist - rad < gap) {
+    gap = dist - rad;
+    if (d2 > 1e-18f) { n[0] = d[0] * id; n[1] = d[1] * id; n[2] = d[2] * id; }
+    else { n[0] = tn[0] * il; n[1] = tn[1] * il; n[2] = tn[2] * il; }
+  }
+}
 // signed gap and world normal of a sphere (world centre C) against the height field (see the oracle's sphere_heightfield): above the surface
-// the closest of the eight triangles of the 2 x 2 cells around the grid point nearest to the centre; below it the plane of the triangle the
-// centre is under; 1e30 where there is no terrain
-DI float sphere_heightfield(const float* __restrict__ hf, int rows, int cols, float sc, const float* C, float rad, float reach, float* n) {
+// the closest of the triangles of the 2 W x 2 W cells around the grid point nearest to the centre -- W = ceil((radius + margin) scale + 1/2),
+// every cell a sphere of that reach can touch; W travels in the slot record (mocca_set_heightfield computes it: 1 for everything but the
+// walker's 14 cm and Mike's 23 cm spheres at 4 points per metre) --; below the surface the plane of the triangle the centre is under;
+// 1e30 where there is no terrain.  The central 2 x 2 cells are unrolled with their nine heights in registers (all lanes); the ring of a
+// wider window is a rolled loop that only runs while such a sphere is within reach of the highest point of ITS window (one more load: the
+// max-pooled copy of the grid that follows the heights, hf + (W - 1) rows cols) -- a fallen robot.
+DI float sphere_heightfield(const float* __restrict__ hf, int rows, int cols, float sc, const float* C, float rad, float reach, int W, float* n) {
   float gap = 1e30f;
   n[0] = 0; n[1] = 0; n[2] = 1;
   const float cell = 1.0f / sc, hx = 0.5f * (float)(cols - 1), hy = 0.5f * (float)(rows - 1);
@@ -1009,7 +1026,11 @@ DI float sphere_heightfield(const float* __restrict__ hf, int rows, int cols, fl
       hv[dj][di] = hf[j * cols + i];
       hmax = fmaxf(hmax, hv[dj][di]);
     }
-  if (C[2] - reach > hmax) return gap;   // above everything nearby: no contact possible (exact: every triangle lies below hmax)
+  if (W > 1) {   // the highest point within W cells of the nearest grid point (>= the nine above)
+    const int i = iv < 0 ? 0 : (iv > cols - 1 ? cols - 1 : iv), j = jv < 0 ? 0 : (jv > rows - 1 ? rows - 1 : jv);
+    hmax = hf[(W - 1) * rows * cols + j * cols + i];
+  }
+  if (C[2] - reach > hmax) return gap;   // above everything nearby: no contact possible (exact: every triangle of the window lies below hmax)
   bool below = false;
 #pragma unroll
   for (int dj = 0; dj < 2; ++dj)
@@ -1026,7 +1047,7 @@ DI float sphere_heightfield(const float* __restrict__ hf, int rows, int cols, fl
         const float* a = t == 0 ? v00 : v10;
         const float* b = t == 0 ? v10 : v11;
         const float* c = v01;
-        float q[3], e1[3], e2[3], tn[3], d[3];
+        float e1[3], e2[3], tn[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) { e1[k] = b[k] - a[k]; e2[k] = c[k] - a[k]; }
         cross3(e1, e2, tn);
@@ -1036,17 +1057,33 @@ DI float sphere_heightfield(const float* __restrict__ hf, int rows, int cols, fl
           if (side < 0) { below = true; gap = side - rad; n[0] = tn[0] * il; n[1] = tn[1] * il; n[2] = tn[2] * il; }
         }
         if (below) continue;
-        closest_on_triangle(C, a, b, c, q);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) d[k] = C[k] - q[k];
-        const float d2 = dot3(d, d), id = rsq(d2), dist = d2 > 0 ? d2 * id : 0.0f;
-        if (dist - rad < gap) {
-          gap = dist - rad;
-          if (d2 > 1e-18f) { n[0] = d[0] * id; n[1] = d[1] * id; n[2] = d[2] * id; }
-          else { n[0] = tn[0] * il; n[1] = tn[1] * il; n[2] = tn[2] * il; }
-        }
+        hf_triangle(C, rad, a, b, c, tn, il, gap, n);
       }
     }
+  if (W > 1 && !below) {   // the ring around the central cells (rare: see above)
+#pragma unroll 1
+    for (int dj = -W; dj < W; ++dj)
+#pragma unroll 1
+      for (int di = -W; di < W; ++di) {
+        const int i = iv + di, j = jv + dj;
+        if ((dj == -1 || dj == 0) && (di == -1 || di == 0)) continue;   // done above
+        if (i < 0 || j < 0 || i > cols - 2 || j > rows - 2) continue;
+        const float h00 = hf[j * cols + i], h10 = hf[j * cols + i + 1], h01 = hf[(j + 1) * cols + i], h11 = hf[(j + 1) * cols + i + 1];
+        if (C[2] - reach > fmaxf(fmaxf(h00, h10), fmaxf(h01, h11))) continue;   // this cell lies below the sphere's reach (exact, as above)
+        const float x0 = ((float)i - hx) * cell, y0 = ((float)j - hy) * cell;
+        const float v00[3] = {x0, y0, h00}, v10[3] = {x0 + cell, y0, h10}, v01[3] = {x0, y0 + cell, h01}, v11[3] = {x0 + cell, y0 + cell, h11};
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
+          const float* a = t == 0 ? v00 : v10;
+          const float* b = t == 0 ? v10 : v11;
+          float e1[3], e2[3], tn[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { e1[k] = b[k] - a[k]; e2[k] = v01[k] - a[k]; }
+          cross3(e1, e2, tn);
+          hf_triangle(C, rad, a, b, v01, tn, rsq(dot3(tn, tn)), gap, n);
+        }
+      }
+  }
   return gap;
 }
 // HeightField.get_height_at (bullet_objects.py:348-353), indices clamped to the grid
@@ -1145,7 +1182,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
     const int ids = __float_as_int(st.z);
     const int g = (ids >> 8) & 0xFF, e = (ids >> 16) & 1;
     bmask = __float_as_uint(st.w);
-    if ((ids >> 25) & 1) {  // flags: bits 17..24 margin code, bit 25 terrain, bits 26..28 foot index + 1, bit 29 torso
+    if ((ids >> 25) & 1) {  // flags: bits 17..24 margin code, bit 25 terrain, bits 26..28 foot index + 1, bit 29 torso, bits 30..31 height-field window - 1 (mocca_set_heightfield)
       gfoot = ((ids >> 26) & 7) - 1;
       gtorso = (ids >> 29) & 1;
       float C[3], Cw[3];
@@ -1155,7 +1192,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
       body = ids & 0xFF;
       if (TASK == MOCCA_TASK_WALKER3D_PLANNER) {
         // height field (HeightField.reload: lateralFriction 1.0, contactStiffness 30000, contactDamping 1000, bullet_objects.py:386-393)
-        gap = sphere_heightfield(hfa.data, hfa.rows, hfa.cols, hfa.scale, Cw, rad, rad + mreach, n);
+        gap = sphere_heightfield(hfa.data, hfa.rows, hfa.cols, hfa.scale, Cw, rad, rad + mreach, 1 + ((ids >> 30) & 3), n);   // bits 30..31: the slot's window - 1
         mu = M->plank_friction * gfric;
         const float kk = M->plank_stiffness, cc = M->plank_damping, dt = M->dt;
         const float ikc = rcp(dt * kk + cc);

@@ -570,7 +570,14 @@ static void closest_on_triangle(const real *p, const real *a, const real *b, con
  * centre (exact while radius + margin <= half a cell), normal from the closest point to the centre.  Centre BELOW the surface (a sphere
  * pushed more than its radius into the ground): signed distance to the plane of the triangle it is under, that triangle's normal.
  * Returns 1e30 where there is no terrain. */
-static real sphere_heightfield(const Oracle *o, const real *C, real rad, real *n) {
+/* the search window of a sphere of reach radius + margin: every cell it can touch lies within W = ceil(reach x scale + 1/2) cells of the grid
+ * point nearest to its centre (the centre is at most half a cell from that point; 1e-6: a reach of exactly half a cell is W = 1).  Evaluated in
+ * double precision by both sides (mocca_set_heightfield computes the kernel's per slot). */
+static int hf_window(const Oracle *o, double reach) {
+  int w = (int)ceil(reach * o->hf_scale + 0.5 - 1e-6);
+  return w < 1 ? 1 : (w > 4 ? 4 : w);
+}
+static real sphere_heightfield(const Oracle *o, const real *C, real rad, int W, real *n) {
   const int cols = o->hf_cols, rows = o->hf_rows;
   const real sc = (real)o->hf_scale, cell = 1 / sc;
   real gap = 1e30;
@@ -580,32 +587,45 @@ static real sphere_heightfield(const Oracle *o, const real *C, real rad, real *n
   if (!(fx >= -1 && fx <= cols && fy >= -1 && fy <= rows)) return gap;
   int iv = (int)floor(fx + (real)0.5), jv = (int)floor(fy + (real)0.5);
   int ic = (int)floor(fx), jc = (int)floor(fy); /* the cell the centre is over */
-  for (int dj = -1; dj <= 0; ++dj)
-    for (int di = -1; di <= 0; ++di) {
+  /* centre below the surface: the plane of the triangle it is under (that cell is one of the central 2 x 2) */
+  if (ic >= 0 && jc >= 0 && ic <= cols - 2 && jc <= rows - 2) {
+    int i = ic, j = jc;
+    real x0 = (i - (real)0.5 * (cols - 1)) * cell, y0 = (j - (real)0.5 * (rows - 1)) * cell;
+    real v00[3] = {x0, y0, o->hf[j * cols + i]}, v10[3] = {x0 + cell, y0, o->hf[j * cols + i + 1]};
+    real v01[3] = {x0, y0 + cell, o->hf[(j + 1) * cols + i]}, v11[3] = {x0 + cell, y0 + cell, o->hf[(j + 1) * cols + i + 1]};
+    real u = fx - i, v = fy - j;
+    const real *a = (u + v <= 1) ? v00 : v10, *b = (u + v <= 1) ? v10 : v11, *c = v01;
+    real e1[3], e2[3], tn[3];
+    for (int k = 0; k < 3; ++k) { e1[k] = b[k] - a[k]; e2[k] = c[k] - a[k]; }
+    cross3(e1, e2, tn); /* counter-clockwise seen from above: points up */
+    real il = 1 / sqrt(dot3(tn, tn));
+    for (int k = 0; k < 3; ++k) tn[k] *= il;
+    real side = (C[0] - a[0]) * tn[0] + (C[1] - a[1]) * tn[1] + (C[2] - a[2]) * tn[2];
+    if (side < 0) { n[0] = tn[0]; n[1] = tn[1]; n[2] = tn[2]; return side - rad; }
+  }
+  for (int dj = -W; dj < W; ++dj)
+    for (int di = -W; di < W; ++di) {
       int i = iv + di, j = jv + dj;
       if (i < 0 || j < 0 || i > cols - 2 || j > rows - 2) continue;
       real x0 = (i - (real)0.5 * (cols - 1)) * cell, y0 = (j - (real)0.5 * (rows - 1)) * cell;
       real v00[3] = {x0, y0, o->hf[j * cols + i]}, v10[3] = {x0 + cell, y0, o->hf[j * cols + i + 1]};
       real v01[3] = {x0, y0 + cell, o->hf[(j + 1) * cols + i]}, v11[3] = {x0 + cell, y0 + cell, o->hf[(j + 1) * cols + i + 1]};
-      real u = fx - i, v = fy - j;
       for (int t = 0; t < 2; ++t) {
         const real *a = t == 0 ? v00 : v10, *b = t == 0 ? v10 : v11, *c = v01;
-        real q[3], e1[3], e2[3], tn[3], d[3];
-        for (int k = 0; k < 3; ++k) { e1[k] = b[k] - a[k]; e2[k] = c[k] - a[k]; }
-        cross3(e1, e2, tn); /* counter-clockwise seen from above: points up */
-        real il = 1 / sqrt(dot3(tn, tn));
-        for (int k = 0; k < 3; ++k) tn[k] *= il;
-        if (i == ic && j == jc && (t == 0) == (u + v <= 1)) { /* the triangle under the centre */
-          real side = (C[0] - a[0]) * tn[0] + (C[1] - a[1]) * tn[1] + (C[2] - a[2]) * tn[2];
-          if (side < 0) { n[0] = tn[0]; n[1] = tn[1]; n[2] = tn[2]; return side - rad; }
-        }
+        real q[3], d[3];
         closest_on_triangle(C, a, b, c, q);
         for (int k = 0; k < 3; ++k) d[k] = C[k] - q[k];
         real d2 = dot3(d, d), dist = sqrt(d2);
         if (dist - rad < gap) {
           gap = dist - rad;
           if (d2 > (real)1e-18) { n[0] = d[0] / dist; n[1] = d[1] / dist; n[2] = d[2] / dist; }
-          else { n[0] = tn[0]; n[1] = tn[1]; n[2] = tn[2]; }
+          else {
+            real e1[3], e2[3], tn[3];
+            for (int k = 0; k < 3; ++k) { e1[k] = b[k] - a[k]; e2[k] = c[k] - a[k]; }
+            cross3(e1, e2, tn);
+            real il = 1 / sqrt(dot3(tn, tn));
+            n[0] = tn[0] * il; n[1] = tn[1] * il; n[2] = tn[2] * il;
+          }
         }
       }
     }
@@ -660,7 +680,7 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
       geom_point(m, w, g, e, C);
       for (int k = 0; k < 3; ++k) Cw[k] = C[k] + s->pos[k];
       if (o->task_id == MOCCA_TASK_WALKER3D_PLANNER) {
-        gap = sphere_heightfield(o, Cw, rad, n);
+        gap = sphere_heightfield(o, Cw, rad, hf_window(o, (double)(float)rad + (double)m->slot_margin[m->g_slot[g] + e]), n);
         mu = (real)m->plank_friction * (real)m->g_friction[g]; /* HeightField.reload: lateralFriction 1.0, contactStiffness 30000, contactDamping 1000 */
         real kk = m->plank_stiffness, cc = m->plank_damping, dt = m->dt;
         erp = dt * kk / (dt * kk + cc);
@@ -1704,10 +1724,10 @@ API int orc_set_heightfield(void *h, const float *data, int rows, int cols, doub
   return 0;
 }
 /* probe for the tests: gap and normal of a sphere (world centre, radius) against the attached height field; get_height_at */
-API double orc_heightfield_probe(void *h, const double *c, double rad, double *n_out) {
+API double orc_heightfield_probe(void *h, const double *c, double rad, double margin, double *n_out) {
   Oracle *o = (Oracle *)h;
   real C[3] = {(real)c[0], (real)c[1], (real)c[2]}, n[3];
-  real g = sphere_heightfield(o, C, (real)rad, n);
+  real g = sphere_heightfield(o, C, (real)rad, hf_window(o, rad + margin), n);
   for (int k = 0; k < 3; ++k) n_out[k] = n[k];
   return g;
 }

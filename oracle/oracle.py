@@ -68,7 +68,7 @@ def _load(precision: str) -> C.CDLL:
     lib.orc_set_trajectory.restype = C.c_int
     lib.orc_set_heightfield.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double]
     lib.orc_set_heightfield.restype = C.c_int
-    lib.orc_heightfield_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+    lib.orc_heightfield_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
     lib.orc_heightfield_probe.restype = C.c_double
     lib.orc_height_at.argtypes = [C.c_void_p, C.c_double, C.c_double]
     lib.orc_height_at.restype = C.c_double
@@ -127,10 +127,10 @@ class Oracle:
         if self.lib.orc_set_heightfield(self.h, _p(d), d.shape[0], d.shape[1], float(scale)) != 0:
             raise ValueError("orc_set_heightfield rejected the grid")
 
-    def heightfield_probe(self, centre, radius: float):
-        """(gap, normal) of a sphere against the attached height field."""
+    def heightfield_probe(self, centre, radius: float, margin: float = 0.0):
+        """(gap, normal) of a sphere against the attached height field; the search window follows radius + margin."""
         c, n = np.ascontiguousarray(centre, np.float64), np.zeros(3)
-        return self.lib.orc_heightfield_probe(self.h, _p(c), float(radius), _p(n)), n
+        return self.lib.orc_heightfield_probe(self.h, _p(c), float(radius), float(margin), _p(n)), n
 
     def height_at(self, x: float, y: float) -> float:
         return self.lib.orc_height_at(self.h, float(x), float(y))

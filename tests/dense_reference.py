@@ -297,10 +297,18 @@ def heightfield_surface(data, scale, x, y):
     return h, tn
 
 
-def heightfield_gap(data, scale, C, radius, window=1):
+def heightfield_window(scale, reach):
+    """Cells each way of the nearest grid point that a sphere of reach = radius + margin can touch (its centre is at most half a cell from
+    that point): ceil(reach x scale + 1/2); 1e-6: a reach of exactly half a cell stays at 1."""
+    return max(1, int(np.ceil(reach * scale + 0.5 - 1e-6)))
+
+
+def heightfield_gap(data, scale, C, radius, window=None, margin=0.0):
     """Signed gap and normal of a sphere against a height field (tests only; conventions in include/mocca.h mocca_set_heightfield):
     explicit vertex coordinate arrays; centre below the surface: distance to the plane of the triangle above it; otherwise every triangle
-    of the cells within `window` cells of the nearest grid point."""
+    of the cells within `window` cells of the nearest grid point (default: heightfield_window(scale, radius + margin))."""
+    if window is None:
+        window = heightfield_window(scale, radius + margin)
     rows, cols = data.shape
     X = (np.arange(cols) - (cols - 1) / 2) / scale
     Y = (np.arange(rows) - (rows - 1) / 2) / scale
@@ -337,7 +345,7 @@ def detect_contacts(mdl: Model, st: State, planks=None, heightfield=None):
         for e in range(2 if g["capsule"] else 1):
             C = o[g["body"]] + R[g["body"]] @ g["p"][e]
             if heightfield is not None:
-                gap, n = heightfield_gap(heightfield[0], heightfield[1], C, g["radius"])
+                gap, n = heightfield_gap(heightfield[0], heightfield[1], C, g["radius"], margin=g["margin"])
                 kk, cc, dt = mdl.plank_stiffness, mdl.plank_damping, mdl.dt
                 mu, erp, cfm = mdl.plank_friction * g["friction"], dt * kk / (dt * kk + cc), 1 / (dt * kk + cc) / dt
             elif planks is None:

@@ -41,6 +41,9 @@ CASES = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("Walker3DStepper
          # the planner envs (env_locomotion.py:982-1133): spheres / capsule ends against the triangles of the height field; the envs are
          # scattered over the field after reset (the episodes start on its flat corner platform)
          ("Walker3DPlannerEnv-v0", M.TASK_WALKER3D_PLANNER, {}), ("MikePlannerEnv-v0", M.TASK_WALKER3D_PLANNER, {}),
+         # ... and on a STEEP random field (3 x HeightField.reload(data=None)): the wide spheres' 4 x 4-cell search windows (Mike's 23 cm waist,
+         # the walker's 14 cm pelvis) meet triangles outside the central 2 x 2 cells
+         ("MikePlannerEnv-v0", M.TASK_WALKER3D_PLANNER, {"_steep": True}), ("Walker3DPlannerEnv-v0", M.TASK_WALKER3D_PLANNER, {"_steep": True, "_caps": (32, 10)}),
          # Cassie with mass on the two links its URDF leaves without inertia: the TopoCassieMassive kernel instance
          ("CassieEnv-v0", M.TASK_CASSIE, {"_massive": True}),
          # the solver's warm-start path (the compiled blobs start from zero, as Bullet's multibody contacts do; a record may say otherwise)
@@ -119,7 +122,9 @@ def test_single_substep_parity_with_matching_active_sets(env_id, task, kw):
     from mocca_envs_amd.vec_env import VecEnv, task_from_float64, _DEFAULT_PARAMS
     from oracle.oracle import Oracle, PARAM_CURRICULUM
     n, steps = 256, 160
-    m = _one_substep_blob(env_id, **dict(kw))
+    kw = dict(kw)
+    steep = kw.pop("_steep", False)
+    m = _one_substep_blob(env_id, **kw)
     blob = m.to_bytes()
     env = VecEnv(env_id, n, auto_reset=False, seed=4, model_blob=blob)
     dbg = env.set_debug(True)
@@ -129,6 +134,9 @@ def test_single_substep_parity_with_matching_active_sets(env_id, task, kw):
         env.set_param(pid, val); orc.set_param(pid, val); o64.set_param(pid, val)
     if task == M.TASK_WALKER3D_STEPPER:
         env.set_param(2, 9); orc.set_param(PARAM_CURRICULUM, 9); o64.set_param(PARAM_CURRICULUM, 9)
+    if steep:
+        from mocca_envs_amd import host_logic as H
+        env.set_heightfield(3.0 * H.random_height_field(np.random.RandomState(11), (128, 128), 4).reshape(128, 128).astype(np.float32), 4)
     if task == M.TASK_WALKER3D_PLANNER:
         orc.set_heightfield(*env.height_field); o64.set_heightfield(*env.height_field)
     env.reset(); orc.reset(seed=4); o64.reset(seed=4)

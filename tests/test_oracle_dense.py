@@ -159,20 +159,43 @@ def test_substep_on_the_height_field():
             np.testing.assert_allclose(n_o, n_d, atol=1e-7)
             worst = max(worst, 1 - n_o[2])
     assert worst > 0.05                                               # slopes were really met
-    # the 2 x 2-cell search against a 4 x 4-cell one (every triangle a sphere of up to 16 cm of reach can touch): on the shipped map the
-    # nearer window never misses the closest triangle, for any of the robots' sphere radii
-    n_contacts = 0
-    for k in range(2500):
-        xy = rng.uniform(-15.5, 15.5, 2)
-        h = data[min(127, max(0, int((xy[1] + 16) * 4))), min(127, max(0, int((xy[0] + 16) * 4)))]
-        rad = rng.choice([0.045, 0.09, 0.11, 0.14])
-        C = np.array([xy[0], xy[1], h + rad + rng.uniform(-0.03, 0.03)])
-        g1, _ = D.heightfield_gap(data.astype(np.float64), scale, C, rad, window=1)
-        if g1 < 0.02:
-            n_contacts += 1
-            g2, _ = D.heightfield_gap(data.astype(np.float64), scale, C, rad, window=2)
-            assert abs(g1 - g2) < 1e-9, (k, C, rad, g1, g2)
-    assert n_contacts > 1500
+    # The search window follows the sphere: W = ceil((radius + margin) x scale + 1/2) cells each way (2 for the walker's 14 cm and Mike's 23 cm
+    # spheres on the shipped 4-points-per-metre map).  For EVERY radius the planner blobs carry (read from the blobs, not typed in), on the
+    # shipped map and on a steep random field (HeightField.reload(data=None), bullet_objects.py:395-441, at 4 points per metre): the window
+    # never misses a triangle -- widening it by two more cells changes no gap -- while for the wide spheres the old fixed 2 x 2 search did.
+    from mocca_envs_amd import host_logic as H
+    radii = {}
+    for name, mm in (("walker3d", m), ("mike", M.compile_mike(planner=True))):
+        for g in range(mm.n_geoms):
+            if mm.g_terrain[g]:
+                radii[(round(float(mm.g_radius[g]), 6), round(float(mm.slot_margin[mm.g_slot[g]]), 6))] = name
+    assert max(r for r, _ in radii) > 0.22 and min(r for r, _ in radii) < 0.05, radii            # Mike's waist sphere (mike.xml:20) is in the list
+    steep = 3.0 * H.random_height_field(np.random.RandomState(11), (128, 128), 4).reshape(128, 128).astype(np.float64)
+    fields = (("shipped", data.astype(np.float64)), ("steep random", steep))
+    n_contacts, missed_by_fixed = 0, 0
+    for fname, fdata in fields:
+        orc.set_heightfield(fdata.astype(np.float32), scale)
+        f32 = fdata.astype(np.float32).astype(np.float64)
+        for (rad, margin) in sorted(radii):
+            W = D.heightfield_window(scale, rad + margin)
+            assert W == (1 if rad + margin <= 0.125 + 1e-9 else 2), (rad, margin, W)
+            for k in range(700):
+                xy = rng.uniform(-15.5, 15.5, 2)
+                h = f32[min(127, max(0, int((xy[1] + 16) * 4))), min(127, max(0, int((xy[0] + 16) * 4)))]
+                C = np.array([xy[0], xy[1], h + rad + rng.uniform(-0.03, 0.03)])
+                g1, n1 = D.heightfield_gap(f32, scale, C, rad, margin=margin)
+                if g1 < margin:
+                    n_contacts += 1
+                    g3, _ = D.heightfield_gap(f32, scale, C, rad, window=W + 2)
+                    assert abs(g1 - g3) < 1e-9, (fname, k, C, rad, g1, g3)
+                    g0, _ = D.heightfield_gap(f32, scale, C, rad, window=1)
+                    missed_by_fixed += abs(g0 - g1) > 1e-9
+                    g_o, n_o = orc.heightfield_probe(C, rad, margin)                    # the oracle uses the same window
+                    assert abs(g_o - g1) < 1e-9, (fname, k, C, rad, g_o, g1)
+                    np.testing.assert_allclose(n_o, n1, atol=1e-7)
+    print(f"\nheight-field windows: {n_contacts} contacts, {missed_by_fixed} of them missed by a fixed 2 x 2 search")
+    assert n_contacts > 3000 and missed_by_fixed >= 1
+    orc.set_heightfield(data, scale)
     rows = []
     for k in range(8):
         row = _random_state(rng, m, 0.0, spread=0.5)
