@@ -55,6 +55,13 @@ enum {
   MOCCA_TASKF_QUADRUPED_STEPPER = 8, /* LaikagoStepperEnv.calc_base_reward (env_locomotion.py:928-979): posture penalty from the hip /
                                       knee angles, progress x 2, posture x 0.2, tall_bonus 2, done = (t > 240 and next step <= 4),
                                       -1 + done when a non-foot link touches a plank                                              */
+  MOCCA_TASKF_STALE_RESET_CONTACTS = 16, /* Walker3DStepperEnv.reset (env_locomotion.py:484-499) calls calc_feet_state() right after
+                                      robot.reset(), BEFORE the terrain is redrawn and next_step_index is rewound: Bullet has not stepped
+                                      since the last frame of the episode before, so getContactPoints still returns that frame's manifolds
+                                      [UNVERIFIED-BULLET: contacts are refreshed by stepSimulation only].  The new episode therefore starts
+                                      with feet_contact = the old episode's last contact flags (they enter the first step's observation,
+                                      :525) and with target_reached_count = 1 if a foot was on the cover of what was then the target plank.
+                                      Set on every Stepper blob (the reference's behaviour); clear it for a clean start.            */
 };
 
 /* MoccaModel.plank_shape */

@@ -1159,12 +1159,15 @@ DI void stage_planks(ModelP M, float* L, int lane, const float* ter) {
 
 struct HeightFieldArgs { const float* data; int rows, cols; float scale; };   // planner envs; data == nullptr otherwise
 struct ContactFlags { int touch0, touch1, target0, target1, touch2, touch3, body_touch, target2, target3; };  // feet 2, 3: quadrupeds; body_touch: a non-foot link on the terrain
+// Stepper: which planks' COVERS each foot touches, 4 bits per foot (bit 4 f + k: foot f on the cover of live plank k).  target_f is bit
+// (next_step_index mod n_planks) of foot f's nibble -- at the step's start for the step itself, at its END for the stale read of reset()
+DI int cover_targets(int cover, int nsi, int n_planks, int f) { return (cover >> (4 * f + nsi % n_planks)) & 1; }
 
 // lane = terrain contact slot, then self-collision pairs strided over the wave.
 // Contacts are compacted in slot order, then pair order (the oracle's priority), up to max_contacts.
 template <class T, int TASK>
 DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next_step_index,
-                        int* nc_out, int32_t* dbg, int* nc_wanted, const HeightFieldArgs hfa) {
+                        int* nc_out, int32_t* dbg, int* nc_wanted, const HeightFieldArgs hfa, int* cover_out = nullptr) {
   STAMP_BEGIN;
   // contacts open within the geom's margin (Bullet's relative breaking threshold of its link, a few mm; decoded from the slot record where
   // it is compared: a separate load spilled).  `mreach`: gContactBreakingThreshold itself, 20 mm -- an upper bound of every relative
@@ -1175,7 +1178,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
   // ---- terrain: lane -> (geom, end)
   bool active = false;
   float n[3] = {0, 0, 1}, P[3] = {0, 0, 0}, gap = 1e30f, mu = 0, erp = M->erp, cfm = 0;
-  int body = -1, slot = lane, is_target = 0, gfoot = -1, gtorso = 0;
+  int body = -1, slot = lane, cover_k = -1 /* Stepper: the plank whose cover this slot rests on */, gfoot = -1, gtorso = 0;
   unsigned bmask = 0u;
   if (lane < T::NSLOT) {
     const f4_t st = *(CF4P)(M->slot_tab[lane]);  // radius, friction, ids, ancestor mask
@@ -1224,7 +1227,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
             n[0] = nn[0]; n[1] = nn[1]; n[2] = nn[2];
             float d[3] = {Cw[0] - rad * nn[0] - bc[0], Cw[1] - rad * nn[1] - bc[1], Cw[2] - rad * nn[2] - bc[2]};
             const float lz = Rb[2] * d[0] + Rb[5] * d[1] + Rb[8] * d[2];
-            is_target = (lz >= h[2] * 0.8f) && (k == next_step_index % n_planks);
+            cover_k = lz >= h[2] * 0.8f ? k : -1;
           }
         }
         mu = M->plank_friction * gfric;
@@ -1284,11 +1287,15 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
       fl.touch3 = __ballot(active && gfoot == 3) != 0ull;
       // LaikagoCustomEnv ends the episode when anything but a foot link meets the ground (env_locomotion.py:880-890)
       fl.body_touch = __ballot(active && gfoot < 0) != 0ull;
-      fl.target2 = __ballot(active && gfoot == 2 && is_target) != 0ull;
-      fl.target3 = __ballot(active && gfoot == 3 && is_target) != 0ull;
     }
-    fl.target0 = __ballot(active && gfoot == 0 && is_target) != 0ull;
-    fl.target1 = __ballot(active && gfoot == 1 && is_target) != 0ull;
+    if (TASK == MOCCA_TASK_WALKER3D_STEPPER) {   // calc_feet_state's target test (env_locomotion.py:634-650) from the cover mask
+      const int cover = (int)wave_or((active && gfoot >= 0 && cover_k >= 0) ? 1u << (4 * gfoot + cover_k) : 0u);
+      const int npl = M->n_planks;
+      fl.target0 = cover_targets(cover, next_step_index, npl, 0);
+      fl.target1 = cover_targets(cover, next_step_index, npl, 1);
+      if constexpr (T::NFEET > 2) { fl.target2 = cover_targets(cover, next_step_index, npl, 2); fl.target3 = cover_targets(cover, next_step_index, npl, 3); }
+      if (cover_out) *cover_out = cover;
+    }
     // Walker3DPlannerEnv: the torso link touches anything -> done (env_locomotion.py:1104-1110); the terrain here, robot links below
     if (TASK == MOCCA_TASK_WALKER3D_PLANNER) fl.body_touch = __ballot(active && gtorso) != 0ull;
   }
@@ -2142,7 +2149,7 @@ DI void stage_joints(ModelP M, float* L, int lane) {
 template <class T, int TASK>
 DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next_step_index,
                         unsigned long long ppk, int32_t* dbg, int prio, int& rows_out, bool keep_warm,
-                        const HeightFieldArgs hfa = HeightFieldArgs{nullptr, 0, 0, 0.0f}, int sidx = 0, int nsub = 1) {
+                        const HeightFieldArgs hfa = HeightFieldArgs{nullptr, 0, 0, 0.0f}, int sidx = 0, int nsub = 1, int* cover_out = nullptr) {
   // pace checkpoints: a substep counts 64 units + MOCCA_PACE_ROWUNIT per constraint row (the row count of the substep before stands in until
   // this one's is known) -- 20 after the collision pass, 36 after the ABA, all at its end: an env with many rows has more of its step
   // ahead of it at the same point of the program, and is given priority BEFORE it falls behind
@@ -2166,7 +2173,7 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
     wsync();
     STAMP(15);
 #ifndef MOCCA_SKIP_COLLIDE
-    fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc, dbg, &nc_wanted, hfa);
+    fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc, dbg, &nc_wanted, hfa, cover_out);
 #endif
     wsync();   // (a compiler fence: phase 2 stores over what the collision pass read)
     const int wb = wl < T::NB ? wl : 0;
@@ -2182,7 +2189,7 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
     wsync();
     STAMP(15);
 #ifndef MOCCA_SKIP_COLLIDE  // profiling builds only (tools/ablate.sh): results are wrong by construction
-    fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc, dbg, &nc_wanted, hfa);
+    fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc, dbg, &nc_wanted, hfa, cover_out);
 #endif
   }
   STAMP(1);
@@ -2287,6 +2294,7 @@ DI RobotObs robot_obs(ModelP M, float* L, int lane, float fc0, float fc1, float*
 struct TaskRegs {  // uniform across the wave
   float wt[3], linpot, angpot, stopf, fc0, fc1, fc2, fc3, dist, angle, gain, prevx, initz;
   int close, done, t, episode, draw, mirrored, nsi, trc, stop, setstop, cur, istep;
+  int cover;   // Stepper: cover mask of the last step's contacts (word 26, as a float; ContactFlags / cover_targets) -- what reset() reads stale
 };
 DI void load_task(const uint32_t* tk, TaskRegs& t, bool quadruped = false) {
   auto f = [&](int i) { return __uint_as_float(tk[i]); };
@@ -2298,7 +2306,11 @@ DI void load_task(const uint32_t* tk, TaskRegs& t, bool quadruped = false) {
   t.nsi = (int)tk[T_NSI]; t.trc = (int)tk[T_TRC]; t.stop = (int)tk[T_STOP]; t.setstop = (int)tk[T_SETSTOP];
   t.cur = (int)tk[T_CUR]; t.gain = f(T_GAIN); t.prevx = f(T_PREVX);
   t.initz = f(T_INITZ); t.istep = (int)tk[T_ISTEP];
+  t.cover = 0;
 }
+enum : int { T_COVER = 26 };
+DI void load_task_cover(const uint32_t* tk, TaskRegs& t) { t.cover = (int)__uint_as_float(tk[T_COVER]); }
+DI void store_task_cover(uint32_t* tk, const TaskRegs& t) { tk[T_COVER] = __float_as_uint((float)t.cover); }
 DI void store_task(uint32_t* tk, const TaskRegs& t, bool quadruped = false) {
   auto u = [](float x) { return __float_as_uint(x); };
   tk[T_WTX] = u(t.wt[0]); tk[T_WTY] = u(t.wt[1]); tk[T_WTZ] = u(t.wt[2]); tk[T_LINPOT] = u(t.linpot); tk[T_ANGPOT] = u(t.angpot);
@@ -2430,8 +2442,18 @@ template <class T, int TASK, bool INJECT = false>
 DI void reset_env(const StepArgs& a, ModelP M, float* L, float* ter, int env, int lane, TaskRegs& t,
                   float* obs) {
   const int ep = t.episode + 1, cur = t.cur;
+  // Walker3DStepperEnv.reset reads the contact manifolds of the episode that just ended (MOCCA_TASKF_STALE_RESET_CONTACTS)
+  const float sfc[4] = {t.fc0, t.fc1, t.fc2, t.fc3};
+  const int snsi = t.nsi, scover = t.cover;
   t = TaskRegs{};
   t.episode = ep;
+  if (TASK == MOCCA_TASK_WALKER3D_STEPPER && (M->task_flags & MOCCA_TASKF_STALE_RESET_CONTACTS)) {
+    t.fc0 = sfc[0]; t.fc1 = sfc[1]; t.fc2 = sfc[2]; t.fc3 = sfc[3];   // robot.feet_contact[:] = info[:, 0] (:656): the first step's observation (:525)
+    const int npl = M->n_planks;
+    int reached = cover_targets(scover, snsi, npl, 0) | cover_targets(scover, snsi, npl, 1);
+    if constexpr (T::NFEET > 2) reached |= cover_targets(scover, snsi, npl, 2) | cover_targets(scover, snsi, npl, 3);
+    if (reached) t.trc = 1;   // target_reached_count += 1 from 0 (:484,661); below 2: nothing advances
+  }
   t.cur = TASK == MOCCA_TASK_WALKER3D_STEPPER ? live_curriculum(a, env - a.env_offset) : cur;
   t.gain = a.gain_v ? a.gain_v[env - a.env_offset] : a.gain;  // robot.applied_gain persists across resets (robots.py:16,33)
   if (TASK == MOCCA_TASK_WALKER3D_CUSTOM) {

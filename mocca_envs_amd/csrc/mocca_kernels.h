@@ -161,6 +161,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   STAMP(28);  // kernel prologue done
   if constexpr (TASK == MOCCA_TASK_WALKER3D_STEPPER) stage_planks(M, L, lane, ter);
   ContactFlags fl = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int cover = 0;   // Stepper: cover mask of the last substep's contacts (mocca_device.h cover_targets)
   const int nsub = INJECT ? 0 : M->n_substeps;
   const int nsi0 = TASK == MOCCA_TASK_WALKER3D_STEPPER ? (int)tk[T_NSI] : 0;
   // the env's row count at the end of the step before (task word 23) sets the issue priority until the first substep knows better:
@@ -175,16 +176,20 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     int ln = lane;  // same for lane-derived offsets and predicates (recomputing them costs a few instructions)
     unsigned long long pk = ppk;  // laundered too: otherwise every (ppk >> 5k) & 31 and the addresses derived from it
     asm volatile("" : "+s"(Ms), "+v"(ln), "+v"(pk));  // are hoisted out of the loop and spilled
-    fl = substep<T, TASK>(Ms, L, ln, ter, nsi0, pk, dbg, a.prio, last_rows, false, HeightFieldArgs{a.hf, a.hf_rows, a.hf_cols, a.hf_scale}, s, nsub);
+    fl = substep<T, TASK>(Ms, L, ln, ter, nsi0, pk, dbg, a.prio, last_rows, false, HeightFieldArgs{a.hf, a.hf_rows, a.hf_cols, a.hf_scale}, s, nsub, &cover);
   }
   if constexpr (INJECT) {  // getContactPoints results handed in by the caller (robots.py:74-86, env_locomotion.py:634-650, :880-890)
     const int32_t* tc = a.inj_touch + (size_t)env * T::NFEET;
     fl.touch0 = tc[0] != 0; fl.touch1 = tc[1] != 0;
     if constexpr (T::NFEET > 2) { fl.touch2 = tc[2] != 0; fl.touch3 = tc[3] != 0; }
-    if (a.inj_target) {
+    if (a.inj_target) {   // per foot: 1 = on the cover of the target plank (plank next_step_index mod n_planks at the step's start), 2 = of the plank after it
       const int32_t* tg = a.inj_target + (size_t)env * T::NFEET;
-      fl.target0 = tg[0] != 0; fl.target1 = tg[1] != 0;
-      if constexpr (T::NFEET > 2) { fl.target2 = tg[2] != 0; fl.target3 = tg[3] != 0; }
+      const int npl = TASK == MOCCA_TASK_WALKER3D_STEPPER ? M->n_planks : 1;
+#pragma unroll
+      for (int f = 0; f < T::NFEET; ++f)
+        if (tg[f] == 1 || tg[f] == 2) cover |= 1 << (4 * f + (nsi0 + tg[f] - 1) % npl);
+      fl.target0 = tg[0] == 1; fl.target1 = tg[1] == 1;
+      if constexpr (T::NFEET > 2) { fl.target2 = tg[2] == 1; fl.target3 = tg[3] == 1; }
     }
     if (a.inj_body) fl.body_touch = a.inj_body[env] != 0;
   }
@@ -359,6 +364,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
       if (a.random_reward == 1) t.draw += 8;
     }
     info = t.nsi;
+    t.cover = cover;   // what a reset() right after this step would still see (MOCCA_TASKF_STALE_RESET_CONTACTS)
   }
   t.prevx = L[L_BASE];
   const int timeout = t.t >= M->max_episode_steps;
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   wsync();
   flush_obs(L, obs_out, lane, a.obs_dim);
   store_dyn(st, L, lane, T::NJ, T::NSLOT, uni(__float_as_int(L[L_KEEPWARM])) != 0);
-  if (lane == 0) store_task(tk, t, T::NFEET > 2);
+  if (lane == 0) { store_task(tk, t, T::NFEET > 2); if (TASK == MOCCA_TASK_WALKER3D_STEPPER) store_task_cover(tk, t); }
   if (!INJECT) pace_finish(a, L, lane, a.pace);
   STAMP(25);  // reset (if any) + write-back done
 #ifdef MOCCA_STAMPS
@@ -396,6 +402,7 @@ __global__ __launch_bounds__(64) void mocca_reset_kernel(StepArgs a) {
   float* ter = TASK == MOCCA_TASK_WALKER3D_STEPPER ? a.terrain + (size_t)env * TERRAIN_STRIDE : nullptr;
   TaskRegs t;
   load_task(tk, t, T::NFEET > 2);
+  if (TASK == MOCCA_TASK_WALKER3D_STEPPER) load_task_cover(tk, t);
   if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
   if constexpr (TASK == MOCCA_TASK_CASSIE) {
     cassie_reset_env<T, INJECT>(a, M, L, env + a.env_offset, lane, t, L + L_OBS);
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(64) void mocca_reset_kernel(StepArgs a) {
   wsync();
   flush_obs(L, a.obs + (size_t)env * a.obs_dim, lane, a.obs_dim);
   store_dyn(st, L, lane, T::NJ, T::NSLOT);
-  if (lane == 0) store_task(tk, t, T::NFEET > 2);
+  if (lane == 0) { store_task(tk, t, T::NFEET > 2); if (TASK == MOCCA_TASK_WALKER3D_STEPPER) store_task_cover(tk, t); }
 }
 
 // calc_state + observation tail on the stored state (no physics, no randomness)

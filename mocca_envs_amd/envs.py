@@ -310,9 +310,24 @@ class Walker3DStepperEnv(EnvBase):
         terrain[120:124] = [0, 1, 2, 3]
         task = H.task_record(next_step_index=self.next_step_index, curriculum=cur, applied_gain=self.robot.applied_gain,
                              mirrored=int(self.robot.mirrored), episode=self._episode, draw=122)
+        # self.calc_feet_state() between robot.reset() and randomize_terrain() (:484-499) reads Bullet's manifolds of the LAST frame of
+        # the episode before (no stepSimulation since): feet_contact and, with a foot on the cover of what was then the target plank,
+        # target_reached_count = 1 carry over (MOCCA_TASKF_STALE_RESET_CONTACTS; the device record of the last step holds both)
+        nf = int(self.model.n_feet)
+        if (self.model.task_flags & M.TASKF_STALE_RESET_CONTACTS) and getattr(self, "_img", None) is not None and self._episode > 0:
+            from .vec_env import task_to_float64
+            old = task_to_float64(self._img["task"])[0]
+            fc = [old[12], old[13], old[24], old[25]][:nf]
+            task[12:14] = fc[:2]
+            if nf > 2:
+                task[24:26] = fc[2:4]
+            cover, old_nsi = int(old[26]), int(old[16])
+            if any((cover >> (4 * f + old_nsi % int(self.model.n_planks))) & 1 for f in range(nf)):
+                task[17] = 1
         self._vec.set_param(2, cur)
         self._push(H.initial_state(self.model, q), task, terrain)
         obs = self._observe()
+        obs[6 + 2 * int(self.model.n_joints):6 + 2 * int(self.model.n_joints) + nf] = 0.0   # robot.reset()'s own calc_state: feet_contact.fill(0) (robots.py:197-200)
         self._pull_robot()
         return obs
 

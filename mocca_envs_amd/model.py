@@ -35,6 +35,7 @@ GEOM_SPHERE, GEOM_CAPSULE = 0, 1
 TASK_WALKER3D_CUSTOM, TASK_WALKER3D_STEPPER, TASK_CASSIE, TASK_WALKER3D_PLANNER = 0, 1, 2, 3
 TASK_WORDS = 40
 TASKF_NEVER_DONE, TASKF_RESET_TAIL_ZERO, TASKF_BODY_CONTACT, TASKF_QUADRUPED_STEPPER = 1, 2, 4, 8  # MoccaModel.task_flags (include/mocca_model.h)
+TASKF_STALE_RESET_CONTACTS = 16   # Stepper reset() reads the contact manifolds of the episode before (env_locomotion.py:484-499): the reference's behaviour
 PLANK_BOX, PLANK_CYLINDER = 0, 1
 MAX_PLANKS = 4
 MAX_CLOSURES = 2
@@ -552,6 +553,8 @@ def set_stepper_params(m: "MoccaModel", *, quadruped: bool = False, plank_class:
         m.plank_half[k] = half[k] * scale
     m.plank_com_z = com_z * scale                  # BaseStep._pos_offset (bullet_objects.py:62)
     m.plank_friction, m.plank_stiffness, m.plank_damping = 1.0, 30000.0, 1000.0      # bullet_objects.py:64-72
+    # reset() -> calc_feet_state() on the manifolds of the episode before (env_locomotion.py:484-499); only the Stepper task reads the flag
+    m.task_flags |= TASKF_STALE_RESET_CONTACTS
     return m
 
 
@@ -857,7 +860,7 @@ def _compile_planar(description, damping: float, armature: float, self_collision
     m = compile_model(root, foot_names=["foot", "foot_left"], init_q_by_name={}, init_pos=root.pos,
                       mirror_right=mirror_right, mirror_left=mirror_left, mirror_neg=[], self_collision=self_collision, **kw)
     m.lin_damp = m.ang_damp = 0.0
-    m.task_flags = TASKF_NEVER_DONE | TASKF_RESET_TAIL_ZERO
+    m.task_flags |= TASKF_NEVER_DONE | TASKF_RESET_TAIL_ZERO
     return m.finalize_tables()
 
 
@@ -1219,7 +1222,7 @@ def compile_laikago(stepper: bool = False, plank_class: str = "LargePlank") -> M
         m.mirror_right[k] = v
     for k, v in enumerate(left):
         m.mirror_left[k] = v
-    m.task_flags = TASKF_BODY_CONTACT
+    m.task_flags |= TASKF_BODY_CONTACT
     if stepper:
         # LaikagoStepperEnv (env_locomotion.py:893-979): sim_frame_skip 4 -> 4 substeps of 1/240 s, start at (0.25, 0, 0.53) moving
         # at (0.5, 0, 0.25), four live planks of step_radius 0.16, its own reward / termination (MOCCA_TASKF_QUADRUPED_STEPPER)
@@ -1227,7 +1230,7 @@ def compile_laikago(stepper: bool = False, plank_class: str = "LargePlank") -> M
         m.init_pos[0], m.init_pos[1], m.init_pos[2] = 0.25, 0.0, 0.53
         m.init_vel[0], m.init_vel[1], m.init_vel[2] = 0.5, 0.0, 0.25
         set_stepper_params(m, quadruped=True, plank_class=plank_class)
-        m.task_flags = TASKF_QUADRUPED_STEPPER
+        m.task_flags = (m.task_flags & ~TASKF_BODY_CONTACT) | TASKF_QUADRUPED_STEPPER
     return m.finalize_tables()
 
 

@@ -185,6 +185,8 @@ typedef struct {
   int32_t istep;
   /* Stepper with random_reward (env_locomotion.py:533-547): this step's eight U(0.8, 1.2) weights */
   real rw[8];
+  /* Stepper: which planks' covers each foot touched in the last step, bit 4 f + k (foot f, live plank k): what reset() reads stale (MOCCA_TASKF_STALE_RESET_CONTACTS) */
+  int32_t cover;
 } Task;
 
 typedef struct {
@@ -206,6 +208,7 @@ typedef struct {
   real c_erp[MAX_CONTACTS], c_cfm[MAX_CONTACTS];
   int foot_touch[MOCCA_MAX_FEET];        /* any terrain contact of foot k this substep */
   int foot_target[MOCCA_MAX_FEET];       /* foot k touches the cover of the target plank */
+  int cover;                             /* bit 4 f + k: foot f touches the cover of live plank k */
   int body_touch;                        /* some non-foot geom touches the terrain */
   /* rows */
   int nr;
@@ -661,6 +664,7 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
   const MoccaModel *m = &o->m;
   w->nc = 0;
   for (int k = 0; k < m->n_feet; ++k) w->foot_touch[k] = w->foot_target[k] = 0;
+  w->cover = 0;
   w->body_touch = 0;
   uint64_t slot_mask = 0;
   int n_self = 0;
@@ -676,7 +680,7 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
     for (int e = 0; e < ne; ++e) {
       real C[3], Cw[3], n[3] = {0, 0, 1}, gap, rad = m->g_radius[g];
       real mu, erp = m->erp, cfm = 0;
-      int is_target = 0;
+      int is_target = 0, cover_k = -1;
       geom_point(m, w, g, e, C);
       for (int k = 0; k < 3; ++k) Cw[k] = C[k] + s->pos[k];
       if (o->task_id == MOCCA_TASK_WALKER3D_PLANNER) {
@@ -704,6 +708,7 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
             real lz = Rb[2] * d[0] + Rb[5] * d[1] + Rb[8] * d[2];
             int cover = lz >= (real)m->plank_half[2] * (real)0.8;
             is_target = cover && (k == tk->next_step_index % m->n_planks);
+            cover_k = cover ? k : -1;
           }
         }
         mu = (real)m->plank_friction * (real)m->g_friction[g];
@@ -714,7 +719,11 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
       if (gap < (real)m->slot_margin[m->g_slot[g] + e]) {
         slot_mask |= (uint64_t)1 << (m->g_slot[g] + e);
         if (o->task_id == MOCCA_TASK_WALKER3D_PLANNER) { if (m->g_torso[g]) w->body_touch = 1; } /* the torso link touches the terrain, :1104-1110 */
-        else if (m->g_foot[g] >= 0) { w->foot_touch[m->g_foot[g]] = 1; if (is_target) w->foot_target[m->g_foot[g]] = 1; }
+        else if (m->g_foot[g] >= 0) {
+          w->foot_touch[m->g_foot[g]] = 1;
+          if (is_target) w->foot_target[m->g_foot[g]] = 1;
+          if (cover_k >= 0) w->cover |= 1 << (4 * m->g_foot[g] + cover_k);
+        }
         else w->body_touch = 1; /* a non-foot link on the terrain (LaikagoCustomEnv, env_locomotion.py:880-890) */
         if (ncand < MOCCA_MAX_SLOTS) {
           TerrainCand *q = &cand[ncand++];
@@ -1431,8 +1440,14 @@ static void reset_env(Oracle *o, int env, float *obs) {
   int nj = m->n_joints;
   int keep_cur = tk->curriculum;
   int ep = tk->episode + 1;
+  /* Walker3DStepperEnv.reset (env_locomotion.py:484-499): calc_feet_state() runs right after robot.reset(), on the contact manifolds of the
+   * episode that just ended (Bullet has not stepped since) and with the OLD next_step_index -- MOCCA_TASKF_STALE_RESET_CONTACTS */
+  real stale_fc[MOCCA_MAX_FEET];
+  for (int k = 0; k < MOCCA_MAX_FEET; ++k) stale_fc[k] = tk->feet_contact[k];
+  int stale_nsi = tk->next_step_index, stale_cover = tk->cover;
   memset(tk, 0, sizeof(*tk));
   tk->episode = ep; tk->curriculum = keep_cur;
+
   tk->applied_gain = 1;
   if (o->task_id == MOCCA_TASK_WALKER3D_CUSTOM) {
     randomize_target(o, env, tk); /* draws 0..2 */
@@ -1491,8 +1506,16 @@ static void reset_env(Oracle *o, int env, float *obs) {
     softsign_tail(dist, ang, obs + nb);
     if (m->task_flags & MOCCA_TASKF_RESET_TAIL_ZERO) { obs[nb] = 0; obs[nb + 1] = 0; } /* Walker2DCustomEnv.reset, :299-300 */
   } else {
-    /* env_locomotion.py:481-513: calc_feet_state() on the fresh pose finds no contacts (planks
-     * not yet placed relative to a robot at rest above them): feet_contact = 0 */
+    /* env_locomotion.py:481-513: robot.reset()'s observation (above) carries feet_contact = 0 (robots.py:197-200); calc_feet_state() then
+     * runs on the manifolds of the episode before -- the first step's observation shows its flags (:525) -- or, flag cleared, finds nothing */
+    if (m->task_flags & MOCCA_TASKF_STALE_RESET_CONTACTS) {
+      int reached = 0;
+      for (int k = 0; k < m->n_feet; ++k) {
+        tk->feet_contact[k] = stale_fc[k];                                         /* robot.feet_contact[:] = info[:, 0], :656 */
+        reached |= (stale_cover >> (4 * k + stale_nsi % m->n_planks)) & 1;
+      }
+      if (reached) tk->target_reached_count = 1;                                   /* += 1 from 0 (:484,661); below 2: nothing advances */
+    }
     generate_step_placements(o, env, tk, tr);
     for (int k = 0; k < MOCCA_MAX_PLANKS; ++k) tr->plank_info[k] = k;
     tk->next_step_index = m->lookbehind; /* :499 */
@@ -1519,15 +1542,21 @@ static void step_env(Oracle *o, int env, const float *act, float *obs, float *re
     a = a < -1 ? -1 : (a > 1 ? 1 : a);
     tau[b] = (real)m->gain[b] * tk->applied_gain * a;
   }
-  int touch[MOCCA_MAX_FEET] = {0}, target[MOCCA_MAX_FEET] = {0}, body_touch = 0;
+  int touch[MOCCA_MAX_FEET] = {0}, target[MOCCA_MAX_FEET] = {0}, body_touch = 0, cover = 0;
   if (!ext_touch) {
     for (int k = 0; k < m->n_substeps; ++k) { substep(o, s, tk, tr, tau, w); dbg_commit(o, env, w); }
     /* contact queries after stepSimulation see the manifolds of the LAST substep's collision pass */
     for (int k = 0; k < m->n_feet; ++k) { touch[k] = w->foot_touch[k]; target[k] = w->foot_target[k]; }
     body_touch = w->body_touch;
+    cover = w->cover;
   } else {
-    /* task-only step (golden tests): the caller injected the post-physics state and the contacts */
-    for (int k = 0; k < m->n_feet; ++k) { touch[k] = ext_touch[k]; target[k] = ext_target[k]; }
+    /* task-only step (golden tests): the caller injected the post-physics state and the contacts; per foot: 1 = on the cover of the target
+     * plank (plank next_step_index mod n_planks at the step's start), 2 = on the cover of the plank after it */
+    int npl = o->task_id == MOCCA_TASK_WALKER3D_STEPPER ? m->n_planks : 1;
+    for (int k = 0; k < m->n_feet; ++k) {
+      touch[k] = ext_touch[k]; target[k] = ext_target[k] == 1;
+      if (ext_target[k] == 1 || ext_target[k] == 2) cover |= 1 << (4 * k + (tk->next_step_index + ext_target[k] - 1) % npl);
+    }
     body_touch = ext_body ? *ext_body : 0;
   }
   tk->t += 1;
@@ -1603,6 +1632,7 @@ static void step_env(Oracle *o, int env, const float *act, float *obs, float *re
       tk->feet_contact[k] = touch[k];
       if (target[k]) target_reached = 1;
     }
+    tk->cover = cover; /* what a reset() right after this step would still read */
     if (target_reached) {
       tk->target_reached_count += 1;
       if (tk->target_reached_count > 120) { tk->stop_on_next_step = 0; tk->set_stop_on_next_step = 0; }
@@ -1831,7 +1861,7 @@ API void orc_get_task(void *h, double *t) {
     for (int j = 0; j < 14; ++j) p[24 + j] = k->jvel[j];
     if (o->m.n_feet > 2) { p[24] = k->feet_contact[2]; p[25] = k->feet_contact[3]; } /* quadrupeds: words shared with Cassie's jvel */
     p[38] = k->initial_z; p[39] = k->istep;
-    if (o->task_id == MOCCA_TASK_WALKER3D_STEPPER) for (int j = 0; j < 8; ++j) p[30 + j] = k->rw[j];
+    if (o->task_id == MOCCA_TASK_WALKER3D_STEPPER) { for (int j = 0; j < 8; ++j) p[30 + j] = k->rw[j]; p[26] = k->cover; }
   }
 }
 API void orc_set_task(void *h, const double *t) {
@@ -1849,6 +1879,7 @@ API void orc_set_task(void *h, const double *t) {
     for (int j = 0; j < 14; ++j) k->jvel[j] = (real)p[24 + j];
     if (o->m.n_feet > 2) { k->feet_contact[2] = (real)p[24]; k->feet_contact[3] = (real)p[25]; }
     k->initial_z = (real)p[38]; k->istep = (int)p[39];
+    if (o->task_id == MOCCA_TASK_WALKER3D_STEPPER) k->cover = (int)p[26];
     if (o->task_id == MOCCA_TASK_WALKER3D_STEPPER) for (int j = 0; j < 8; ++j) k->rw[j] = (real)p[30 + j];
   }
 }

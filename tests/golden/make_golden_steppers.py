@@ -277,6 +277,77 @@ def main():
     for k, v in rec.items():
         out[f"rr_ep0_{k}"] = np.asarray(v)
 
+    # ---------------- reset() on the contact manifolds of the episode before (env_locomotion.py:484-499)
+    # Walker3DStepperEnv.reset calls calc_feet_state() right after robot.reset() -- before the terrain is redrawn and next_step_index is
+    # rewound, and with no stepSimulation in between, so getContactPoints still answers with the last frame of the OLD episode.  The fake
+    # client does what Bullet does there: it keeps returning the contacts of its last step.  Four endings: a foot on the target cover
+    # (count 0 -> 1 in the last step); the same with the count at 1 (the last step advances next_step_index: the cover touched is no
+    # longer the target's); one foot on the target cover and the other on the cover of the plank AFTER it while the index advances
+    # (that plank is the target by the time reset() looks); no contact at all.
+    env, p = make_env("Walker3DStepperEnv", FakeWalker)
+    rob = env.robot
+    plank_ids = [s.id for s in env.steps]
+    joint_ids = rob.ordered_joint_ids
+    foot_links = [rob.parts[f].bodyPartIndex for f in rob.foot_names]
+
+    def push_k(st, kinds):   # per foot: 0 no contact, 1 cover of the target plank, 2 cover of the plank after it, 3 base link of the plank after it
+        full = np.zeros((1, orc.state_dim))
+        full[0, :55] = st
+        orc.set_state(full)
+        fr = orc.link_frames(0, mdl.n_bodies)
+        p.base_pos, p.base_quat, p.base_vel = st[0:3].copy(), st[3:7].copy(), st[7:10].copy()
+        for k, jid in enumerate(joint_ids):
+            p.q[jid], p.qd[jid] = st[13 + k], st[13 + nj + k]
+        for k, fl in enumerate(foot_links):
+            p.link_pos[fl] = fr[mdl.foot_body[k], 12:15].copy()
+        n0 = env.next_step_index
+        p.contacts = {fl: {0: [], 1: [(plank_ids[n0 % 3], 0)], 2: [(plank_ids[(n0 + 1) % 3], 0)], 3: [(plank_ids[(n0 + 1) % 3], -1)]}[int(kinds[k])]
+                      for k, fl in enumerate(foot_links)}
+
+    endings = {"count0": [(1, 3)], "count1": [(1, 0), (1, 3)], "advance": [(1, 0), (1, 2)], "none": [(3, 3), (0, 0)]}
+    for si, (name, tail) in enumerate(endings.items()):
+        env.seed(950 + si)
+        env.robot.np_random = env.np_random
+        env.curriculum = 5
+        p.contacts = {}
+        pos0 = env.np_random.pos
+        env.reset()
+        tape_a = env.np_random.tape[pos0:env.np_random.pos].copy()
+        rng = np.random.default_rng(960 + si)
+        kinds_seq = [(3, 0), (0, 3)] + list(tail)            # two plain frames, then the ending
+        states, kinds_l, actions, obs_l, rew_l, nsi_l, trc_l = ([] for _ in range(7))
+
+        def frame(kinds):
+            tgt = env.terrain_info[env.next_step_index]
+            st = np.zeros(55)
+            st[0:3] = [tgt[0] + rng.normal(0, 0.1), tgt[1] + rng.normal(0, 0.1), tgt[2] + rng.uniform(1.0, 1.3)]
+            st[3:7] = G.quat_from_euler(rng.normal(0, 0.2), rng.normal(0.1, 0.2), rng.normal(0, 0.3))
+            st[7:10] = rng.normal(0, 1.0, 3); st[10:13] = rng.normal(0, 1.0, 3)
+            st[13:13 + nj] = lo + (hi - lo) * rng.uniform(0.1, 0.9, nj)
+            st[13 + nj:55] = rng.normal(0, 3.0, nj)
+            a = rng.uniform(-1.5, 1.5, nj)
+            p.on_step = (lambda st=st, kinds=kinds: push_k(st, kinds))
+            o, r, dn, info = env.step(a)
+            states.append(st); kinds_l.append(kinds); actions.append(a); obs_l.append(o); rew_l.append(r)
+            nsi_l.append(env.next_step_index); trc_l.append(env.target_reached_count)
+
+        for kinds in kinds_seq:
+            frame(kinds)
+        n_before = len(states)
+        p.on_step = None
+        pos1 = env.np_random.pos
+        obs_r = env.reset()                                   # NO p.contacts = {} here: the client still holds the last frame's contacts
+        tape_b = env.np_random.tape[pos1:env.np_random.pos].copy()
+        rec = dict(tape_a=tape_a, tape_b=tape_b, curriculum=5, n_before=n_before, reset_obs=obs_r, reset_trc=env.target_reached_count,
+                   reset_nsi=env.next_step_index, reset_feet_contact=np.array(rob.feet_contact, dtype=np.float64), terrain_b=env.terrain_info.copy())
+        for kinds in [(1, 0), (1, 3), (0, 0)]:                # the new episode: a foot on the target cover in its very first frames
+            frame(kinds)
+        rec.update(states=np.array(states), kinds=np.array(kinds_l), actions=np.array(actions), obs=np.array(obs_l), rew=np.array(rew_l),
+                   next_step_index=np.array(nsi_l), trc=np.array(trc_l))
+        for k, v in rec.items():
+            out[f"stale_{name}_{k}"] = np.asarray(v)
+    out["stale_names"] = np.array(list(endings))
+
     # ---------------- the other step objects
     for pc in ("Plank", "Pillar", "LargePlank", "NoSuchPlank"):
         env, p = make_env("Walker3DStepperEnv", FakeWalker, plank_class=pc)

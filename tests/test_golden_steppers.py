@@ -146,3 +146,62 @@ def test_step_objects(sg, pc):
     np.testing.assert_allclose(list(m.plank_half), half, atol=1e-6)
     assert abs(shapes[1, 3] / height - 0.1) < 1e-12           # the cover is the top tenth: the kernel's target test (lz >= 0.8 h)
     assert str(sg["plank_NoSuchPlank_file"]) == "plank_large.urdf"     # unknown names fall back to the default
+
+
+def _stale_replay(g, name, step_fn, reset_fn, tol):
+    """Replays one `stale_*` record: the frames before the reset, the reset (on the contacts of the last frame), the frames after it."""
+    k = lambda key: g[f"stale_{name}_{key}"]
+    states, kinds, actions, nb = k("states"), k("kinds"), k("actions"), int(k("n_before"))
+    for t in range(len(states)):
+        if t == nb:
+            obs_r, trc, nsi, fc, terrain = reset_fn(k("tape_b"))
+            np.testing.assert_allclose(obs_r[1:], k("reset_obs")[1:], atol=5 * tol)  # robot.reset()'s own observation: feet_contact 0 (robots.py:197-200); [0], the height, needs the link poses the fake client does not compute
+            assert (trc, nsi) == (int(k("reset_trc")), int(k("reset_nsi"))), (name, trc, nsi)
+            np.testing.assert_array_equal(fc, k("reset_feet_contact"))               # robot.feet_contact[:] = the OLD episode's last contacts (:656)
+            np.testing.assert_allclose(terrain, k("terrain_b"), atol=10 * tol)
+        touch = (kinds[t] != 0).astype(np.int32)
+        target = np.where(kinds[t] == 1, 1, np.where(kinds[t] == 2, 2, 0)).astype(np.int32)
+        o, r, info, trc = step_fn(states[t], actions[t], touch, target)
+        np.testing.assert_allclose(o, k("obs")[t], atol=5 * tol, err_msg=f"{name} t{t}")
+        np.testing.assert_allclose(r, k("rew")[t], atol=max(5e-6, 20 * tol), err_msg=f"{name} t{t} reward")
+        assert (info, trc) == (int(k("next_step_index")[t]), int(k("trc")[t])), (name, t, info, trc)
+
+
+@pytest.mark.parametrize("prec,tol", [("f64", 2e-6), ("f32", 3e-5)])
+def test_reset_reads_the_contacts_of_the_episode_before(sg, prec, tol):
+    """Walker3DStepperEnv.reset -> calc_feet_state() on Bullet's stale manifolds (env_locomotion.py:484-499, MOCCA_TASKF_STALE_RESET_CONTACTS):
+    the reference's own class over a client that keeps answering with its last frame's contacts, replayed through the oracle -- the new
+    episode starts with the old feet_contact flags (first step's observation) and target_reached_count = 1 where a foot was on the cover of
+    the plank that was the target by then; with the flag cleared the episode starts clean."""
+    m = M.compile_walker3d(M.TASK_WALKER3D_STEPPER)
+    assert m.task_flags & M.TASKF_STALE_RESET_CONTACTS
+    for name in [str(n) for n in sg["stale_names"]]:
+        orc = Oracle(m.to_bytes(), M.TASK_WALKER3D_STEPPER, 1, prec)
+        orc.set_param(PARAM_CURRICULUM, int(sg[f"stale_{name}_curriculum"]))
+        orc.set_tape(sg[f"stale_{name}_tape_a"])
+        orc.reset(seed=0)
+
+        def step_fn(st, a, touch, target):
+            full = np.zeros((1, orc.state_dim)); full[0, :55] = st
+            orc.set_state(full)
+            o, r, d, info = orc.task_step(a[None], touch[None], target[None])
+            return o[0], r[0], int(info[0]), int(orc.get_task()[0][17])
+
+        def reset_fn(tape):
+            orc.set_tape(tape)
+            obs = orc.reset(seed=0)
+            tk = orc.get_task()[0]
+            return obs[0], int(tk[17]), int(tk[16]), tk[12:14], orc.get_terrain()[0][:120].reshape(20, 6)
+
+        _stale_replay(sg, name, step_fn, reset_fn, tol)
+    # flag cleared: a clean start whatever the old episode ended on
+    m2 = M.compile_walker3d(M.TASK_WALKER3D_STEPPER)
+    m2.task_flags &= ~M.TASKF_STALE_RESET_CONTACTS
+    orc = Oracle(m2.to_bytes(), M.TASK_WALKER3D_STEPPER, 1, prec)
+    orc.set_tape(sg["stale_count0_tape_a"]); orc.reset(seed=0)
+    full = np.zeros((1, orc.state_dim)); full[0, :55] = sg["stale_count0_states"][0]
+    orc.set_state(full)
+    orc.task_step(sg["stale_count0_actions"][0][None], np.array([[1, 1]], np.int32), np.array([[1, 0]], np.int32))
+    orc.set_tape(sg["stale_count0_tape_b"]); orc.reset(seed=0)
+    tk = orc.get_task()[0]
+    assert int(tk[17]) == 0 and (tk[12:14] == 0).all()

@@ -279,3 +279,30 @@ def test_planner_env_with_an_injected_base_controller():
     with pytest.raises(RuntimeError):
         env.step(np.zeros(15))
     env.close()
+
+
+def test_stepper_class_reset_reads_the_contacts_of_the_episode_before():
+    """Walker3DStepperEnv.reset (env_locomotion.py:484-499): calc_feet_state() runs on the manifolds of the last frame of the episode before --
+    the gym class carries the device record's contact flags across its host-side reset: they show in the FIRST step's observation, the
+    reset's own observation has feet_contact = 0 (robots.py:197-200)."""
+    import mocca_envs_amd
+    from mocca_envs_amd.vec_env import task_to_float64
+    env = mocca_envs_amd.make("Walker3DStepperEnv-v0")
+    base = env.unwrapped
+    env.seed(3)
+    env.reset()
+    a = np.zeros(21)
+    for _ in range(12):                                   # standing still on the first plank: both feet touch
+        obs, _, done, _ = env.step(a)
+    assert not done and (obs[48:50] == 1).any()
+    old = task_to_float64(base._img["task"])[0]
+    fc_old = old[12:14].copy()
+    obs_r = env.reset()
+    assert (obs_r[48:50] == 0).all()
+    tk = task_to_float64(base._vec.get_task())[0]
+    np.testing.assert_array_equal(tk[12:14], fc_old)
+    cover, nsi = int(old[26]), int(old[16])
+    assert int(tk[17]) == int(any((cover >> (4 * f + nsi % 3)) & 1 for f in range(2)))
+    obs1, _, _, _ = env.step(a)
+    np.testing.assert_array_equal(obs1[48:50], fc_old)    # Stepper.step: calc_state() BEFORE calc_feet_state() (:525)
+    env.close()

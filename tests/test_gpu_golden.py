@@ -380,6 +380,35 @@ def test_random_reward_episode_on_the_gpu(sg):
     env.close()
 
 
+def test_reset_reads_the_contacts_of_the_episode_before_on_the_gpu(sg):
+    """Walker3DStepperEnv.reset -> calc_feet_state() on Bullet's stale manifolds (env_locomotion.py:484-499, MOCCA_TASKF_STALE_RESET_CONTACTS):
+    the reference's own class over a client that keeps answering with its last frame's contacts, replayed through the HIP task layer and the
+    reset kernel (tests/test_golden_steppers.py holds the oracle's replay of the same records)."""
+    import torch
+    from mocca_envs_amd import lib as L
+    from mocca_envs_amd.vec_env import task_to_float64
+    from test_golden_steppers import _stale_replay
+    tile = lambda x: np.tile(np.asarray(x, np.int32).reshape(1, -1), (REPL, 1))
+    for name in [str(n) for n in sg["stale_names"]]:
+        env = _env("Walker3DStepperEnv-v0", sg[f"stale_{name}_tape_a"], [(L.PARAM_CURRICULUM, int(sg[f"stale_{name}_curriculum"]))])
+        env.reset()
+
+        def step_fn(st, a, touch, target):
+            _set_state(env, st)
+            o, r, d, info = env.task_step(torch.from_numpy(np.tile(a[None].astype(np.float32), (REPL, 1))), tile(touch), tile(target))
+            _same_in_every_replica(o, r, d, info)
+            return o.cpu().numpy()[0], float(r[0]), int(info[0]), int(task_to_float64(env.get_task())[0][17])
+
+        def reset_fn(tape):
+            env.set_draw_tape(np.tile(np.asarray(tape, np.float32)[None], (REPL, 1)))
+            obs = env.reset().cpu().numpy()
+            tk = task_to_float64(env.get_task())[0]
+            return obs[0], int(tk[17]), int(tk[16]), tk[12:14], env.get_terrain().cpu().numpy()[0][:120].reshape(20, 6)
+
+        _stale_replay(sg, name, step_fn, reset_fn, TOL)
+        env.close()
+
+
 @pytest.mark.parametrize("tag,env_id", [("planner", "Walker3DPlannerEnv-v0"), ("mikeplanner", "MikePlannerEnv-v0")])
 def test_planner_env_episodes_on_the_gpu(tag, env_id):
     """Walker3DPlannerEnv / MikePlannerEnv (env_locomotion.py:982-1133) through the HIP task layer: reset (robot.reset draws, then the
