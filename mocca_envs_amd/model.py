@@ -937,6 +937,26 @@ CASSIE_2D_LIMITS = {"hip_abduction_left": (-0.01, 0.01), "hip_rotation_left": (-
                     "hip_abduction_right": (-0.01, 0.01), "hip_rotation_right": (-0.01, 0.01)}
 
 
+def cassie_joint_names():
+    """(joint names, link names) of the Cassie blob's bodies 1 .. 18, in blob order: the URDF's moving joints, depth-first as compile_cassie
+    walks them (a joint named "fixed_*_achilles_rod_joint_*" is a CONTINUOUS joint: the reference only keeps it out of its ordered joints,
+    env_cassie.py:189).  What pybullet_dump.from_pybullet_dump matches a PyBullet record against."""
+    from . import cassie_table as CT
+    kids: Dict[str, list] = {}
+    for j in CT.JOINTS:
+        kids.setdefault(j["parent"], []).append(j)
+    jn, ln = [], []
+
+    def walk(link):
+        for j in kids.get(link, []):
+            if j["type"] != "fixed":
+                jn.append(j["name"]); ln.append(j["child"])
+            walk(j["child"])
+
+    walk("pelvis")
+    return jn, ln
+
+
 def compile_cassie(planar: bool = False, power_coef: float = 1.0, residual_control: bool = True, mode: int = CASSIE_PLAIN,
                    rsi: bool = True) -> MoccaModel:
     """Cassie blob: URDF tree with inertia from file (env_cassie.py:81-99), two point-to-point loop closures

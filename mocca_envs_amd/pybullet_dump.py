@@ -26,7 +26,10 @@ import numpy as np
 
 from . import model as M
 
-JOINT_REVOLUTE, JOINT_FIXED = 0, 4
+JOINT_REVOLUTE, JOINT_FIXED, JOINT_POINT2POINT = 0, 4, 5
+# solver parameters from_pybullet_dump takes from the record (as "engine_<name>"); tools/dump_pybullet_trace.py writes the ones pybullet reports and,
+# for the ones the session itself set, the values it set
+ENGINE_KEYS = ("erp", "contactERP", "numSolverIterations", "contactBreakingThreshold", "enableConeFriction")
 
 
 def _qmat(q) -> np.ndarray:
@@ -128,6 +131,17 @@ def from_pybullet_dump(dump: Mapping[str, np.ndarray], template: M.MoccaModel, j
             out.g_margin[g] = template.g_margin[g] * f
     if "engine_enableConeFriction" in dump:
         out.friction_cone = int(dump["engine_enableConeFriction"])   # 0: pyramid (SOLVER_DISABLE_IMPLICIT_CONE_FRICTION)
+    missing = [k for k in ENGINE_KEYS if "engine_" + k not in dump]
+    if missing:
+        # pybullet.getPhysicsEngineParameters() is not guaranteed to report every solver parameter (older builds: fixedTimeStep, numSubSteps,
+        # numSolverIterations, useRealTimeSimulation, gravity only): what is absent keeps this project's [UNVERIFIED-BULLET] default, and the
+        # trace test then pins the default, not Bullet's value -- say so instead of implying the opposite
+        import warnings
+        warnings.warn("PyBullet dump: engine parameter(s) %s not recorded; the blob keeps the compiled defaults (erp_noncontact %.2f, contact erp %.2f, "
+                      "friction_cone %d, contact margins x %.3f)" % (", ".join(missing), out.erp_noncontact, out.erp, out.friction_cone, out.contact_margin))
+    if any(out.margin_code(g) >= 255 for g in range(out.n_geoms)):
+        import warnings
+        warnings.warn("PyBullet dump: a contact margin saturates the 8-bit code of the slot records (31 mm); the kernel uses the capped value")
     for key in ("rolling_friction", "spinning_friction", "restitution"):
         if key in dump and np.abs(np.asarray(dump[key], float)).max() > 0:
             raise ValueError(f"the dump reports non-zero {key} on a robot link: not modelled by this stepper (DESIGN.md section 9)")
@@ -197,6 +211,34 @@ def from_pybullet_dump(dump: Mapping[str, np.ndarray], template: M.MoccaModel, j
             p = (frame[fb].inv() @ tf[fb]).apply(list(template.foot_point[f]))
             for k in range(3):
                 out.foot_point[f][k] = p[k]
+    # loop closures (Cassie: createConstraint(JOINT_POINT2POINT) tarsus <-> achilles rod, env_cassie.py:114-137): the record's
+    # `constraints` rows [parent link, child link, joint type, parent pivot xyz, child pivot xyz] -- pivots in each link's INERTIAL frame,
+    # as createConstraint takes them -- become the blob's pivots in its body frames
+    if template.n_closures > 0:
+        if "constraints" not in dump:
+            raise ValueError("the template has loop closures but the dump records no constraints")
+        rows = np.asarray(dump["constraints"], float).reshape(-1, 9)
+        used = set()
+        for k in range(template.n_closures):
+            hit = None
+            for r, row in enumerate(rows):
+                la, lb = int(row[0]), int(row[1])
+                if r in used or int(row[2]) != JOINT_POINT2POINT:
+                    continue
+                if (owner(la), owner(lb)) == (template.cl_body_a[k], template.cl_body_b[k]):
+                    hit = (r, la, lb, row[3:6], row[6:9], False)
+                elif (owner(lb), owner(la)) == (template.cl_body_a[k], template.cl_body_b[k]):
+                    hit = (r, lb, la, row[6:9], row[3:6], True)
+                if hit:
+                    break
+            if hit is None:
+                raise ValueError(f"no point-to-point constraint between the links of closure {k} in the dump")
+            r, la, lb, pa, pb, _ = hit
+            used.add(r)
+            pa_b = (frame[template.cl_body_a[k]].inv() @ C[la]).apply(pa)
+            pb_b = (frame[template.cl_body_b[k]].inv() @ C[lb]).apply(pb)
+            for i in range(3):
+                out.cl_point_a[k][i], out.cl_point_b[k][i] = pa_b[i], pb_b[i]
     # init_pos / init_quat are kept: the reference resets with resetBasePositionAndOrientation (bullet_utils.py:97-102), which
     # places Bullet's base frame -- now this blob's base frame -- at those values
     return out.finalize_tables()
@@ -260,7 +302,8 @@ def warm_start_from_contacts(m: M.MoccaModel, bodies_of_links: np.ndarray, state
 
 
 def synthetic_dump(m: M.MoccaModel, joint_names: Sequence[str], fixed_children: Dict[int, float] = None,
-                   base_axes_aligned: bool = False, link_names: Optional[Sequence[str]] = None) -> Dict[str, np.ndarray]:
+                   base_axes_aligned: bool = False, link_names: Optional[Sequence[str]] = None, all_axes_aligned: bool = False,
+                   fixed_prefix: str = "jointfix_") -> Dict[str, np.ndarray]:
     """The record tools/dump_pybullet_trace.py WOULD write for a Bullet multibody equal to blob `m` (tests: loader round trip).
     Inertial frames are the principal-axes frames at the COM, as Bullet reports them.  `fixed_children`: {body: fraction}
     splits that fraction of the body's mass off into an extra FIXED link (exercises the merge of fixed links).
@@ -272,8 +315,8 @@ def synthetic_dump(m: M.MoccaModel, joint_names: Sequence[str], fixed_children: 
 
     def principal(b, mass_scale=1.0):
         xx, yy, zz, xy, xz, yz = m.inertia[b]
-        if b == 0 and base_axes_aligned:
-            return np.array([xx, yy, zz]) * mass_scale, np.eye(3)
+        if (b == 0 and base_axes_aligned) or all_axes_aligned:   # (all_axes_aligned: every inertial frame keeps its link's axes -- a createConstraint
+            return np.array([xx, yy, zz]) * mass_scale, np.eye(3)   # pivot given in "the COM frame" then means the same point as in the URDF's link axes)
         Im = np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]]) * mass_scale
         w, V = np.linalg.eigh(Im)
         if np.linalg.det(V) < 0:
@@ -303,7 +346,7 @@ def synthetic_dump(m: M.MoccaModel, joint_names: Sequence[str], fixed_children: 
                          link=link_names[b - 1] if link_names is not None else joint_names[b - 1] + "_link"))
         link_index[b] = len(rows) - 1
         if b in fixed_children:
-            rows.append(dict(name=f"jointfix_{b}", type=JOINT_FIXED, parent=link_index[b], L=fr[b], body=b, frac=fixed_children[b], link=f"fixed_part_{b}"))
+            rows.append(dict(name=f"{fixed_prefix}{b}", type=JOINT_FIXED, parent=link_index[b], L=fr[b], body=b, frac=fixed_children[b], link=f"fixed_part_{b}"))
     n = len(rows)
     out = dict(joint_names=np.array([r["name"] for r in rows]), link_names=np.array([r["link"] for r in rows]),
                joint_type=np.array([r["type"] for r in rows]), parent_index=np.array([r["parent"] for r in rows]),
@@ -328,4 +371,15 @@ def synthetic_dump(m: M.MoccaModel, joint_names: Sequence[str], fixed_children: 
             out["joint_limits"][j] = [m.jlo[b], m.jhi[b]]
             out["joint_damping"][j] = m.jdamp[b]
     out["_base_inertial_in_template_base"] = np.concatenate([C0.t, C0.R.reshape(-1)])
+    # the session's solver parameters, as the tool writes them (engine_*): here the blob's own
+    out.update(engine_erp=np.array(float(m.erp_noncontact)), engine_contactERP=np.array(float(m.erp)), engine_numSolverIterations=np.array(float(m.n_iters)),
+               engine_contactBreakingThreshold=np.array(float(m.contact_margin)), engine_enableConeFriction=np.array(float(m.friction_cone)))
+    if m.n_closures > 0:   # createConstraint rows: parent link, child link, type, pivots in the links' inertial frames
+        cons = []
+        for k in range(m.n_closures):
+            ja, jb = link_index[m.cl_body_a[k]], link_index[m.cl_body_b[k]]
+            Ia = _T(principal(m.cl_body_a[k])[1], list(m.com[m.cl_body_a[k]])) if ja >= 0 else C0
+            Ib = _T(principal(m.cl_body_b[k])[1], list(m.com[m.cl_body_b[k]])) if jb >= 0 else C0
+            cons.append([ja, jb, JOINT_POINT2POINT, *Ia.inv().apply(list(m.cl_point_a[k])), *Ib.inv().apply(list(m.cl_point_b[k]))])
+        out["constraints"] = np.array(cons, float)
     return out

@@ -186,3 +186,204 @@ def make_module(fixed_children=None):
     p.getJointStates, p.resetBasePositionAndOrientation, p.resetBaseVelocity, p.resetJointState = getJointStates, resetBasePositionAndOrientation, resetBaseVelocity, resetJointState
     p.setJointMotorControlArray, p.stepSimulation, p.getContactPoints, p.getLinkState = setJointMotorControlArray, stepSimulation, getContactPoints, getLinkState
     return p
+
+
+def make_cassie_module():
+    """The same for the Cassie section of the tool (main_cassie): loadURDF(cassie_collide.urdf) with the reference's flags, per-joint
+    changeDynamics(jointDamping), the two createConstraint(JOINT_POINT2POINT) calls -- whose pivots the fake TAKES: its multibody is the
+    blob the loader builds from the record with exactly those constraint rows --, setCollisionFilterGroupMask, getConstraintInfo / State."""
+    tm = M.compile_cassie()
+    jn, ln = M.cassie_joint_names()
+    rec = PD.synthetic_dump(tm, jn, fixed_children={3: 0.2}, base_axes_aligned=True, all_axes_aligned=True, link_names=ln, fixed_prefix="fixed_extra_")
+    names = [str(n) for n in rec["joint_names"]]
+    n_links = len(names)
+    nj = tm.n_joints
+    bodies = PD.link_bodies(rec, tm, jn)
+    link_of_body = {0: -1}
+    for j in range(n_links):
+        link_of_body.setdefault(int(bodies[1 + j]), j)
+    hinge_links = {j: int(bodies[1 + j]) for j in range(n_links) if int(rec["joint_type"][j]) == PD.JOINT_REVOLUTE}
+    st = {"forces": np.zeros(nj), "cons": [], "damping": {}, "filter_off": [], "o": None, "blob": None, "pending_state": None}
+    ROBOT, PLANE = 1, 0
+    p = types.ModuleType("pybullet")
+    p.DIRECT = 2
+    p.POSITION_CONTROL, p.TORQUE_CONTROL = 2, 1
+    p.URDF_USE_SELF_COLLISION, p.URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS, p.URDF_USE_INERTIA_FROM_FILE = 8, 16, 2
+    p.JOINT_REVOLUTE, p.JOINT_FIXED, p.JOINT_POINT2POINT = 0, 4, 5
+    p.fake_record = rec
+
+    def world():
+        """The oracle behind the API: built once both constraints exist, from the record AS THE TOOL WIRED IT (its damping, its pivots)."""
+        if st["o"] is None:
+            r = dict(rec)
+            assert len(st["cons"]) == 2, "the tool must create both point-to-point constraints before it simulates"
+            r["constraints"] = np.array([[la, lb, p.JOINT_POINT2POINT, *pa, *pb] for la, lb, pa, pb in st["cons"]], float)
+            dmp = np.array(rec["joint_damping"], float)
+            for j, v in st["damping"].items():
+                dmp[j] = v
+            r["joint_damping"] = dmp
+            st["blob"] = PD.from_pybullet_dump(r, tm, jn)
+            st["o"] = Oracle(st["blob"].to_bytes(), M.TASK_CASSIE, 1, "f64")
+            st["o"].reset(seed=0)
+            if st["pending_state"] is not None:
+                st["o"].set_state(st["pending_state"][None].copy())
+            p.fake_blob = st["blob"]
+        return st["o"]
+
+    def state():
+        if st["o"] is None and len(st["cons"]) < 2:       # before the constraints exist the tool only places the robot: keep a plain row
+            if st["pending_state"] is None:
+                st["pending_state"] = np.zeros(13 + 2 * nj + tm.n_slots)
+                st["pending_state"][6] = 1.0
+            return st["pending_state"]
+        return world().get_state()[0]
+
+    def put(row):
+        if st["o"] is None and len(st["cons"]) < 2:
+            st["pending_state"] = row.copy()
+        else:
+            world().set_state(row[None].copy())
+
+    p.connect = lambda *a, **k: 0
+    p.setGravity = lambda *a: None
+    p.setDefaultContactERP = lambda v: None
+    p.setPhysicsEngineParameter = lambda **k: None
+    p.getPhysicsEngineParameters = lambda: {"fixedTimeStep": float(tm.dt), "numSubSteps": 1, "numSolverIterations": int(tm.n_iters), "useRealTimeSimulation": 0}   # an older build: few keys
+    p.loadSDF = lambda f: (PLANE,)
+    p.getNumJoints = lambda body: n_links
+    p.setJointMotorControl2 = lambda *a, **k: None
+    p.getCollisionShapeData = lambda body, link: []
+    p.setCollisionFilterGroupMask = lambda body, link, g, msk: st["filter_off"].append(link)
+
+    def loadURDF(f, basePosition=None, baseOrientation=None, useFixedBase=False, flags=0, globalScaling=1.0):
+        assert f.endswith("cassie_collide.urdf") and not useFixedBase
+        assert flags == p.URDF_USE_SELF_COLLISION | p.URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS | p.URDF_USE_INERTIA_FROM_FILE
+        s = state().copy(); s[0:3], s[3:7] = basePosition, baseOrientation; put(s)
+        return ROBOT
+
+    def changeDynamics(body, link, **k):
+        if body == ROBOT and "jointDamping" in k:
+            st["damping"][link] = float(k["jointDamping"])
+
+    def getJointInfo(body, j):
+        info = [None] * 17
+        info[0], info[1], info[2] = j, names[j].encode(), int(rec["joint_type"][j])
+        info[6] = st["damping"].get(j, float(rec["joint_damping"][j]))
+        info[8], info[9] = float(rec["joint_limits"][j][0]), float(rec["joint_limits"][j][1])
+        info[12], info[13] = str(rec["link_names"][j]).encode(), tuple(rec["joint_axis"][j])
+        info[14], info[15], info[16] = tuple(rec["parent_frame_pos"][j]), tuple(rec["parent_frame_orn"][j]), int(rec["parent_index"][j])
+        return tuple(info)
+
+    def getDynamicsInfo(body, link):
+        k = link + 1
+        return (float(rec["mass"][k]), 1.0, tuple(rec["local_inertia_diag"][k]), tuple(rec["inertial_pos"][k]), tuple(rec["inertial_orn"][k]), 0.0, 0.0, 0.0, -1, -1)
+
+    def createConstraint(pb_, pl, cb, cl, jointType=None, jointAxis=None, parentFramePosition=None, childFramePosition=None, **k):
+        assert pb_ == ROBOT and cb == ROBOT and jointType == p.JOINT_POINT2POINT and st["o"] is None
+        st["cons"].append((pl, cl, list(parentFramePosition), list(childFramePosition)))
+        return len(st["cons"])
+
+    def getConstraintInfo(cid):
+        la, lb, pa, pb = st["cons"][cid - 1]
+        return (ROBOT, la, ROBOT, lb, p.JOINT_POINT2POINT, (0, 0, 0), tuple(pa), tuple(pb), (0, 0, 0, 1), (0, 0, 0, 1), 500.0)
+
+    def getConstraintState(cid):
+        lam, kind = world().last_lambda()
+        cl = lam[kind == 3]
+        k = cid - 1
+        return tuple(cl[3 * k:3 * k + 3] / st["blob"].dt) if len(cl) >= 3 * k + 3 else (0.0, 0.0, 0.0)
+
+    p.loadURDF, p.changeDynamics, p.getJointInfo, p.getDynamicsInfo = loadURDF, changeDynamics, getJointInfo, getDynamicsInfo
+    p.createConstraint, p.getConstraintInfo, p.getConstraintState = createConstraint, getConstraintInfo, getConstraintState
+    p.getBasePositionAndOrientation = lambda body: (tuple(state()[0:3]), tuple(state()[3:7]))
+    p.getBaseVelocity = lambda body: (tuple(state()[7:10]), tuple(state()[10:13]))
+
+    def getJointStates(body, ids):
+        s = state()
+        return [(s[13 + hinge_links[j] - 1], s[13 + nj + hinge_links[j] - 1], (0,) * 6, 0.0) for j in ids]
+
+    def resetBasePositionAndOrientation(body, pos=None, orn=None, posObj=None, ornObj=None):
+        s = state().copy()
+        s[0:3], s[3:7] = (posObj if pos is None else pos), (ornObj if orn is None else orn)
+        s[13 + 2 * nj:] = 0
+        put(s)
+
+    def resetBaseVelocity(body, lin, ang):
+        s = state().copy(); s[7:10], s[10:13] = lin, ang; put(s)
+
+    def resetJointState(body, j, q, qd=0.0):
+        s = state().copy(); b = hinge_links[j]; s[13 + b - 1], s[13 + nj + b - 1] = q, qd; put(s)
+
+    def setJointMotorControlArray(body, ids, mode, forces=None, **k):
+        if mode == p.TORQUE_CONTROL:
+            st["forces"] = np.zeros(nj)
+            for j, f in zip(ids, forces):
+                st["forces"][hinge_links[j] - 1] = f
+
+    def stepSimulation():
+        world().physics_substeps(0, st["forces"], 1)
+        st["forces"] = np.zeros(nj)
+
+    def getContactPoints(bodyA=None, linkIndexA=None):
+        o = world()
+        lam, kind = o.last_lambda()
+        normals = lam[kind == 1]
+        base = state()[0:3]
+        out = []
+        for k, c in enumerate(o.last_contacts()):
+            la = link_of_body[int(c[0])]
+            if linkIndexA is not None and la != linkIndexA:
+                continue
+            force = normals[k] / st["blob"].dt if k < len(normals) else 0.0
+            out.append((0, ROBOT, PLANE, la, -1, tuple(c[3:6] + base), tuple(c[3:6] + base), tuple(c[6:9]), -float(c[9]), float(force)))
+        return out
+
+    def getLinkState(body, link, **k):
+        fr = world().link_frames(0, tm.n_bodies)
+        return (tuple(fr[int(bodies[1 + link]), 12:15]), (0, 0, 0, 1), None, None, None, None)
+
+    p.getJointStates, p.resetBasePositionAndOrientation, p.resetBaseVelocity, p.resetJointState = getJointStates, resetBasePositionAndOrientation, resetBaseVelocity, resetJointState
+    p.setJointMotorControlArray, p.stepSimulation, p.getContactPoints, p.getLinkState = setJointMotorControlArray, stepSimulation, getContactPoints, getLinkState
+    return p
+
+
+def make_heightfield_module():
+    """... and for the tool's height-field frame (main_heightfield): GEOM_HEIGHTFIELD + probe spheres + getClosestPoints, answered by the
+    dense reference's exhaustive triangle search (tests/dense_reference.py heightfield_gap with a wide window)."""
+    import dense_reference as D
+    st = {"field": None, "scale": None, "z0": 0.0, "balls": {}, "pose": {}, "next": 1}
+    p = types.ModuleType("pybullet")
+    p.DIRECT, p.GEOM_HEIGHTFIELD, p.GEOM_SPHERE = 2, 9, 2
+    p.connect = lambda *a, **k: 0
+    p.changeDynamics = lambda *a, **k: None
+
+    def createCollisionShape(shapeType=None, radius=None, meshScale=None, heightfieldData=None, numHeightfieldRows=None, numHeightfieldColumns=None, **k):
+        if shapeType == p.GEOM_HEIGHTFIELD:
+            st["field"] = np.asarray(heightfieldData, np.float64).reshape(numHeightfieldRows, numHeightfieldColumns)
+            st["scale"] = 1.0 / meshScale[0]
+            return "hf"
+        return ("ball", float(radius))
+
+    def createMultiBody(mass, shape, visual=-1, basePosition=(0, 0, 0)):
+        bid = st["next"]; st["next"] += 1
+        if shape == "hf":
+            # Bullet centres the shape's local AABB on the body: with the body at (max + min) / 2 the surface sits at its data values
+            assert abs(basePosition[2] - (st["field"].max() + st["field"].min()) / 2) < 1e-6
+            st["terrain"] = bid
+        else:
+            st["balls"][bid] = shape[1]
+        return bid
+
+    def resetBasePositionAndOrientation(body, pos, orn):
+        st["pose"][body] = np.array(pos, float)
+
+    def getClosestPoints(a, b, distance):
+        rad, C = st["balls"][a], st["pose"][a]
+        gap, n = D.heightfield_gap(st["field"], st["scale"], C, rad, window=4)
+        if gap > distance:
+            return []
+        return [(0, a, b, -1, -1, tuple(C - rad * n), tuple(C - (rad + gap) * n), tuple(n), float(gap), 0.0)]
+
+    p.createCollisionShape, p.createMultiBody, p.resetBasePositionAndOrientation, p.getClosestPoints = createCollisionShape, createMultiBody, resetBasePositionAndOrientation, getClosestPoints
+    p.removeBody = lambda b: None
+    return p

@@ -97,3 +97,60 @@ def synthetic_record(template: M.MoccaModel = None, fixed_children=None, n_trace
             states.append(o.get_state()[0, :13 + 2 * NJ].copy()); actions.append(a.astype(np.float64))
         rec[f"{tag}_states"], rec[f"{tag}_actions"] = np.array(states), np.array(actions)
     return rec, m
+
+
+# ---------------------------------------------------------------------------------------------------------------- Cassie (BASELINE config 4)
+def cassie_rows(g, m, key):
+    """State rows of a Cassie record (columns 13..: q then qd of `state_joint_names`) in the BLOB's body order, padded to the blob's state width."""
+    jn, _ = M.cassie_joint_names()
+    cols = [list(map(str, g["state_joint_names"])).index(n) for n in jn]
+    src = np.asarray(g[key], float)
+    ns = len(g["state_joint_names"])
+    out = np.zeros((len(src), M.MoccaModel.state_dim(m) if False else 13 + 2 * m.n_joints + m.n_slots))
+    out[:, :13] = src[:, :13]
+    out[:, 13:13 + m.n_joints] = src[:, 13:13 + ns][:, cols]
+    out[:, 13 + m.n_joints:13 + 2 * m.n_joints] = src[:, 13 + ns:13 + 2 * ns][:, cols]
+    return out
+
+
+def cassie_jvel(g, key):
+    """[N][14] filtered / finite-difference joint speeds in the blob's ordered-joint order (env_cassie.py ordered_joints)."""
+    cols = [list(map(str, g["ordered_joint_names"])).index(n) for n in M.CASSIE_ORDERED_JOINTS]
+    return np.asarray(g[key], float)[:, cols]
+
+
+def synthetic_record_cassie(n_trace: int = 12, n_free: int = 10, seed: int = 0, action_scale: float = 0.1):
+    """(record in the format of tools/dump_pybullet_trace.py's Cassie section, the blob loaded from it): multibody from the compiled Cassie
+    blob in PyBullet's conventions (one fixed link split off, the two createConstraint rows), traces = CassieEnv.step of the f64 oracle ON
+    THE LOADED BLOB -- teacher-forced env steps (state, jvel, action) -> (state, jvel) and one free-running rollout."""
+    tm = M.compile_cassie()
+    jn, ln = M.cassie_joint_names()
+    g = PD.synthetic_dump(tm, jn, fixed_children={3: 0.2}, base_axes_aligned=True, link_names=ln, fixed_prefix="fixed_extra_")
+    m = upright_reset(PD.from_pybullet_dump(g, tm, jn), g, tm)
+    g = dict(g, format_version=np.array(3), robot=np.array("cassie"),
+             state_joint_names=np.array([n for n, t in zip(g["joint_names"], g["joint_type"]) if int(t) != PD.JOINT_FIXED]),
+             ordered_joint_names=np.array(M.CASSIE_ORDERED_JOINTS), cas_action_scale=np.array(action_scale))
+    nj = m.n_joints
+
+    def run(n, restart):
+        o = Oracle(m.to_bytes(), M.TASK_CASSIE, 1, "f64")
+        o.reset(seed=seed)
+        rng = np.random.default_rng(seed + (0 if restart else 1))
+        rows = {k: [] for k in ("before", "jvel_before", "action", "after", "jvel_after")}
+        for t in range(n):
+            a = (action_scale * rng.uniform(-1, 1, 10)).astype(np.float32)
+            rows["before"].append(o.get_state()[0, :13 + 2 * nj].copy()); rows["jvel_before"].append(o.get_task()[0, 24:38].copy()); rows["action"].append(a.astype(np.float64))
+            _, _, d, _ = o.step(a[None])
+            rows["after"].append(o.get_state()[0, :13 + 2 * nj].copy()); rows["jvel_after"].append(o.get_task()[0, 24:38].copy())
+            if restart and d[0]:
+                o.reset(seed=seed)
+        return {k: np.array(v) for k, v in rows.items()}
+
+    tr = run(n_trace, True)
+    for k, v in tr.items():
+        g["cas_" + k] = v
+    fr = run(n_free, False)
+    g["casfree_states"] = np.concatenate([fr["before"][:1], fr["after"]])
+    g["casfree_jvel"] = np.concatenate([fr["jvel_before"][:1], fr["jvel_after"]])
+    g["casfree_actions"] = fr["action"]
+    return g, m

@@ -89,7 +89,8 @@ def main(data_dir, n_steps):
         out["spinning_friction"] = np.array([d[7] for d in dyn])
     # the solver parameters this session ran with (the reference sets fixedTimeStep / numSolverIterations / numSubSteps and the contact
     # ERP only, bullet_utils.py:338-350; `erp` -- joint limits, point-to-point constraints -- stays at Bullet's default)
-    if hasattr(p, "getPhysicsEngineParameters"):
+    out["engine_contactERP"], out["engine_numSolverIterations"] = np.array(0.9), np.array(5.0)     # what this session set itself (above)
+    if hasattr(p, "getPhysicsEngineParameters"):   # ... then whatever this build reports (older ones: a handful of keys; the loader warns about the rest)
         for k, v in p.getPhysicsEngineParameters().items():
             if isinstance(v, (int, float)):
                 out["engine_" + k] = np.array(float(v))
@@ -208,5 +209,231 @@ def main(data_dir, n_steps):
     print("wrote pybullet_walker3d.npz")
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Cassie (BASELINE config 4): python tools/dump_pybullet_trace.py /path/to/mocca_envs/data 300 cassie   ->  pybullet_cassie.npz
+# The robot is loaded and wired exactly as env_cassie.py does it (Cassie.load_robot_model :81-149, parse_joints_and_links :155-201) and
+# driven by CassieEnv.step's own low-level loop (:433-479): 50 x {filtered joint speeds, PD torques with the clip of :225-230, one
+# stepSimulation of 0.6 ms}.  Constants restated from the class attributes (the tool must run without importing the package).
+CASSIE_BASE_ANGLES = [0.035615837, -0.01348790, 0.391940848, -0.95086160, -0.08376049, 1.305643634, -1.61174064] * 2      # env_cassie.py:21-38
+CASSIE_ROD_ANGLES = [-0.8967891835, 0.063947468, -0.8967891835, -0.063947468]                                             # :40
+CASSIE_DAMPING = [1, 1, 1, 1, 0.1, 0, 1, 1, 1, 1, 1, 0.1, 0, 1]                                                           # :57
+CASSIE_POWER = {"hip_abduction": 112.5, "hip_rotation": 112.5, "hip_flexion": 195.2, "knee_joint": 195.2, "knee_to_shin": 200.0,
+                "ankle_joint": 200.0, "toe_joint": 45.0}                                                                  # :42-56
+CASSIE_POWERED, CASSIE_SPRINGS = [0, 1, 2, 3, 6, 7, 8, 9, 10, 13], [4, 11]                                                # :59-60
+CASSIE_KP = np.array([100, 100, 88, 96, 50, 100, 100, 88, 96, 50, 400, 400]) / 1.9                                        # :292-317
+CASSIE_PIVOTS = {"left": ([-0.22735404, 0.05761813, 0.00711836], [0.254001, 0, 0]),
+                 "right": ([-0.22735404, 0.05761813, -0.00711836], [0.254001, 0, 0])}                                     # :114-137
+
+
+def main_cassie(data_dir, n_steps, action_scale=0.1):
+    import pybullet as p
+    p.connect(p.DIRECT)
+    p.setGravity(0, 0, -9.8)
+    p.setDefaultContactERP(0.9)                                                          # bullet_utils.py:345
+    llc, control_step = 50, 0.03                                                         # env_cassie.py:286-288 (sim_frame_skip 1)
+    p.setPhysicsEngineParameter(fixedTimeStep=control_step / llc, numSolverIterations=5, numSubSteps=1)
+    plane = p.loadSDF(f"{data_dir}/objects/misc/plane_stadium.sdf")[0]
+    p.changeDynamics(plane, -1, lateralFriction=0.8, restitution=0.5)
+    flags = p.URDF_USE_SELF_COLLISION | p.URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS | p.URDF_USE_INERTIA_FROM_FILE
+    start = [0.0, 0.0, 1.085]
+    robot = p.loadURDF(f"{data_dir}/robots/cassie/urdf/cassie_collide.urdf", basePosition=start, baseOrientation=[0, 0, 0, 1],
+                       useFixedBase=False, flags=flags)
+    nj = p.getNumJoints(robot)
+    ordered, rods, part = [], [], {}
+    for j in range(nj):                                                                  # parse_joints_and_links, :155-201
+        p.setJointMotorControl2(robot, j, p.POSITION_CONTROL, positionGain=0.1, velocityGain=0.1, force=0)
+        ji = p.getJointInfo(robot, j)
+        name, link = ji[1].decode(), ji[12].decode()
+        part[link] = j
+        if "achilles" in name:
+            p.resetJointState(robot, j, CASSIE_ROD_ANGLES[len(rods)], 0.0)
+            rods.append(j)
+        if name[:5] != "fixed":
+            p.changeDynamics(robot, j, jointDamping=CASSIE_DAMPING[len(ordered)])
+            ordered.append(j)
+    assert len(ordered) == 14 and len(rods) == 4, (len(ordered), len(rods))
+    cons = []
+    for side in ("left", "right"):
+        pa, pb = CASSIE_PIVOTS[side]
+        la, lb = part[f"{side}_tarsus"], part[f"{side}_achilles_rod"]
+        cid = p.createConstraint(robot, la, robot, lb, jointType=p.JOINT_POINT2POINT, jointAxis=[0, 0, 0], parentFramePosition=pa,
+                                 childFramePosition=pb, parentFrameOrientation=[0, 0, 0, 1], childFrameOrientation=[0, 0, 0, 1])
+        cons.append((cid, la, lb, pa, pb))
+    off = [part[n] for n in ("left_achilles_rod", "left_achilles_rod_y", "right_achilles_rod", "right_achilles_rod_y")]
+    for l in off:
+        p.setCollisionFilterGroupMask(robot, l, 0, 0)
+
+    out = {"n_links": np.array(nj), "format_version": np.array(3), "robot": np.array("cassie")}
+    jinfo = [p.getJointInfo(robot, j) for j in range(nj)]                                # AFTER changeDynamics: [6] is the damping the env set
+    out["joint_names"] = np.array([ji[1].decode() for ji in jinfo])
+    out["link_names"] = np.array([ji[12].decode() for ji in jinfo])
+    out["joint_type"] = np.array([ji[2] for ji in jinfo])
+    out["joint_damping"] = np.array([ji[6] for ji in jinfo])
+    out["joint_limits"] = np.array([[ji[8], ji[9]] for ji in jinfo])
+    out["joint_axis"] = np.array([ji[13] for ji in jinfo])
+    out["parent_frame_pos"] = np.array([ji[14] for ji in jinfo])
+    out["parent_frame_orn"] = np.array([ji[15] for ji in jinfo])
+    out["parent_index"] = np.array([ji[16] for ji in jinfo])
+    dyn = [p.getDynamicsInfo(robot, l) for l in range(-1, nj)]
+    out["mass"] = np.array([d[0] for d in dyn])
+    out["lateral_friction"] = np.array([d[1] for d in dyn])
+    out["local_inertia_diag"] = np.array([d[2] for d in dyn])
+    out["inertial_pos"] = np.array([d[3] for d in dyn])
+    out["inertial_orn"] = np.array([d[4] for d in dyn])
+    shapes = []
+    for l in range(-1, nj):
+        for sh in p.getCollisionShapeData(robot, l):
+            shapes.append([l, sh[2], *sh[3], *sh[5], *sh[6]])
+    out["collision_shapes"] = np.array(shapes, dtype=np.float64).reshape(-1, 12)
+    # the solver parameters: what the session set itself, then whatever this pybullet build reports (the loader warns about the rest)
+    out["engine_contactERP"], out["engine_numSolverIterations"] = np.array(0.9), np.array(5.0)
+    if hasattr(p, "getPhysicsEngineParameters"):
+        for k, v in p.getPhysicsEngineParameters().items():
+            if isinstance(v, (int, float)):
+                out["engine_" + k] = np.array(float(v))
+    # createConstraint as called (pivots in the links' inertial frames) and, where the build has it, as Bullet stored it
+    out["constraints"] = np.array([[la, lb, p.JOINT_POINT2POINT, *pa, *pb] for _, la, lb, pa, pb in cons], float)
+    if hasattr(p, "getConstraintInfo"):
+        info = [p.getConstraintInfo(cid) for cid, *_ in cons]
+        out["constraint_info_pivots"] = np.array([[*ci[6], *ci[7]] for ci in info], float)
+    out["collision_filter_off"] = np.array(off)
+    moving = [j for j in range(nj) if jinfo[j][2] != p.JOINT_FIXED]
+    out["state_joint_names"] = np.array([jinfo[j][1].decode() for j in moving])           # columns 13.. of every state row: q then qd of these
+    out["ordered_joint_names"] = np.array([jinfo[j][1].decode() for j in ordered])
+    out["rod_joint_names"] = np.array([jinfo[j][1].decode() for j in rods])
+    lo = np.array([jinfo[j][8] for j in ordered]); hi = np.array([jinfo[j][9] for j in ordered])
+    limit = np.array([CASSIE_POWER[jinfo[j][1].decode().rsplit("_", 1)[0]] for j in ordered])   # base_power 1 x power_coef, :192-195
+    toes = [part["right_toe"], part["left_toe"]]                                                  # foot_names, :72
+    ctrl = CASSIE_POWERED + CASSIE_SPRINGS
+    MAXC = 24
+
+    def snap():
+        pos, orn = p.getBasePositionAndOrientation(robot)
+        lin, ang = p.getBaseVelocity(robot)
+        js = p.getJointStates(robot, moving)
+        return np.concatenate([pos, orn, lin, ang, [x[0] for x in js], [x[1] for x in js]])
+
+    def place():
+        p.resetBasePositionAndOrientation(robot, start, [0, 0, 0, 1])
+        p.resetBaseVelocity(robot, [0, 0, 0], [0, 0, 0])
+        for j, q in zip(ordered, CASSIE_BASE_ANGLES):
+            p.resetJointState(robot, j, q, 0.0)
+        for j, q in zip(rods, CASSIE_ROD_ANGLES):
+            p.resetJointState(robot, j, q, 0.0)
+
+    def robot_state():                                                                   # Cassie.calc_state :238-276: float32 normalised angles
+        js = p.getJointStates(robot, ordered)
+        nrm = np.array([2 * (x[0] - 0.5 * (l + h)) / (h - l) for x, l, h in zip(js, lo, hi)], dtype=np.float32)
+        spd = np.array([x[1] for x in js], dtype=np.float32)
+        rad = (hi - lo) * (nrm + 1) / 2 + lo                                              # to_radians, :206-210
+        return rad, spd
+
+    def contact_points():
+        rows = np.full((MAXC, 9), 0.0)
+        rows[:, 0] = -2
+        cps = p.getContactPoints(bodyA=robot)
+        for k, c in enumerate(cps[:MAXC]):
+            rows[k] = [c[3], -1 if c[2] == plane else c[4], *c[5], *c[7], c[9]]           # position ON THE ROBOT: what Bullet's 4-point manifold kept
+        return rows, len(cps)
+
+    def constraint_forces():
+        if not hasattr(p, "getConstraintState"):
+            return np.zeros((len(cons), 3))
+        return np.array([list(p.getConstraintState(cid))[:3] for cid, *_ in cons], float)
+
+    def env_step(a, jvel):
+        """CassieEnv.step(a), :433-479; returns the new finite-difference jvel, the last torques."""
+        target = np.concatenate([np.array(CASSIE_BASE_ANGLES)[CASSIE_POWERED] + a, [0.0, 0.0]])
+        rad0, spd = robot_state()
+        rad = rad0
+        tq = np.zeros(12)
+        alpha = min(10 / llc, 1)
+        for _ in range(llc):
+            jvel = (1 - alpha) * jvel + alpha * spd
+            perr = target - rad[ctrl]
+            verr = np.clip(0.0 - jvel[ctrl], -5, 5)
+            tq = CASSIE_KP * perr + (CASSIE_KP / 10) * verr
+            lim = limit[ctrl]
+            p.setJointMotorControlArray(robot, [ordered[i] for i in ctrl], p.TORQUE_CONTROL, forces=list(np.clip(tq, -lim, lim)))
+            p.stepSimulation()
+            rad, spd = robot_state()
+        return (rad - rad0) / control_step, tq
+
+    def alive():
+        z = p.getBasePositionAndOrientation(robot)[0][2]
+        return z - min(p.getLinkState(robot, t)[0][2] for t in toes) > 0.6                # compute_rewards, :406-412
+
+    # ---- teacher-forced env steps: (state, jvel, action) -> (state, jvel) through 50 low-level iterations
+    rng = np.random.default_rng(0)
+    place()
+    jvel = np.zeros(14)
+    rec = {k: [] for k in ("before", "jvel_before", "action", "after", "jvel_after", "torques_last", "contact_points", "n_contact_points", "constraint_forces")}
+    for t in range(n_steps):
+        a = action_scale * rng.uniform(-1, 1, 10)
+        rec["before"].append(snap()); rec["jvel_before"].append(jvel.copy()); rec["action"].append(a)
+        jvel, tq = env_step(a, jvel)
+        rec["after"].append(snap()); rec["jvel_after"].append(jvel.copy()); rec["torques_last"].append(tq)
+        cp, n = contact_points()
+        rec["contact_points"].append(cp); rec["n_contact_points"].append(n); rec["constraint_forces"].append(constraint_forces())
+        if not alive():
+            place()
+            jvel = np.zeros(14)
+    for k, v in rec.items():
+        out["cas_" + k] = np.array(v)
+    # ---- free-running rollout from the reset pose, no restart
+    rng = np.random.default_rng(1)
+    place()
+    jvel = np.zeros(14)
+    states, jvels, actions = [snap()], [jvel.copy()], []
+    for t in range(n_steps):
+        a = action_scale * rng.uniform(-1, 1, 10)
+        jvel, _ = env_step(a, jvel)
+        states.append(snap()); jvels.append(jvel.copy()); actions.append(a)
+    out.update(casfree_states=np.array(states), casfree_jvel=np.array(jvels), casfree_actions=np.array(actions), cas_action_scale=np.array(action_scale))
+    np.savez_compressed("pybullet_cassie.npz", **out)
+    print("wrote pybullet_cassie.npz")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# One frame of the planner envs' terrain: python tools/dump_pybullet_trace.py /path/to/mocca_envs/data 0 heightfield -> pybullet_heightfield.npz
+# HeightField.reload (bullet_objects.py:369-393): createCollisionShape(GEOM_HEIGHTFIELD, meshScale [1/scale, 1/scale, 1]), body at the
+# mid height; a sphere of each of the walkers' contact radii is lowered onto a grid of probe points and Bullet's closest point is recorded.
+def main_heightfield(data_dir):
+    import pybullet as p
+    p.connect(p.DIRECT)
+    data = np.load(f"{data_dir}/objects/misc/height_field_map_0.npy").astype(np.float32)
+    rows, cols = data.shape
+    scale = 4
+    shape = p.createCollisionShape(shapeType=p.GEOM_HEIGHTFIELD, meshScale=[1 / scale, 1 / scale, 1], heightfieldTextureScaling=4,
+                                   heightfieldData=data.flatten(), numHeightfieldRows=rows, numHeightfieldColumns=cols)
+    terrain = p.createMultiBody(0, shape, -1, (0, 0, float(data.max() + data.min()) / 2))
+    p.changeDynamics(terrain, -1, lateralFriction=1.0, restitution=0.1, contactStiffness=30000, contactDamping=1000)
+    rng = np.random.default_rng(0)
+    probes = []
+    for rad in (0.045, 0.09, 0.14, 0.23):
+        ball = p.createMultiBody(1.0, p.createCollisionShape(p.GEOM_SPHERE, radius=rad))
+        for k in range(200):
+            x, y = rng.uniform(-15, 15, 2)
+            h = float(data[int((y + 16) * scale), int((x + 16) * scale)])                 # get_height_at, :348-353
+            c = [x, y, h + rad + rng.uniform(-0.02, 0.02)]
+            p.resetBasePositionAndOrientation(ball, c, [0, 0, 0, 1])
+            best = None
+            for cp in p.getClosestPoints(ball, terrain, 0.05):
+                if best is None or cp[8] < best[8]:
+                    best = cp
+            probes.append([rad, *c, *(best[7] if best else (0, 0, 1)), best[8] if best else 1e30])
+        p.removeBody(ball)
+    np.savez_compressed("pybullet_heightfield.npz", probes=np.array(probes), scale=np.array(scale), shape=np.array([rows, cols]),
+                        body_z=np.array(float(data.max() + data.min()) / 2))
+    print("wrote pybullet_heightfield.npz")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 1000)
+    what = sys.argv[3] if len(sys.argv) > 3 else "walker3d"
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    if what == "cassie":
+        main_cassie(sys.argv[1], n)
+    elif what == "heightfield":
+        main_heightfield(sys.argv[1])
+    else:
+        main(sys.argv[1], n)
