@@ -335,7 +335,9 @@ class Walker3DStepperEnv(EnvBase):
         self.timestep += 1
         if self.random_reward:   # np_random.uniform(0.8, 1.2, 8), :533-535: drawn here, handed to the kernel in task words 30..37
             from .vec_env import task_to_float64, task_from_float64
-            tk = task_to_float64(self._img["task"])
+            # the LIVE record, not the host image of the last step: set_robot_params / VecEnv.seed / set_task may have changed the device
+            # record since (a stale image written back would silently revert them -- ADVICE r3); one 160-byte download, this mode only
+            tk = task_to_float64(self._vec.get_task())
             tk[0, 30:38] = self.np_random.uniform(0.8, 1.2, 8)
             self._vec.set_task(task_from_float64(tk))
         cur = min(int(self.curriculum), self.max_curriculum)
