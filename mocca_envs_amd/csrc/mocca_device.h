@@ -93,8 +93,8 @@ constexpr int TERRAIN_STRIDE = 128; // floats per env in the terrain buffer
 // ---- LDS layout, float offsets (one wave = one env) ----
 // [0, L_V)      survives the whole step (state, torques, new velocity, warm-start impulses)
 // [L_V, end)    one region with two views: the ABA view (joint vectors, articulated inertias, geom points,
-//               contacts) and the solver view (Delassus matrix A[48][48]; Jacobian rows parked in its tail,
-//               row k of J is consumed before row k of A reaches it: 48 k + 47 < 960 + 28 (k + 1) for k <= 47)
+//               contacts) and the solver view (Delassus matrix A[MAXR][MAXR]; Jacobian rows parked in / behind it: every J row
+//               has been read into registers before the first A entry is stored)
 enum : int {
   L_Q = 0,        // [24] q, index = body
   L_QD = 24,      // [24]
@@ -1669,8 +1669,7 @@ DI void pace_checkpoint(const float* L, int done, int total) {
   else __builtin_amdgcn_s_setprio(0);
 }
 template <class T>
-DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wanted, unsigned long long ppk, int32_t* dbg, const float* Afac, int prio, int& rows_out,
-                          bool keep_warm_unused) {
+DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wanted, unsigned long long ppk, int32_t* dbg, const float* Afac, int prio, int& rows_out) {
   const bool keep_warm = uni(__float_as_int(L[L_KEEPWARM])) != 0;   // (wave-uniform) the slots' normal impulses are wanted after the substep (warm start / diagnostic)
   STAMP_BEGIN;
   // wave-uniform scalars live in SGPRs: loop control becomes s_cmp/s_cbranch instead of exec-mask bookkeeping
@@ -2148,7 +2147,7 @@ DI void stage_joints(ModelP M, float* L, int lane) {
 // one physics substep (what stepSimulation does numSubSteps times, bullet_utils.py:346-353)
 template <class T, int TASK>
 DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next_step_index,
-                        unsigned long long ppk, int32_t* dbg, int prio, int& rows_out, bool keep_warm,
+                        unsigned long long ppk, int32_t* dbg, int prio, int& rows_out,
                         const HeightFieldArgs hfa = HeightFieldArgs{nullptr, 0, 0, 0.0f}, int sidx = 0, int nsub = 1, int* cover_out = nullptr) {
   // pace checkpoints: a substep counts 64 units + MOCCA_PACE_ROWUNIT per constraint row (the row count of the substep before stands in until
   // this one's is known) -- 20 after the collision pass, 36 after the ABA, all at its end: an env with many rows has more of its step
@@ -2200,7 +2199,7 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
   STAMP(2);
   pace_checkpoint(L, done0 + 36, total);
 #ifndef MOCCA_SKIP_SOLVE
-  solve_constraints<T>(M, L, lane, nc, nc_wanted, ppk, dbg, Afac, prio, rows_out, keep_warm);
+  solve_constraints<T>(M, L, lane, nc, nc_wanted, ppk, dbg, Afac, prio, rows_out);
 #endif
   STAMP(3);
 #ifdef MOCCA_DUMMY_VALU  // experiment: is the kernel VALU-issue-bound?  (tools/ab.sh variants)

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
         L[L_TAU + b] = tq < -lim ? -lim : (tq > lim ? lim : tq);
       }
       wsync();
-      substep<T, TASK>(Ms, L, ln, nullptr, 0, pk, dbg, a.prio, last_rows, false, HeightFieldArgs{nullptr, 0, 0, 0.0f}, it, nllc);
+      substep<T, TASK>(Ms, L, ln, nullptr, 0, pk, dbg, a.prio, last_rows, HeightFieldArgs{nullptr, 0, 0, 0.0f}, it, nllc);
     }
     if (!INJECT && lane == 0) tk[T_RES23] = (uint32_t)last_rows;
     TaskRegs t;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     int ln = lane;  // same for lane-derived offsets and predicates (recomputing them costs a few instructions)
     unsigned long long pk = ppk;  // laundered too: otherwise every (ppk >> 5k) & 31 and the addresses derived from it
     asm volatile("" : "+s"(Ms), "+v"(ln), "+v"(pk));  // are hoisted out of the loop and spilled
-    fl = substep<T, TASK>(Ms, L, ln, ter, nsi0, pk, dbg, a.prio, last_rows, false, HeightFieldArgs{a.hf, a.hf_rows, a.hf_cols, a.hf_scale}, s, nsub, &cover);
+    fl = substep<T, TASK>(Ms, L, ln, ter, nsi0, pk, dbg, a.prio, last_rows, HeightFieldArgs{a.hf, a.hf_rows, a.hf_cols, a.hf_scale}, s, nsub, &cover);
   }
   if constexpr (INJECT) {  // getContactPoints results handed in by the caller (robots.py:74-86, env_locomotion.py:634-650, :880-890)
     const int32_t* tc = a.inj_touch + (size_t)env * T::NFEET;
