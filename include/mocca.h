@@ -94,8 +94,8 @@ enum {
 };
 
 /* words of the per-env debug record (mocca_set_debug_buffer): words 0..11 the active set of the LAST physics substep, words 12..15
- * cumulative over every substep since the caller last cleared the buffer */
-#define MOCCA_DEBUG_WORDS 16
+ * cumulative over every substep since the caller last cleared the buffer, words 16..18 a signature of EVERY substep of the last mocca_step */
+#define MOCCA_DEBUG_WORDS 20
 enum {
   MOCCA_DBG_ROWS = 0,        /* constraint rows solved                                  */
   MOCCA_DBG_LIMIT_ROWS = 1,  /* of which joint-limit rows                               */
@@ -115,6 +115,13 @@ enum {
   MOCCA_DBG_CAP_ROWS = 13,     /* substeps in which limit + closure + 3 x (kept contacts) rows exceeded max_rows                        */
   MOCCA_DBG_SUBSTEPS = 14,     /* substeps counted                                                                                      */
   MOCCA_DBG_ROWS_WANTED = 15,  /* largest row count an uncapped solver would have held                                                  */
+  /* every discrete decision of the last mocca_step, all its substeps (4; Cassie: 50): h = 0 at the step's start, then per substep and for
+   * w = 0 .. 11:  h = (h ^ (uint32) word w) * 0x9E3779B97F4A7C15 (mod 2^64).  Two implementations that took the same decisions in every
+   * substep agree on it: whole-step comparisons can then be held to arithmetic tolerances (tests/test_gpu_parity.py) */
+  MOCCA_DBG_STEPSIG_LO = 16,
+  MOCCA_DBG_STEPSIG_HI = 17,
+  MOCCA_DBG_STEPSIG_N = 18,    /* substeps folded into it */
+  MOCCA_DBG_RESERVED = 19,
 };
 
 int mocca_abi_version(void);

@@ -1668,6 +1668,15 @@ DI void pace_checkpoint(const float* L, int done, int total) {
   else if (lhs > r - (r >> MOCCA_PACE_SHIFT)) __builtin_amdgcn_s_setprio(1);
   else __builtin_amdgcn_s_setprio(0);
 }
+// debug record: fold this substep's twelve words into the step signature (MOCCA_DBG_STEPSIG_*; off the product path)
+DI void dbg_fold_step(int32_t* dbg, int lane) {
+  if (dbg && lane == 0) {
+    unsigned long long h = ((unsigned long long)(unsigned)dbg[17] << 32) | (unsigned)dbg[16];
+#pragma unroll 1
+    for (int w = 0; w < 12; ++w) h = (h ^ (unsigned long long)(unsigned)dbg[w]) * 0x9E3779B97F4A7C15ull;
+    dbg[16] = (int32_t)(unsigned)h; dbg[17] = (int32_t)(unsigned)(h >> 32); dbg[18] += 1;
+  }
+}
 template <class T>
 DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wanted, unsigned long long ppk, int32_t* dbg, const float* Afac, int prio, int& rows_out) {
   const bool keep_warm = uni(__float_as_int(L[L_KEEPWARM])) != 0;   // (wave-uniform) the slots' normal impulses are wanted after the substep (warm start / diagnostic)
@@ -2201,6 +2210,7 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
 #ifndef MOCCA_SKIP_SOLVE
   solve_constraints<T>(M, L, lane, nc, nc_wanted, ppk, dbg, Afac, prio, rows_out);
 #endif
+  if (dbg) { __builtin_amdgcn_s_waitcnt(0); dbg_fold_step(dbg, lane); }   // (lane 0 wrote the twelve words above; it reads them back itself)
   STAMP(3);
 #ifdef MOCCA_DUMMY_VALU  // experiment: is the kernel VALU-issue-bound?  (tools/ab.sh variants)
   {

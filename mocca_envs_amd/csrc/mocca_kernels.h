@@ -50,6 +50,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
 
   // the slots' normal impulses: loaded iff the blob warm-starts, stored iff it does or the caller wants them (INJECT: no physics, the record passes through)
   const bool warm_ld = INJECT || uni(__float_as_int(M->warmstart)) != 0, warm_st = warm_ld || a.persist_warm != 0;
+  if (dbg && lane == 0) { dbg[16] = 0; dbg[17] = 0; dbg[18] = 0; }   // step signature: restarted by every mocca_step
   load_dyn(st, L, lane, T::NJ, T::NSLOT, warm_ld);
   pace_start(a, L, lane, INJECT ? 0 : a.pace);
   if (lane == 0) L[L_KEEPWARM] = __int_as_float(warm_st ? 1 : 0);

@@ -19,7 +19,7 @@ PARAM_PERSIST_IMPULSES = 10  # keep the last substep's normal impulses in the st
 PARAM_KERNEL_VARIANT = 11    # timing only: 1 forces the 48-row step-kernel instance for a blob that would run the compact one
 PARAM_ORDER_EVERY = 12       # timing only: every K-th step re-sorts the launch order, heaviest envs (most constraint rows) first
 PARAM_PACE_TICKS = 13        # timing only: pace priorities (target ticks per env.step of a wave) instead of the row-count priorities
-DEBUG_WORDS = 16
+DEBUG_WORDS = 20
 
 # every symbol include/mocca.h declares: (name, restype, argtypes)
 _vp, _i, _u64, _sz, _d = C.c_void_p, C.c_int, C.c_uint64, C.c_size_t, C.c_double

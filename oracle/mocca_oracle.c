@@ -41,7 +41,7 @@ typedef REAL real;
 #define NDOF_MAX (6 + MB)
 #define MAX_CONTACTS 16 /* storage; the live caps are MoccaModel.max_contacts / max_rows */
 #define MAX_ROWS 64
-#define DBG_WORDS 16    /* MOCCA_DEBUG_WORDS of include/mocca.h */
+#define DBG_WORDS 20    /* MOCCA_DEBUG_WORDS of include/mocca.h */
 #define KERNEL_MAXR 48  /* the HIP solver's lane layout (mocca_device.h MAXR): friction rows of contact i sit on lanes 46 - 2i, 47 - 2i */
 
 #if defined(__GNUC__)
@@ -1076,6 +1076,14 @@ static void dbg_commit(Oracle *o, int env, const Work *w) {
   memcpy(d, w->dbg, 12 * sizeof(int32_t));
   d[12] += w->dbg[12]; d[13] += w->dbg[13]; d[14] += w->dbg[14];
   if (w->dbg[15] > d[15]) d[15] = w->dbg[15];
+  /* step signature (MOCCA_DBG_STEPSIG_*): every substep's twelve words folded in order; restarted by dbg_step_start() */
+  uint64_t h = ((uint64_t)(uint32_t)d[17] << 32) | (uint32_t)d[16];
+  for (int k = 0; k < 12; ++k) h = (h ^ (uint64_t)(uint32_t)d[k]) * 0x9E3779B97F4A7C15ull;
+  d[16] = (int32_t)(uint32_t)h; d[17] = (int32_t)(uint32_t)(h >> 32); d[18] += 1;
+}
+static void dbg_step_start(Oracle *o, int env) {
+  int32_t *d = o->dbg + (size_t)DBG_WORDS * env;
+  d[16] = 0; d[17] = 0; d[18] = 0;
 }
 
 /* ------------------------------------------------------------------ */
@@ -1387,6 +1395,7 @@ static void cassie_step(Oracle *o, int env, const float *act, float *obs, float 
   }
   /* jpos = robot.rad_joint_angles (:447,467): to_radians of the float32 normalised angles */
   for (int k = 0; k < no; ++k) q0[k] = cassie_rad(m, k, cassie_nrm(m, k, s->q[m->ordered_body[k]]));
+  if (physics) dbg_step_start(o, env);
   for (int it = 0; physics && it < m->n_llc; ++it) { /* :450-459 */
     for (int k = 0; k < no; ++k)
       tk->jvel[k] = (1 - (real)m->jvel_alpha) * tk->jvel[k] + (real)m->jvel_alpha * (real)(float)s->qd[m->ordered_body[k]];
@@ -1544,6 +1553,7 @@ static void step_env(Oracle *o, int env, const float *act, float *obs, float *re
   }
   int touch[MOCCA_MAX_FEET] = {0}, target[MOCCA_MAX_FEET] = {0}, body_touch = 0, cover = 0;
   if (!ext_touch) {
+    dbg_step_start(o, env);
     for (int k = 0; k < m->n_substeps; ++k) { substep(o, s, tk, tr, tau, w); dbg_commit(o, env, w); }
     /* contact queries after stepSimulation see the manifolds of the LAST substep's collision pass */
     for (int k = 0; k < m->n_feet; ++k) { touch[k] = w->foot_touch[k]; target[k] = w->foot_target[k]; }

@@ -246,9 +246,9 @@ class Oracle:
         return lam[:n], kind[:n]
 
     def get_debug(self) -> np.ndarray:
-        """Debug record of every env, [N][16] int32 (include/mocca.h MOCCA_DBG_*): words 0..11 the active set of the last substep
+        """Debug record of every env, [N][20] int32 (include/mocca.h MOCCA_DBG_*): words 0..11 the active set of the last substep
         (rows, contacts, slot / limit masks, PGS clamp mask and signature), words 12..15 cumulative cap pressure."""
-        out = np.zeros((self.n_envs, 16), np.int32)
+        out = np.zeros((self.n_envs, 20), np.int32)
         self.lib.orc_get_debug(self.h, _p(out))
         return out
 
