@@ -131,6 +131,11 @@ def parse_args(argv=None):
     ap.add_argument("--kernel-variant", type=int, default=0, help="TIMING ONLY: 1 forces the 48-row kernel instance for a blob that fits the compact one (A/B)")
     ap.add_argument("--order-every", type=int, default=None, help="TIMING ONLY: MOCCA_PARAM_ORDER_EVERY (heaviest envs first, re-sorted every K steps; 0 off; default: VecEnv's choice)")
     ap.add_argument("--pace", type=int, default=None, help="TIMING ONLY: MOCCA_PARAM_PACE_TICKS (pace priorities; 0 off)")
+    ap.add_argument("--stagger", type=int, default=0,
+                    help="NOT the headline protocol: split the batch into this many sub-batches (own handles, own HIP streams) whose steps are not "
+                         "ordered against each other -- what a trainer does that computes the policy for one half while the other half steps "
+                         "(every env still advances exactly K times inside the timed region).  The tail of one sub-batch's launch is filled by the "
+                         "next launch of another; reported with config.pipelined = true, never as BENCH_rNN's value")
     ap.add_argument("--action-scale", type=float, default=1.0,
                     help="actions are action_scale x U(-1,1) (SURVEY 8d config 4 asks for 0.1 on Cassie: a robot that stays up instead of one that "
                          "falls every ~17 steps); reported in config.workload")
@@ -252,18 +257,48 @@ def main():
         if args.prio:
             t1, t2, t3 = (int(x) for x in args.prio.split(","))
             env.set_param(9, t1 + 64 * t2 + 4096 * t3)  # MOCCA_PARAM_ISSUE_PRIORITY
-        env.reset()
+        subs = []
+        if args.stagger > 1:   # sub-batches on their own streams (the first one IS `env`'s first share: same global env ids, same seed)
+            env.close()
+            per = args.envs // args.stagger
+            assert per * args.stagger == args.envs, "--stagger must divide --envs"
+            for k in range(args.stagger):
+                st_k = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(st_k):
+                    e_k = VecEnv(args.env_id, per, device=local_rank, auto_reset=True, seed=1000, env_offset=lo + k * per, max_rows=args.max_rows)
+                    e_k.reset()
+                e_k.stream = st_k      # the handle's launches go to its own stream from here on (no stream context per step)
+                subs.append((e_k, st_k, slice(k * per, (k + 1) * per)))
+            env = subs[0][0]
+            torch.cuda.synchronize()
+        else:
+            env.reset()
         g = torch.Generator(device=dev)
         g.manual_seed(1 + rank)
         tape = (torch.rand(64, args.envs, env.act_dim, device=dev, generator=g) * 2 - 1) * args.action_scale  # action_scale x U(-1,1) action tape, looped
 
         # the synthetic input of this metric is a batch of envs in mid-episode, not 4096 identical first frames: age it
+        sub_tapes = [tape[:, sl].contiguous() for _, _, sl in subs]
+        torch.cuda.synchronize()
+
+        def step_all(i):
+            """one env.step of every env of this rank; returns the done flags of (the first sub-batch of) it"""
+            if not subs:
+                return env.step(tape[i % 64])[2]
+            d0 = None
+            for k, (e_k, st_k, sl) in enumerate(subs):
+                d = e_k.step(sub_tapes[k][i % 64])[2]
+                d0 = d if d0 is None else d0
+            return d0
+
         for i in range(args.preroll):
-            env.step(tape[(i + 17) % 64])
+            step_all(i + 17)
         n_done = torch.zeros((), device=dev)
         for i in range(args.warmup):
-            _, _, done, _ = env.step(tape[i % 64])
-            n_done += (done != 0).sum()  # reset fraction is sampled during warm-up, outside the timed region
+            done = step_all(i)
+            if subs:
+                torch.cuda.current_stream().wait_stream(subs[0][1])
+            n_done += (done != 0).sum() * (len(subs) or 1)  # reset fraction is sampled during warm-up, outside the timed region
         reset_frac = float(n_done.item()) / max(1, args.envs * args.warmup)
         # The K timed steps are bracketed by barrier + synchronize on both sides.  Each rank's clock runs from its release out of the
         # start barrier to the return of ITS OWN synchronize after the K-th launch; the stop barrier comes after the clock is read
@@ -276,8 +311,14 @@ def main():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
+        if subs:
+            for _, st_k, _ in subs:
+                st_k.wait_stream(torch.cuda.current_stream())      # the sub-batches start after ev0
         for i in range(args.steps):
-            env.step(tape[i % 64])
+            step_all(i)
+        if subs:
+            for _, st_k, _ in subs:
+                torch.cuda.current_stream().wait_stream(st_k)      # ev1 after the last launch of every sub-batch
         ev1.record()
         torch.cuda.synchronize()
         elapsed_rank = time.perf_counter() - t0
@@ -353,6 +394,10 @@ def main():
         if not args.dry_run and host_io_ms is not None:
             out["host_io"] = {"ms_per_step": host_io_ms, "value": args.envs * world / (host_io_ms * 1e-3), "unit": "env-steps/s",
                               "note": "actions from pinned host memory, obs + reward + done copied to the host and waited for every step"}
+        if args.stagger > 1:
+            out["config"]["pipelined"] = True
+            out["config"]["workload"] += f"; {args.stagger} sub-batches on their own streams, their steps overlap (NOT the headline protocol)"
+            out["roofline"]["kernel_ms_note"] = "time per step of the whole rank (all sub-batches), not one launch's duration"
         if args.dry_run:
             out["dry_run"] = True
         if args.oversubscribe:

@@ -111,6 +111,7 @@ class VecEnv:
         if not torch.cuda.is_available():
             raise _lib.MoccaError("no HIP device visible: the stepper only runs on the GPU (no CPU fallback)")
         self.lib = _lib.load()
+        self.stream = None    # None: every call goes to torch's CURRENT stream; set to a torch.cuda.Stream to pin this handle's work to it
         self.env_id, self.task_id, self.n_envs = env_id, TASKS[env_id], int(n_envs)
         self.device_index = torch.cuda.current_device() if device is None else int(device)
         self.device = torch.device("cuda", self.device_index)
@@ -164,6 +165,8 @@ class VecEnv:
 
     # ------------------------------------------------------------------
     def _stream(self) -> C.c_void_p:
+        if self.stream is not None:      # a handle bound to a stream of its own (sub-batches that step independently: bench.py --stagger)
+            return C.c_void_p(self.stream.cuda_stream)
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def close(self):

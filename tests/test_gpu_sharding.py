@@ -54,3 +54,40 @@ def test_bench_two_ranks_on_this_box():
     assert len(line) == 1
     out = json.loads(line[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["envs_per_gpu"] == 512
+
+
+@pytest.mark.gpu
+def test_sub_batches_on_their_own_streams_reproduce_the_single_batch():
+    """bench.py --stagger: a GPU's batch as two handles bound to two HIP streams (`VecEnv.stream`), stepping without
+    waiting for each other -- every env's results equal the single handle's bit for bit (draws are keyed by the global env id), on the
+    48-row and on the compact kernel instance."""
+    import torch
+    from mocca_envs_amd.vec_env import VecEnv
+    n, steps = 1024, 60
+    for kw in ({}, {"max_rows": 32}):
+        one = VecEnv("Walker3DCustomEnv-v0", n, auto_reset=True, seed=5, **kw)
+        one.reset()
+        halves = []
+        for k in range(2):
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                e = VecEnv("Walker3DCustomEnv-v0", n // 2, auto_reset=True, seed=5, env_offset=k * (n // 2), **kw)
+                e.reset()
+            e.stream = st
+            halves.append(e)
+        torch.cuda.synchronize()
+        g = torch.Generator(device="cuda"); g.manual_seed(2)
+        acts = torch.rand(steps, n, 21, device="cuda", generator=g) * 2 - 1
+        parts = [acts[:, :n // 2].contiguous(), acts[:, n // 2:].contiguous()]
+        torch.cuda.synchronize()
+        for t in range(steps):
+            one.step(acts[t])
+            for k, e in enumerate(halves):
+                e.step(parts[k][t])            # no synchronisation between the halves, nor with the single batch
+        torch.cuda.synchronize()
+        nd = 13 + 2 * 21
+        both = torch.cat([halves[0].get_state(), halves[1].get_state()])
+        assert torch.equal(one.get_state()[:, :nd], both[:, :nd])
+        assert torch.equal(one.obs, torch.cat([halves[0].obs, halves[1].obs])) and torch.equal(one.done, torch.cat([halves[0].done, halves[1].done]))
+        for e in halves + [one]:
+            e.close()
