@@ -260,6 +260,8 @@ int mocca_create(const void* model_blob, size_t nbytes, int task_id, int n_envs,
   if ((e = hipMalloc(&h->d_dyn, dyn_b)) != hipSuccess) return fail("hipMalloc(state)", e);
   if ((e = hipMalloc(&h->d_task, task_b)) != hipSuccess) return fail("hipMalloc(task)", e);
   if ((e = hipMalloc(&h->d_terrain, ter_b)) != hipSuccess) return fail("hipMalloc(terrain)", e);
+  if ((e = hipMalloc(&h->d_pace_acc, 6 * sizeof(unsigned))) != hipSuccess) return fail("hipMalloc(pace samples)", e);
+  if ((e = hipMemset(h->d_pace_acc, 0, 6 * sizeof(unsigned))) != hipSuccess) return fail("hipMemset", e);
   if ((e = hipMemset(h->d_dyn, 0, dyn_b)) != hipSuccess) return fail("hipMemset", e);
   if ((e = hipMemset(h->d_terrain, 0, ter_b)) != hipSuccess) return fail("hipMemset", e);
   // task records: episode = -1 so the first reset is episode 0; applied_gain = 1
@@ -380,18 +382,12 @@ int mocca_step(mocca_handle h, const float* act_dev, float* obs_dev, float* rew_
   a.act = act_dev; a.obs = obs_dev; a.rew = rew_dev; a.done = done_dev; a.info = info_dev;
   hipStream_t s = (hipStream_t)stream;
   if (int rc = flush_pending(h, s)) return rc;
-  if (h->pace < 0) {   // self-calibrating pace priorities: three sample slots, rotated per launch (StepArgs.pace_acc)
-    if (!h->d_pace_acc) {
-      HIP_TRY(h, hipMalloc(&h->d_pace_acc, 6 * sizeof(unsigned)));
-      HIP_TRY(h, hipMemsetAsync(h->d_pace_acc, 0, 6 * sizeof(unsigned), s));
-      h->pace_step = 0;
-    }
-    a.pace_acc = h->d_pace_acc;
+  if (h->pace < 0) {   // self-calibrating pace priorities: three sample slots, rotated per launch (StepArgs.pace_acc; allocated by mocca_create:
+    a.pace_acc = h->d_pace_acc;   // mocca_step itself never allocates, so a caller may capture it in a hipGraph)
     a.pace_slot_w = (int)(h->pace_step % 3u); a.pace_slot_r = (int)((h->pace_step + 2u) % 3u); a.pace_slot_c = (int)((h->pace_step + 1u) % 3u);
     ++h->pace_step;
   }
-  if (h->order_every > 0) {   // heaviest envs first: the permutation is rebuilt on the caller's stream, ahead of the step that reads it
-    if (!h->d_order) { HIP_TRY(h, hipMalloc(&h->d_order, (size_t)h->n_envs * sizeof(int32_t))); h->order_age = h->order_every; }
+  if (h->order_every > 0 && h->d_order) {   // heaviest envs first: the permutation is rebuilt on the caller's stream, ahead of the step that reads it
     if (h->order_age >= h->order_every) {
       hipLaunchKernelGGL(order_by_rows_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)h->d_task, h->d_order, h->n_envs);
       HIP_TRY(h, hipGetLastError());
@@ -604,7 +600,12 @@ int mocca_set_param(mocca_handle h, int param_id, double value) {
       h->pace = (int)value; break;
     case MOCCA_PARAM_ORDER_EVERY:
       if (value < 0 || value > 1e6) { h->err = "MOCCA_PARAM_ORDER_EVERY is a step count >= 0"; return MOCCA_E_ARG; }
-      h->order_every = (int)value; h->order_age = h->order_every; break;
+      h->order_every = (int)value; h->order_age = h->order_every;
+      if (h->order_every > 0 && !h->d_order) {   // (allocated here, not in mocca_step)
+        DeviceGuard guard(h->device);
+        HIP_TRY(h, hipMalloc(&h->d_order, (size_t)h->n_envs * sizeof(int32_t)));
+      }
+      break;
     case MOCCA_PARAM_KERNEL_VARIANT:
       if (value != 0 && value != 1) { h->err = "MOCCA_PARAM_KERNEL_VARIANT is 0 (automatic) or 1 (force the 48-row instance)"; return MOCCA_E_ARG; }
       h->force_full = (int)value; break;

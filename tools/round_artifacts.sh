@@ -43,4 +43,9 @@ hipcc --offload-arch=gfx950 -O3 -o /tmp/dispatch_probe tools/dispatch_probe.hip 
 # 6. rocprofv3: kernel-trace stats + separate PMC passes at steady state, the other two configs
 tools/profile_round.sh ${tag}_stepper Walker3DStepperEnv-v0 4096 > /dev/null 2>&1
 tools/profile_round.sh ${tag}_cassie CassieEnv-v0 2048 > /dev/null 2>&1
+# 7. config 5's per-GPU shard: 48-row and compact instance (counters at 4 and 5 resident waves per SIMD), and the pipelined two-sub-batch lines
+tools/profile_round.sh ${tag}_custom8192 Walker3DCustomEnv-v0 8192 > /dev/null 2>&1
+BENCH_EXTRA="--max-rows 32" tools/profile_round.sh ${tag}_custom8192compact Walker3DCustomEnv-v0 8192 > /dev/null 2>&1
+python bench.py --envs 8192 --stagger 2 --steps 400 --warmup 100 --no-cpu-baseline > $O/${tag}_custom8192_staggered_bench.json 2>/dev/null
+python bench.py --envs 8192 --stagger 2 --max-rows 32 --steps 400 --warmup 100 --no-cpu-baseline > $O/${tag}_custom8192_staggered_compact_bench.json 2>/dev/null
 ls $O | grep "^${tag}" | head -80
