@@ -90,7 +90,8 @@ enum {
                                         priority 3 / 2 / 1 / 0 as its estimated finish lies beyond 17/16 of, beyond, within 1/16 below, or
                                         further below P: the waves of a SIMD finish together.  value > 0: P in ticks; value = -k (1 <= k <= 64):
                                         self-calibrating, P = k/16 of the mean wave time of the previous launch (every 61st wave adds a sample;
-                                        the first launch of a handle falls back to the row-count priorities); 0: off.  Default -18. */
+                                        the first launch of a handle falls back to the row-count priorities); 0: off.  Default -18; 0 for a blob that
+                                        runs the compact instance (batches beyond one generation of resident waves: measured slower with it). */
 };
 
 /* words of the per-env debug record (mocca_set_debug_buffer): words 0..11 the active set of the LAST physics substep, words 12..15
