@@ -41,7 +41,7 @@ __global__ __launch_bounds__(1024) void order_by_rows_kernel(const uint32_t* tas
   if (t < 64) hist[t] = 0;
   __syncthreads();
   for (int e = t; e < n; e += 1024) {
-    const uint32_t r = task[(size_t)e * MOCCA_TASK_WORDS + 23];
+    const uint32_t r = task[(size_t)e * MOCCA_TASK_WORDS + T_RES23];
     atomicAdd(&hist[63 - (r > 63u ? 63u : r)], 1);   // bucket 0 = heaviest
   }
   __syncthreads();
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(1024) void order_by_rows_kernel(const uint32_t* tas
   }
   __syncthreads();
   for (int e = t; e < n; e += 1024) {
-    const uint32_t r = task[(size_t)e * MOCCA_TASK_WORDS + 23];
+    const uint32_t r = task[(size_t)e * MOCCA_TASK_WORDS + T_RES23];
     order[atomicAdd(&start[63 - (r > 63u ? 63u : r)], 1)] = e;
   }
 }

@@ -1637,11 +1637,12 @@ DI void set_issue_priority(int nr, int prio) {
 #ifndef MOCCA_PACE_SHIFT
 #define MOCCA_PACE_SHIFT 4   // width of the priority bands around the pace: 2^-4
 #endif
+constexpr int PACE_TICK_SHIFT = 6;   // elapsed ticks and the pace are compared in units of 64 ticks
 enum : int { L_T0 = L_BASE + 13, L_PACE = L_BASE + 14, L_KEEPWARM = L_BASE + 15 /* StepArgs.persist_warm or a warm-starting blob: same reason */ };
 DI void pace_start(const StepArgs& a, float* L, int lane, int pace) {
   if (lane == 0) {
-    int p16 = pace >> 4;
-    if (pace < 0) {   // self-calibrating: the previous launch's mean wave time (ticks / 16) x (-pace) / 16; no sample yet: row-count priorities
+    int p16 = pace >> PACE_TICK_SHIFT;
+    if (pace < 0) {   // self-calibrating: the previous launch's mean wave time (ticks / 64) x (-pace) / 16; no sample yet: row-count priorities
       const unsigned sum = a.pace_acc[2 * a.pace_slot_r], cnt = a.pace_acc[2 * a.pace_slot_r + 1];
       p16 = cnt > 0u ? (int)((float)sum / (float)cnt * (float)(-pace) * 0.0625f) : 0;
       if (blockIdx.x == 0) { a.pace_acc[2 * a.pace_slot_c] = 0u; a.pace_acc[2 * a.pace_slot_c + 1] = 0u; }
@@ -1653,16 +1654,17 @@ DI void pace_start(const StepArgs& a, float* L, int lane, int pace) {
 DI void pace_finish(const StepArgs& a, const float* L, int lane, int pace) {   // (after a barrier: lane 0's words are visible to itself anyway)
   if (pace < 0 && lane == 0 && (blockIdx.x % 61u) == 0u) {   // one wave in 61: a sample spread over the XCDs and CUs
     const unsigned el = (unsigned)__builtin_amdgcn_s_memtime() - __float_as_uint(L[L_T0]);
-    atomicAdd(&a.pace_acc[2 * a.pace_slot_w], el >> 4);
+    atomicAdd(&a.pace_acc[2 * a.pace_slot_w], el >> PACE_TICK_SHIFT);
     atomicAdd(&a.pace_acc[2 * a.pace_slot_w + 1], 1u);
   }
 }
 DI bool pace_on(const float* L) { return uni(__float_as_int(L[L_PACE])) > 0; }
 DI void pace_checkpoint(const float* L, int done, int total) {
-  const unsigned p16 = (unsigned)uni(__float_as_int(L[L_PACE]));   // pace / 16; 0 = off (wave-uniform branch)
+  const unsigned p16 = (unsigned)uni(__float_as_int(L[L_PACE]));   // pace in units of 64 ticks; 0 = off (wave-uniform branch)
   if (p16 == 0u) return;
   const unsigned el = (unsigned)__builtin_amdgcn_s_memtime() - (unsigned)uni(__float_as_int(L[L_T0]));
-  const unsigned lhs = (el >> 4) * (unsigned)total, r = p16 * (unsigned)done;   // ticks / 16: the products stay below 2^32
+  // units of 64 ticks: the products stay below 2^32 with room to spare (Cassie: 2.4 M ticks per step, 50 x (64 + 2 x 48) units: 3e8)
+  const unsigned lhs = (el >> PACE_TICK_SHIFT) * (unsigned)total, r = p16 * (unsigned)done;
   if (lhs > r + (r >> MOCCA_PACE_SHIFT)) __builtin_amdgcn_s_setprio(3);
   else if (lhs > r) __builtin_amdgcn_s_setprio(2);
   else if (lhs > r - (r >> MOCCA_PACE_SHIFT)) __builtin_amdgcn_s_setprio(1);
