@@ -4,7 +4,9 @@
   python bench.py --gpus N --steps K --warmup W            (BASELINE.json configs[1]; N = 1, 2, 4, 8)
   python bench.py --gpus 8 --envs 8192                     (configs[4]: 8 x 8192 envs, weak scaling)
   python bench.py --env-id Walker3DStepperEnv-v0 [--curriculum 9]     (configs[2])
-  python bench.py --env-id CassieEnv-v0 --envs 2048                   (configs[3])
+  python bench.py --env-id CassieEnv-v0 --envs 2048 --action-scale 0.1          (configs[3]; SURVEY 8d: a ~ 0.1 U(-1,1))
+  python bench.py --envs 8192 --stagger 2 --max-rows 32              (NOT the headline protocol: the GPU's batch as two independently stepping
+                                                                       sub-batches on the compact kernel instance, config.pipelined = true)
 
 One "step" = one env.step() of all envs of a rank = ONE launch of the step kernel (4 physics substeps, observation,
 reward, termination, in-kernel auto-reset), inputs resident in HBM.
