@@ -354,6 +354,11 @@ def test_planner_env_on_a_random_height_field():
     assert (z > 0.5).mean() > 0.5                               # most robots still stand on the slopes they were put on (40 steps of flailing)
     with pytest.raises(L.MoccaError):
         env.set_heightfield(np.zeros((1, 64), np.float32), 2)
+    with pytest.raises(L.MoccaError, match="too fine"):       # 40 points per metre: the 14 cm pelvis sphere would span 7 cells each way (window > 4)
+        env.set_heightfield(np.zeros((64, 64), np.float32), 40)
+    env.set_heightfield(field, 2)                             # a refused grid leaves the handle as it was
+    env.step(torch.zeros(n, 21, device="cuda"))
+    assert torch.isfinite(env.get_state()).all()
     env.close()
 
 
