@@ -2,9 +2,11 @@ import sys, torch
 import os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from mocca_envs_amd.vec_env import VecEnv, TASKS
+# SOAK_MAX_ROWS=32 soaks the compact kernel instance (handles whose robot has loop closures keep the 48-row instance)
+caps = {"max_rows": 32, "max_contacts": 10} if os.environ.get("SOAK_MAX_ROWS") == "32" else {}
 for env_id in TASKS:
     n = 2048 if "Cassie" in env_id else 4096
-    env = VecEnv(env_id, n, auto_reset=True, seed=123)
+    env = VecEnv(env_id, n, auto_reset=True, seed=123, **caps)
     env.reset()
     g = torch.Generator(device="cuda").manual_seed(1)
     steps = 300 if "Cassie" in env_id else 3000
