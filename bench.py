@@ -123,6 +123,11 @@ def parse_args(argv=None):
                          "episode ages and contact counts (SURVEY 8d config 2 asks for >= 200; 1000 = one max_episode_steps, so TimeLimit truncations "
                          "are in the mix) and bring the GPU to its operating clocks -- after idling the first ~50 ms of launches run 9 %% slow "
                          "(tools/ramp_probe.py, profiles/r02_ramp_probe.txt); untimed, reported in config.preroll_steps")
+    ap.add_argument("--preroll-seconds", type=float, default=0.5,
+                    help="keep pre-rolling (same launches, untimed) until the GPU has been busy this long.  A 20-launch window that follows a "
+                         "synchronize samples the power management's recovery as much as the kernel: after 3 s of idling it runs 108 us per "
+                         "launch, with >= 0.1 s of launches behind it 100 - 102 us, although 1000 launches back to back take 100 us either way "
+                         "(tools/short_window_probe.py, profiles/r04_short_window.txt).  0 = steps only; reported in config.preroll_seconds")
     ap.add_argument("--curriculum", type=int, default=None, help="Stepper envs: curriculum 0..9 (SURVEY 8d config 3)")
     ap.add_argument("--prio", default=None,
                     help="TUNING ONLY: t1,t2,t3 row-count thresholds of the step kernel's issue priorities (MOCCA_PARAM_ISSUE_PRIORITY) in place of "
@@ -239,6 +244,7 @@ def main():
         elapsed_rank = time.perf_counter() - t0
         barrier()
         kern_ms = 1.0 + rank
+        preroll_steps, preroll_s = args.preroll, 0.0     # declared, not run
     else:
         import torch
         if args.oversubscribe:
@@ -293,8 +299,28 @@ def main():
                 d0 = d if d0 is None else d0
             return d0
 
+        # First use of everything the warm-up and the timed window call besides mocca_step, BEFORE the pre-roll: torch loads the code objects
+        # of its reduction kernels on first use (40 - 150 ms on the host, the GPU idle meanwhile).  With that gap between the pre-roll and
+        # the timed window, all K = 20 launches of the window run 7 - 14 % slow (tools/short_window_probe3.py, profiles/r04_short_window4.txt).
+        n_done = torch.zeros((), device=dev)
+        n_done += (env.done != 0).sum()
+        n_done.item()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(); ev1.record()
+        torch.cuda.synchronize()
+        ev0.elapsed_time(ev1)
         for i in range(args.preroll):
             step_all(i + 17)
+        preroll_steps, preroll_s = args.preroll, 0.0
+        if args.preroll_seconds > 0:
+            torch.cuda.synchronize()
+            t_pre = time.perf_counter()
+            while preroll_s < args.preroll_seconds:      # chunks of 256 launches, one synchronize per chunk
+                for i in range(256):
+                    step_all(preroll_steps + i + 17)
+                preroll_steps += 256
+                torch.cuda.synchronize()
+                preroll_s = time.perf_counter() - t_pre
         n_done = torch.zeros((), device=dev)
         for i in range(args.warmup):
             done = step_all(i)
@@ -371,7 +397,7 @@ def main():
             "config": {"workload": f"{args.env_id}, {args.envs} envs/GPU, {terrain}, {scale_txt}U(-1,1) action tape, auto-reset",
                        "max_rows": int(env.model.max_rows) if env is not None else None, "max_contacts": int(env.model.max_contacts) if env is not None else None,
                        "envs_per_gpu": args.envs, "parallelism": f"independent env shards x{world}, no collective",
-                       "reset_fraction_per_step": reset_frac, "preroll_steps": args.preroll},
+                       "reset_fraction_per_step": reset_frac, "preroll_steps": preroll_steps, "preroll_seconds": round(preroll_s, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mocca_step_kernel", "kernel_ms": kern_ms,

@@ -93,7 +93,7 @@ def test_bench_launches_its_own_ranks():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline"):
         assert key in out, key
-    assert out["steps"] == 2 and out["config"]["preroll_steps"] == 1000 and out["dtype"] == "f32" and out["vs_baseline"] is None
+    assert out["steps"] == 2 and out["config"]["preroll_steps"] == 1000 and "preroll_seconds" in out["config"] and out["dtype"] == "f32" and out["vs_baseline"] is None
     assert _bench("--gpus", "1", "--steps", "2", "--dry-run", "--preroll", "7")["config"]["preroll_steps"] == 7
 
 

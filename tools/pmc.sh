@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/$1; shift
-cd /tmp && rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out.log 2>&1
+cd /tmp && rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --preroll-seconds 0 > $out.log 2>&1
 f=$(find $out -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections

@@ -9,14 +9,14 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_trace -- python3 $R/bench.py --env-id $envid --envs $envs --steps 400 --warmup 100 --no-cpu-baseline $BENCH_EXTRA > $O/${tag}_bench.json 2> $O/${tag}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_trace -- python3 $R/bench.py --env-id $envid --envs $envs --steps 400 --warmup 100 --no-cpu-baseline --preroll-seconds 0 $BENCH_EXTRA > $O/${tag}_bench.json 2> $O/${tag}_bench.err
 cp $(find $O/${tag}_trace -name "*kernel_stats.csv" | head -1) $O/${tag}_kernel_stats.csv
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_WRREQ TCC_EA0_WRREQ_64B" "TCC_HIT TCC_MISS TCC_REQ" \
             "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
             "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU" \
             "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   n=$(echo $pass | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $O/${tag}_pmc_$n -- python3 $R/bench.py --env-id $envid --envs $envs --steps 20 --warmup 200 --no-cpu-baseline $BENCH_EXTRA > /dev/null 2>&1
+  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $O/${tag}_pmc_$n -- python3 $R/bench.py --env-id $envid --envs $envs --steps 20 --warmup 200 --no-cpu-baseline --preroll-seconds 0 $BENCH_EXTRA > /dev/null 2>&1
 done
 python3 - $O $tag <<'PY'
 import csv, glob, json, sys, collections
