@@ -309,16 +309,22 @@ def main():
         ev0.record(); ev1.record()
         torch.cuda.synchronize()
         ev0.elapsed_time(ev1)
+        barrier()   # N > 1: the ranks start their pre-roll together (and gloo's connections exist before the start barrier needs them)
         for i in range(args.preroll):
             step_all(i + 17)
         preroll_steps, preroll_s = args.preroll, 0.0
         if args.preroll_seconds > 0:
+            # N > 1: every rank's timed pre-roll ends preroll_seconds after its release from this barrier, in chunks of 8 launches, so the
+            # ranks reach the start barrier of the timed window within ~1 ms of each other.  A rank that waits there with an idle GPU for
+            # 5 ms runs its whole 20-launch window 4 % slow, for >= 10 ms 9 % slow (tools/idle_gap_probe.py, profiles/r04_idle_gap.txt),
+            # and the job's time is the slowest rank's.
             torch.cuda.synchronize()
+            barrier()
             t_pre = time.perf_counter()
-            while preroll_s < args.preroll_seconds:      # chunks of 256 launches, one synchronize per chunk
-                for i in range(256):
+            while preroll_s < args.preroll_seconds:
+                for i in range(8):
                     step_all(preroll_steps + i + 17)
-                preroll_steps += 256
+                preroll_steps += 8
                 torch.cuda.synchronize()
                 preroll_s = time.perf_counter() - t_pre
         n_done = torch.zeros((), device=dev)
