@@ -303,10 +303,11 @@ def warm_start_from_contacts(m: M.MoccaModel, bodies_of_links: np.ndarray, state
 
 def synthetic_dump(m: M.MoccaModel, joint_names: Sequence[str], fixed_children: Dict[int, float] = None,
                    base_axes_aligned: bool = False, link_names: Optional[Sequence[str]] = None, all_axes_aligned: bool = False,
-                   fixed_prefix: str = "jointfix_") -> Dict[str, np.ndarray]:
+                   fixed_prefix: str = "jointfix_", fixed_link_names: Optional[Dict[int, str]] = None) -> Dict[str, np.ndarray]:
     """The record tools/dump_pybullet_trace.py WOULD write for a Bullet multibody equal to blob `m` (tests: loader round trip).
     Inertial frames are the principal-axes frames at the COM, as Bullet reports them.  `fixed_children`: {body: fraction}
-    splits that fraction of the body's mass off into an extra FIXED link (exercises the merge of fixed links).
+    splits that fraction of the body's mass off into an extra FIXED link (exercises the merge of fixed links), named
+    `fixed_link_names[body]` if given (Laikago's toe links are such fixed children of the lower legs).
     `base_axes_aligned`: the base link's inertial frame keeps the link's axes (its inertia's off-diagonal terms are dropped), so that
     resetting Bullet's base to the identity orientation stands the robot up -- what an MJCF import whose root body carries no inertial
     rotation gives."""
@@ -346,7 +347,8 @@ def synthetic_dump(m: M.MoccaModel, joint_names: Sequence[str], fixed_children: 
                          link=link_names[b - 1] if link_names is not None else joint_names[b - 1] + "_link"))
         link_index[b] = len(rows) - 1
         if b in fixed_children:
-            rows.append(dict(name=f"{fixed_prefix}{b}", type=JOINT_FIXED, parent=link_index[b], L=fr[b], body=b, frac=fixed_children[b], link=f"fixed_part_{b}"))
+            rows.append(dict(name=f"{fixed_prefix}{b}", type=JOINT_FIXED, parent=link_index[b], L=fr[b], body=b, frac=fixed_children[b],
+                             link=(fixed_link_names or {}).get(b, f"fixed_part_{b}")))
     n = len(rows)
     out = dict(joint_names=np.array([r["name"] for r in rows]), link_names=np.array([r["link"] for r in rows]),
                joint_type=np.array([r["type"] for r in rows]), parent_index=np.array([r["parent"] for r in rows]),

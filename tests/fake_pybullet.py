@@ -347,6 +347,127 @@ def make_cassie_module():
     return p
 
 
+def make_laikago_module():
+    """The client tools/dump_pybullet_trace.py's Laikago section talks to: loadURDF(laikago_toes_limits.urdf, URDF_USE_SELF_COLLISION), twelve
+    revolute joints in URDF order, the four toe links as FIXED children of the lower legs (robots.py:559), 8 substeps per stepSimulation;
+    contacts of a toe sphere are reported on the toe link, those of a hull point on the link that carries it."""
+    tm = M.compile_laikago()
+    nj = tm.n_joints
+    toes = {int(tm.foot_body[f]): M.LAIKAGO_FEET[f] for f in range(4)}
+    rec = PD.synthetic_dump(tm, M.LAIKAGO_JOINTS, fixed_children={b: 0.02 for b in toes}, base_axes_aligned=True, fixed_prefix="jtoe_",
+                            link_names=[n.split("_2_")[0] for n in M.LAIKAGO_JOINTS], fixed_link_names=toes)
+    blob = PD.from_pybullet_dump(rec, tm, M.LAIKAGO_JOINTS)
+    bodies = PD.link_bodies(rec, tm, M.LAIKAGO_JOINTS)
+    names = [str(n) for n in rec["joint_names"]]
+    links = [str(n) for n in rec["link_names"]]
+    n_links = len(names)
+    hinge_links = {j: int(bodies[1 + j]) for j in range(n_links) if int(rec["joint_type"][j]) == PD.JOINT_REVOLUTE}
+    link_of_body = {0: -1, **{b: j for j, b in hinge_links.items()}}
+    toe_link = [links.index(n) for n in M.LAIKAGO_FEET]
+    o = Oracle(blob.to_bytes(), M.TASK_WALKER3D_CUSTOM, 1, "f64")
+    o.reset(seed=0)
+    st = {"forces": np.zeros(nj), "calls": []}
+    ROBOT, PLANE = 1, 0
+
+    p = types.ModuleType("pybullet")
+    p.DIRECT, p.GUI = 2, 1
+    p.POSITION_CONTROL, p.VELOCITY_CONTROL, p.TORQUE_CONTROL = 2, 0, 1
+    p.JOINT_REVOLUTE, p.JOINT_PRISMATIC, p.JOINT_FIXED = PD.JOINT_REVOLUTE, 1, PD.JOINT_FIXED
+    p.URDF_USE_SELF_COLLISION, p.URDF_USE_INERTIA_FROM_FILE = 8, 2
+    p.fake_blob, p.fake_record, p.fake_calls = blob, rec, st["calls"]
+
+    def state():
+        return o.get_state()[0]
+
+    def put(row):
+        o.set_state(row[None].copy())
+
+    def loadURDF(f, basePosition=None, baseOrientation=None, useFixedBase=False, flags=0, globalScaling=1.0):
+        assert f.endswith("robots/laikago/laikago_toes_limits.urdf") and not useFixedBase and list(baseOrientation) == [0, 0, 0, 1]
+        st["calls"].append(("loadURDF", flags))
+        return ROBOT
+
+    p.connect = lambda *a, **k: 0
+    p.setGravity = lambda *a: None
+    p.setDefaultContactERP = lambda v: st["calls"].append(("contactERP", v))
+    p.setPhysicsEngineParameter = lambda **k: st["calls"].append(("engine", k))
+    p.getPhysicsEngineParameters = lambda: {"fixedTimeStep": float(blob.dt) * int(blob.n_substeps), "numSubSteps": int(blob.n_substeps),
+                                            "numSolverIterations": int(blob.n_iters), "erp": float(blob.erp_noncontact),
+                                            "contactERP": float(blob.erp), "frictionERP": 0.2, "useRealTimeSimulation": 0,
+                                            "enableConeFriction": int(blob.friction_cone), "contactBreakingThreshold": float(blob.contact_margin)}
+    p.changeDynamics = lambda *a, **k: None
+    p.loadSDF = lambda f: (PLANE,)
+    p.loadURDF = loadURDF
+    p.getNumJoints = lambda body: n_links if body == ROBOT else 1
+    p.setJointMotorControl2 = lambda *a, **k: None
+    p.getCollisionShapeData = lambda body, link: []
+
+    def getJointInfo(body, j):
+        info = [None] * 17
+        info[0], info[1], info[2], info[6] = j, names[j].encode(), int(rec["joint_type"][j]), float(rec["joint_damping"][j])
+        info[8], info[9] = float(rec["joint_limits"][j][0]), float(rec["joint_limits"][j][1])
+        info[12], info[13] = links[j].encode(), tuple(rec["joint_axis"][j])
+        info[14], info[15], info[16] = tuple(rec["parent_frame_pos"][j]), tuple(rec["parent_frame_orn"][j]), int(rec["parent_index"][j])
+        return tuple(info)
+
+    def getDynamicsInfo(body, link):
+        k = link + 1
+        return (float(rec["mass"][k]), 1.0, tuple(rec["local_inertia_diag"][k]), tuple(rec["inertial_pos"][k]), tuple(rec["inertial_orn"][k]), 0.0, 0.0, 0.0, -1, -1)
+
+    def getJointStates(body, ids):
+        s = state()
+        return [(s[13 + hinge_links[j] - 1], s[13 + nj + hinge_links[j] - 1], (0,) * 6, 0.0) for j in ids]
+
+    def resetBasePositionAndOrientation(body, pos=None, orn=None, posObj=None, ornObj=None):
+        s = state().copy()
+        s[0:3], s[3:7] = (posObj if pos is None else pos), (ornObj if orn is None else orn)
+        s[13 + 2 * nj:] = 0
+        put(s)
+
+    def resetBaseVelocity(body, lin, ang):
+        s = state().copy()
+        s[7:10], s[10:13] = lin, ang
+        put(s)
+
+    def resetJointState(body, j, q, qd=0.0):
+        s = state().copy()
+        s[13 + hinge_links[j] - 1], s[13 + nj + hinge_links[j] - 1] = q, qd
+        put(s)
+
+    def setJointMotorControlArray(body, ids, mode, forces=None, **k):
+        if mode == p.TORQUE_CONTROL:
+            st["forces"] = np.zeros(nj)
+            for j, f in zip(ids, forces):
+                st["forces"][hinge_links[j] - 1] = f
+
+    def stepSimulation():
+        o.physics_substeps(0, st["forces"], int(blob.n_substeps))
+        st["forces"] = np.zeros(nj)
+
+    def getContactPoints(bodyA=None, linkIndexA=None):
+        lam, kind = o.last_lambda()
+        normals = lam[kind == 1]
+        base = state()[0:3]
+        out = []
+        for k, c in enumerate(o.last_contacts()):
+            slot = int(c[2])
+            foot = int(blob.g_foot[slot]) if slot >= 0 else -1         # Laikago blobs: terrain slot index == geom index (compile_laikago)
+            la = toe_link[foot] if foot >= 0 else link_of_body[int(c[0])]
+            if linkIndexA is not None and la != linkIndexA:
+                continue
+            bodyB, lb = (PLANE, -1) if int(c[1]) < 0 else (ROBOT, link_of_body[int(c[1])])
+            force = normals[k] / blob.dt if k < len(normals) else 0.0
+            out.append((0, ROBOT, bodyB, la, lb, tuple(c[3:6] + base), tuple(c[3:6] + base), tuple(c[6:9]), -float(c[9]), float(force)))
+        return out
+
+    p.getJointInfo, p.getDynamicsInfo = getJointInfo, getDynamicsInfo
+    p.getBasePositionAndOrientation = lambda body: (tuple(state()[0:3]), tuple(state()[3:7]))
+    p.getBaseVelocity = lambda body: (tuple(state()[7:10]), tuple(state()[10:13]))
+    p.getJointStates, p.resetBasePositionAndOrientation, p.resetBaseVelocity, p.resetJointState = getJointStates, resetBasePositionAndOrientation, resetBaseVelocity, resetJointState
+    p.setJointMotorControlArray, p.stepSimulation, p.getContactPoints = setJointMotorControlArray, stepSimulation, getContactPoints
+    return p
+
+
 def make_heightfield_module():
     """... and for the tool's height-field frame (main_heightfield): GEOM_HEIGHTFIELD + probe spheres + getClosestPoints, answered by the
     dense reference's exhaustive triangle search (tests/dense_reference.py heightfield_gap with a wide window)."""

@@ -25,7 +25,8 @@ assumptions left) and tests/test_pybullet_trace.py (the branches on the real fil
 "before" state goes through the f64 oracle and through the HIP stepper and the one-step error against Bullet's "after" is
 bounded by the north star's 1e-4; the free-running rollouts are replayed from free_states[0] and the joint-state error is
 reported at steps 1 / 10 / 100 / 1000.  Copy the file to tests/golden/pybullet_walker3d.npz.
-Usage: python tools/dump_pybullet_trace.py /path/to/mocca_envs/data 1000
+Usage: python tools/dump_pybullet_trace.py /path/to/mocca_envs/data 1000 [walker3d | cassie | laikago | heightfield]
+(sections of their own below: Cassie -> pybullet_cassie.npz, Laikago -> pybullet_laikago.npz, one height-field frame -> pybullet_heightfield.npz)
 """
 import sys
 
@@ -55,18 +56,11 @@ STEPPER_TERRAIN = np.array([[0.0, 0.0, 0.0, 0.0, 0.0, 0.0],
 STEPPER_START = [0.3, 0.0, 1.32]      # Walker3DStepperEnv.robot_init_position, env_locomotion.py:339
 
 
-def main(data_dir, n_steps):
-    import pybullet as p
-    p.connect(p.DIRECT)
-    p.setGravity(0, 0, -9.8)
-    p.setDefaultContactERP(0.9)
-    p.setPhysicsEngineParameter(fixedTimeStep=1 / 60, numSolverIterations=5, numSubSteps=4)
-    plane = p.loadSDF(f"{data_dir}/objects/misc/plane_stadium.sdf")[0]
-    p.changeDynamics(plane, -1, lateralFriction=0.8, restitution=0.5)
-    flags = p.MJCF_COLORS_FROM_FILE | p.URDF_USE_SELF_COLLISION | p.URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS
-    robot = p.loadMJCF(f"{data_dir}/robots/walker3d.xml", flags=flags)[0]
+def multibody_record(p, robot):
+    """What Bullet reports about the multibody it built: getJointInfo / getDynamicsInfo / getCollisionShapeData of every link, and the solver
+    parameters of the session (getPhysicsEngineParameters, where the build has it).  Returns (record, jinfo)."""
     nj = p.getNumJoints(robot)
-    out = {"n_links": np.array(nj), "format_version": np.array(2)}
+    out = {"n_links": np.array(nj)}
     jinfo = [p.getJointInfo(robot, j) for j in range(nj)]
     out["joint_names"] = np.array([ji[1].decode() for ji in jinfo])
     out["link_names"] = np.array([ji[12].decode() for ji in jinfo])
@@ -87,18 +81,34 @@ def main(data_dir, n_steps):
         out["restitution"] = np.array([d[5] for d in dyn])
         out["rolling_friction"] = np.array([d[6] for d in dyn])
         out["spinning_friction"] = np.array([d[7] for d in dyn])
+    shapes = []
+    for l in range(-1, nj):
+        for sh in p.getCollisionShapeData(robot, l):
+            shapes.append([l, sh[2], *sh[3], *sh[5], *sh[6]])
+    out["collision_shapes"] = np.array(shapes, dtype=np.float64).reshape(-1, 12)
     # the solver parameters this session ran with (the reference sets fixedTimeStep / numSolverIterations / numSubSteps and the contact
     # ERP only, bullet_utils.py:338-350; `erp` -- joint limits, point-to-point constraints -- stays at Bullet's default)
-    out["engine_contactERP"], out["engine_numSolverIterations"] = np.array(0.9), np.array(5.0)     # what this session set itself (above)
+    out["engine_contactERP"], out["engine_numSolverIterations"] = np.array(0.9), np.array(5.0)     # what every session of this tool sets itself
     if hasattr(p, "getPhysicsEngineParameters"):   # ... then whatever this build reports (older ones: a handful of keys; the loader warns about the rest)
         for k, v in p.getPhysicsEngineParameters().items():
             if isinstance(v, (int, float)):
                 out["engine_" + k] = np.array(float(v))
-    shapes = []
-    for l in range(-1, nj):
-        for s in p.getCollisionShapeData(robot, l):
-            shapes.append([l, s[2], *s[3], *s[5], *s[6]])
-    out["collision_shapes"] = np.array(shapes, dtype=np.float64)
+    return out, jinfo
+
+
+def main(data_dir, n_steps):
+    import pybullet as p
+    p.connect(p.DIRECT)
+    p.setGravity(0, 0, -9.8)
+    p.setDefaultContactERP(0.9)
+    p.setPhysicsEngineParameter(fixedTimeStep=1 / 60, numSolverIterations=5, numSubSteps=4)
+    plane = p.loadSDF(f"{data_dir}/objects/misc/plane_stadium.sdf")[0]
+    p.changeDynamics(plane, -1, lateralFriction=0.8, restitution=0.5)
+    flags = p.MJCF_COLORS_FROM_FILE | p.URDF_USE_SELF_COLLISION | p.URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS
+    robot = p.loadMJCF(f"{data_dir}/robots/walker3d.xml", flags=flags)[0]
+    nj = p.getNumJoints(robot)
+    out, jinfo = multibody_record(p, robot)
+    out["format_version"] = np.array(2)
     act = [j for j in range(nj) if not jinfo[j][1].decode().startswith(("jointfix", "ignore"))]
     for j in range(nj):
         p.setJointMotorControl2(robot, j, p.POSITION_CONTROL, positionGain=0.1, velocityGain=0.1, force=0)
@@ -263,34 +273,8 @@ def main_cassie(data_dir, n_steps, action_scale=0.1):
     for l in off:
         p.setCollisionFilterGroupMask(robot, l, 0, 0)
 
-    out = {"n_links": np.array(nj), "format_version": np.array(3), "robot": np.array("cassie")}
-    jinfo = [p.getJointInfo(robot, j) for j in range(nj)]                                # AFTER changeDynamics: [6] is the damping the env set
-    out["joint_names"] = np.array([ji[1].decode() for ji in jinfo])
-    out["link_names"] = np.array([ji[12].decode() for ji in jinfo])
-    out["joint_type"] = np.array([ji[2] for ji in jinfo])
-    out["joint_damping"] = np.array([ji[6] for ji in jinfo])
-    out["joint_limits"] = np.array([[ji[8], ji[9]] for ji in jinfo])
-    out["joint_axis"] = np.array([ji[13] for ji in jinfo])
-    out["parent_frame_pos"] = np.array([ji[14] for ji in jinfo])
-    out["parent_frame_orn"] = np.array([ji[15] for ji in jinfo])
-    out["parent_index"] = np.array([ji[16] for ji in jinfo])
-    dyn = [p.getDynamicsInfo(robot, l) for l in range(-1, nj)]
-    out["mass"] = np.array([d[0] for d in dyn])
-    out["lateral_friction"] = np.array([d[1] for d in dyn])
-    out["local_inertia_diag"] = np.array([d[2] for d in dyn])
-    out["inertial_pos"] = np.array([d[3] for d in dyn])
-    out["inertial_orn"] = np.array([d[4] for d in dyn])
-    shapes = []
-    for l in range(-1, nj):
-        for sh in p.getCollisionShapeData(robot, l):
-            shapes.append([l, sh[2], *sh[3], *sh[5], *sh[6]])
-    out["collision_shapes"] = np.array(shapes, dtype=np.float64).reshape(-1, 12)
-    # the solver parameters: what the session set itself, then whatever this pybullet build reports (the loader warns about the rest)
-    out["engine_contactERP"], out["engine_numSolverIterations"] = np.array(0.9), np.array(5.0)
-    if hasattr(p, "getPhysicsEngineParameters"):
-        for k, v in p.getPhysicsEngineParameters().items():
-            if isinstance(v, (int, float)):
-                out["engine_" + k] = np.array(float(v))
+    out, jinfo = multibody_record(p, robot)                                              # AFTER changeDynamics: [6] is the damping the env set
+    out["format_version"], out["robot"] = np.array(3), np.array("cassie")
     # createConstraint as called (pivots in the links' inertial frames) and, where the build has it, as Bullet stored it
     out["constraints"] = np.array([[la, lb, p.JOINT_POINT2POINT, *pa, *pb] for _, la, lb, pa, pb in cons], float)
     if hasattr(p, "getConstraintInfo"):
@@ -395,6 +379,99 @@ def main_cassie(data_dir, n_steps, action_scale=0.1):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
+# Laikago (LaikagoCustomEnv): python tools/dump_pybullet_trace.py /path/to/mocca_envs/data 1000 laikago  ->  pybullet_laikago.npz
+# Loaded as Laikago.initialize does it (robots.py:584-600: loadURDF(laikago_toes_limits.urdf, identity base orientation,
+# URDF_USE_SELF_COLLISION, no URDF_USE_INERTIA_FROM_FILE)), stepped with LaikagoCustomEnv's parameters (env_locomotion.py:856-864: control step
+# 1/60 s as 8 substeps of 1/480 s, start height 0.56, "running_start" = lower legs at -pi/6, robots.py:654-655), torques = 40 x action on the twelve
+# revolute joints in URDF order (robots.py:560-574, 618-626).  What the record pins that nothing else can: the inertia Bullet derives for
+# the mesh links (the file's inertia tensors are zero), the links' contact geometry as far as getContactPoints shows it (positions on the
+# robot), and `lk_body_contact`, the env's termination test (a non-foot link on the ground, env_locomotion.py:880-890).
+LAIKAGO_GAIN = 40.0
+LAIKAGO_FEET = ["toeFR", "toeFL", "toeRR", "toeRL"]                                      # robots.py:559
+LAIKAGO_START = [0.0, 0.0, 0.56]
+
+
+def main_laikago(data_dir, n_steps):
+    import pybullet as p
+    p.connect(p.DIRECT)
+    p.setGravity(0, 0, -9.8)
+    p.setDefaultContactERP(0.9)
+    p.setPhysicsEngineParameter(fixedTimeStep=1 / 60, numSolverIterations=5, numSubSteps=8)
+    plane = p.loadSDF(f"{data_dir}/objects/misc/plane_stadium.sdf")[0]
+    p.changeDynamics(plane, -1, lateralFriction=0.8, restitution=0.5)
+    robot = p.loadURDF(f"{data_dir}/robots/laikago/laikago_toes_limits.urdf", baseOrientation=[0, 0, 0, 1], flags=p.URDF_USE_SELF_COLLISION,
+                       useFixedBase=False)
+    out, jinfo = multibody_record(p, robot)
+    out["format_version"], out["robot"] = np.array(3), np.array("laikago")
+    nj = len(jinfo)
+    act = [j for j in range(nj) if jinfo[j][2] in (p.JOINT_REVOLUTE, p.JOINT_PRISMATIC)]
+    assert len(act) == 12, len(act)
+    out["ordered_joint_names"] = np.array([jinfo[j][1].decode() for j in act])
+    for j in range(nj):
+        p.setJointMotorControl2(robot, j, p.POSITION_CONTROL, positionGain=0.1, velocityGain=0.1, force=0)
+    links = [str(n) for n in out["link_names"]]
+    feet = [links.index(n) for n in LAIKAGO_FEET]
+    out["foot_links"] = np.array(feet)
+    q0 = np.zeros(12)
+    q0[[2, 5, 8, 11]] = -np.pi / 6
+
+    def snap():
+        pos, orn = p.getBasePositionAndOrientation(robot)
+        lin, ang = p.getBaseVelocity(robot)
+        js = p.getJointStates(robot, act)
+        return np.concatenate([pos, orn, lin, ang, [x[0] for x in js], [x[1] for x in js]])
+
+    def place():
+        p.resetBasePositionAndOrientation(robot, LAIKAGO_START, [0, 0, 0, 1])
+        p.resetBaseVelocity(robot, [0, 0, 0], [0, 0, 0])
+        for k, j in enumerate(act):
+            p.resetJointState(robot, j, float(q0[k]), 0.0)
+
+    def contacts():
+        """rows as in the walker section; feet flags; the env's termination test."""
+        rows = np.full((MAX_CP, 9), 0.0)
+        rows[:, 0] = -2
+        cps = p.getContactPoints(bodyA=robot)
+        for k, c in enumerate(cps[:MAX_CP]):
+            rows[k] = [c[3], -1 if c[2] == plane else c[4], *c[5], *c[7], c[9]]
+        on_ground = [c[3] for c in cps if c[2] == plane]
+        return rows, len(cps), [int(f in on_ground) for f in feet], int(any(l not in feet for l in on_ground))
+
+    # ---- teacher forcing
+    rng = np.random.default_rng(0)
+    place()
+    rec = {k: [] for k in ("before", "after", "torques", "feet_contact", "contact_points", "n_contact_points", "body_contact")}
+    for t in range(n_steps):
+        a = rng.uniform(-1, 1, 12)
+        rec["before"].append(snap())
+        p.setJointMotorControlArray(robot, act, p.TORQUE_CONTROL, forces=list(LAIKAGO_GAIN * a))
+        p.stepSimulation()
+        rec["after"].append(snap()); rec["torques"].append(LAIKAGO_GAIN * a)
+        cp, n, fc, bc = contacts()
+        rec["contact_points"].append(cp); rec["n_contact_points"].append(n); rec["feet_contact"].append(fc); rec["body_contact"].append(bc)
+        if bc or rec["after"][-1][2] < 0.2:       # the episode would have ended here: restart
+            place()
+    for k, v in rec.items():
+        out["lk_" + k] = np.array(v)
+    # ---- free running from the reset pose, no restart
+    for tag, scale in (("lkfree", 1.0), ("lkfree03", 0.3)):
+        rng = np.random.default_rng(1)
+        place()
+        states, actions, cpts, bcs = [snap()], [], [], []
+        for t in range(n_steps):
+            a = scale * rng.uniform(-1, 1, 12)
+            p.setJointMotorControlArray(robot, act, p.TORQUE_CONTROL, forces=list(LAIKAGO_GAIN * a))
+            p.stepSimulation()
+            states.append(snap()); actions.append(a)
+            cp, _, _, bc = contacts()
+            cpts.append(cp); bcs.append(bc)
+        out.update({f"{tag}_states": np.array(states), f"{tag}_actions": np.array(actions), f"{tag}_contact_points": np.array(cpts),
+                    f"{tag}_body_contact": np.array(bcs)})
+    np.savez_compressed("pybullet_laikago.npz", **out)
+    print("wrote pybullet_laikago.npz")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
 # One frame of the planner envs' terrain: python tools/dump_pybullet_trace.py /path/to/mocca_envs/data 0 heightfield -> pybullet_heightfield.npz
 # HeightField.reload (bullet_objects.py:369-393): createCollisionShape(GEOM_HEIGHTFIELD, meshScale [1/scale, 1/scale, 1]), body at the
 # mid height; a sphere of each of the walkers' contact radii is lowered onto a grid of probe points and Bullet's closest point is recorded.
@@ -433,6 +510,8 @@ if __name__ == "__main__":
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     if what == "cassie":
         main_cassie(sys.argv[1], n)
+    elif what == "laikago":
+        main_laikago(sys.argv[1], n)
     elif what == "heightfield":
         main_heightfield(sys.argv[1])
     else:
