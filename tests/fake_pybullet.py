@@ -17,8 +17,15 @@ from oracle.oracle import Oracle
 NJ = 21
 
 
-def make_module(fixed_children=None):
-    tm = M.compile_walker3d()
+_MJCF = {"walker3d": (M.compile_walker3d, lambda: M.compile_walker3d(M.TASK_WALKER3D_STEPPER), "walker3d.xml"),
+         "child3d": (M.compile_child3d, None, "child3d.xml"),            # Child3DCustomEnv only: no stepping-stone world
+         "mike": (M.compile_mike, M.compile_mike, "mike.xml")}           # MikeStepperEnv: the same blob serves both worlds of the fake
+
+
+def make_module(fixed_children=None, robot="walker3d"):
+    """`robot`: walker3d | child3d | mike -- the three MJCF walkers that share the tree and the joint names (tools/dump_pybullet_trace.py MJCF_ROBOTS)."""
+    flat_builder, stepper_builder, xml = _MJCF[robot]
+    tm = flat_builder()
     rec = PD.synthetic_dump(tm, M.WALKER3D_JOINT_NAMES, fixed_children=fixed_children or {2: 0.25}, base_axes_aligned=True,
                             link_names=M.WALKER3D_LINK_NAMES)
     blob = PD.from_pybullet_dump(rec, tm, M.WALKER3D_JOINT_NAMES)       # "Bullet's multibody": what the fake simulates
@@ -44,8 +51,8 @@ def make_module(fixed_children=None):
     p.POSITION_CONTROL, p.VELOCITY_CONTROL, p.TORQUE_CONTROL = 2, 0, 1
     p.MJCF_COLORS_FROM_FILE, p.URDF_USE_SELF_COLLISION, p.URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS = 512, 8, 16
     p.fake_blob, p.fake_record = blob, rec
-    stepper_blob = PD.from_pybullet_dump(rec, M.compile_walker3d(M.TASK_WALKER3D_STEPPER), M.WALKER3D_JOINT_NAMES)
-    p.fake_stepper_blob = stepper_blob
+    stepper_blob = PD.from_pybullet_dump(rec, stepper_builder(), M.WALKER3D_JOINT_NAMES) if stepper_builder else None
+    p.fake_stepper_blob, p.fake_calls = stepper_blob, []
 
     def quat_from_euler(e):
         r, pt, y = e
@@ -92,9 +99,14 @@ def make_module(fixed_children=None):
                                             "numSolverIterations": int(blob.n_iters), "erp": float(blob.erp_noncontact),
                                             "contactERP": float(blob.erp), "frictionERP": 0.2, "useRealTimeSimulation": 0,
                                             "enableConeFriction": int(blob.friction_cone), "contactBreakingThreshold": float(blob.contact_margin)}
-    p.changeDynamics = lambda *a, **k: None
+    p.changeDynamics = lambda *a, **k: p.fake_calls.append(("changeDynamics", a, k))
+
+    def loadMJCF(f, flags=0):
+        assert f.endswith("robots/" + xml), f
+        return (ROBOT,)
+
     p.loadSDF = lambda f: (PLANE,)
-    p.loadMJCF = lambda f, flags=0: (ROBOT,)
+    p.loadMJCF = loadMJCF
     p.getNumJoints = lambda body: n_links if body == ROBOT else 1
     p.setJointMotorControl2 = lambda *a, **k: None
     p.getCollisionShapeData = lambda body, link: []

@@ -25,7 +25,7 @@ assumptions left) and tests/test_pybullet_trace.py (the branches on the real fil
 "before" state goes through the f64 oracle and through the HIP stepper and the one-step error against Bullet's "after" is
 bounded by the north star's 1e-4; the free-running rollouts are replayed from free_states[0] and the joint-state error is
 reported at steps 1 / 10 / 100 / 1000.  Copy the file to tests/golden/pybullet_walker3d.npz.
-Usage: python tools/dump_pybullet_trace.py /path/to/mocca_envs/data 1000 [walker3d | cassie | laikago | heightfield]
+Usage: python tools/dump_pybullet_trace.py /path/to/mocca_envs/data 1000 [walker3d | child3d | mike | cassie | laikago | heightfield]
 (sections of their own below: Cassie -> pybullet_cassie.npz, Laikago -> pybullet_laikago.npz, one height-field frame -> pybullet_heightfield.npz)
 """
 import sys
@@ -54,6 +54,33 @@ STEPPER_TERRAIN = np.array([[0.0, 0.0, 0.0, 0.0, 0.0, 0.0],
                             [0.75, 0.0, 0.0, 0.2, 0.15, 0.0],
                             [1.55, 0.15, 0.12, -0.25, 0.0, -0.2]])
 STEPPER_START = [0.3, 0.0, 1.32]      # Walker3DStepperEnv.robot_init_position, env_locomotion.py:339
+
+
+def crawl():
+    """Walker3D.set_base_pose("crawl"), robots.py:309-318 (Child3DCustomEnv, env_locomotion.py:324); the base is pitched 90 degrees."""
+    q = np.zeros(21)
+    q[[13, 17]] = np.pi / 2
+    q[[14, 18]] = np.pi / 2
+    q[[16, 20]] = np.pi / 3
+    q[[5, 10]] = -np.pi / 2
+    q[[6, 11]] = -120 * np.pi / 180
+    q[[7, 12]] = -20 * np.pi / 180
+    return q
+
+
+MIKE_GAINS = np.array([0, 0, 0, 80, 60, 100, 90, 60, 80, 60, 100, 90, 60, 30, 30, 25, 30, 30, 30, 25, 30], float)   # robots.py:477-499, base_power 1
+# The MJCF walkers that share Walker3D's tree and joint names (robots.py:326-335 Child3D, :474-510 Mike).  `python tools/dump_pybullet_trace.py
+# <data> 1000 child3d | mike` -> pybullet_child3d.npz / pybullet_mike.npz with the same keys as the Walker3D file; Child3D has no stepping-stone
+# env (flat sections only), Mike no flat one (MikeStepperEnv: planks only, no ground plane -- its record holds the stp_* keys only).
+MJCF_ROBOTS = {
+    "walker3d": dict(xml="walker3d.xml", gains=GAINS, start=[0, 0, 1.32], orn=[0, 0, 0, 1], tf_pose=lambda: np.zeros(21), pose=running_start,
+                     fallen=0.5, flat=True, planks=True, plank_start=STEPPER_START, out="pybullet_walker3d.npz"),
+    "child3d": dict(xml="child3d.xml", gains=0.4 * GAINS, start=[0, 0, 0.38], orn=[0, np.sqrt(0.5), 0, np.sqrt(0.5)], tf_pose=crawl, pose=crawl,
+                    fallen=0.1, flat=True, planks=False, out="pybullet_child3d.npz"),                    # robots.py:328,335; env_locomotion.py:320-324
+    "mike": dict(xml="mike.xml", gains=MIKE_GAINS, start=[0.3, 0, 1.0], orn=[0, 0, 0, 1], tf_pose=running_start, pose=running_start,
+                 fallen=0.5, flat=False, planks=True, plank_start=[0.3, 0.0, 1.0], link_mass={"waist": 8.0},   # robots.py:507-510; env_locomotion.py:845
+                 out="pybullet_mike.npz"),
+}
 
 
 def multibody_record(p, robot):
@@ -96,8 +123,10 @@ def multibody_record(p, robot):
     return out, jinfo
 
 
-def main(data_dir, n_steps):
+def main(data_dir, n_steps, robot_name="walker3d"):
     import pybullet as p
+    spec = MJCF_ROBOTS[robot_name]
+    gains = np.asarray(spec["gains"], float)
     p.connect(p.DIRECT)
     p.setGravity(0, 0, -9.8)
     p.setDefaultContactERP(0.9)
@@ -105,10 +134,13 @@ def main(data_dir, n_steps):
     plane = p.loadSDF(f"{data_dir}/objects/misc/plane_stadium.sdf")[0]
     p.changeDynamics(plane, -1, lateralFriction=0.8, restitution=0.5)
     flags = p.MJCF_COLORS_FROM_FILE | p.URDF_USE_SELF_COLLISION | p.URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS
-    robot = p.loadMJCF(f"{data_dir}/robots/walker3d.xml", flags=flags)[0]
+    robot = p.loadMJCF(f"{data_dir}/robots/{spec['xml']}", flags=flags)[0]
     nj = p.getNumJoints(robot)
+    for name, mass in spec.get("link_mass", {}).items():          # Mike.load_robot_model: changeDynamics(waist, mass=8) BEFORE anything is recorded
+        idx = [p.getJointInfo(robot, j)[12].decode() for j in range(nj)].index(name)
+        p.changeDynamics(robot, idx, mass=mass)
     out, jinfo = multibody_record(p, robot)
-    out["format_version"] = np.array(2)
+    out["format_version"], out["robot"] = np.array(2), np.array(robot_name)
     act = [j for j in range(nj) if not jinfo[j][1].decode().startswith(("jointfix", "ignore"))]
     for j in range(nj):
         p.setJointMotorControl2(robot, j, p.POSITION_CONTROL, positionGain=0.1, velocityGain=0.1, force=0)
@@ -133,90 +165,92 @@ def main(data_dir, n_steps):
         return rows, len(cps)
 
     def place(q):
-        p.resetBasePositionAndOrientation(robot, [0, 0, 1.32], [0, 0, 0, 1])
+        p.resetBasePositionAndOrientation(robot, spec["start"], spec["orn"])
         p.resetBaseVelocity(robot, [0, 0, 0], [0, 0, 0])
         for k, j in enumerate(act):
             p.resetJointState(robot, j, float(q[k]), 0.0)
 
-    # ---- teacher-forcing trace
-    rng = np.random.default_rng(0)
-    place(np.zeros(21))
-    before, after, torques, contacts, feet_pos, cpts, ncp = [], [], [], [], [], [], []
-    for t in range(n_steps):
-        a = rng.uniform(-1, 1, 21)
-        before.append(snap())
-        p.setJointMotorControlArray(robot, act, p.TORQUE_CONTROL, forces=list(GAINS * a))
-        p.stepSimulation()
-        after.append(snap()); torques.append(GAINS * a)
-        contacts.append([int(any(c[2] == plane for c in p.getContactPoints(bodyA=robot, linkIndexA=f))) for f in feet])
-        feet_pos.append([p.getLinkState(robot, f)[0] for f in feet])
-        cp, n = contact_points()
-        cpts.append(cp); ncp.append(n)
-        if after[-1][2] < 0.5:  # fallen: restart from the initial pose
-            place(np.zeros(21))
-    out.update(before=np.array(before), after=np.array(after), torques=np.array(torques), feet_contact=np.array(contacts),
-               feet_pos=np.array(feet_pos), contact_points=np.array(cpts), n_contact_points=np.array(ncp))
-
-    # ---- free-running rollouts: no restart, whatever happens to the robot
-    for tag, scale in (("free", 1.0), ("free03", 0.3)):
+    if spec["flat"]:
+        # ---- teacher-forcing trace
         rng = np.random.default_rng(0)
-        place(running_start())
-        states, actions, cpts, fc = [snap()], [], [], []
+        place(spec["tf_pose"]())
+        before, after, torques, contacts, feet_pos, cpts, ncp = [], [], [], [], [], [], []
         for t in range(n_steps):
-            a = scale * rng.uniform(-1, 1, 21)
-            p.setJointMotorControlArray(robot, act, p.TORQUE_CONTROL, forces=list(GAINS * a))
+            a = rng.uniform(-1, 1, 21)
+            before.append(snap())
+            p.setJointMotorControlArray(robot, act, p.TORQUE_CONTROL, forces=list(gains * a))
             p.stepSimulation()
-            states.append(snap()); actions.append(a)
-            cpts.append(contact_points()[0])
-            fc.append([int(any(c[2] == plane for c in p.getContactPoints(bodyA=robot, linkIndexA=f))) for f in feet])
-        out.update({f"{tag}_states": np.array(states), f"{tag}_actions": np.array(actions), f"{tag}_contact_points": np.array(cpts),
-                    f"{tag}_feet_contact": np.array(fc)})
-    # ---- stepping stones: no ground plane, three planks placed like Walker3DStepperEnv.set_step_state
-    p.removeBody(plane)
-    scale = 2 * 0.25                                              # LargePlank(bc, step_radius): globalScaling = 2 * width
-    planks, offset = [], None
-    for k in range(3):
-        pid = p.loadURDF(f"{data_dir}/objects/steps/plank_large.urdf", basePosition=[0, 0, 0], baseOrientation=[0, 0, 0, 1],
-                         useFixedBase=False, globalScaling=scale)
-        offset = np.array(p.getBasePositionAndOrientation(pid)[0])
-        for link_id in range(-1, p.getNumJoints(pid)):
-            p.changeDynamics(pid, link_id, lateralFriction=1.0, restitution=0.1, contactStiffness=30000, contactDamping=1000)
-        x, y, z, phi, xt, yt = STEPPER_TERRAIN[k]
-        p.resetBasePositionAndOrientation(pid, posObj=list(np.array([x, y, z]) + offset), ornObj=p.getQuaternionFromEuler([xt, yt, phi]))
-        planks.append(pid)
+            after.append(snap()); torques.append(gains * a)
+            contacts.append([int(any(c[2] == plane for c in p.getContactPoints(bodyA=robot, linkIndexA=f))) for f in feet])
+            feet_pos.append([p.getLinkState(robot, f)[0] for f in feet])
+            cp, n = contact_points()
+            cpts.append(cp); ncp.append(n)
+            if after[-1][2] < spec["fallen"]:  # fallen: restart from the initial pose
+                place(spec["tf_pose"]())
+        out.update(before=np.array(before), after=np.array(after), torques=np.array(torques), feet_contact=np.array(contacts),
+                   feet_pos=np.array(feet_pos), contact_points=np.array(cpts), n_contact_points=np.array(ncp))
 
-    def contact_points_planks():
-        rows = np.full((MAX_CP, 9), 0.0)
-        rows[:, 0] = -2
-        cps = p.getContactPoints(bodyA=robot)
-        for k, c in enumerate(cps[:MAX_CP]):
-            other = -1 if c[2] in planks else c[4]
-            rows[k] = [c[3], other, *c[5], *c[7], c[9]]
-        return rows, len(cps)
+        # ---- free-running rollouts: no restart, whatever happens to the robot
+        for tag, scale in (("free", 1.0), ("free03", 0.3)):
+            rng = np.random.default_rng(0)
+            place(spec["pose"]())
+            states, actions, cpts, fc = [snap()], [], [], []
+            for t in range(n_steps):
+                a = scale * rng.uniform(-1, 1, 21)
+                p.setJointMotorControlArray(robot, act, p.TORQUE_CONTROL, forces=list(gains * a))
+                p.stepSimulation()
+                states.append(snap()); actions.append(a)
+                cpts.append(contact_points()[0])
+                fc.append([int(any(c[2] == plane for c in p.getContactPoints(bodyA=robot, linkIndexA=f))) for f in feet])
+            out.update({f"{tag}_states": np.array(states), f"{tag}_actions": np.array(actions), f"{tag}_contact_points": np.array(cpts),
+                        f"{tag}_feet_contact": np.array(fc)})
+    if spec["planks"]:
+        # ---- stepping stones: no ground plane, three planks placed like Walker3DStepperEnv.set_step_state
+        p.removeBody(plane)
+        scale = 2 * 0.25                                              # LargePlank(bc, step_radius): globalScaling = 2 * width
+        planks, offset = [], None
+        for k in range(3):
+            pid = p.loadURDF(f"{data_dir}/objects/steps/plank_large.urdf", basePosition=[0, 0, 0], baseOrientation=[0, 0, 0, 1],
+                             useFixedBase=False, globalScaling=scale)
+            offset = np.array(p.getBasePositionAndOrientation(pid)[0])
+            for link_id in range(-1, p.getNumJoints(pid)):
+                p.changeDynamics(pid, link_id, lateralFriction=1.0, restitution=0.1, contactStiffness=30000, contactDamping=1000)
+            x, y, z, phi, xt, yt = STEPPER_TERRAIN[k]
+            p.resetBasePositionAndOrientation(pid, posObj=list(np.array([x, y, z]) + offset), ornObj=p.getQuaternionFromEuler([xt, yt, phi]))
+            planks.append(pid)
 
-    def place_stepper(q):
-        p.resetBasePositionAndOrientation(robot, STEPPER_START, [0, 0, 0, 1])
-        p.resetBaseVelocity(robot, [0, 0, 0], [0, 0, 0])
-        for k, j in enumerate(act):
-            p.resetJointState(robot, j, float(q[k]), 0.0)
+        def contact_points_planks():
+            rows = np.full((MAX_CP, 9), 0.0)
+            rows[:, 0] = -2
+            cps = p.getContactPoints(bodyA=robot)
+            for k, c in enumerate(cps[:MAX_CP]):
+                other = -1 if c[2] in planks else c[4]
+                rows[k] = [c[3], other, *c[5], *c[7], c[9]]
+            return rows, len(cps)
 
-    rng = np.random.default_rng(1)
-    place_stepper(running_start())
-    before, after, torques, cpts, fc = [], [], [], [], []
-    for t in range(n_steps):
-        a = 0.5 * rng.uniform(-1, 1, 21)                          # gentler than U(-1, 1): the robot spends more steps on the planks
-        before.append(snap())
-        p.setJointMotorControlArray(robot, act, p.TORQUE_CONTROL, forces=list(GAINS * a))
-        p.stepSimulation()
-        after.append(snap()); torques.append(GAINS * a)
-        cpts.append(contact_points_planks()[0])
-        fc.append([int(any(c[2] in planks for c in p.getContactPoints(bodyA=robot, linkIndexA=f))) for f in feet])
-        if after[-1][2] < 0.5 or abs(after[-1][1]) > 2.0 or after[-1][0] > 2.2:     # fallen or walked off the planks: restart
-            place_stepper(running_start())
-    out.update(stp_before=np.array(before), stp_after=np.array(after), stp_torques=np.array(torques), stp_contact_points=np.array(cpts),
-               stp_feet_contact=np.array(fc), stp_terrain=STEPPER_TERRAIN, stp_pos_offset=offset, stp_plank_scale=np.array(scale))
-    np.savez_compressed("pybullet_walker3d.npz", **out)
-    print("wrote pybullet_walker3d.npz")
+        def place_stepper(q):
+            p.resetBasePositionAndOrientation(robot, spec["plank_start"], [0, 0, 0, 1])
+            p.resetBaseVelocity(robot, [0, 0, 0], [0, 0, 0])
+            for k, j in enumerate(act):
+                p.resetJointState(robot, j, float(q[k]), 0.0)
+
+        rng = np.random.default_rng(1)
+        place_stepper(spec["pose"]())
+        before, after, torques, cpts, fc = [], [], [], [], []
+        for t in range(n_steps):
+            a = 0.5 * rng.uniform(-1, 1, 21)                          # gentler than U(-1, 1): the robot spends more steps on the planks
+            before.append(snap())
+            p.setJointMotorControlArray(robot, act, p.TORQUE_CONTROL, forces=list(gains * a))
+            p.stepSimulation()
+            after.append(snap()); torques.append(gains * a)
+            cpts.append(contact_points_planks()[0])
+            fc.append([int(any(c[2] in planks for c in p.getContactPoints(bodyA=robot, linkIndexA=f))) for f in feet])
+            if after[-1][2] < spec["fallen"] or abs(after[-1][1]) > 2.0 or after[-1][0] > 2.2:     # fallen or walked off the planks: restart
+                place_stepper(spec["pose"]())
+        out.update(stp_before=np.array(before), stp_after=np.array(after), stp_torques=np.array(torques), stp_contact_points=np.array(cpts),
+                   stp_feet_contact=np.array(fc), stp_terrain=STEPPER_TERRAIN, stp_pos_offset=offset, stp_plank_scale=np.array(scale))
+    np.savez_compressed(spec["out"], **out)
+    print("wrote " + spec["out"])
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
@@ -510,6 +544,8 @@ if __name__ == "__main__":
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     if what == "cassie":
         main_cassie(sys.argv[1], n)
+    elif what in ("child3d", "mike"):
+        main(sys.argv[1], n, what)
     elif what == "laikago":
         main_laikago(sys.argv[1], n)
     elif what == "heightfield":
