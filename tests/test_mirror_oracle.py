@@ -1,0 +1,338 @@
+"""Mirror symmetry of the DYNAMICS on the CPU oracle (the HIP path: tests/test_gpu_mirror.py).
+
+The one physics statement the reference itself makes: exchanging the right / left index sets and negating the `neg` set is a symmetry
+of the robot -- `WalkerBase.reset` mirrors start poses with it (/root/reference/mocca_envs/robots.py:182-188, sets :282-290, Laikago
+:578-580), `get_mirror_indices()` publishes it to SymmetricRL (env_locomotion.py:224-282), Cassie's `mirror_indices` to its trainers
+(env_cassie.py:536-571).  Kernel, oracle and dense reference all read ONE compiled blob, so a left / right error of `compile_model`
+(frames, inertia composition, axis signs) is invisible to every HIP-vs-oracle test; it is visible here:
+
+  T1  reflected world -- `reflect_model` builds the mirror-image robot (same joint order): step(reflect(model), S s, a) == S step(model, s, a).
+      A law of mechanics; rows keep their order, IEEE arithmetic is symmetric in sign, so it holds BIT FOR BIT in every contact set.
+  T2  the reference's claim on the compiled blob -- step(model, M s, M a) == M step(model, s, a) with M from the blob's index sets: exact
+      (rounding) in free flight and with a single row (one limit or one contact); with more rows Gauss-Seidel visits the mirrored rows in
+      another order and 5 sweeps do not converge, so those strata are bounded statistically (their MEDIAN is still rounding-sized).
+  T3  the blob itself: reflect(relabel(model)) == model field by field.
+Asset asymmetries of the reference's own files show up as numbers, not as failures: Laikago's URDF (hip offsets 53.6 / 55.9 mm, the
+inertial frame's rpy -1.57) and Cassie's (pelvis inertia products, unequal toe meshes, a nominal pose that is not mirror symmetric).
+"""
+import numpy as np
+import pytest
+
+from mocca_envs_amd import model as M
+from mocca_envs_amd.vec_env import TASKS, compile_model_for
+
+from mirror_util import IndexMirror, obs_mirror, reflect_model, reflect_state, reflect_terrain, relabel_model
+
+CASSIE_MIRROR = dict(right=range(9, 18), left=range(0, 9), neg=[],     # blob joint order: left leg 0..8 (7 joints + 2 rod hinges), right leg 9..17
+                     extra_neg=[0, 1, 8, 9, 10, 17])                     # hip abduction, hip rotation (sideneg_*, env_cassie.py:554-571), rod y
+
+
+def one_substep_model(env_id, n_iters=None, pd_off=False):
+    m = compile_model_for(env_id)
+    m.n_substeps = 1
+    if n_iters:
+        m.n_iters = n_iters
+    if TASKS[env_id] == M.TASK_CASSIE:
+        m.n_llc = 1
+        if pd_off:
+            for k in range(M.MAX_CTRL):
+                m.ctrl_kp[k] = m.ctrl_kd[k] = 0.0
+    return m
+
+
+def _oracles(blob_a, blob_b, env_id, n, prec):
+    from oracle.oracle import Oracle, PARAM_CURRICULUM, PARAM_RANDOM_POSE
+    task = TASKS[env_id]
+    a, b = Oracle(blob_a, task, n, prec), Oracle(blob_b, task, n, prec)
+    for o in (a, b):
+        if "Laikago" in env_id:
+            o.set_param(PARAM_RANDOM_POSE, 0)
+        if task == M.TASK_WALKER3D_STEPPER:
+            o.set_param(PARAM_CURRICULUM, 9)
+    a.reset(seed=3); b.reset(seed=3)
+    return a, b
+
+
+def _strata(dbg):
+    """0: free flight, 1: one limit row or one contact, 2: more (MOCCA_DBG words 1 = limit rows, 2 = contacts)."""
+    k = dbg[:, 1] + dbg[:, 2]
+    return np.minimum(k, 2)
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("env_id", ["Walker3DCustomEnv-v0", "Walker3DStepperEnv-v0", "MikeStepperEnv-v0", "Child3DCustomEnv-v0",
+                                    "LaikagoCustomEnv-v0", "LaikagoStepperEnv-v0", "CassieEnv-v0", "Cassie2DEnv-v0", "Crab2DCustomEnv-v0"])
+def test_reflected_world_evolves_like_the_reflection(env_id, prec):
+    """T1, every contact configuration, bit for bit: state, active set, solver clamp signature, reward, done."""
+    task = TASKS[env_id]
+    m = one_substep_model(env_id)
+    nj, n = m.n_joints, 128
+    A, B = _oracles(m.to_bytes(), reflect_model(m).to_bytes(), env_id, n, prec)
+    rng = np.random.default_rng(1)
+    nd = 13 + 2 * nj
+    rows_seen, multi = 0, 0
+    for t in range(120):
+        s, tk = A.get_state(), A.get_task()
+        tk[:, 1] *= -1                                   # walk target y
+        B.set_state(reflect_state(s, nj)); B.set_task(tk)
+        if task == M.TASK_WALKER3D_STEPPER:
+            B.set_terrain(reflect_terrain(A.get_terrain()))
+        a = rng.uniform(-1, 1, (n, A.act_dim)).astype(np.float32)
+        _, ra, da, _ = A.step(a)
+        _, rb, db, _ = B.step(a)
+        sa, sb = A.get_state(), B.get_state()
+        fin = np.isfinite(sa).all(axis=1)
+        np.testing.assert_array_equal(reflect_state(sa, nj)[fin][:, :nd], sb[fin][:, :nd])
+        np.testing.assert_array_equal(A.get_debug()[fin][:, :12], B.get_debug()[fin][:, :12])
+        np.testing.assert_array_equal(da, db)
+        np.testing.assert_array_equal(ra[fin], rb[fin])
+        rows_seen = max(rows_seen, int(A.get_debug()[:, 0].max()))
+        multi += int((_strata(A.get_debug()) == 2).sum())
+        if t % 10 == 9:
+            A.reset(seed=3, mask=(da != 0).astype(np.uint8))
+    assert rows_seen >= (6 if ("Laikago" in env_id or "Cassie" in env_id) else 12) and multi > 1000, "the sample must contain contact-rich substeps"
+
+
+@pytest.mark.parametrize("env_id,kind", [("Walker3DCustomEnv-v0", "axis"), ("CassieEnv-v0", "inertia")])
+def test_the_reflection_test_catches_a_wrong_handedness(env_id, kind):
+    """Negative control of T1: a 'mirror image' whose hinge axes are reflected like points (S a instead of -S a), or whose inertia products
+    keep their signs (Cassie's URDF inertias have them; the walkers' capsule bodies do not), is NOT the mirror-image robot -- the test
+    above must be able to tell."""
+    m = one_substep_model(env_id, pd_off=True)
+    nj, n = m.n_joints, 64
+    bad = reflect_model(m)
+    if kind == "axis":
+        for b in range(1, m.n_bodies):
+            for k in range(3):
+                bad.jaxis[b][k] = -bad.jaxis[b][k]
+    else:
+        assert max(abs(m.inertia[b][3]) for b in range(m.n_bodies)) > 1e-4
+        for b in range(m.n_bodies):
+            bad.inertia[b][3], bad.inertia[b][5] = m.inertia[b][3], m.inertia[b][5]
+    A, B = _oracles(m.to_bytes(), bad.to_bytes(), env_id, n, "f64")
+    s = A.get_state()
+    s[:, 2] += 1.0                                                      # free flight: no contact can mask the difference
+    s[:, 13 + nj:13 + 2 * nj] = np.random.default_rng(0).uniform(-3, 3, (n, nj))
+    s[:, 10:13] = np.random.default_rng(2).uniform(-3, 3, (n, 3))
+    A.set_state(s); B.set_state(reflect_state(s, nj))
+    a = np.random.default_rng(1).uniform(-1, 1, (n, A.act_dim)).astype(np.float32)
+    A.step(a); B.step(a)
+    err = np.abs(reflect_state(A.get_state(), nj) - B.get_state()).max()
+    assert err > 1e-4, err
+
+
+def _run_index_mirror(env_id, m, mir, prec="f64", n=256, steps=160, act_mirror=None, lift=0.0, shake=0.0, stepper_terrain=True):
+    """step(model, M s, M a) against M step(model, s, a) on `steps` teacher-forced substeps; returns per-stratum error arrays in units of
+    (1 + |x|), the obs / reward / done comparison of the strata that must be exact, and the row counts."""
+    task = TASKS[env_id]
+    nj = m.n_joints
+    A, B = _oracles(m.to_bytes(), m.to_bytes(), env_id, n, prec)
+    rng = np.random.default_rng(1)
+    nd = 13 + 2 * nj
+    err = {0: [], 1: [], 2: []}
+    obs_err, rew_err, done_diff = [], [], 0
+    operm = osign = None
+    if task in (M.TASK_WALKER3D_CUSTOM,) and m.n_mirror_side and mir.plane == "xz":
+        from mocca_envs_amd import host_logic as H
+        operm, osign = obs_mirror(H.mirror_indices(m, stepper=False), A.obs_dim)
+    for t in range(steps):
+        s, tk = A.get_state(), A.get_task()
+        if lift or shake:
+            s[:, 2] += lift
+            s[:, 13:13 + nj] += shake * rng.uniform(-1, 1, (n, nj))
+            s[:, 13 + nj:13 + 2 * nj] += 10 * shake * rng.uniform(-1, 1, (n, nj))
+            s[:, 7:13] += 3 * shake * rng.uniform(-1, 1, (n, 6))
+            A.set_state(s)
+        B.set_state(mir.state(s)); B.set_task(mir.task(tk))
+        if task == M.TASK_WALKER3D_STEPPER and stepper_terrain:
+            B.set_terrain(reflect_terrain(A.get_terrain()))
+        a = rng.uniform(-1, 1, (n, A.act_dim)).astype(np.float32)
+        oa, ra, da, _ = A.step(a)
+        ob, rb, db, _ = B.step(mir.action(a) if act_mirror is None else act_mirror(a))
+        sa, sb = A.get_state(), B.get_state()
+        fin = np.isfinite(sa).all(axis=1) & np.isfinite(sb).all(axis=1)
+        e = (np.abs(mir.state(sa)[:, :nd] - sb[:, :nd]) / (1.0 + np.abs(sb[:, :nd]))).max(axis=1)
+        st = _strata(A.get_debug())
+        for k in err:
+            err[k].append(e[fin & (st == k)])
+        if operm is not None:
+            ex = fin & (st <= 1)
+            d = np.abs(oa[ex][:, operm] * osign - ob[ex])
+            d = np.minimum(d, np.abs(d - 2 * np.pi))      # a planar walker upside down: roll / yaw = +pi on one side, -pi on the other
+            obs_err.append(d.max(initial=0.0))
+            rew_err.append(np.abs(ra[ex] - rb[ex]).max(initial=0.0))
+            done_diff += int((da[ex] != db[ex]).sum())
+        if t % 10 == 9:
+            A.reset(seed=3, mask=(da != 0).astype(np.uint8))
+    return {k: np.concatenate(v) for k, v in err.items()}, (max(obs_err, default=0.0), max(rew_err, default=0.0), done_diff)
+
+
+@pytest.mark.parametrize("env_id", ["Walker3DCustomEnv-v0", "Child3DCustomEnv-v0", "MikeStepperEnv-v0", "Walker3DStepperEnv-v0",
+                                    "Walker2DCustomEnv-v0", "Crab2DCustomEnv-v0"])
+def test_the_reference_mirror_sets_are_a_symmetry_of_the_compiled_robot(env_id):
+    """T2 on the f64 oracle: the blob's copies of robots.py:282-288's index sets (and get_mirror_indices()'s observation sets for the Custom
+    task) map solutions to solutions -- to 1e-9 wherever at most one constraint row is active, statistically beyond."""
+    m = one_substep_model(env_id)
+    # the crab walks sideways: its right / left legs stand at x = +-0.25 IN the plane of motion (crab2d.xml:16-37), the mirror is x -> -x
+    err, (oe, re_, dd) = _run_index_mirror(env_id, m, IndexMirror(m, plane="yz" if "Crab" in env_id else "xz"))
+    q = lambda x, p: float(np.percentile(x, p)) if len(x) else 0.0
+    print(f"\n{env_id}: mirror residual in units of (1 + |x|): free flight n={len(err[0])} max {err[0].max():.2e}; one row n={len(err[1])} max "
+          f"{err[1].max():.2e}; more rows n={len(err[2])} median {q(err[2], 50):.2e} p90 {q(err[2], 90):.2e} p99 {q(err[2], 99):.2e}; obs {oe:.2e} reward {re_:.2e}")
+    assert len(err[0]) > 200 and len(err[1]) > 30 and len(err[2]) > 5000
+    assert err[0].max() < 1e-9 and err[1].max() < 1e-9
+    assert oe < 1e-5 and re_ < 1e-4 and dd == 0          # float32 observations; reward holds -distance x 60
+    # more rows: the same rows are visited in another order (right and left swap their places in the limit / slot order) and five sweeps
+    # from zero do not converge -- an algorithmic asymmetry of Gauss-Seidel, the same in Bullet.  Most such samples still agree to rounding
+    # (their rows do not couple, or come in the same relative order; fewer on the tilted planks of Stepper curriculum 9, where a foot
+    # rests on both of its capsules), the tail is O(0.1-1) in the speeds.
+    exact = float((err[2] < 1e-9).mean())
+    print(f"  more rows: {100 * exact:.1f} % of the samples still agree to 1e-9")
+    assert exact > 0.3 and q(err[2], 99) < 2.0
+
+
+def _pair_maps(m, mir, env_id):
+    """For every body b the 3 x 3 map T_b (det -1) that takes a point of body b to its mirror image in the partner body bperm[b], from the
+    oracle's forward kinematics at q = 0 (a mirror-symmetric pose): T_b = R_b'^T S R_b; also returns how well the body ORIGINS mirror."""
+    from oracle.oracle import Oracle
+    nb, nj = m.n_bodies, m.n_joints
+    o = Oracle(m.to_bytes(), TASKS[env_id], 1, "f64")
+    st = np.zeros((1, o.state_dim)); st[0, 6] = 1.0
+    o.set_state(st)
+    fr = o.link_frames(0, nb)
+    bperm = np.concatenate(([0], 1 + mir.perm))
+    Sm = np.diag([1.0, -1.0, 1.0])
+    T, origin_err = [], 0.0
+    for b in range(nb):
+        R, R2 = fr[b, :9].reshape(3, 3), fr[int(bperm[b]), :9].reshape(3, 3)
+        T.append(R2.T @ Sm @ R)
+        origin_err = max(origin_err, float(np.abs(Sm @ fr[b, 9:12] - fr[int(bperm[b]), 9:12]).max()))
+    return bperm, T, origin_err
+
+
+def _inertia(m, b):
+    xx, yy, zz, xy, xz, yz = list(m.inertia[b])
+    return np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]])
+
+
+def test_cassie_legs_are_mirror_images_up_to_the_assets_asymmetry():
+    """T2 for Cassie, physics only: PD gains zero (CassieEnv's nominal pose repeats ONE leg's angles on both legs, env_cassie.py:20-39 -- the
+    controller is not mirror symmetric by the reference's own constants), states shaken and lifted off the ground (the two toe meshes are
+    sampled by different hull points).  Three statements:
+      (a) KINEMATICS mirror exactly: origins, frames and hinge axes of the two legs (compile_cassie's flatten of cassie_collide.urdf);
+      (b) the URDF's inertial parameters do not: pelvis inertia products xy / yz (2e-3 / 5e-3 of the diagonal), left_hip's products repeated
+          unmirrored on right_hip, COM entries rounded to 0.1 mm -- listed below, and the dynamics mirror only to ~1e-2 because of them;
+      (c) with the right leg's masses / COMs / inertias REPLACED by the mirror images of the left leg's (through the kinematic maps of (a))
+          and the pelvis symmetrised, the same code mirrors to 1e-9: tree, joint frames, axes, damping and the two loop closures are right.
+    A swapped axis or an unmirrored frame of compile_cassie breaks (a) and (c)."""
+    env_id = "CassieEnv-v0"
+    m = one_substep_model(env_id, n_iters=400, pd_off=True)      # the closure rows of the two legs are visited in another order: converge them
+    mir = IndexMirror(m, **CASSIE_MIRROR)
+    bperm, T, origin_err = _pair_maps(m, mir, env_id)
+    assert origin_err < 1e-9                                     # (a) at q = 0; shaken poses below
+    for b in range(1, m.n_bodies):
+        b2 = int(bperm[b])
+        np.testing.assert_allclose(T[b] @ np.array(list(m.jaxis[b])), -mir.sign[b - 1] * np.array(list(m.jaxis[b2])), atol=1e-6)   # axes are pseudovectors
+        assert (m.jlo[b2], m.jhi[b2]) == ((m.jlo[b], m.jhi[b]) if mir.sign[b - 1] > 0 else (-m.jhi[b], -m.jlo[b]))
+        assert m.jdamp[b] == m.jdamp[b2] and m.mass[b] == m.mass[b2] and m.torque_limit[b] == m.torque_limit[b2]
+    # (b) what the asset's inertial parameters miss
+    worst_c, worst_i = 0.0, 0.0
+    for b in range(m.n_bodies):
+        b2 = int(bperm[b])
+        if m.mass[b] > 0:
+            worst_c = max(worst_c, float(np.abs(T[b] @ np.array(list(m.com[b])) - np.array(list(m.com[b2]))).max()))
+            I, I2 = _inertia(m, b), _inertia(m, b2)
+            worst_i = max(worst_i, float(np.abs(T[b] @ I @ T[b].T - I2).max() / np.abs(np.diag(I)).max()))
+    err, _ = _run_index_mirror(env_id, m, mir, steps=40, lift=1.0, shake=0.1, act_mirror=lambda a: a)   # no PD: the action does nothing
+    e = np.concatenate([err[0], err[1]])
+    print(f"\nCassie asset: COMs miss their mirror image by up to {1e3 * worst_c:.2f} mm, inertia tensors by {100 * worst_i:.2f} % of the diagonal; "
+          f"mirror residual of a substep in free flight with closures (n={len(e)}): median {np.median(e):.2e} max {e.max():.2e}")
+    assert worst_c < 5e-4 and 1e-4 < worst_i < 2e-2 and len(e) > 3000 and np.median(e) < 2e-2
+    # (c) the same blob with mirror-image inertial parameters
+    ms = M.MoccaModel.from_bytes(m.to_bytes())
+    I0 = _inertia(m, 0)
+    I0 = 0.5 * (I0 + T[0] @ I0 @ T[0].T)
+    ms.com[0][1] = 0.0
+    for k, (i, j) in enumerate([(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)]):
+        ms.inertia[0][k] = I0[i, j]
+    for b in list(1 + np.array(list(CASSIE_MIRROR["left"]))):
+        b2 = int(bperm[b])
+        c2, I2 = T[b] @ np.array(list(m.com[b])), T[b] @ _inertia(m, b) @ T[b].T
+        for k in range(3):
+            ms.com[b2][k] = c2[k]
+        for k, (i, j) in enumerate([(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)]):
+            ms.inertia[b2][k] = I2[i, j]
+    for k in range(3):       # closure pivots (env_cassie.py:114-137) mirror too
+        assert abs((T[m.cl_body_a[0]] @ np.array(list(m.cl_point_a[0])))[k] - m.cl_point_a[1][k]) < 1e-6
+        assert abs((T[m.cl_body_b[0]] @ np.array(list(m.cl_point_b[0])))[k] - m.cl_point_b[1][k]) < 1e-6
+    ms.finalize_tables()
+    err, _ = _run_index_mirror(env_id, ms, mir, steps=40, lift=1.0, shake=0.1, act_mirror=lambda a: a)
+    e = np.concatenate([err[0], err[1]])
+    print(f"Cassie with mirror-image inertial parameters: residual median {np.median(e):.2e} max {e.max():.2e} (n={len(e)})")
+    # float32 blob constants: the mirrored COMs / inertias are rounded once more; the worst samples are what 400 sweeps leave of the closure rows
+    assert len(e) > 3000 and np.median(e) < 1e-9 and e.max() < 1e-4
+    # negative control: forgetting the rod hinge's sign is seen
+    bad = IndexMirror(m, **dict(CASSIE_MIRROR, extra_neg=[0, 1, 9, 10]))
+    err, _ = _run_index_mirror(env_id, ms, bad, steps=5, lift=1.0, shake=0.1, act_mirror=lambda a: a)
+    assert np.median(np.concatenate([err[0], err[1]])) > 1e-3
+
+
+def _symmetrised_laikago(monkeypatch):
+    """The Laikago table with its left legs replaced by mirror images of the right ones and an exactly upright chassis frame, hull points dropped."""
+    import copy, math
+    from mocca_envs_amd import laikago_table as LT
+    links, joints = copy.deepcopy(LT.LINKS), copy.deepcopy(LT.JOINTS)
+    mx = lambda v: [-v[0], v[1], v[2]]                  # URDF frame: x is lateral
+    for l in links.values():
+        l["points"] = []
+    links["chassis"]["rpy"] = [-math.pi / 2, -math.pi / 2, 0.0]
+    for leg_l, leg_r in (("FL", "FR"), ("RL", "RR")):
+        for part in ("hip_motor", "upper_leg", "lower_leg"):
+            src = links[f"{leg_r}_{part}"]
+            links[f"{leg_l}_{part}"].update(com=mx(src["com"]), box_half=list(src["box_half"]), mass=src["mass"])
+    byname = {j["name"]: j for j in joints}
+    for leg_l, leg_r in (("FL", "FR"), ("RL", "RR")):
+        for jn in ("hip_motor_2_chassis_joint", "upper_leg_2_hip_motor_joint", "lower_leg_2_upper_leg_joint"):
+            byname[f"{leg_l}_{jn}"]["xyz"] = mx(byname[f"{leg_r}_{jn}"]["xyz"])
+    monkeypatch.setattr(LT, "LINKS", links)
+    monkeypatch.setattr(LT, "JOINTS", joints)
+
+
+def test_laikago_mirror_sets_exact_on_a_symmetrised_table_and_bounded_on_the_asset(monkeypatch):
+    """T2 for Laikago (robots.py:578-580: right = FR, RR; left = FL, RL; nothing negated).  The URDF is not mirror symmetric itself (upper-leg
+    offsets -53.565 / +55.855 mm, chassis inertial rpy -1.57 instead of -pi/2, unequal hull points): on the asset the claim holds to
+    about 1 % per substep in free flight.  compile_laikago is not the cause: on a table whose left legs ARE the mirrored right legs the same
+    code gives a blob on which the claim holds to rounding."""
+    env_id = "LaikagoCustomEnv-v0"
+    m = one_substep_model(env_id)
+    err, _ = _run_index_mirror(env_id, m, IndexMirror(m), steps=40, lift=1.0, shake=0.1)
+    asset = err[0]
+    print(f"\nLaikago asset, free flight (n={len(asset)}): mirror residual median {np.median(asset):.2e} p99 {np.percentile(asset, 99):.2e}")
+    assert len(asset) > 5000 and 1e-5 < np.median(asset) < 3e-2
+    _symmetrised_laikago(monkeypatch)
+    ms = one_substep_model(env_id)
+    err, _ = _run_index_mirror(env_id, ms, IndexMirror(ms), steps=40, lift=1.0, shake=0.1)
+    print(f"Laikago symmetrised table, free flight (n={len(err[0])}): max {err[0].max():.2e}")
+    assert len(err[0]) > 5000 and err[0].max() < 1e-9
+
+
+@pytest.mark.parametrize("env_id", ["Walker3DCustomEnv-v0", "Child3DCustomEnv-v0", "MikeStepperEnv-v0"])
+def test_the_blob_is_its_own_mirror_image(env_id):
+    """T3: reflecting the blob and exchanging its right / left bodies gives the blob back -- joint frames, axes, limits, gains, inertial
+    parameters field by field, geoms as a set (the two capsules of a foot exchange their places: right_foot_1 is left_foot_2's image)."""
+    m = compile_model_for(env_id)
+    mir = IndexMirror(m)
+    r = reflect_model(relabel_model(m, mir))
+    nb = m.n_bodies
+    bperm = np.concatenate(([0], 1 + mir.perm))
+    for b in range(1, nb):
+        assert m.parent[int(bperm[b])] == bperm[m.parent[b]]                  # the tree itself is symmetric
+    for name in ("jpos", "jrot", "jaxis", "com", "inertia"):
+        a, b_ = np.array([list(x) for x in getattr(m, name)])[:nb], np.array([list(x) for x in getattr(r, name)])[:nb]
+        np.testing.assert_allclose(b_[1:] if name.startswith("j") else b_, a[1:] if name.startswith("j") else a, atol=2e-7, err_msg=name)
+    for name in ("jlo", "jhi", "jdamp", "jarm", "gain", "mass"):      # (init_q is the "running start", one leg ahead: not symmetric by design)
+        a, b_ = np.array(list(getattr(m, name)))[:nb], np.array(list(getattr(r, name)))[:nb]
+        np.testing.assert_allclose(b_[1:] if name != "mass" else b_, a[1:] if name != "mass" else a, atol=2e-7, err_msg=name)
+    geoms = lambda mm, bmap: sorted((int(bmap[mm.g_body[g]]), round(float(mm.g_radius[g]), 6), int(mm.g_type[g]), int(mm.g_terrain[g]),
+                                     tuple(sorted((tuple(np.round(list(mm.g_p1[g]), 6) + 0.0), tuple(np.round(list(mm.g_p2[g]), 6) + 0.0)))))
+                                    for g in range(mm.n_geoms))
+    assert geoms(m, np.arange(nb)) == geoms(reflect_model(m), bperm)
