@@ -155,7 +155,10 @@ def parse_args(argv=None):
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST ONLY: let ranks share GPUs (device = rank %% visible GPUs) so the N-rank path can be exercised on a 1-GPU box; "
                          "the line is marked and is not a scaling measurement")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.host_io and args.stagger > 1:
+        ap.error("--host-io times the synchronous host loop of ONE handle; it does not combine with --stagger")
+    return args
 
 
 def _free_port() -> int:
@@ -252,8 +255,15 @@ def main():
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         from mocca_envs_amd.vec_env import VecEnv
+        from mocca_envs_amd.multi import SubBatchedVecEnv
         # same seed on every rank, draws keyed by the GLOBAL env id: the job's result does not depend on how many GPUs share it
-        env = VecEnv(args.env_id, args.envs, device=local_rank, auto_reset=True, seed=1000, env_offset=lo, max_rows=args.max_rows)
+        kw = dict(device=local_rank, auto_reset=True, seed=1000, env_offset=lo, max_rows=args.max_rows)
+        if args.stagger > 1:   # sub-batches with their own handles and HIP streams (same global env ids, same seed, same results as one handle)
+            assert args.envs % args.stagger == 0, "--stagger must divide --envs"
+            env = SubBatchedVecEnv(args.env_id, args.envs, sub_batches=args.stagger, **kw)
+        else:
+            env = VecEnv(args.env_id, args.envs, **kw)
+        # handle parameters: set_param of a SubBatchedVecEnv reaches every sub-batch's handle
         if args.order_every is not None:
             env.set_param(12, args.order_every)  # MOCCA_PARAM_ORDER_EVERY
         if args.pace is not None:
@@ -265,39 +275,25 @@ def main():
         if args.prio:
             t1, t2, t3 = (int(x) for x in args.prio.split(","))
             env.set_param(9, t1 + 64 * t2 + 4096 * t3)  # MOCCA_PARAM_ISSUE_PRIORITY
-        subs = []
-        if args.stagger > 1:   # sub-batches on their own streams (the first one IS `env`'s first share: same global env ids, same seed)
-            env.close()
-            per = args.envs // args.stagger
-            assert per * args.stagger == args.envs, "--stagger must divide --envs"
-            for k in range(args.stagger):
-                st_k = torch.cuda.Stream(device=dev)
-                with torch.cuda.stream(st_k):
-                    e_k = VecEnv(args.env_id, per, device=local_rank, auto_reset=True, seed=1000, env_offset=lo + k * per, max_rows=args.max_rows)
-                    e_k.reset()
-                e_k.stream = st_k      # the handle's launches go to its own stream from here on (no stream context per step)
-                subs.append((e_k, st_k, slice(k * per, (k + 1) * per)))
-            env = subs[0][0]
-            torch.cuda.synchronize()
-        else:
-            env.reset()
+        subs = list(range(args.stagger)) if args.stagger > 1 else []
+        env.reset()
+        torch.cuda.synchronize()
         g = torch.Generator(device=dev)
         g.manual_seed(1 + rank)
         tape = (torch.rand(64, args.envs, env.act_dim, device=dev, generator=g) * 2 - 1) * args.action_scale  # action_scale x U(-1,1) action tape, looped
 
         # the synthetic input of this metric is a batch of envs in mid-episode, not 4096 identical first frames: age it
-        sub_tapes = [tape[:, sl].contiguous() for _, _, sl in subs]
+        sub_tapes = [tape[:, env.slices[k]].contiguous() for k in subs]
         torch.cuda.synchronize()
 
         def step_all(i):
-            """one env.step of every env of this rank; returns the done flags of (the first sub-batch of) it"""
+            """one env.step of every env of this rank; returns the done flags of the batch (sub-batches: not yet ordered against the
+            current stream -- env.wait(k) does that)"""
             if not subs:
                 return env.step(tape[i % 64])[2]
-            d0 = None
-            for k, (e_k, st_k, sl) in enumerate(subs):
-                d = e_k.step(sub_tapes[k][i % 64])[2]
-                d0 = d if d0 is None else d0
-            return d0
+            for k in subs:      # SubBatchedVecEnv.step_async: one launch on sub-batch k's own stream; the tape is resident, nothing to order
+                env.step_async(k, sub_tapes[k][i % 64], ordered=False)
+            return env.done
 
         # First use of everything the warm-up and the timed window call besides mocca_step, BEFORE the pre-roll: torch loads the code objects
         # of its reduction kernels on first use (40 - 150 ms on the host, the GPU idle meanwhile).  With that gap between the pre-roll and
@@ -330,9 +326,9 @@ def main():
         n_done = torch.zeros((), device=dev)
         for i in range(args.warmup):
             done = step_all(i)
-            if subs:
-                torch.cuda.current_stream().wait_stream(subs[0][1])
-            n_done += (done != 0).sum() * (len(subs) or 1)  # reset fraction is sampled during warm-up, outside the timed region
+            for k in subs:
+                env.wait(k)
+            n_done += (done != 0).sum()  # reset fraction is sampled during warm-up, outside the timed region
         reset_frac = float(n_done.item()) / max(1, args.envs * args.warmup)
         # The K timed steps are bracketed by barrier + synchronize on both sides.  Each rank's clock runs from its release out of the
         # start barrier to the return of ITS OWN synchronize after the K-th launch; the stop barrier comes after the clock is read
@@ -345,14 +341,12 @@ def main():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
-        if subs:
-            for _, st_k, _ in subs:
-                st_k.wait_stream(torch.cuda.current_stream())      # the sub-batches start after ev0
+        for k in subs:
+            env._before(k)                                         # the sub-batches start after ev0
         for i in range(args.steps):
             step_all(i)
-        if subs:
-            for _, st_k, _ in subs:
-                torch.cuda.current_stream().wait_stream(st_k)      # ev1 after the last launch of every sub-batch
+        for k in subs:
+            env._after(k)                                          # ev1 after the last launch of every sub-batch
         ev1.record()
         torch.cuda.synchronize()
         elapsed_rank = time.perf_counter() - t0
@@ -395,6 +389,8 @@ def main():
         achieved = algo * args.envs / (kern_ms * 1e-3) / 1e9
         terrain = "20 stepping planks" if "Stepper" in args.env_id else ("height field" if "Planner" in args.env_id else "flat ground")
         scale_txt = "" if args.action_scale == 1.0 else f"{args.action_scale:g} x "
+        if args.curriculum is not None:
+            terrain += f", curriculum {args.curriculum}"
         out = {
             "metric": "env-steps/sec, Walker3DCustomEnv-v0 @ 4096 envs, 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -430,7 +426,7 @@ def main():
                               "note": "actions from pinned host memory, obs + reward + done copied to the host and waited for every step"}
         if args.stagger > 1:
             out["config"]["pipelined"] = True
-            out["config"]["workload"] += f"; {args.stagger} sub-batches on their own streams, their steps overlap (NOT the headline protocol)"
+            out["config"]["workload"] += f"; {args.stagger} sub-batches on their own streams (mocca_envs_amd.multi.SubBatchedVecEnv.step_async), their steps overlap (NOT the headline protocol)"
             out["roofline"]["kernel_ms_note"] = "time per step of the whole rank (all sub-batches), not one launch's duration"
         if args.dry_run:
             out["dry_run"] = True

@@ -165,9 +165,25 @@ class VecEnv:
 
     # ------------------------------------------------------------------
     def _stream(self) -> C.c_void_p:
-        if self.stream is not None:      # a handle bound to a stream of its own (sub-batches that step independently: bench.py --stagger)
+        if self.stream is not None:      # a handle bound to a stream of its own (sub-batches that step independently: multi.SubBatchedVecEnv)
             return C.c_void_p(self.stream.cuda_stream)
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # A handle pinned to a stream of its own (`self.stream`) runs its C calls there, while the torch operations around them (uploads,
+    # .contiguous(), the caller's reads of what a getter returns) run on torch's CURRENT stream.  Every method except step() orders the
+    # two, stream against stream, never through the host: _in() before a call that consumes caller tensors, _out() after a call whose
+    # result the caller will read.  step() is the hot path and stays unordered on a pinned stream: the caller orders it (SubBatchedVecEnv's
+    # step_async / wait do), or passes ready, contiguous float32 device tensors and reads the outputs after a synchronize.
+    def _in(self):
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _out(self):
+        if self.stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def _sync(self):
+        (self.stream if self.stream is not None else torch.cuda.current_stream(self.device)).synchronize()
 
     def close(self):
         if getattr(self, "h", None):
@@ -244,7 +260,9 @@ class VecEnv:
         v = torch.as_tensor(values, dtype=torch.float32).to(self.device).contiguous().reshape(-1)
         if v.numel() != (1 if broadcast else self.n_envs):
             raise ValueError("values must hold one float per env (or one float with broadcast=True)")
+        self._in()
         _lib.check(self.lib.mocca_set_param_v(self.h, pid, C.c_void_p(v.data_ptr()), int(broadcast), self._stream()), self.h)
+        self._out()       # `v` may be freed (and its memory reused on the current stream) as soon as this returns
 
     def seed(self, seed: int, rewind: bool = True):
         """Philox key of the in-kernel draws (gym's env.seed(s), env_base.py:164-166).  With rewind (default) the per-env episode
@@ -268,9 +286,15 @@ class VecEnv:
         self._tape = torch.as_tensor(tape, dtype=torch.float32).to(self.device).contiguous().reshape(self.n_envs, -1)
         _lib.check(self.lib.mocca_set_draw_tape(self.h, C.c_void_p(self._tape.data_ptr()), self._tape.shape[1]), self.h)
 
-    def keep_terminal_obs(self, on: bool = True) -> Optional[torch.Tensor]:
-        """Attach (or detach) the terminal-observation buffer [N][obs_dim] (include/mocca.h mocca_set_terminal_obs_buffer)."""
-        self.terminal_obs = torch.zeros(self.n_envs, self.obs_dim, dtype=torch.float32, device=self.device) if on else None
+    def keep_terminal_obs(self, on: bool = True, buffer: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """Attach (or detach) the terminal-observation buffer [N][obs_dim] (include/mocca.h mocca_set_terminal_obs_buffer); `buffer`:
+        a caller-owned contiguous float32 [N][obs_dim] tensor on the device (e.g. this handle's rows of a larger batch's buffer)."""
+        if on and buffer is not None:
+            if buffer.shape != (self.n_envs, self.obs_dim) or buffer.dtype != torch.float32 or not buffer.is_contiguous() or buffer.device != self.device:
+                raise ValueError("terminal-observation buffer must be a contiguous float32 [n_envs, obs_dim] tensor on the env's device")
+            self.terminal_obs = buffer
+        else:
+            self.terminal_obs = torch.zeros(self.n_envs, self.obs_dim, dtype=torch.float32, device=self.device) if on else None
         _lib.check(self.lib.mocca_set_terminal_obs_buffer(self.h, C.c_void_p(self.terminal_obs.data_ptr()) if on else None), self.h)
         return self.terminal_obs
 
@@ -288,10 +312,11 @@ class VecEnv:
         i32 = lambda x: None if x is None else torch.as_tensor(x, dtype=torch.int32).to(self.device).contiguous()
         touch, target, body = i32(touch), i32(target), i32(body)
         ptr = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+        self._in()
         _lib.check(self.lib.mocca_task_step(self.h, C.c_void_p(actions.data_ptr()), ptr(touch), ptr(target), ptr(body),
                                             C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.rew.data_ptr()),
                                             C.c_void_p(self.done.data_ptr()), C.c_void_p(self.info.data_ptr()), self._stream()), self.h)
-        torch.cuda.current_stream(self.device).synchronize()   # the int32 temporaries above must outlive the launch
+        self._sync()   # the int32 temporaries above must outlive the launch
         return self.obs, self.rew, self.done, self.info
 
     def reset(self, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -299,10 +324,14 @@ class VecEnv:
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
             mp = C.c_void_p(mask.data_ptr())
+        self._in()
         _lib.check(self.lib.mocca_reset(self.h, mp, self.seed_value, C.c_void_p(self.obs.data_ptr()), self._stream()), self.h)
+        self._out()
         return self.obs
 
     def step(self, actions: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """One env.step of all envs: one kernel launch on torch's current stream (or on `self.stream`, unordered against the current
+        stream: see _in / _out above)."""
         if actions.device != self.device or actions.dtype != torch.float32 or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         if actions.shape != (self.n_envs, self.act_dim):
@@ -346,6 +375,7 @@ class VecEnv:
         d = self._dev_views
         _lib.check(self.lib.mocca_get_state(self.h, C.c_void_p(d["state"].data_ptr()), self._stream()), self.h)
         _lib.check(self.lib.mocca_get_task(self.h, C.c_void_p(d["task"].data_ptr()), self._stream()), self.h)
+        self._out()
         self._pack_host.copy_(self._pack, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
         return self._host_np
@@ -356,6 +386,7 @@ class VecEnv:
         hnp = self.host_mirror()
         self._act_host.numpy()[...] = actions_np
         self._act_dev.copy_(self._act_host, non_blocking=True)
+        self._in()
         self.step(self._act_dev)
         return self._download()
 
@@ -371,39 +402,50 @@ class VecEnv:
 
     def observe(self) -> torch.Tensor:
         """calc_state() + observation tail of the current state, no stepping (include/mocca.h mocca_observe)."""
+        self._in()
         _lib.check(self.lib.mocca_observe(self.h, C.c_void_p(self.obs.data_ptr()), self._stream()), self.h)
+        self._out()
         return self.obs
 
     # ---- snapshots (saveState/restoreState role; used by the parity tests) ----
     def get_state(self) -> torch.Tensor:
         st = torch.empty(self.n_envs, self.state_dim, dtype=torch.float32, device=self.device)
+        self._in()      # (st's memory may have been in use on the current stream a moment ago)
         _lib.check(self.lib.mocca_get_state(self.h, C.c_void_p(st.data_ptr()), self._stream()), self.h)
+        self._out()
         return st
 
     def set_state(self, st) -> None:
         st = torch.as_tensor(st, dtype=torch.float32).to(self.device).contiguous().reshape(self.n_envs, self.state_dim)
+        self._in()
         _lib.check(self.lib.mocca_set_state(self.h, C.c_void_p(st.data_ptr()), self._stream()), self.h)
-        torch.cuda.current_stream(self.device).synchronize()
+        self._sync()
 
     def get_task(self) -> torch.Tensor:
         t = torch.empty(self.n_envs, M.TASK_WORDS, dtype=torch.int32, device=self.device)
+        self._in()
         _lib.check(self.lib.mocca_get_task(self.h, C.c_void_p(t.data_ptr()), self._stream()), self.h)
+        self._out()
         return t
 
     def set_task(self, t: torch.Tensor) -> None:
         t = t.to(device=self.device, dtype=torch.int32).contiguous().reshape(self.n_envs, M.TASK_WORDS)
+        self._in()
         _lib.check(self.lib.mocca_set_task(self.h, C.c_void_p(t.data_ptr()), self._stream()), self.h)
-        torch.cuda.current_stream(self.device).synchronize()
+        self._sync()
 
     def get_terrain(self) -> torch.Tensor:
         t = torch.empty(self.n_envs, 128, dtype=torch.float32, device=self.device)
+        self._in()
         _lib.check(self.lib.mocca_get_terrain(self.h, C.c_void_p(t.data_ptr()), self._stream()), self.h)
+        self._out()
         return t
 
     def set_terrain(self, t) -> None:
         t = torch.as_tensor(t, dtype=torch.float32).to(self.device).contiguous().reshape(self.n_envs, 128)
+        self._in()
         _lib.check(self.lib.mocca_set_terrain(self.h, C.c_void_p(t.data_ptr()), self._stream()), self.h)
-        torch.cuda.current_stream(self.device).synchronize()
+        self._sync()
 
     def kernel_info(self) -> dict:
         v = [C.c_int() for _ in range(5)]
