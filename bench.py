@@ -65,11 +65,10 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def _oracle_rate(env_id, n_envs, seconds_target, max_steps=None):
-    import numpy as np
+def _make_oracle(env_id, n_envs, blob=None):
     from oracle.oracle import Oracle, PARAM_AUTO_RESET
     from mocca_envs_amd.vec_env import TASKS, compile_model_for
-    orc = Oracle(compile_model_for(env_id).to_bytes(), TASKS[env_id], n_envs, "f32")
+    orc = Oracle(blob if blob is not None else compile_model_for(env_id).to_bytes(), TASKS[env_id], n_envs, "f32")
     if "Planner" in env_id:     # the planner envs stand on the height field
         from mocca_envs_amd.terrain import load_height_field
         orc.set_heightfield(*load_height_field())
@@ -79,6 +78,12 @@ def _oracle_rate(env_id, n_envs, seconds_target, max_steps=None):
         orc.set_trajectory(tr.table(), tr.max_time(), 0.03)
     orc.set_param(PARAM_AUTO_RESET, 1)
     orc.reset(seed=0)
+    return orc
+
+
+def _oracle_rate(env_id, n_envs, seconds_target, max_steps=None):
+    import numpy as np
+    orc = _make_oracle(env_id, n_envs)
     tape = np.random.default_rng(0).uniform(-1, 1, (64, n_envs, orc.act_dim)).astype(np.float32)
     t0 = time.perf_counter()
     steps = 0
@@ -88,10 +93,31 @@ def _oracle_rate(env_id, n_envs, seconds_target, max_steps=None):
     return n_envs * steps / (time.perf_counter() - t0), steps
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually run on: the affinity mask, cut by the cgroup's CPU quota (a GPU box of the pool reports 256 host CPUs
+    and grants a 16-CPU share: 256 threads there measure the quota, not the host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(env_id: str = ENV_ID, seconds_target: float = 10.0):
     """The CPU oracle (a scalar C port of the same algorithm; PyBullet is not installable here) on the host cores:
     one core (the headline `value`), BASELINE.json configs[0] (1 env x 1000 steps, 1 thread) and all cores."""
+    import numpy as np
     from concurrent.futures import ThreadPoolExecutor
+    from mocca_envs_amd.vec_env import compile_model_for
     n = 16
     rate1, steps1 = _oracle_rate(env_id, n, seconds_target)
     out = {"value": rate1, "unit": "env-steps/s", "cores": 1, "kind": "port",
@@ -99,14 +125,77 @@ def cpu_baseline(env_id: str = ENV_ID, seconds_target: float = 10.0):
     # configs[0]: "1 env, 1000 random-action steps" on one thread (the reference's own CPU-runnable case)
     r0, s0 = _oracle_rate(env_id, 1, 30.0, max_steps=1000)
     out["config0_1env_1000steps"] = {"value": r0, "unit": "env-steps/s", "cores": 1, "steps": s0}
-    # every host core: one independent oracle instance per thread (ctypes releases the GIL inside orc_step)
-    cores = os.cpu_count() or 1
+    # every host core: one oracle instance per thread, each running its K steps inside ONE C call (orc_rollout: the interpreter lock is
+    # released for the whole call; round 4 called orc_step once per step from 256 Python threads and measured the lock, 10.6 x one core)
+    cores = usable_cpus()
+    blob = compile_model_for(env_id).to_bytes()
+    orcs = [_make_oracle(env_id, n, blob) for _ in range(cores)]
+    tape = np.random.default_rng(0).uniform(-1, 1, (64, n, orcs[0].act_dim)).astype(np.float32)
+    k = max(8, int(rate1 / n * 0.5 * seconds_target))      # ~ half the single-core sample's duration per thread
     with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda o: o.rollout(tape, 2), orcs))   # threads started, pages touched
         t0 = time.perf_counter()
-        res = list(ex.map(lambda _: _oracle_rate(env_id, n, 0.6 * seconds_target), range(cores)))
+        list(ex.map(lambda o: o.rollout(tape, k), orcs))
         wall = time.perf_counter() - t0
-    out["all_cores"] = {"value": sum(n * s for _, s in res) / wall, "unit": "env-steps/s", "cores": cores,
-                        "sample": f"{cores} threads x {n} envs, {sum(s for _, s in res)} steps in total"}
+    out["all_cores"] = {"value": cores * n * k / wall, "unit": "env-steps/s", "cores": cores, "host_cpus": os.cpu_count(),
+                        "sample": f"{cores} threads (the CPUs this process may use: affinity mask and cgroup quota) x {n} envs x {k} steps, "
+                                  "one C call per thread (orc_rollout)"}
+    return out
+
+
+PHYSICS_VARIANTS = ("limit_rows_from_predicted_gap", "absolute_2cm_margins", "pyramid_friction", "warmstart_0.85", "all_four")
+
+
+def physics_variant_model(env_id, variant):
+    """The blob with one (or all) of the [UNVERIFIED-BULLET] solver laws of DESIGN.md section 3 switched to its other reading -- each is a blob field
+    that kernel and oracle honour (tests/test_gpu_substep.py runs every one against the oracle): limit rows from a predicted gap of
+    limit_slack on instead of at the stop only; one absolute 2 cm contact margin instead of Bullet's relative breaking thresholds
+    (millimetres); pyramid instead of cone friction; contact rows warm-started with 0.85 x the last impulse instead of from zero
+    (bullet_utils.py:340-350 sets none of them: they are Bullet defaults as recalled)."""
+    from mocca_envs_amd.vec_env import compile_model_for
+    m = compile_model_for(env_id)
+    if variant in ("limit_rows_from_predicted_gap", "all_four"):
+        m.limit_at_violation = 0
+    if variant in ("absolute_2cm_margins", "all_four"):
+        for g in range(m.n_geoms):
+            m.g_margin[g] = 0.0
+        m.finalize_tables()
+    if variant in ("pyramid_friction", "all_four"):
+        m.friction_cone = 0
+    if variant in ("warmstart_0.85", "all_four"):
+        m.warmstart = 0.85
+    return m
+
+
+def physics_bracket(args, local_rank, lo, tape, steps=200, preroll=800):
+    """The headline launch re-timed on blobs that read Bullet's unverifiable laws the OTHER way (untimed for `value`): how much of the
+    rate is the builder's reading of Bullet.  Returns {variant: {ms_per_step, value, rows_per_substep}}."""
+    import torch
+    from mocca_envs_amd.vec_env import VecEnv
+    out = {}
+    for variant in ("as_built",) + PHYSICS_VARIANTS:
+        m = physics_variant_model(args.env_id, variant) if variant != "as_built" else None
+        env = VecEnv(args.env_id, args.envs, device=local_rank, auto_reset=True, seed=1000, env_offset=lo,
+                     model_blob=m.to_bytes() if m is not None else None)
+        if args.curriculum is not None:
+            env.set_param(2, args.curriculum)
+        env.reset()
+        for i in range(preroll):
+            env.step(tape[i % 64])
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        rows = torch.zeros((), device=tape.device)
+        torch.cuda.synchronize()
+        ev0.record()
+        for i in range(steps):
+            env.step(tape[i % 64])
+        ev1.record()
+        torch.cuda.synchronize()
+        for i in range(16):     # rows of the last substep of 16 more steps (task word 23), outside the timed loop
+            env.step(tape[i % 64])
+            rows += env.get_task()[:, 23].float().mean()
+        ms = ev0.elapsed_time(ev1) / steps
+        out[variant] = {"ms_per_step": ms, "value": args.envs / (ms * 1e-3), "rows_per_substep": float(rows.item()) / 16}
+        env.close()
     return out
 
 
@@ -146,6 +235,10 @@ def parse_args(argv=None):
     ap.add_argument("--action-scale", type=float, default=1.0,
                     help="actions are action_scale x U(-1,1) (SURVEY 8d config 4 asks for 0.1 on Cassie: a robot that stays up instead of one that "
                          "falls every ~17 steps); reported in config.workload")
+    ap.add_argument("--no-physics-bracket", action="store_true",
+                    help="skip the sensitivity block: after the timed region the headline launch is re-timed (200 launches each, N = 1 only) on blobs "
+                         "that read the unverifiable Bullet laws the other way -- limit rows from a predicted gap, 2 cm absolute margins, pyramid "
+                         "friction, warm start 0.85, and all four; reported as `sensitivity`, never as `value`")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise launch / rendezvous / reporting only (CPU tests)")
     ap.add_argument("--test-barrier-delay", type=float, default=0.0,
                     help="TEST ONLY: every rank sleeps this many seconds inside each barrier (a slow rendezvous); the timed window must not see it")
@@ -354,6 +447,9 @@ def main():
         torch.cuda.synchronize()
         kern_ms = ev0.elapsed_time(ev1) / args.steps  # back-to-back launches: average launch duration incl. launch gaps
         kinfo = env.kernel_info()
+        bracket = None
+        if world == 1 and not args.no_physics_bracket and not subs and args.max_rows is None and "Cassie" not in args.env_id:
+            bracket = physics_bracket(args, local_rank, lo, tape)
         host_io_ms = None
         if args.host_io:   # a trainer on the host: actions up, obs / reward / done down, every step, through PCIe
             h_act = tape.cpu().pin_memory()
@@ -424,6 +520,11 @@ def main():
         if not args.dry_run and host_io_ms is not None:
             out["host_io"] = {"ms_per_step": host_io_ms, "value": args.envs * world / (host_io_ms * 1e-3), "unit": "env-steps/s",
                               "note": "actions from pinned host memory, obs + reward + done copied to the host and waited for every step"}
+        if not args.dry_run and bracket:
+            worst = min(bracket.values(), key=lambda v: v["value"])
+            out["sensitivity"] = {"note": "the same launch on blobs that read Bullet's unverifiable solver laws the other way (DESIGN.md section 3; 200 launches "
+                                          "each after an 800-step pre-roll, kernel time by HIP events); `value` above is the as-built reading",
+                                  "variants": bracket, "worst_case_value": worst["value"]}
         if args.stagger > 1:
             out["config"]["pipelined"] = True
             out["config"]["workload"] += f"; {args.stagger} sub-batches on their own streams (mocca_envs_amd.multi.SubBatchedVecEnv.step_async), their steps overlap (NOT the headline protocol)"

@@ -91,7 +91,9 @@ enum {
                                         further below P: the waves of a SIMD finish together.  value > 0: P in ticks; value = -k (1 <= k <= 64):
                                         self-calibrating, P = k/16 of the mean wave time of the previous launch (every 61st wave adds a sample;
                                         the first launch of a handle falls back to the row-count priorities); 0: off.  Default -18; 0 for a blob that
-                                        runs the compact instance (batches beyond one generation of resident waves: measured slower with it). */
+                                        runs the compact instance (batches beyond one generation of resident waves: measured slower with it).
+                                        The self-calibrating form and ORDER_EVERY > 0 keep HOST state per launch (sample-slot rotation, re-sort
+                                        schedule): capture mocca_step in a hipGraph only with value >= 0 and ORDER_EVERY = 0. */
 };
 
 /* words of the per-env debug record (mocca_set_debug_buffer): words 0..11 the active set of the LAST physics substep, words 12..15
@@ -224,7 +226,8 @@ int mocca_set_trajectory(mocca_handle h, const float *table_host, int n_frames, 
  * (the reference loads the same file for every env).  Required before reset / step / observe with MOCCA_TASK_WALKER3D_PLANNER. */
 int mocca_set_heightfield(mocca_handle h, const float *heights_host, int rows, int cols, double scale);
 
-/* name, registers, LDS and scratch of the step kernel as built (for DESIGN.md / bench) */
+/* registers, LDS and scratch of the step kernel as built (for DESIGN.md / bench), as the HIP runtime reports them; *sgprs = -1: the
+ * runtime has no scalar-register attribute (hipFuncAttributes), the count is printed by `python -m mocca_envs_amd.build -v` */
 int mocca_kernel_info(mocca_handle h, int *vgprs, int *sgprs, int *lds_bytes, int *scratch_bytes, int *max_blocks_per_cu);
 
 const char *mocca_last_error(mocca_handle h);

@@ -386,8 +386,11 @@ int mocca_step(mocca_handle h, const float* act_dev, float* obs_dev, float* rew_
   a.act = act_dev; a.obs = obs_dev; a.rew = rew_dev; a.done = done_dev; a.info = info_dev;
   hipStream_t s = (hipStream_t)stream;
   if (int rc = flush_pending(h, s)) return rc;
-  if (h->pace < 0) {   // self-calibrating pace priorities: three sample slots, rotated per launch (StepArgs.pace_acc; allocated by mocca_create:
-    a.pace_acc = h->d_pace_acc;   // mocca_step itself never allocates, so a caller may capture it in a hipGraph)
+  // mocca_step never allocates and never synchronises.  hipGraph capture: the slot rotation below and the re-sort schedule are HOST state
+  // that a capture bakes into the kernel arguments (a replayed launch would keep writing one sample slot and reading one that is never
+  // refreshed: the pace freezes at its pre-capture value) -- capture with MOCCA_PARAM_PACE_TICKS >= 0 and MOCCA_PARAM_ORDER_EVERY = 0.
+  if (h->pace < 0) {   // self-calibrating pace priorities: three sample slots, rotated per launch (StepArgs.pace_acc; allocated by mocca_create)
+    a.pace_acc = h->d_pace_acc;
     a.pace_slot_w = (int)(h->pace_step % 3u); a.pace_slot_r = (int)((h->pace_step + 2u) % 3u); a.pace_slot_c = (int)((h->pace_step + 1u) % 3u);
     ++h->pace_step;
   }
@@ -512,9 +515,15 @@ int mocca_set_heightfield(mocca_handle h, const float* heights_host, int rows, i
   delete[] host;
   if (e != hipSuccess) { if (d) (void)hipFree(d); h->err = std::string("mocca_set_heightfield: ") + hipGetErrorString(e); return MOCCA_E_HIP; }
   (void)hipDeviceSynchronize();   // ... nor the old slot records
-  for (int sl = 0; sl < h->model.n_slots; ++sl) std::memcpy(&h->model.slot_tab[sl][2], &wbits[sl], 4);
-  e = hipMemcpy(h->d_model, &h->model, sizeof(MoccaModel), hipMemcpyHostToDevice);
-  if (e != hipSuccess) { (void)hipFree(d); h->err = std::string("hipMemcpy(model): ") + hipGetErrorString(e); return MOCCA_E_HIP; }
+  // the window bits go into a COPY of the model; the handle's host image takes them only once the device has them (a failed upload leaves
+  // host and device records as they were: "refused and leaves the handle intact")
+  MoccaModel* next = new (std::nothrow) MoccaModel(h->model);
+  if (!next) { (void)hipFree(d); h->err = "mocca_set_heightfield: out of host memory"; return MOCCA_E_ARG; }
+  for (int sl = 0; sl < next->n_slots; ++sl) std::memcpy(&next->slot_tab[sl][2], &wbits[sl], 4);
+  e = hipMemcpy(h->d_model, next, sizeof(MoccaModel), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { delete next; (void)hipFree(d); h->err = std::string("hipMemcpy(model): ") + hipGetErrorString(e); return MOCCA_E_HIP; }
+  h->model = *next;
+  delete next;
   if (h->d_hf) (void)hipFree(h->d_hf);
   h->d_hf = d; h->hf_rows = rows; h->hf_cols = cols; h->hf_scale = (float)scale;
   return MOCCA_OK;
@@ -656,7 +665,7 @@ int mocca_kernel_info(mocca_handle h, int* vgprs, int* sgprs, int* lds_bytes, in
   else dispatch<KernelInfo>(h->topo, h->task_id, &fa, &nb, &e);
   HIP_TRY(h, e);
   if (vgprs) *vgprs = fa.numRegs;
-  if (sgprs) *sgprs = 0;
+  if (sgprs) *sgprs = -1;   // hipFuncAttributes has no scalar-register field: -1 = not reported (the count is in the code object's metadata: build.py -v prints it)
   if (lds_bytes) *lds_bytes = (int)fa.sharedSizeBytes;
   if (scratch_bytes) *scratch_bytes = (int)fa.localSizeBytes;
   if (max_blocks_per_cu) *max_blocks_per_cu = nb;

@@ -450,8 +450,10 @@ class VecEnv:
     def kernel_info(self) -> dict:
         v = [C.c_int() for _ in range(5)]
         _lib.check(self.lib.mocca_kernel_info(self.h, *[C.byref(x) for x in v]), self.h)
-        return dict(vgprs=v[0].value, sgprs=v[1].value, lds_bytes=v[2].value, scratch_bytes=v[3].value,
-                    max_blocks_per_cu=v[4].value)
+        out = dict(vgprs=v[0].value, lds_bytes=v[2].value, scratch_bytes=v[3].value, max_blocks_per_cu=v[4].value)
+        if v[1].value >= 0:      # the HIP runtime reports no scalar-register count (-1)
+            out["sgprs"] = v[1].value
+        return out
 
 
 # task-record helpers: the device record is 24 x 32-bit words, floats and ints mixed (mocca_model.h)

@@ -1802,6 +1802,17 @@ API void orc_step(void *h, const float *act, float *obs, float *rew, uint8_t *do
     if (info) info[e] = inf;
   }
 }
+/* `steps` env.steps in ONE call, actions from a looped tape [tape_len][N][act_dim]; outputs discarded.  bench.py's all-cores CPU baseline:
+ * one call per host thread, so the threads never meet at the interpreter lock between steps. */
+API void orc_rollout(void *h, const float *tape, int tape_len, int steps) {
+  Oracle *o = (Oracle *)h;
+  int od = obs_dim(o), nj = o->task_id == MOCCA_TASK_CASSIE ? o->m.n_ctrl - 2 : o->m.n_joints;
+  float *obs = (float *)malloc(sizeof(float) * (size_t)o->n_envs * od), *rew = (float *)malloc(sizeof(float) * o->n_envs);
+  uint8_t *done = (uint8_t *)malloc(o->n_envs);
+  if (obs && rew && done)
+    for (int k = 0; k < steps; ++k) orc_step(h, tape + (size_t)(k % tape_len) * o->n_envs * nj, obs, rew, done, NULL);
+  free(obs); free(rew); free(done);
+}
 /* task logic only: the dynamic state currently stored is taken as the post-stepSimulation state,
  * touch/target [N][2] are the foot contact query results. */
 API void orc_task_step(void *h, const float *act, const int32_t *touch, const int32_t *target, float *obs, float *rew,

@@ -50,6 +50,7 @@ def _load(precision: str) -> C.CDLL:
     for name in ("orc_get_state", "orc_set_state", "orc_get_task", "orc_set_task",
                  "orc_get_terrain", "orc_set_terrain"):
         getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.orc_task_step.argtypes = [C.c_void_p] * 8
     lib.orc_task_step_feet.argtypes = [C.c_void_p] * 9
     lib.orc_set_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -150,6 +151,12 @@ class Oracle:
         info = np.zeros(self.n_envs, np.int32)
         self.lib.orc_step(self.h, _p(act), _p(obs), _p(rew), _p(done), _p(info))
         return obs, rew, done, info
+
+    def rollout(self, tape: np.ndarray, steps: int) -> None:
+        """`steps` env.steps inside one C call (the interpreter lock is released for all of it), actions from a looped tape
+        [tape_len][N][act_dim] float32; observations / rewards are discarded: bench.py's all-cores CPU baseline."""
+        tape = np.ascontiguousarray(tape, np.float32).reshape(-1, self.n_envs, self.act_dim)
+        self.lib.orc_rollout(self.h, _p(tape), tape.shape[0], int(steps))
 
     def task_step(self, act: np.ndarray, touch: np.ndarray, target: Optional[np.ndarray] = None,
                   body_touch: Optional[np.ndarray] = None):
