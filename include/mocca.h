@@ -77,8 +77,12 @@ enum {
   MOCCA_PARAM_KERNEL_VARIANT = 11,   /* TIMING ONLY.  mocca_create picks the step-kernel instance from the blob: max_rows <= 32 and
                                         max_contacts <= 10 on a tree without loop closures run the COMPACT instance (32 x 32 Delassus matrix,
                                         the articulated-body view aliased under it: less LDS per env, more resident waves per CU); every other
-                                        blob the 48-row instance.  1 forces the 48-row instance for such a blob (A/B runs), 0 = automatic.
-                                        Both instances execute the same arithmetic in the same order: results are bit-identical. */
+                                        blob within 48 rows / 12 contacts the 48-row instance; a blob whose caps exceed those (max_rows <= 64,
+                                        max_contacts <= 20) the 64-row ACCURACY instance (every lane of the wave a row; 17 KB of LDS per env and
+                                        a two-waves-per-SIMD register budget: Bullet caps neither rows nor contacts, and this instance exists to
+                                        measure what the product's caps change).  1 forces the 48-row instance for a blob that would run the
+                                        compact one, 2 forces the 64-row instance for any blob (A/B runs), 0 = automatic.  The instances execute
+                                        the same arithmetic in the same order: on the same blob results are bit-identical. */
   MOCCA_PARAM_ORDER_EVERY = 12,      /* TIMING ONLY.  K > 0: every K-th mocca_step first sorts the envs by the constraint-row count their last step
                                         ended with and the step kernel starts the heaviest first (a launch of more envs than the chip holds at
                                         once ends with the waves it started last: they should be the light ones); 0: index order.  Envs never

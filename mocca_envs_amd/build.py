@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libmocca_hip.so")
-SOURCES = ["mocca_api.hip", "mocca_task.hip", "mocca_r32.hip"]   # physics kernels + C ABI; task-layer (INJECT) kernel instances; compact (32-row) step kernels
+SOURCES = ["mocca_api.hip", "mocca_task.hip", "mocca_r32.hip", "mocca_r64.hip"]   # physics kernels + C ABI; task-layer (INJECT) kernel instances; compact (32-row) step kernels; 64-row accuracy instance
 DEPS = SOURCES + ["mocca_kernels.h", "mocca_device.h", "topo_walker3d.h", "topo_cassie.h", "topo_walker2d.h", "topo_crab2d.h", "topo_laikago.h"]
 
 

@@ -19,6 +19,12 @@ extern "C" int mocca_r32_max_rows(void);
 extern "C" int mocca_r32_max_contacts(void);
 extern "C" void mocca_r32_launch_step(int topo, int task_id, int n, hipStream_t s, const void* args);
 extern "C" void mocca_r32_kernel_info(int topo, int task_id, hipFuncAttributes* fa, int* nb, hipError_t* e);
+// the 64-row / 20-contact accuracy instance (mocca_r64.hip)
+extern "C" size_t mocca_r64_args_sizeof(void);
+extern "C" int mocca_r64_max_rows(void);
+extern "C" int mocca_r64_max_contacts(void);
+extern "C" void mocca_r64_launch_step(int topo, int task_id, int n, hipStream_t s, const void* args);
+extern "C" void mocca_r64_kernel_info(int topo, int task_id, hipFuncAttributes* fa, int* nb, hipError_t* e);
 
 // --------------------------------------------------------------------------------------------
 // host side
@@ -67,7 +73,8 @@ struct mocca_ctx {
   int auto_reset = 0, eval_mode = 0, random_pose = 1, curriculum = 0, host_retarget = 0, env_offset = 0, random_reward = 0;
   float gain = 1.0f;
   bool compact = false;        // the blob fits the compact step-kernel instance (compact_ok); MOCCA_PARAM_KERNEL_VARIANT = 1 overrides
-  int force_full = 0;
+  bool wide = false;           // the blob's caps exceed 48 rows / 12 contacts: the 64-row accuracy instance (mocca_r64.hip)
+  int force_full = 0;          // MOCCA_PARAM_KERNEL_VARIANT: 1 forces the 48-row instance, 2 the 64-row one
   int persist_warm = 0;        // MOCCA_PARAM_PERSIST_IMPULSES
   int pace = -18;              // MOCCA_PARAM_PACE_TICKS: self-calibrating pace priorities, 18/16 of the previous launch's mean wave time (profiles/r04_pace_*.jsonl)
   unsigned* d_pace_acc = nullptr;  // [3][2] self-calibration samples of the pace (StepArgs.pace_acc), owned by the handle
@@ -134,9 +141,9 @@ static int check_topology_t(const MoccaModel& m, const char* name, std::string& 
     err = std::string("this topology's geom points overlap the contact records: blobs with self-collision pairs are not supported (") + name + ")";
     return MOCCA_E_ARG;
   }
-  if (m.max_rows > MAXR || m.max_contacts > MAXC || m.max_rows < 1 + 3 * T::NCLOS + (T::NCLOS > 0 && m.planar ? 3 : 0) || m.n_pairs > MOCCA_MAX_PAIRS || m.n_feet != T::NFEET ||
-      m.n_ctrl > MOCCA_MAX_CTRL || m.n_ordered > MOCCA_MAX_CTRL) {
-    err = "model blob caps exceed the kernel's (max_rows <= 48 and >= 1 + the closure / planar rows, max_contacts <= 12, n_feet as compiled)";
+  if (m.max_rows > mocca_r64_max_rows() || m.max_contacts > mocca_r64_max_contacts() || m.max_rows < 1 + 3 * T::NCLOS + (T::NCLOS > 0 && m.planar ? 3 : 0) ||
+      m.n_pairs > MOCCA_MAX_PAIRS || m.n_feet != T::NFEET || m.n_ctrl > MOCCA_MAX_CTRL || m.n_ordered > MOCCA_MAX_CTRL) {
+    err = "model blob caps exceed the kernel's (max_rows <= 64 and >= 1 + the closure / planar rows, max_contacts <= 20 -- beyond 48 / 12 the 64-row instance runs --, n_feet as compiled)";
     return MOCCA_E_ARG;
   }
   return MOCCA_OK;
@@ -176,6 +183,9 @@ static bool compact_ok(const MoccaModel& m, int topo) {
   return topo != TOPO_CASSIE && topo != TOPO_CASSIE_MASSIVE && m.n_closures == 0 && m.max_rows <= mocca_r32_max_rows() &&
          m.max_contacts <= mocca_r32_max_contacts() && mocca_r32_args_sizeof() == sizeof(StepArgs);
 }
+// ... and one whose caps exceed the 48-row instance's (48 rows / 12 contacts) runs the 64-row accuracy instance
+static bool wide_needed(const MoccaModel& m) { return m.max_rows > MAXR || m.max_contacts > MAXC; }
+enum { INST_FULL = 0, INST_COMPACT = 1, INST_WIDE = 2 };
 template <class T, int TASK> struct LaunchStep {
   static void run(int n, hipStream_t s, StepArgs a) { hipLaunchKernelGGL((mocca_step_kernel<T, TASK>), dim3(n), dim3(64), 0, s, a); }
 };
@@ -203,6 +213,13 @@ struct DeviceGuard {
   }
   ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
+
+// which instance of the step kernel a handle's mocca_step launches (reset / observe / task-step kernels exist once)
+static int step_instance(const mocca_ctx* h) {
+  if (h->wide || h->force_full == 2) return INST_WIDE;
+  if (h->compact && !h->force_full) return INST_COMPACT;
+  return INST_FULL;
+}
 
 extern "C" {
 
@@ -234,6 +251,8 @@ int mocca_create(const void* model_blob, size_t nbytes, int task_id, int n_envs,
   }
   h->task_id = task_id; h->n_envs = n_envs; h->device = device;
   h->compact = compact_ok(h->model, h->topo);
+  h->wide = wide_needed(h->model);
+  if (h->wide && mocca_r64_args_sizeof() != sizeof(StepArgs)) { g_err = "the 64-row kernel instance was built from another StepArgs"; delete h; return MOCCA_E_ARG; }
   // pace priorities make the waves of a SIMD finish together -- right when all of a batch is resident (or whole generations are); the compact
   // instance exists for batches beyond one generation, whose partial last generation wants its slots refilled one by one: measured 1.5 - 2.5 %
   // slower with the pace than with the row-count priorities (8192 / 16384 envs), so its default is off
@@ -403,8 +422,11 @@ int mocca_step(mocca_handle h, const float* act_dev, float* obs_dev, float* rew_
     ++h->order_age;
     a.order = h->d_order;
   }
-  if (h->compact && !h->force_full) mocca_r32_launch_step(h->topo, h->task_id, h->n_envs, s, &a);
-  else dispatch<LaunchStep>(h->topo, h->task_id, h->n_envs, s, a);
+  switch (step_instance(h)) {
+    case INST_COMPACT: mocca_r32_launch_step(h->topo, h->task_id, h->n_envs, s, &a); break;
+    case INST_WIDE: mocca_r64_launch_step(h->topo, h->task_id, h->n_envs, s, &a); break;
+    default: dispatch<LaunchStep>(h->topo, h->task_id, h->n_envs, s, a);
+  }
   HIP_TRY(h, hipGetLastError());
   return MOCCA_OK;
 }
@@ -620,7 +642,8 @@ int mocca_set_param(mocca_handle h, int param_id, double value) {
       }
       break;
     case MOCCA_PARAM_KERNEL_VARIANT:
-      if (value != 0 && value != 1) { h->err = "MOCCA_PARAM_KERNEL_VARIANT is 0 (automatic) or 1 (force the 48-row instance)"; return MOCCA_E_ARG; }
+      if (value != 0 && value != 1 && value != 2) { h->err = "MOCCA_PARAM_KERNEL_VARIANT is 0 (automatic), 1 (force the 48-row instance) or 2 (force the 64-row instance)"; return MOCCA_E_ARG; }
+      if (value == 1 && h->wide) { h->err = "MOCCA_PARAM_KERNEL_VARIANT = 1: this blob's caps exceed the 48-row instance's (48 rows / 12 contacts)"; return MOCCA_E_ARG; }
       h->force_full = (int)value; break;
     default: h->err = "unknown parameter id"; return MOCCA_E_ARG;
   }
@@ -661,8 +684,11 @@ int mocca_kernel_info(mocca_handle h, int* vgprs, int* sgprs, int* lds_bytes, in
   hipFuncAttributes fa;
   int nb = 0;
   hipError_t e = hipSuccess;
-  if (h->compact && !h->force_full) mocca_r32_kernel_info(h->topo, h->task_id, &fa, &nb, &e);
-  else dispatch<KernelInfo>(h->topo, h->task_id, &fa, &nb, &e);
+  switch (step_instance(h)) {
+    case INST_COMPACT: mocca_r32_kernel_info(h->topo, h->task_id, &fa, &nb, &e); break;
+    case INST_WIDE: mocca_r64_kernel_info(h->topo, h->task_id, &fa, &nb, &e); break;
+    default: dispatch<KernelInfo>(h->topo, h->task_id, &fa, &nb, &e);
+  }
   HIP_TRY(h, e);
   if (vgprs) *vgprs = fa.numRegs;
   if (sgprs) *sgprs = -1;   // hipFuncAttributes has no scalar-register field: -1 = not reported (the count is in the code object's metadata: build.py -v prints it)

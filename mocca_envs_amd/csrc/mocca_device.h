@@ -35,9 +35,11 @@
 
 #define DI __device__ __forceinline__
 
-// The device code is compiled into the library TWICE: namespace mocca (48 rows per env: every blob) and namespace mocca_r32
+// The device code is compiled into the library THREE times: namespace mocca (48 rows / 12 contacts per env: the product), namespace mocca_r32
 // (mocca_r32.hip: MOCCA_MAXR = 32, MOCCA_COMPACT = 1 -- the compact LDS layout below; blobs with max_rows <= 32, max_contacts <= 10 and no
-// loop closures, picked by mocca_create).  Same source, same arithmetic in the same order: the two instances are bit-identical.
+// loop closures) and namespace mocca_r64 (mocca_r64.hip: MOCCA_MAXR = 64 rows / 20 contacts -- every lane of the wave a row; 17 KB of LDS and
+// a two-waves-per-SIMD register budget: the ACCURACY instance, for blobs whose caps exceed 48 / 12: Bullet has no cap at all), picked by
+// mocca_create from the blob's caps.  Same source, same arithmetic in the same order: on the same blob the instances are bit-identical.
 #ifndef MOCCA_NS
 #define MOCCA_NS mocca
 #endif
@@ -82,7 +84,7 @@ typedef const MOCCA_AS_CONST f4_t* CF4P;
 #define MOCCA_PRIO_T1 4
 #endif
 constexpr int MAXR = MOCCA_MAXR;                  // rows held by one wave (MoccaModel.max_rows must be <= MAXR)
-constexpr int MAXC = MAXR >= 36 ? 12 : MAXR / 3;  // contacts            (MoccaModel.max_contacts <= MAXC)
+constexpr int MAXC = MAXR >= 64 ? 20 : (MAXR >= 36 ? 12 : MAXR / 3);  // contacts (MoccaModel.max_contacts <= MAXC)
 constexpr bool COMPACT = MOCCA_COMPACT != 0;
 constexpr int DYN_STRIDE = 96;      // floats per env in the dynamic-state buffer
 constexpr int TERRAIN_STRIDE = 128; // floats per env in the terrain buffer
@@ -151,18 +153,18 @@ enum : int {
   L_OBS = L_V + 520,    // [<= 136] task layer (after the substeps: the geom points are dead): the observation is assembled here and leaves
                         //          in one coalesced store -- twice for an env that ends under auto-reset (terminal observation, then the
                         //          first observation of the next episode)
-  L_CT = L_V + 656,     // [MAXC][16] contact records (192)
+  L_CT = L_V + 656,     // [MAXC][16] contact records (192; 320 in the 64-row instance, which moves everything behind them up by 128)
   GP_FLOATS = L_CT - L_GP,
-  L_ROWD = L_V + 848,   // [48] compacted limit-row candidates (int)
-  L_RT = L_V + 896,     // [NB][3][4] body frames: row i of the rotation (3) + component i of the origin rel. the base origin: one 16-byte
+  L_ROWD = L_CT + 16 * MAXC,   // (L_V + 848) [48] compacted limit-row candidates (int)
+  L_RT = L_ROWD + 48,   // (L_V + 896) [NB][3][4] body frames: row i of the rotation (3) + component i of the origin rel. the base origin: one 16-byte
                         //            write per (body, row) lane of the walk, three 16-byte reads per consumer
-  L_M = L_V + 1160,     // [NB][36] link / articulated inertias, full 6x6 rows (lane = row in the inward pass)
-  L_P = L_V + 1952,     // [NB][6]  bias forces
-  L_ABA_END = L_V + 2084,
+  L_M = L_RT + 264,     // (L_V + 1160) [NB][36] link / articulated inertias, full 6x6 rows (lane = row in the inward pass)
+  L_P = L_M + 792,      // (L_V + 1952) [NB][6]  bias forces
+  L_ABA_END = L_P + 132,   // (L_V + 2084)
   L_CAND = L_ABA_END,   // [MAX_PAIRS] u16 self-collision candidates (collide only: the slack the joint records 9.. used during the walk)
   // ---- solver view
   L_A = L_V,            // [MAXR][MAXR] Delassus matrix, row = updated row, column = lane
-  L_J = L_V + 960,      // [MAXR][28] Jacobian rows (tail of the A region)
+  L_J = (L_V + 960 > L_RT ? L_V + 960 : L_RT),   // [MAXR][28] Jacobian rows (tail of the A region; never below the body frames, see the assert)
   L_XL = L_V,           // [MAXR][28] M^-1 J^T lambda, after the iterations
   L_TOTAL = L_V + MAXR * MAXR + 28 + MOCCA_LDS_PAD,  // + one dummy J row for lanes that own no row (A-row prefetches clamp to row MAXR - 1)
 #endif
@@ -178,7 +180,9 @@ static_assert(L_TOTAL * 4 <= 8192 || MOCCA_LDS_PAD > 0, "more than 8 KB of LDS p
 static_assert(L_J >= L_SV + 22 * SVS, "J rows are written while S, V, 1/D are still being read");
 static_assert(L_CAND + (MOCCA_MAX_PAIRS + 1) / 2 <= L_ABA_END && L_RT + 264 <= L_GP, "frames, geom points and the candidate list live under the link inertias");
 #else
-static_assert(L_TOTAL * 4 <= 10240 || MOCCA_LDS_PAD > 0, "more than 10 KB of LDS per wave: fewer than 16 waves per CU, the 4096-env batch no longer fits one round");
+static_assert(L_TOTAL * 4 <= 10240 || MOCCA_LDS_PAD > 0 || MAXR > 48, "more than 10 KB of LDS per wave: fewer than 16 waves per CU, the 4096-env batch no longer fits one round");
+static_assert(MAXR != 48 || (L_ROWD == L_V + 848 && L_RT == L_V + 896 && L_M == L_V + 1160 && L_P == L_V + 1952 && L_ABA_END == L_V + 2084 && L_J == L_V + 960), "the product's layout is unchanged");
+static_assert(COMPACT || L_CAND + (MOCCA_MAX_PAIRS + 1) / 2 <= L_TOTAL, "candidate list behind the ABA view");
 static_assert(L_J >= L_RT, "J rows may be written while S, U, 1/D, the factor of IA0 and the contacts are still being read");
 #endif
 
@@ -2028,9 +2032,15 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
       const bool on_circle = lam * lam + lpart * lpart >= lm * lm * (1.0f - 1e-5f);   // cone: the pair sits on the circle (the oracle's expression)
       const bool clamped = has_row && (kind == 2 ? (cone ? on_circle : fabsf(lam) == lm) : (kind != 3 && lam == 0.0f));
       clamp_last = __ballot(clamped);
-      if constexpr (MAXR != 48) {   // the record names friction rows by the lanes of the 48-row instance (46 - 2i, 47 - 2i; include/mocca.h): move this instance's up
-        const int lo = MAXR - 2 * nc;
-        clamp_last = (clamp_last & ((1ull << lo) - 1ull)) | ((clamp_last >> lo) << (48 - 2 * nc));
+      if constexpr (MAXR != 48) {
+        // The record names friction rows by the lanes of the 48-row instance (46 - 2i, 47 - 2i; include/mocca.h): move this instance's there.
+        // A blob whose caps exceed 48 rows / 12 contacts (it can only run the 64-row instance) is recorded in that instance's own lanes,
+        // 62 - 2i / 63 - 2i: the oracle follows the blob's caps.
+        const bool native = MAXR > 48 && (maxr > 48 || uni(M->max_contacts) > 12);
+        if (!native && nc > 0) {
+          const int lo = MAXR - 2 * nc;
+          clamp_last = (clamp_last & ((1ull << lo) - 1ull)) | ((clamp_last >> lo) << (48 - 2 * nc));
+        }
       }
       clamp_sig = ((clamp_sig << 7) | (clamp_sig >> 57)) ^ clamp_last;
     }

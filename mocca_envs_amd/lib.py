@@ -16,7 +16,7 @@ ABI_VERSION = 5
 PARAM_AUTO_RESET, PARAM_EVAL_MODE, PARAM_CURRICULUM, PARAM_RANDOM_POSE, PARAM_HOST_RETARGET, PARAM_SEED, PARAM_ENV_OFFSET, PARAM_APPLIED_GAIN, PARAM_RANDOM_REWARD = 0, 1, 2, 3, 4, 5, 6, 7, 8
 PARAM_ISSUE_PRIORITY = 9   # timing only: row-count thresholds of the step kernel's issue priorities, t1 + 64 t2 + 4096 t3
 PARAM_PERSIST_IMPULSES = 10  # keep the last substep's normal impulses in the state record although the blob does not warm-start (diagnostic)
-PARAM_KERNEL_VARIANT = 11    # timing only: 1 forces the 48-row step-kernel instance for a blob that would run the compact one
+PARAM_KERNEL_VARIANT = 11    # timing only: 1 forces the 48-row step-kernel instance for a blob that would run the compact one, 2 the 64-row one for any blob
 PARAM_ORDER_EVERY = 12       # timing only: every K-th step re-sorts the launch order, heaviest envs (most constraint rows) first
 PARAM_PACE_TICKS = 13        # timing only: pace priorities (target ticks per env.step of a wave) instead of the row-count priorities
 DEBUG_WORDS = 20

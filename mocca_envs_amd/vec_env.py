@@ -125,9 +125,16 @@ class VecEnv:
             # <= 32 rows / <= 10 contacts runs the COMPACT instance of the step kernel (include/mocca.h MOCCA_PARAM_KERNEL_VARIANT: less LDS
             # per env, more resident waves -- what batches beyond one residency round, > 4096 envs per GPU, want); an env that asks for
             # more in a substep keeps its deepest contacts, exactly as under the default 48 / 12 caps (how often: tools/cap_pressure.py).
+            # Caps beyond 48 rows / 12 contacts (up to 64 / 20: every lane of the wave a row) run the ACCURACY instance (mocca_r64.hip: 17 KB of LDS
+            # per env, two waves per SIMD) -- Bullet has no cap; `max_rows=64` alone asks for its 20 contacts too.
             if max_rows is not None:
                 self.model.max_rows = int(max_rows)
-            self.model.max_contacts = int(max_contacts) if max_contacts is not None else min(int(self.model.max_contacts), int(self.model.max_rows) // 3)
+            if max_contacts is not None:
+                self.model.max_contacts = int(max_contacts)
+            elif int(self.model.max_rows) > 48:
+                self.model.max_contacts = min(20, int(self.model.max_rows) // 3)
+            else:
+                self.model.max_contacts = min(int(self.model.max_contacts), int(self.model.max_rows) // 3)
             model_blob = self.model.to_bytes()
         if self.lib.mocca_model_sizeof() != len(model_blob):
             raise _lib.MoccaError("MoccaModel layout mismatch between model.py and libmocca_hip.so")

@@ -39,10 +39,12 @@ typedef REAL real;
 
 #define MB MOCCA_MAX_BODIES
 #define NDOF_MAX (6 + MB)
-#define MAX_CONTACTS 16 /* storage; the live caps are MoccaModel.max_contacts / max_rows */
+#define MAX_CONTACTS 24 /* storage; the live caps are MoccaModel.max_contacts / max_rows (<= 20 / 64: the HIP accuracy instance's) */
 #define MAX_ROWS 64
 #define DBG_WORDS 20    /* MOCCA_DEBUG_WORDS of include/mocca.h */
-#define KERNEL_MAXR 48  /* the HIP solver's lane layout (mocca_device.h MAXR): friction rows of contact i sit on lanes 46 - 2i, 47 - 2i */
+/* the HIP solver's lane layout (mocca_device.h MAXR): friction rows of contact i sit on lanes 46 - 2i, 47 - 2i -- 62 - 2i, 63 - 2i in the
+ * 64-row instance, which runs the blobs whose caps exceed 48 rows / 12 contacts */
+#define KERNEL_MAXR(m) (((m)->max_rows > 48 || (m)->max_contacts > 12) ? 64 : 48)
 
 #if defined(__GNUC__)
 #define API __attribute__((visibility("default")))
@@ -981,7 +983,7 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
           real l2 = w->lam[r] * w->lam[r] + w->lam[rb] * w->lam[rb];
           int clamped = l2 >= lim * lim * (real)(1 - 1e-5);
           for (int k = 0; k < 2; ++k) {
-            int q = r + k, lane = KERNEL_MAXR - 2 - 2 * ((q - first_fric) / 2) + ((q - first_fric) & 1);
+            int q = r + k, lane = KERNEL_MAXR(m) - 2 - 2 * ((q - first_fric) / 2) + ((q - first_fric) & 1);
             if (clamped) clamp_last |= (uint64_t)1 << lane;
           }
         }
@@ -1009,7 +1011,7 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
       {
         real hi_f = w->row_kind[r] == 2 ? w->row_mu[r] * w->lam[w->row_normal[r]] : 0;
         int clamped = w->row_kind[r] == 2 ? fabs(nl) == hi_f : (w->row_kind[r] != 3 && nl == 0);
-        int lane = r < first_fric ? r : KERNEL_MAXR - 2 - 2 * ((r - first_fric) / 2) + ((r - first_fric) & 1);
+        int lane = r < first_fric ? r : KERNEL_MAXR(m) - 2 - 2 * ((r - first_fric) / 2) + ((r - first_fric) & 1);
         if (clamped) clamp_last |= (uint64_t)1 << lane;
       }
     }

@@ -239,7 +239,7 @@ class Oracle:
         return out
 
     def last_contacts(self) -> np.ndarray:
-        out = np.zeros((16, 11), np.float64)
+        out = np.zeros((24, 11), np.float64)
         n = self.lib.orc_last_contacts(self.h, _p(out))
         return out[:n]
 

@@ -48,6 +48,68 @@ def test_compact_and_full_instances_agree_bit_for_bit(env_id):
     a_env.close(); b_env.close()
 
 
+@pytest.mark.parametrize("env_id", ["Walker3DCustomEnv-v0", "Walker3DStepperEnv-v0", "CassieEnv-v0", "LaikagoStepperEnv-v0", "Crab2DCustomEnv-v0", "MikePlannerEnv-v0"])
+def test_wide_and_full_instances_agree_bit_for_bit(env_id):
+    """mocca_r64.hip (64 rows / 20 contacts, the accuracy instance) forced onto a blob with the product's caps (MOCCA_PARAM_KERNEL_VARIANT = 2)
+    against the 48-row instance on the same blob: the same program with another lane layout (friction rows on lanes 62 - 2i / 63 - 2i) and
+    another LDS layout -- everything must agree bit for bit, debug records included (recorded in the 48-row lane numbering for such a blob)."""
+    import torch
+    from mocca_envs_amd import lib as L
+    from mocca_envs_amd.vec_env import VecEnv
+    n, steps = 512, (40 if "Cassie" in env_id else 300)
+    a_env = VecEnv(env_id, n, auto_reset=True, seed=21)
+    b_env = VecEnv(env_id, n, auto_reset=True, seed=21)
+    b_env.set_param(L.PARAM_KERNEL_VARIANT, 2)
+    ka, kb = a_env.kernel_info(), b_env.kernel_info()
+    assert ka["lds_bytes"] <= 10240 and kb["lds_bytes"] > 16384, (ka, kb)
+    if "Stepper" in env_id:
+        a_env.set_param(L.PARAM_CURRICULUM, 9); b_env.set_param(L.PARAM_CURRICULUM, 9)
+    dbg_a, dbg_b = a_env.set_debug(True), b_env.set_debug(True)
+    assert torch.equal(a_env.reset(), b_env.reset())
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    for t in range(steps):
+        act = (torch.rand(n, a_env.act_dim, device="cuda", generator=g) * 2 - 1) * (1.0 if t % 3 else 0.3)
+        for x, y in zip(a_env.step(act), b_env.step(act)):
+            assert torch.equal(x, y), (env_id, t)
+    nd = 13 + 2 * a_env.model.n_joints
+    assert torch.equal(a_env.get_state()[:, :nd], b_env.get_state()[:, :nd]) and torch.equal(a_env.get_task(), b_env.get_task())
+    assert torch.equal(dbg_a, dbg_b)
+    assert int(dbg_a[:, 15].max()) >= (6 if "Cassie" in env_id else 12)
+    with pytest.raises(L.MoccaError):
+        VecEnv(env_id, 4, max_rows=64).set_param(L.PARAM_KERNEL_VARIANT, 1)     # caps beyond the 48-row instance cannot be forced onto it
+    a_env.close(); b_env.close()
+
+
+def test_the_wide_instance_holds_what_the_product_caps_drop():
+    """Stepper curriculum 9 (BASELINE config 3's hard end): with 64 rows / 20 contacts the cap-pressure counters of the debug record stay at
+    zero where the 48 / 12 caps drop contacts or rows (profiles/r04_cap_pressure.jsonl: 11 % of the envs at least once in 1000 steps), and
+    row counts above 48 are really solved."""
+    import torch
+    from mocca_envs_amd import lib as L
+    from mocca_envs_amd.vec_env import VecEnv
+    n, steps = 2048, 400
+    res = {}
+    for name, kw in (("capped", {}), ("wide", {"max_rows": 64})):
+        env = VecEnv("Walker3DStepperEnv-v0", n, auto_reset=True, seed=3, **kw)
+        assert (env.model.max_rows, env.model.max_contacts) == ((64, 20) if kw else (48, 12))
+        env.set_param(L.PARAM_CURRICULUM, 9)
+        dbg = env.set_debug(True)
+        env.reset()
+        g = torch.Generator(device="cuda"); g.manual_seed(1)
+        rows_max = 0
+        for t in range(steps):
+            env.step(torch.rand(n, 21, device="cuda", generator=g) * 2 - 1)
+            if t % 20 == 0:
+                rows_max = max(rows_max, int(dbg[:, 0].max()))
+        d = dbg.cpu().numpy()
+        res[name] = dict(contact_drops=int(d[:, 12].sum()), row_drops=int(d[:, 13].sum()), envs_capped=int(((d[:, 12] + d[:, 13]) > 0).sum()),
+                         wanted_max=int(d[:, 15].max()), rows_max=rows_max)
+        env.close()
+    print(res)
+    assert res["capped"]["envs_capped"] > 0 and res["capped"]["wanted_max"] > 48
+    assert res["wide"]["wanted_max"] > 48 and res["wide"]["envs_capped"] <= res["capped"]["envs_capped"] // 20
+
+
 def test_caps_above_the_compact_instance_run_the_full_one():
     from mocca_envs_amd.vec_env import VecEnv
     for kw, compact in (({}, False), ({"max_rows": 33}, False), ({"max_rows": 32, "max_contacts": 11}, False), ({"max_rows": 32}, True), ({"max_rows": 16}, True)):

@@ -57,6 +57,10 @@ CASES = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("Walker3DStepper
          ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_caps": (32, 10)}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_caps": (32, 10)}),
          ("LaikagoStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_caps": (32, 10)}), ("Crab2DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_caps": (32, 10)}),
          ("Walker3DPlannerEnv-v0", M.TASK_WALKER3D_PLANNER, {"_caps": (32, 10)}), ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_caps": (24, 6), "_warm": 0.85}),
+         # the ACCURACY instance (mocca_r64.hip: 64 rows / 20 contacts per env -- Bullet has no cap) against the oracle with the same caps; the 2 cm
+         # margins put more contacts on the lying robots, so that row counts beyond 48 are in the sample
+         ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_caps": (64, 20)}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_caps": (64, 20), "_abs_margin": True}),
+         ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_caps": (64, 20), "_abs_margin": True}), ("CassieEnv-v0", M.TASK_CASSIE, {"_caps": (64, 20)}),
          # one absolute contact margin of 2 cm for every pair (g_margin <= 0; the compiled blobs carry Bullet's relative thresholds, millimetres)
          ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_abs_margin": True}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_abs_margin": True})]
 
@@ -204,6 +208,8 @@ def test_single_substep_parity_with_matching_active_sets(env_id, task, kw):
           f"p90 {q(e_gpu, 90):.3g} p99 {q(e_gpu, 99):.3g} max {e_gpu.max():.3g} | f32 oracle vs f64 oracle median {q(e_f32, 50):.3g} "
           f"p90 {q(e_f32, 90):.3g} p99 {q(e_f32, 99):.3g} max {e_f32.max():.3g}")
     assert rows.max() >= (6 if task == M.TASK_CASSIE else 12), "the sample must contain contact-rich substeps"
+    if kw.get("_caps") == (64, 20) and kw.get("_abs_margin"):
+        assert rows.max() > 48, "the accuracy instance's sample must contain substeps beyond the product's 48-row cap"
     assert frac < 0.01, f"active sets differ in {100 * frac:.2f} % of the substeps"
     if e_flip:
         e_flip = np.concatenate(e_flip)
