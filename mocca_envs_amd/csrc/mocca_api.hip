@@ -474,7 +474,7 @@ int mocca_set_seed(mocca_handle h, uint64_t seed) {
 
 int mocca_is_diagnostic_build(void) {
 #if defined(MOCCA_SKIP_COLLIDE) || defined(MOCCA_SKIP_ABA) || defined(MOCCA_SKIP_SOLVE) || defined(MOCCA_DUMMY_VALU) || defined(MOCCA_STAMPS) || \
-    defined(MOCCA_NO_TWO_PATHS) || MOCCA_LDS_PAD > 0
+    defined(MOCCA_NO_TWO_PATHS) || defined(MOCCA_ABL_PAIRLOAD) || defined(MOCCA_ABL_NOPASS2) || defined(MOCCA_ABL_NOHITS) || MOCCA_LDS_PAD > 0
   return 1;
 #else
   return 0;

@@ -1344,7 +1344,12 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
     const int k = base + lane;
     bool near = false;
     if (k < npairs) {
+#ifdef MOCCA_ABL_PAIRLOAD   // ablation (tools/r05_l2chain_ab.sh; results WRONG by construction): the broad phase's pair record made up from the lane
+      f4_t pt;              // instead of loaded -- what ANY staging of the pair table could save at most (measured: 0.2 % of the launch)
+      pt.x = __int_as_float((k % T::NG) | (((k * 7 + 3) % T::NG) << 5) | (24 << 20)); pt.y = 0.05f; pt.z = 0.05f; pt.w = 0.04f;
+#else
       const f4_t pt = *(CF4P)(M->pair_tab[k]);  // geoms, bodies, radii, reach: one load
+#endif
       const int ids = __float_as_int(pt.x);   // geom_a | geom_b << 5 | body_a << 10 | body_b << 15 | margin code << 20
       const int ga = ids & 31, gb = (ids >> 5) & 31;
       float dm[3];  // distance of the two segment midpoints (x2); the segments' half lengths and radii are constants of the pair (pt.w)
@@ -1359,6 +1364,9 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
     ncand += __popcll(nm);
   }
   ncand = uni(ncand);
+#ifdef MOCCA_ABL_NOPASS2   // ablation (results WRONG by construction): the broad phase runs, its survivors are dropped -- narrow phase + the rows its contacts add
+  ncand = 0;
+#endif
   wsync();
 #pragma unroll 1
   for (int base = 0; base < ncand; base += 64) {
@@ -1382,6 +1390,9 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
       const float d2 = dot3(d, d), id = rsq(d2), dist = d2 * id, ra = pt.y, rb = pt.z;  // v_rsq_f32 (1 ulp)
       g2 = dist - ra - rb;
       hit = g2 < (float)((ids >> 20) & 0xFF) * (1.0f / 8192.0f) && d2 > 1e-18f;   // the smaller of the two links' relative thresholds
+#ifdef MOCCA_ABL_NOHITS      // ablation (results WRONG by construction): the narrow phase runs, its contacts are dropped -- separates its own cost from the rows it adds
+      hit = hit && g2 < -1e30f;
+#endif
       if (hit) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {

@@ -93,3 +93,15 @@ def test_diagnostic_builds_are_refused(tmp_path):
     assert r.returncode == 0, r.stderr
     from mocca_envs_amd import lib
     assert lib.load().mocca_is_diagnostic_build() == 0          # the product build is not one
+
+
+def test_multi_handle_envs_validate_their_arguments_before_touching_a_gpu():
+    """mocca_envs_amd.multi: the cuts must be even, and sub-batches do not combine with several devices (shard first)."""
+    import pytest
+    from mocca_envs_amd.multi import ShardedVecEnv, SubBatchedVecEnv, make_vec_env
+    with pytest.raises(ValueError):
+        SubBatchedVecEnv("Walker3DCustomEnv-v0", 100, sub_batches=3)
+    with pytest.raises(ValueError):
+        ShardedVecEnv("Walker3DCustomEnv-v0", 100, devices=[0, 1, 2])
+    with pytest.raises(ValueError):
+        make_vec_env("Walker3DCustomEnv-v0", 128, sub_batches=2, devices=[0, 1])

@@ -176,14 +176,16 @@ def test_the_reference_mirror_sets_on_hip(env_id, one_substep):
         eo = _units(mir.state(s1)[:, :nd], s2[:, :nd]).max(axis=1)
         multi_orc.append(eo[np.isfinite(eo) & ~few[:n_orc]])
     exact, multi, multi_orc = np.concatenate(exact), np.concatenate(multi), np.concatenate(multi_orc)
-    q = lambda x, p: float(np.percentile(x, p))
+    q = lambda x, p: float(np.percentile(x, p)) if len(x) else 0.0
     frac = lambda x: float((x < 10).mean())
     print(f"\n{env_id} ({'one substep' if one_substep else 'full step'}): at most one row (n={len(exact)}): mirror residual median {q(exact, 50):.3g} p99 {q(exact, 99):.3g} "
-          f"max {exact.max():.3g} units of 1e-5 (1 + |x|); more rows (n={len(multi)}): {100 * frac(multi):.1f} % below 10 units, p90 {q(multi, 90):.3g} | f64 oracle on {len(multi_orc)} of "
+          f"max {exact.max(initial=0.0):.3g} units of 1e-5 (1 + |x|); more rows (n={len(multi)}): {100 * frac(multi):.1f} % below 10 units, p90 {q(multi, 90):.3g} | f64 oracle on {len(multi_orc)} of "
           f"the same states: {100 * frac(multi_orc):.1f} % below 10 units, p90 {q(multi_orc, 90):.3g}; obs {obs_err:.2e} reward {rew_err:.2e} done flips {done_diff}")
-    assert len(exact) > 150 and len(multi) > 10000     # (Mike on the planks is rarely on fewer than two rows)
+    # (Mike on the planks is rarely on fewer than two rows in a substep, and never through a whole env.step)
+    assert len(multi) > 10000 and (len(exact) > (150 if "Mike" in env_id else (2000 if one_substep else 500)) or ("Mike" in env_id and not one_substep))
     # free flight / one row: the mirrored state runs the same arithmetic on other lanes -- fp32 rounding, the yardstick of the substep test
-    assert q(exact, 50) < 1.0 and q(exact, 99) < 10.0 and exact.max() < (30.0 if one_substep else 300.0)
+    if len(exact):
+        assert q(exact, 50) < 1.0 and q(exact, 99) < 10.0 and exact.max() < (30.0 if one_substep else 300.0)
     assert obs_err < 5e-3 and rew_err < 5e-2 and done_diff <= 2
     # more rows: Gauss-Seidel's visiting order is not mirrored; HIP must be as (a)symmetric as the exact algorithm is
     assert abs(frac(multi) - frac(multi_orc)) < 0.08

@@ -208,7 +208,7 @@ def test_single_substep_parity_with_matching_active_sets(env_id, task, kw):
           f"p90 {q(e_gpu, 90):.3g} p99 {q(e_gpu, 99):.3g} max {e_gpu.max():.3g} | f32 oracle vs f64 oracle median {q(e_f32, 50):.3g} "
           f"p90 {q(e_f32, 90):.3g} p99 {q(e_f32, 99):.3g} max {e_f32.max():.3g}")
     assert rows.max() >= (6 if task == M.TASK_CASSIE else 12), "the sample must contain contact-rich substeps"
-    if kw.get("_caps") == (64, 20) and kw.get("_abs_margin"):
+    if kw.get("_caps") == (64, 20) and kw.get("_abs_margin") and task == M.TASK_WALKER3D_STEPPER:
         assert rows.max() > 48, "the accuracy instance's sample must contain substeps beyond the product's 48-row cap"
     assert frac < 0.01, f"active sets differ in {100 * frac:.2f} % of the substeps"
     if e_flip:
