@@ -9,14 +9,14 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_trace -- python3 $R/bench.py --env-id $envid --envs $envs --steps 400 --warmup 100 --no-cpu-baseline --preroll-seconds 0 $BENCH_EXTRA > $O/${tag}_bench.json 2> $O/${tag}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_trace -- python3 $R/bench.py --env-id $envid --envs $envs --steps 400 --warmup 100 --no-cpu-baseline --no-physics-bracket --preroll-seconds 0 $BENCH_EXTRA > $O/${tag}_bench.json 2> $O/${tag}_bench.err
 cp $(find $O/${tag}_trace -name "*kernel_stats.csv" | head -1) $O/${tag}_kernel_stats.csv
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_WRREQ TCC_EA0_WRREQ_64B" "TCC_HIT TCC_MISS TCC_REQ" \
             "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
             "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU" \
             "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   n=$(echo $pass | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $O/${tag}_pmc_$n -- python3 $R/bench.py --env-id $envid --envs $envs --steps 20 --warmup 200 --no-cpu-baseline --preroll-seconds 0 $BENCH_EXTRA > /dev/null 2>&1
+  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $O/${tag}_pmc_$n -- python3 $R/bench.py --env-id $envid --envs $envs --steps 20 --warmup 200 --no-cpu-baseline --no-physics-bracket --preroll-seconds 0 $BENCH_EXTRA > /dev/null 2>&1
 done
 python3 - $O $tag <<'PY'
 import csv, glob, json, sys, collections
@@ -41,19 +41,31 @@ O, tag, R, envs = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 sys.path.insert(0, R)
 import bench
 p = json.load(open(f"{O}/{tag}_pmc_summary.json"))
+# FETCH_SIZE calibration for THIS kernel's access pattern (tools/fetch_size_probe.hip, profiles/r05_fetch_size_probe.txt): a kernel that does nothing but
+# the step's reads and writes (dyn 55 words of a 96-word record, task 40 words, action 21 words per env in; dyn, task, obs 52, reward, done out)
+# touches 500 B of 64-B lines per env and FETCH_SIZE reports 360 B -- gfx950 tallies the 128-B requests of the record reads at 64 B (the guide's
+# factor 2, which the probe reproduces for 16-B-per-lane AND 4-B-per-lane streams) but counts the short contiguous reads in full: factor 500 / 360.
+# WRITE_SIZE reads the same pattern's stores exactly (648 B per env at 32-B sector granularity).
+FETCH_CAL = 500.0 / 360.0
 t = {"kernel": "mocca_step_kernel", "envs_per_launch": envs, "kernel_source_sha256": bench.kernel_source_hash(),
      "FETCH_SIZE_KB": p["FETCH_SIZE"], "WRITE_SIZE_KB": p["WRITE_SIZE"], "TCC_EA0_RDREQ": p.get("TCC_EA0_RDREQ"),
      "TCC_EA0_WRREQ": p.get("TCC_EA0_WRREQ"),
-     "traffic_bytes_per_launch": 1024 * (p["FETCH_SIZE"] + p["WRITE_SIZE"]),
+     "fetch_calibration": FETCH_CAL,
+     "traffic_bytes_per_launch": 1024 * (FETCH_CAL * p["FETCH_SIZE"] + p["WRITE_SIZE"]),
+     "traffic_bytes_per_launch_uncorrected": 1024 * (p["FETCH_SIZE"] + p["WRITE_SIZE"]),
      "traffic_bytes_per_launch_if_fetch_doubled": 1024 * (2 * p["FETCH_SIZE"] + p["WRITE_SIZE"]),
      "valu": {"valu_insts_per_env_step": p["SQ_INSTS_VALU"] / envs,
               "active_lane_ops_per_launch": p["SQ_THREAD_CYCLES_VALU"] / 4.0,
               "active_lanes_per_valu_inst": p["SQ_THREAD_CYCLES_VALU"] / 4.0 / p["SQ_INSTS_VALU"]},
      "method": "rocprofv3 --pmc, separate passes (FETCH_SIZE; WRITE_SIZE; TCC_EA0_*; SQ_*) over `bench.py --steps 20 --warmup 200` "
                "(tools/profile_round.sh): steady state of the auto-reset workload, averaged over the last 20 launches; KB -> bytes x1024. "
-               "FETCH_SIZE is reported uncorrected: the gfx950 x2 correction of MI355X_MICROARCH.md is calibrated for 16-B-per-lane "
-               "streams, this kernel issues 4-B-per-lane loads (TCC_EA0_RDREQ x 64 B equals FETCH_SIZE); the doubled figure is an upper "
-               "bound. active_lane_ops = SQ_THREAD_CYCLES_VALU / 4 (a wave64 VALU instruction occupies each active lane for 4 cycles).",
+               "traffic = fetch_calibration x FETCH_SIZE + WRITE_SIZE.  The calibration (1.39) is MEASURED on this kernel's own access pattern "
+               "(tools/fetch_size_probe.hip: a kernel with exactly the step's reads and writes touches 500 B of 64-B lines per env, FETCH_SIZE reports "
+               "360 B; profiles/r05_fetch_size_probe.txt): gfx950 tallies the 128-B requests of the strided record reads at 64 B -- the guide's factor 2, "
+               "which the probe reproduces for 4-B-per-lane as well as 16-B-per-lane streams, so round 4's claim that the factor does not apply to "
+               "4-B-per-lane loads was wrong -- and counts the short contiguous reads (task record, actions) in full; WRITE_SIZE is exact for the "
+               "pattern.  The uncorrected and the doubled figure are kept as bounds. active_lane_ops = SQ_THREAD_CYCLES_VALU / 4 (a wave64 VALU "
+               "instruction occupies each active lane for 4 cycles).",
      "source": f"profiles/{tag}_pmc_summary.json"}
 json.dump(t, open(f"{O}/{tag}_traffic.json", "w"), indent=1)
 PY

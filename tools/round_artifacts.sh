@@ -16,7 +16,7 @@ for n in 512 1024 2048 4096 8192 16384; do
     python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'envs': $n, 'kernel_us': round(1000*d['roofline']['kernel_ms'],1), 'env_steps_per_s': round(d['value'])}))"
 done > $O/${tag}_batch_sweep.jsonl
 # 3. the other configs / env ids (untraced bench lines)
-python bench.py --envs 8192 --steps 400 --warmup 200 --no-cpu-baseline > $O/${tag}_custom8192_bench.json 2>/dev/null
+python bench.py --envs 8192 --steps 400 --warmup 200 --no-cpu-baseline --no-physics-bracket > $O/${tag}_custom8192_untraced_bench.json 2>/dev/null
 python bench.py --env-id Walker3DStepperEnv-v0 --curriculum 0 --steps 400 --warmup 200 --no-cpu-baseline > $O/${tag}_stepper_c0_bench.json 2>/dev/null
 python bench.py --env-id Walker3DStepperEnv-v0 --curriculum 9 --steps 400 --warmup 200 --no-cpu-baseline > $O/${tag}_stepper_c9_bench.json 2>/dev/null
 python bench.py --env-id CassieEnv-v0 --envs 2048 --steps 100 --warmup 30 --no-cpu-baseline > $O/${tag}_cassie_bench.json 2>/dev/null
