@@ -88,27 +88,33 @@ def obs_mirror(mirror_indices, dim):
 _POLAR3 = ("jpos", "com", "g_p1", "g_p2", "foot_point", "cl_point_a", "cl_point_b")
 
 
-def reflect_model(m):
-    """The mirror-image robot: every body seen through the x-z plane of its own frame (frames stay right-handed: F' = S F S).
-    Body-fixed points S p; hinge axes -S a (the same angle then describes the mirrored rotation); rotations S R S; inertia
-    products xy and yz change sign.  Joint order, limits, gains, masses are untouched: the SAME q, qd and torques drive it."""
+def reflect_model(m, plane: str = "xz"):
+    """The mirror-image robot: every body seen through the x-z plane of its own frame (plane="yz": its y-z plane -- the in-plane mirror of
+    the planar robots); frames stay right-handed: F' = S F S.  Body-fixed points S p; hinge axes -S a (the same angle then describes the
+    mirrored rotation); rotations S R S; the inertia products that involve the mirrored axis change sign.  Joint order, limits, gains,
+    masses are untouched: the SAME q, qd and torques drive it."""
+    k = 1 if plane == "xz" else 0                       # the axis that changes sign
     r = type(m).from_bytes(m.to_bytes())
     for name in _POLAR3:
         arr = getattr(r, name)
         for i in range(len(arr)):
-            arr[i][1] = -arr[i][1]
+            arr[i][k] = -arr[i][k]
+    rot_idx = [3 * i + j for i in range(3) for j in range(3) if (i == k) != (j == k)]   # S R S: entries with exactly one index on the axis
+    prod_idx = {1: (3, 5), 0: (3, 4)}[k]                 # xx yy zz xy xz yz
     for b in range(len(r.jaxis)):
-        r.jaxis[b][0] = -r.jaxis[b][0]
-        r.jaxis[b][2] = -r.jaxis[b][2]
-        for k in (1, 3, 5, 7):          # S R S: entries with exactly one index = y
-            r.jrot[b][k] = -r.jrot[b][k]
-        r.inertia[b][3] = -r.inertia[b][3]   # xy
-        r.inertia[b][5] = -r.inertia[b][5]   # yz
-    r.init_pos[1] = -r.init_pos[1]
-    r.init_vel[1] = -r.init_vel[1]
-    r.cassie_target[1] = -r.cassie_target[1]
-    r.init_quat[0] = -r.init_quat[0]
-    r.init_quat[2] = -r.init_quat[2]
+        for i in range(3):
+            if i != k:
+                r.jaxis[b][i] = -r.jaxis[b][i]
+        for x in rot_idx:
+            r.jrot[b][x] = -r.jrot[b][x]
+        for x in prod_idx:
+            r.inertia[b][x] = -r.inertia[b][x]
+    r.init_pos[k] = -r.init_pos[k]
+    r.init_vel[k] = -r.init_vel[k]
+    r.cassie_target[k] = -r.cassie_target[k]
+    for i in range(3):
+        if i != k:
+            r.init_quat[i] = -r.init_quat[i]
     r.finalize_tables()
     return r
 

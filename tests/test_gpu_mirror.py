@@ -60,15 +60,20 @@ def _units(x, ref):
 
 @pytest.mark.parametrize("one_substep", [True, False])
 @pytest.mark.parametrize("env_id", ["Walker3DCustomEnv-v0", "Walker3DStepperEnv-v0", "Child3DCustomEnv-v0", "MikeStepperEnv-v0",
-                                    "LaikagoCustomEnv-v0", "CassieEnv-v0"])
+                                    "LaikagoCustomEnv-v0", "CassieEnv-v0", "Walker2DCustomEnv-v0:yz", "Crab2DCustomEnv-v0:yz", "Walker3DCustomEnv-v0:yz"])
 def test_reflected_world_on_hip(env_id, one_substep):
-    """T1 at 4096 envs (Cassie 2048): the kernel is covariant under the reflection of the world, in every contact configuration."""
+    """T1 at 4096 envs (Cassie 2048): the kernel is covariant under the reflection of the world, in every contact configuration.  ":yz" = the
+    world mirrored in its y-z plane (x -> -x): the planar robots' geometry lies IN the x-z plane, this is their mirror that is not the identity
+    (their whole-step parity with the oracle rests on looser bounds than the 3-D robots': two coplanar end spheres share a load the solver
+    cannot split uniquely -- here the kernel is held to ITSELF, bit for bit, on exactly those states)."""
     import torch
+    env_id, _, plane = env_id.partition(":")
+    plane = plane or "xz"
     task = TASKS[env_id]
     n = 2048 if task == M.TASK_CASSIE else 4096
     m = _model(env_id, one_substep)
     nj, nd = m.n_joints, 13 + 2 * m.n_joints
-    gen, A, B = _envs(env_id, m.to_bytes(), reflect_model(m).to_bytes(), n)
+    gen, A, B = _envs(env_id, m.to_bytes(), reflect_model(m, plane).to_bytes(), n)
     dA, dB = A.set_debug(True), B.set_debug(True)
     g = torch.Generator(device="cuda").manual_seed(3)
     rounds = 6 if task == M.TASK_CASSIE else 12
@@ -80,7 +85,7 @@ def test_reflected_world_on_hip(env_id, one_substep):
         s = gen.get_state().cpu().numpy()
         tk = gen.get_task()
         A.set_state(s); A.set_task(tk)
-        B.set_state(reflect_state(s, nj)); B.set_task(_flip_task_words(tk, [1]))
+        B.set_state(reflect_state(s, nj, plane)); B.set_task(_flip_task_words(tk, [1] if plane == "xz" else [0, 22]))
         if task == M.TASK_WALKER3D_STEPPER:
             ter = gen.get_terrain().cpu().numpy()
             A.set_terrain(ter); B.set_terrain(reflect_terrain(ter))
@@ -93,10 +98,11 @@ def test_reflected_world_on_hip(env_id, one_substep):
         sig_words = slice(0, 12) if one_substep else slice(16, 19)       # last substep's active set / the whole step's decision signature
         same = (ga[:, sig_words] == gb[:, sig_words]).all(axis=1) & fin
         n_sig_diff += int((~same & fin).sum()); n_cmp += int(fin.sum())
-        e = _units(reflect_state(sa, nj)[:, :nd], sb[:, :nd]).max(axis=1)
+        e = _units(reflect_state(sa, nj, plane)[:, :nd], sb[:, :nd]).max(axis=1)
         errs.append(e[same])
         assert torch.equal(da, db)
-        assert float((ra - rb).abs()[torch.from_numpy(same).cuda()].max()) <= 1e-4
+        if plane == "xz":
+            assert float((ra - rb).abs()[torch.from_numpy(same).cuda()].max()) <= 1e-4
         rows_max = max(rows_max, int(ga[:, 0].max())); n_multi += int(((ga[:, 1] + ga[:, 2]) >= 2).sum())
     errs = np.concatenate(errs)
     print(f"\n{env_id} ({'one substep' if one_substep else 'full step'}): {n_cmp} samples, {n_multi} with >= 2 limit rows / contacts (max {rows_max} rows); "

@@ -173,6 +173,19 @@ def test_teacher_forced_steps(env_id, task):
         # worth up to 0.1 (1 + |x|) on the sample it hits (floor 100 units); how often that happens is bounded by the next line
         if (~same).any():
             assert cat[k][~same].max() < max(10 * ref.max() + 2.0, 100.0), (k, cat[k][~same].max(), ref.max())
+        # ... and where such steps are a large share of the run (the planar walkers: a third to a half of their steps, because two coplanar
+        # end spheres share a load the solver cannot split uniquely) their error DISTRIBUTION is held to the fp32 oracle's own on ITS
+        # non-matching steps against the f64 oracle: a kernel that went wrong by 1e-2 on every flipped step would pass the worst-sample
+        # bound above and fail here
+        if (~same).sum() >= 200 and (~same_ref).sum() >= 200:
+            qg = [float(np.percentile(cat[k][~same], p)) for p in (50, 90, 99)]
+            qr = [float(np.percentile(ref[~same_ref], p)) for p in (50, 90, 99)]
+            print(f"  {k}: non-matching steps, p50 / p90 / p99: {qg[0]:.3g} / {qg[1]:.3g} / {qg[2]:.3g} (f32 vs f64 oracle on its own: {qr[0]:.3g} / {qr[1]:.3g} / {qr[2]:.3g})")
+            # measured: Walker2D 2.9 / 3.6 / 4 x the yardstick's percentiles, Crab2D 8 / 12 / 12 x (the kernel's v_rcp / v_rsq / fast sincos differ
+            # from the oracle's libm by more than fp32 differs from fp64 rounding, so its flips happen a little further from the razor's edge);
+            # 20 x + 0.1 units still sits two orders of magnitude below an error of 1e-2 per flipped step (10 units)
+            for a_, b_ in zip(qg, qr):
+                assert a_ <= 20 * b_ + 0.1, (k, qg, qr)
         assert (cat[k] > 5.0).mean() < 2e-3, (k, (cat[k] > 5.0).mean())      # and such outliers stay below 0.2 %
     # the GPU is as close to the f64 oracle as the f32 CPU oracle is
     assert np.median(eg) <= 3 * np.median(ec) + 0.01

@@ -61,20 +61,27 @@ def _strata(dbg):
 
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 @pytest.mark.parametrize("env_id", ["Walker3DCustomEnv-v0", "Walker3DStepperEnv-v0", "MikeStepperEnv-v0", "Child3DCustomEnv-v0",
-                                    "LaikagoCustomEnv-v0", "LaikagoStepperEnv-v0", "CassieEnv-v0", "Cassie2DEnv-v0", "Crab2DCustomEnv-v0"])
+                                    "LaikagoCustomEnv-v0", "LaikagoStepperEnv-v0", "CassieEnv-v0", "Cassie2DEnv-v0", "Crab2DCustomEnv-v0",
+                                    "Walker2DCustomEnv-v0:yz", "Crab2DCustomEnv-v0:yz", "Walker3DCustomEnv-v0:yz"])
 def test_reflected_world_evolves_like_the_reflection(env_id, prec):
-    """T1, every contact configuration, bit for bit: state, active set, solver clamp signature, reward, done."""
+    """T1, every contact configuration, bit for bit: state, active set, solver clamp signature, reward, done.  ":yz" = the world mirrored in
+    its y-z plane instead (x -> -x): for the planar robots, whose geometry lies IN the x-z plane, the mirror that is not the identity."""
+    env_id, _, plane = env_id.partition(":")
+    plane = plane or "xz"
+    ax = 1 if plane == "xz" else 0
     task = TASKS[env_id]
     m = one_substep_model(env_id)
     nj, n = m.n_joints, 128
-    A, B = _oracles(m.to_bytes(), reflect_model(m).to_bytes(), env_id, n, prec)
+    A, B = _oracles(m.to_bytes(), reflect_model(m, plane).to_bytes(), env_id, n, prec)
     rng = np.random.default_rng(1)
     nd = 13 + 2 * nj
     rows_seen, multi = 0, 0
     for t in range(120):
         s, tk = A.get_state(), A.get_task()
-        tk[:, 1] *= -1                                   # walk target y
-        B.set_state(reflect_state(s, nj)); B.set_task(tk)
+        tk[:, ax] *= -1                                  # walk target y (x)
+        if ax == 0:
+            tk[:, 22] *= -1                              # prev_body_x (not a Custom-task word; kept consistent)
+        B.set_state(reflect_state(s, nj, plane)); B.set_task(tk)
         if task == M.TASK_WALKER3D_STEPPER:
             B.set_terrain(reflect_terrain(A.get_terrain()))
         a = rng.uniform(-1, 1, (n, A.act_dim)).astype(np.float32)
@@ -82,10 +89,11 @@ def test_reflected_world_evolves_like_the_reflection(env_id, prec):
         _, rb, db, _ = B.step(a)
         sa, sb = A.get_state(), B.get_state()
         fin = np.isfinite(sa).all(axis=1)
-        np.testing.assert_array_equal(reflect_state(sa, nj)[fin][:, :nd], sb[fin][:, :nd])
+        np.testing.assert_array_equal(reflect_state(sa, nj, plane)[fin][:, :nd], sb[fin][:, :nd])
         np.testing.assert_array_equal(A.get_debug()[fin][:, :12], B.get_debug()[fin][:, :12])
         np.testing.assert_array_equal(da, db)
-        np.testing.assert_array_equal(ra[fin], rb[fin])
+        if ax == 1:       # (mirrored in y-z the robot walks AWAY from where the reward wants it: state and decisions only)
+            np.testing.assert_array_equal(ra[fin], rb[fin])
         rows_seen = max(rows_seen, int(A.get_debug()[:, 0].max()))
         multi += int((_strata(A.get_debug()) == 2).sum())
         if t % 10 == 9:
