@@ -105,3 +105,17 @@ def test_multi_handle_envs_validate_their_arguments_before_touching_a_gpu():
         ShardedVecEnv("Walker3DCustomEnv-v0", 100, devices=[0, 1, 2])
     with pytest.raises(ValueError):
         make_vec_env("Walker3DCustomEnv-v0", 128, sub_batches=2, devices=[0, 1])
+
+
+def test_trainer_infos_container_behaves_like_a_list_of_dicts():
+    """trainer_api._Infos: what `for info in infos` / `infos[i]` / `len(infos)` of the PPO trainers see, without building N dicts per step."""
+    from mocca_envs_amd.trainer_api import _Infos
+    fin = {3: {"episode": {"r": 1.5, "l": 7}}, 9: {"episode": {"r": -2.0, "l": 1000}, "bad_transition": True}}
+    infos = _Infos(12, fin)
+    assert len(infos) == 12 and infos[3]["episode"]["l"] == 7 and infos[0] == {} and infos[-3] is fin[9]
+    assert [("episode" in i) for i in infos] == [k in fin for k in range(12)]
+    assert sum("bad_transition" in i.keys() for i in infos) == 1 and dict(infos.finished()) == fin
+    assert [len(x) for x in infos[2:5]] == [0, 1, 0]
+    import pytest
+    with pytest.raises(IndexError):
+        infos[12]
