@@ -243,7 +243,13 @@ typedef struct MoccaModel {
                                        createConstraintRows: "if (penetration > 0) continue"), pushed back with erp_noncontact; 0 = a row exists from a
                                        predicted gap of limit_slack on and stops the joint at the limit within the step (the file's older form,
                                        whose positive-gap branch is still in the source)                                   [UNVERIFIED-BULLET] */
-  int32_t reserved_[4];
+  float linear_slop;                /* Bullet's infoGlobal.m_linearSlop: added to every contact distance before the row is built (penetration = distance +
+                                       slop, btMultiBodyConstraintSolver::setupMultiBodyContactConstraint) -- a contact shallower than the slop gets a gap
+                                       row, a deeper one is corrected by erp x (depth - slop).  pybullet: setPhysicsEngineParameter(contactSlop=...),
+                                       1e-5 m where the server sets its default [UNVERIFIED-BULLET].  0 in the compiled blobs (the term was not
+                                       modelled before round 5 and moves nothing measurable: 1e-5 m x erp / dt = 2 mm/s of bias); a dump's
+                                       engine_contactSlop sets it.  (Takes the first of the former four reserved words: blobs of version 13 read as 0.) */
+  int32_t reserved_[3];
 
   /* ---- derived lookup tables (model.py finalize_tables): one 16-byte load instead of chains of dependent loads ---- */
   float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | margin_code<<17 (8 bits, x 2^-13 m) | terrain<<25 | (foot + 1)<<26 | torso<<29), bits(anc_mask[body]) */

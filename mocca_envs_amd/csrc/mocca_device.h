@@ -1808,7 +1808,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
     if (!is_fric) {
       kind = 1;
       dir[0] = n[0]; dir[1] = n[1]; dir[2] = n[2];
-      const float depth = ct[C_DEPTH];
+      const float depth = ct[C_DEPTH] - unif(M->linear_slop);   // penetration = distance + m_linearSlop (0 in the compiled blobs)
       bias = depth > 0 ? ct[C_ERP] * depth * idt : depth * idt;
       cfm = ct[C_CFM];
       slot = __float_as_int(ct[C_SLOT]);

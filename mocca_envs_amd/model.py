@@ -162,7 +162,8 @@ class MoccaModel(C.Structure):
         ("erp_noncontact", C.c_float),
         ("friction_cone", C.c_int32),
         ("limit_at_violation", C.c_int32),
-        ("reserved_", C.c_int32 * 4),
+        ("linear_slop", C.c_float),
+        ("reserved_", C.c_int32 * 3),
         ("slot_tab", (C.c_float * 4) * MAX_SLOTS),
         ("gp_tab", (C.c_float * 4) * (2 * MAX_GEOMS)),
         ("pair_tab", (C.c_float * 4) * MAX_PAIRS),

@@ -131,6 +131,8 @@ def from_pybullet_dump(dump: Mapping[str, np.ndarray], template: M.MoccaModel, j
             out.g_margin[g] = template.g_margin[g] * f
     if "engine_enableConeFriction" in dump:
         out.friction_cone = int(dump["engine_enableConeFriction"])   # 0: pyramid (SOLVER_DISABLE_IMPLICIT_CONE_FRICTION)
+    if "engine_contactSlop" in dump:                                # infoGlobal.m_linearSlop (setPhysicsEngineParameter(contactSlop=...)); absent: the blob's own
+        out.linear_slop = float(dump["engine_contactSlop"])
     missing = [k for k in ENGINE_KEYS if "engine_" + k not in dump]
     if missing:
         # pybullet.getPhysicsEngineParameters() is not guaranteed to report every solver parameter (older builds: fixedTimeStep, numSubSteps,
@@ -375,7 +377,8 @@ def synthetic_dump(m: M.MoccaModel, joint_names: Sequence[str], fixed_children: 
     out["_base_inertial_in_template_base"] = np.concatenate([C0.t, C0.R.reshape(-1)])
     # the session's solver parameters, as the tool writes them (engine_*): here the blob's own
     out.update(engine_erp=np.array(float(m.erp_noncontact)), engine_contactERP=np.array(float(m.erp)), engine_numSolverIterations=np.array(float(m.n_iters)),
-               engine_contactBreakingThreshold=np.array(float(m.contact_margin)), engine_enableConeFriction=np.array(float(m.friction_cone)))
+               engine_contactBreakingThreshold=np.array(float(m.contact_margin)), engine_enableConeFriction=np.array(float(m.friction_cone)),
+               engine_contactSlop=np.array(float(m.linear_slop)))
     if m.n_closures > 0:   # createConstraint rows: parent link, child link, type, pivots in the links' inertial frames
         cons = []
         for k in range(m.n_closures):

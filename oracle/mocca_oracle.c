@@ -906,7 +906,7 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
     int r = nr++;
     contact_jacobian(m, w, w->c_a[i], w->c_b[i], w->c_P[i], w->c_n[i], w->J[r]);
     w->row_kind[r] = 1; w->row_normal[r] = -1; w->row_mu[r] = 0; w->row_slot[r] = w->c_slot[i];
-    real depth = w->c_depth[i];
+    real depth = w->c_depth[i] - (real)m->linear_slop; /* penetration = distance + m_linearSlop [UNVERIFIED-BULLET]; 0 in the compiled blobs */
     w->bias[r] = depth > 0 ? w->c_erp[i] * depth * idt : depth * idt;
     w->cfm[r] = w->c_cfm[i];
     w->lam[r] = (w->c_slot[i] >= 0) ? (real)m->warmstart * s->warm[w->c_slot[i]] : 0;

@@ -88,7 +88,7 @@ class Model:
         self.closures = [dict(a=m.cl_body_a[c], b=m.cl_body_b[c], pa=np.array(list(m.cl_point_a[c]), float),
                               pb=np.array(list(m.cl_point_b[c]), float)) for c in range(m.n_closures)]
         for k in ("gravity", "dt", "n_iters", "erp", "erp_noncontact", "friction_cone", "limit_at_violation", "contact_margin", "lin_damp", "ang_damp", "max_qd", "warmstart", "ground_friction",
-                  "plank_friction", "plank_stiffness", "plank_damping", "limit_slack", "plank_com_z", "max_contacts", "max_rows", "n_slots", "manifold_max"):
+                  "plank_friction", "plank_stiffness", "plank_damping", "limit_slack", "plank_com_z", "max_contacts", "max_rows", "n_slots", "manifold_max", "linear_slop"):
             setattr(self, k, getattr(m, k))
         self.gravity, self.dt = float(np.float32(self.gravity)), float(np.float32(self.dt))
         self.plank_half = np.array(list(m.plank_half), float)
@@ -456,7 +456,8 @@ def substep(mdl: Model, st: State, tau, planks=None, heightfield=None):
     for i in range(nc):
         c = contacts[i]
         lam0 = mdl.warmstart * st.warm[c["slot"]] if c["slot"] >= 0 else 0.0
-        rows.append(dict(J=c["n"] @ cj[i], bias=c["erp"] * c["depth"] / dt if c["depth"] > 0 else c["depth"] / dt, cfm=c["cfm"], lo=0.0, hi=1e30,
+        dep = c["depth"] - float(np.float32(mdl.linear_slop))      # penetration = distance + slop
+        rows.append(dict(J=c["n"] @ cj[i], bias=c["erp"] * dep / dt if dep > 0 else dep / dt, cfm=c["cfm"], lo=0.0, hi=1e30,
                          lam=lam0, kind=1, slot=c["slot"]))
     for i in range(nc):
         c = contacts[i]

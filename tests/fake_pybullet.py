@@ -98,7 +98,8 @@ def make_module(fixed_children=None, robot="walker3d"):
     p.getPhysicsEngineParameters = lambda: {"fixedTimeStep": float(blob.dt) * int(blob.n_substeps), "numSubSteps": int(blob.n_substeps),
                                             "numSolverIterations": int(blob.n_iters), "erp": float(blob.erp_noncontact),
                                             "contactERP": float(blob.erp), "frictionERP": 0.2, "useRealTimeSimulation": 0,
-                                            "enableConeFriction": int(blob.friction_cone), "contactBreakingThreshold": float(blob.contact_margin)}
+                                            "enableConeFriction": int(blob.friction_cone), "contactBreakingThreshold": float(blob.contact_margin),
+                                            "contactSlop": float(blob.linear_slop)}
     p.changeDynamics = lambda *a, **k: p.fake_calls.append(("changeDynamics", a, k))
 
     def loadMJCF(f, flags=0):
@@ -406,7 +407,8 @@ def make_laikago_module():
     p.getPhysicsEngineParameters = lambda: {"fixedTimeStep": float(blob.dt) * int(blob.n_substeps), "numSubSteps": int(blob.n_substeps),
                                             "numSolverIterations": int(blob.n_iters), "erp": float(blob.erp_noncontact),
                                             "contactERP": float(blob.erp), "frictionERP": 0.2, "useRealTimeSimulation": 0,
-                                            "enableConeFriction": int(blob.friction_cone), "contactBreakingThreshold": float(blob.contact_margin)}
+                                            "enableConeFriction": int(blob.friction_cone), "contactBreakingThreshold": float(blob.contact_margin),
+                                            "contactSlop": float(blob.linear_slop)}
     p.changeDynamics = lambda *a, **k: None
     p.loadSDF = lambda f: (PLANE,)
     p.loadURDF = loadURDF

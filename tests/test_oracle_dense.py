@@ -75,7 +75,8 @@ def _compare(orc, m, mdl, row, tau, planks=None, tol=2e-8, heightfield=None):
                                                     ("walker3d-pyramid", M.compile_walker3d, 0, 0.25),
                                                     ("walker3d-predicted-limits", M.compile_walker3d, 0, 0.25),
                                                     ("walker3d-absolute-margin", M.compile_walker3d, 0, 0.25),
-                                                    ("walker3d-wide-caps-absolute-margin", M.compile_walker3d, 0, 0.12)])
+                                                    ("walker3d-wide-caps-absolute-margin", M.compile_walker3d, 0, 0.12),
+                                                    ("walker3d-slop", M.compile_walker3d, 0, 0.25)])
 def test_substep_on_random_contact_states(name, compile_fn, task, z):
     """Tumbling robots close to the ground: 3-12 contacts (terrain + self), limit rows, stale warm starts, the row cap.
     "-warm": the compiled blobs start every impulse from zero (Bullet's multibody contacts do not warm start); the warm-start path of
@@ -85,6 +86,9 @@ def test_substep_on_random_contact_states(name, compile_fn, task, z):
         m.warmstart = 0.85
     else:
         assert m.warmstart == 0.0
+    assert m.linear_slop == 0.0
+    if name.endswith("-slop"):               # Bullet's m_linearSlop (pybullet contactSlop), exaggerated 20 x so that a sign error could not hide in the tolerance
+        m.linear_slop = 2e-4
     if "-wide-caps" in name:                 # 64 rows / 20 contacts: the caps of the HIP accuracy instance (mocca_r64.hip), rows beyond 48 really solved
         m.max_rows, m.max_contacts = 64, 20
     if name.endswith("-absolute-margin"):    # 2 cm for every pair (g_margin <= 0); the compiled blobs: Bullet's relative thresholds, millimetres
