@@ -78,7 +78,7 @@ enum {
                                         max_contacts <= 10 on a tree without loop closures run the COMPACT instance (32 x 32 Delassus matrix,
                                         the articulated-body view aliased under it: less LDS per env, more resident waves per CU); every other
                                         blob within 48 rows / 12 contacts the 48-row instance; a blob whose caps exceed those (max_rows <= 64,
-                                        max_contacts <= 20) the 64-row ACCURACY instance (every lane of the wave a row; 17 KB of LDS per env and
+                                        max_contacts <= 20) or that sets MoccaModel.sweep_alternate the 64-row ACCURACY instance (every lane of the wave a row; 17 KB of LDS per env and
                                         a two-waves-per-SIMD register budget: Bullet caps neither rows nor contacts, and this instance exists to
                                         measure what the product's caps change).  1 forces the 48-row instance for a blob that would run the
                                         compact one, 2 forces the 64-row instance for any blob (A/B runs), 0 = automatic.  The instances execute

@@ -249,7 +249,12 @@ typedef struct MoccaModel {
                                        1e-5 m where the server sets its default [UNVERIFIED-BULLET].  0 in the compiled blobs (the term was not
                                        modelled before round 5 and moves nothing measurable: 1e-5 m x erp / dt = 2 mm/s of bias); a dump's
                                        engine_contactSlop sets it.  (Takes the first of the former four reserved words: blobs of version 13 read as 0.) */
-  int32_t reserved_[3];
+  int32_t sweep_alternate;          /* 1: the rows that are not contacts (joint limits, closures, planar-base rows) are swept last-to-first in the even
+                                       Gauss-Seidel iterations and first-to-last in the odd ones (btMultiBodyConstraintSolver::solveSingleIteration:
+                                       `index = iteration & 1 ? j : size - 1 - j` over m_multiBodyNonContactConstraints); contact and friction rows
+                                       always forward.  0: always forward (every blob before round 5, and the compiled ones).  A blob with the flag runs the
+                                       64-row accuracy instance of the step kernel, the only one that carries the second visit sequence  [UNVERIFIED-BULLET] */
+  int32_t reserved_[2];
 
   /* ---- derived lookup tables (model.py finalize_tables): one 16-byte load instead of chains of dependent loads ---- */
   float slot_tab[MOCCA_MAX_SLOTS][4];       /* radius, friction, bits(body | geom<<8 | end<<16 | margin_code<<17 (8 bits, x 2^-13 m) | terrain<<25 | (foot + 1)<<26 | torso<<29), bits(anc_mask[body]) */

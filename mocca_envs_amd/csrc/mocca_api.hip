@@ -184,7 +184,8 @@ static bool compact_ok(const MoccaModel& m, int topo) {
          m.max_contacts <= mocca_r32_max_contacts() && mocca_r32_args_sizeof() == sizeof(StepArgs);
 }
 // ... and one whose caps exceed the 48-row instance's (48 rows / 12 contacts) runs the 64-row accuracy instance
-static bool wide_needed(const MoccaModel& m) { return m.max_rows > MAXR || m.max_contacts > MAXC; }
+// ... or that asks for Bullet's alternating sweep direction of the non-contact rows (compiled into that instance only: mocca_device.h ALT_SWEEPS)
+static bool wide_needed(const MoccaModel& m) { return m.max_rows > MAXR || m.max_contacts > MAXC || m.sweep_alternate != 0; }
 enum { INST_FULL = 0, INST_COMPACT = 1, INST_WIDE = 2 };
 template <class T, int TASK> struct LaunchStep {
   static void run(int n, hipStream_t s, StepArgs a) { hipLaunchKernelGGL((mocca_step_kernel<T, TASK>), dim3(n), dim3(64), 0, s, a); }
@@ -643,7 +644,7 @@ int mocca_set_param(mocca_handle h, int param_id, double value) {
       break;
     case MOCCA_PARAM_KERNEL_VARIANT:
       if (value != 0 && value != 1 && value != 2) { h->err = "MOCCA_PARAM_KERNEL_VARIANT is 0 (automatic), 1 (force the 48-row instance) or 2 (force the 64-row instance)"; return MOCCA_E_ARG; }
-      if (value == 1 && h->wide) { h->err = "MOCCA_PARAM_KERNEL_VARIANT = 1: this blob's caps exceed the 48-row instance's (48 rows / 12 contacts)"; return MOCCA_E_ARG; }
+      if (value == 1 && h->wide) { h->err = "MOCCA_PARAM_KERNEL_VARIANT = 1: this blob needs the 64-row instance (caps beyond 48 rows / 12 contacts, or sweep_alternate)"; return MOCCA_E_ARG; }
       h->force_full = (int)value; break;
     default: h->err = "unknown parameter id"; return MOCCA_E_ARG;
   }

@@ -86,6 +86,7 @@ typedef const MOCCA_AS_CONST f4_t* CF4P;
 constexpr int MAXR = MOCCA_MAXR;                  // rows held by one wave (MoccaModel.max_rows must be <= MAXR)
 constexpr int MAXC = MAXR >= 64 ? 20 : (MAXR >= 36 ? 12 : MAXR / 3);  // contacts (MoccaModel.max_contacts <= MAXC)
 constexpr bool COMPACT = MOCCA_COMPACT != 0;
+constexpr bool ALT_SWEEPS = MAXR >= 64;          // MoccaModel.sweep_alternate is honoured by the 64-row accuracy instance (solve_constraints)
 constexpr int DYN_STRIDE = 96;      // floats per env in the dynamic-state buffer
 constexpr int TERRAIN_STRIDE = 128; // floats per env in the terrain buffer
 
@@ -1619,6 +1620,30 @@ DI void pgs_fixed_rows(const float* Acol, const float* ar, float a0, float a1, f
   pgs_fixed_tail<PGS_REG_ROWS, RR, 3>(ar, a0, a1, a2, r_fr, y, lam, invdiag, lo0);
 }
 
+// MoccaModel.sweep_alternate (Bullet sweeps its non-contact rows last-to-first in the even iterations, btMultiBodyConstraintSolver::
+// solveSingleIteration): the even iterations of such a blob visit lanes nnc - 1 .. 0 in a ROLLED loop (dynamic lane: v_readlane with an SGPR
+// select, a compare-and-select commit, the gain read from LDS -- a handful of limit rows for the walkers, 6 - 12 closure / planar / limit rows
+// for Cassie), then the contact normals nnc .. r_fr - 1 forward through the unrolled visits with a uniform skip below `start`.  The odd
+// iterations, and every iteration of a blob without the flag, take pgs_fixed_rows as before.
+DI void pgs_reverse_rows(const float* Acol, int nnc, int lane, float& y, float& lam, float invdiag, float lo0) {
+#pragma unroll 1
+  for (int j = nnc - 1; j >= 0; --j) {
+    const float as = Acol[MAXR * j] * invdiag;
+    const float nl_ = __builtin_amdgcn_fmed3f(y, lo0, 1e30f);
+    const float dl = readlane(nl_ - lam, j);
+    lam = lane == j ? nl_ : lam;
+    y = fmaf(-as, dl, y);
+  }
+}
+template <int PGS_REG_ROWS, int RR>
+DI void pgs_fixed_rows_from(const float* Acol, const float* ar, int start, int r_fr, float& y, float& lam, float invdiag, float lo0) {
+  if constexpr (RR < MAXR) {
+    if (RR >= r_fr) return;
+    if (RR >= start) pgs_visit<RR>(RR < PGS_REG_ROWS ? ar[RR < PGS_REG_ROWS ? RR : 0] : Acol[MAXR * RR] * invdiag, y, lam, lo0);
+    pgs_fixed_rows_from<PGS_REG_ROWS, RR + 1>(Acol, ar, start, r_fr, y, lam, invdiag, lo0);
+  }
+}
+
 // ------------------------------------------------------------------ constraint rows + PGS
 // lane = row.  See oracle solve_constraints() for the reference formulation.
 //   1. limit-row candidates are compacted with a ballot; contacts come from collide()
@@ -2020,13 +2045,27 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
     if (k < nc) { af[2 * k] = Acol_fr[MAXR * fric_lane(k, 0)] * invdiag; af[2 * k + 1] = Acol_fr[MAXR * fric_lane(k, 1)] * invdiag; }  // wave-uniform
   }
   unsigned long long clamp_sig = 0ull, clamp_last = 0ull;   // debug record only
+  const int nnc = nl + NFIX;                                 // rows that are not contacts: lanes 0 .. nnc - 1
+  // (compiled into the 64-row ACCURACY instance only -- mocca_create routes a blob with the flag there -- so that the product's instruction
+  // stream stays what it was: with the second visit sequence in it the 48-row kernel measured 0.6 % (walker) / 1.5 % (Cassie) slower)
+  const bool alt = ALT_SWEEPS && uni(M->sweep_alternate) != 0 && nnc > 1;  // (one such row: last-to-first is first-to-last)
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
     // the row counts are laundered per iteration: as loop invariants the optimiser hoisted every `RR >= r_fr` / `I >= nc` exit test of
     // the unrolled visits out of the loop as a 64-bit lane mask each -- ~100 SGPRs, spilled to VGPR lanes and re-read per iteration
     int rf = r_fr, ncc = nc;
     asm volatile("" : "+s"(rf), "+s"(ncc));
-    pgs_fixed_rows<PGS_REG_ROWS, 0>(Acol, ar, 0.0f, 0.0f, 0.0f, 0.0f, rf, y, lam, invdiag, lo0);
+    bool fwd = true;
+    if constexpr (ALT_SWEEPS) {
+      if (alt && !(it & 1)) {   // wave-uniform: the non-contact rows last-to-first, then the normals forward (pgs_reverse_rows)
+        int nn = nnc;
+        asm volatile("" : "+s"(nn));
+        pgs_reverse_rows(Acol, nn, lane, y, lam, invdiag, lo0);
+        pgs_fixed_rows_from<PGS_REG_ROWS, 0>(Acol, ar, nn, rf, y, lam, invdiag, lo0);
+        fwd = false;
+      }
+    }
+    if (fwd) pgs_fixed_rows<PGS_REG_ROWS, 0>(Acol, ar, 0.0f, 0.0f, 0.0f, 0.0f, rf, y, lam, invdiag, lo0);
     float lm = 0.0f;
     if (ncc > 0) {  // wave-uniform
       float f0 = 0.0f, f1 = 0.0f, g0 = 0.0f, g1 = 0.0f;

@@ -163,7 +163,8 @@ class MoccaModel(C.Structure):
         ("friction_cone", C.c_int32),
         ("limit_at_violation", C.c_int32),
         ("linear_slop", C.c_float),
-        ("reserved_", C.c_int32 * 3),
+        ("sweep_alternate", C.c_int32),
+        ("reserved_", C.c_int32 * 2),
         ("slot_tab", (C.c_float * 4) * MAX_SLOTS),
         ("gp_tab", (C.c_float * 4) * (2 * MAX_GEOMS)),
         ("pair_tab", (C.c_float * 4) * MAX_PAIRS),

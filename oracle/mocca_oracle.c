@@ -954,7 +954,12 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
   int first_fric = first_normal + nc;
   for (int it = 0; it < m->n_iters; ++it) {
     clamp_last = 0;
-    for (int r = 0; r < nr; ++r) {
+    /* MoccaModel.sweep_alternate: the rows that are not contacts (limits, closures, planar rows: 0 .. first_normal - 1) are visited LAST TO FIRST
+     * in the even iterations and first to last in the odd ones -- btMultiBodyConstraintSolver::solveSingleIteration: `index = iteration & 1 ? j
+     * : size - 1 - j` over m_multiBodyNonContactConstraints; contact normals and friction rows always forward  [UNVERIFIED-BULLET] */
+    const int rev = m->sweep_alternate && !(it & 1);
+    for (int ro = 0; ro < nr; ++ro) {
+      int r = (rev && ro < first_normal) ? first_normal - 1 - ro : ro;
       if (m->friction_cone && w->row_kind[r] == 2) {
         /* Implicit cone friction (btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows): the contact's two friction rows r, r + 1
          * take their candidate impulses from the SAME velocity state, the pair is clipped to the circle of radius mu * lambda_n (Bullet:
@@ -987,7 +992,7 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
             if (clamped) clamp_last |= (uint64_t)1 << lane;
           }
         }
-        ++r;
+        ++ro;
         continue;
       }
       real lo = 0, hi = (real)1e30;

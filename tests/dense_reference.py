@@ -88,7 +88,7 @@ class Model:
         self.closures = [dict(a=m.cl_body_a[c], b=m.cl_body_b[c], pa=np.array(list(m.cl_point_a[c]), float),
                               pb=np.array(list(m.cl_point_b[c]), float)) for c in range(m.n_closures)]
         for k in ("gravity", "dt", "n_iters", "erp", "erp_noncontact", "friction_cone", "limit_at_violation", "contact_margin", "lin_damp", "ang_damp", "max_qd", "warmstart", "ground_friction",
-                  "plank_friction", "plank_stiffness", "plank_damping", "limit_slack", "plank_com_z", "max_contacts", "max_rows", "n_slots", "manifold_max", "linear_slop"):
+                  "plank_friction", "plank_stiffness", "plank_damping", "limit_slack", "plank_com_z", "max_contacts", "max_rows", "n_slots", "manifold_max", "linear_slop", "sweep_alternate"):
             setattr(self, k, getattr(m, k))
         self.gravity, self.dt = float(np.float32(self.gravity)), float(np.float32(self.dt))
         self.plank_half = np.array(list(m.plank_half), float)
@@ -470,12 +470,14 @@ def substep(mdl: Model, st: State, tau, planks=None, heightfield=None):
         Mi = np.linalg.solve(M, J.T)              # nd x nr
         A = J @ Mi
         w = J @ nus + A @ lam                      # warm-start impulses act before the first iteration
-        for _ in range(mdl.n_iters):
+        for it in range(mdl.n_iters):
             skip = False
-            for r in range(nr):
+            rev = bool(mdl.sweep_alternate) and not (it & 1)     # Bullet: the non-contact rows last-to-first in the even iterations
+            for ro in range(nr):
                 if skip:
                     skip = False
                     continue
+                r = first_normal - 1 - ro if (rev and ro < first_normal) else ro
                 row = rows[r]
                 if mdl.friction_cone and row["kind"] == 2:      # implicit cone friction: the pair from one velocity state, clipped to the circle
                     lim = row["mu"] * lam[row["normal"]]

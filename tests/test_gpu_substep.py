@@ -63,6 +63,11 @@ CASES = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("Walker3DStepper
          ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_caps": (64, 20), "_abs_margin": True}), ("CassieEnv-v0", M.TASK_CASSIE, {"_caps": (64, 20)}),
          # Bullet's m_linearSlop (MoccaModel.linear_slop; pybullet contactSlop 1e-5 m, here 20 x that)
          ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_slop": 2e-4}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_slop": 2e-4}),
+         # Bullet's alternating sweep direction of the non-contact rows (MoccaModel.sweep_alternate): limit rows (many of them with the predicted-gap
+         # law), Cassie's closures + limits, the planar Cassie's closures + planar rows + its hips on their limits
+         ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_alt": True}), ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_alt": True, "_predict": True}),
+         ("CassieEnv-v0", M.TASK_CASSIE, {"_alt": True}), ("Cassie2DEnv-v0", M.TASK_CASSIE, {"_alt": True}),
+         ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_alt": True, "_caps": (32, 10)}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_alt": True, "_caps": (64, 20)}),
          # one absolute contact margin of 2 cm for every pair (g_margin <= 0; the compiled blobs carry Bullet's relative thresholds, millimetres)
          ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_abs_margin": True}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_abs_margin": True})]
 
@@ -71,7 +76,7 @@ def _one_substep_blob(env_id, **kw):
     from mocca_envs_amd.vec_env import compile_model_for
     dump, massive, warm, cone = kw.pop("_dump", None), kw.pop("_massive", False), kw.pop("_warm", None), kw.pop("_cone", None)
     predict, abs_margin, caps = kw.pop("_predict", False), kw.pop("_abs_margin", False), kw.pop("_caps", None)
-    slop = kw.pop("_slop", None)
+    slop, alt = kw.pop("_slop", None), kw.pop("_alt", False)
     m = compile_model_for(env_id, **kw)
     if caps:
         m.max_rows, m.max_contacts = caps
@@ -86,6 +91,8 @@ def _one_substep_blob(env_id, **kw):
         assert abs(m.slot_margin[0] - 0.02) < 1e-4 and (m.n_pairs == 0 or abs(m.pair_margin[0] - 0.02) < 1e-4)
     if slop is not None:
         m.linear_slop = slop
+    if alt:
+        m.sweep_alternate = 1
     if warm is not None:
         m.warmstart = warm
     if cone is not None:

@@ -76,7 +76,8 @@ def _compare(orc, m, mdl, row, tau, planks=None, tol=2e-8, heightfield=None):
                                                     ("walker3d-predicted-limits", M.compile_walker3d, 0, 0.25),
                                                     ("walker3d-absolute-margin", M.compile_walker3d, 0, 0.25),
                                                     ("walker3d-wide-caps-absolute-margin", M.compile_walker3d, 0, 0.12),
-                                                    ("walker3d-slop", M.compile_walker3d, 0, 0.25)])
+                                                    ("walker3d-slop", M.compile_walker3d, 0, 0.25),
+                                                    ("walker3d-alternate-predicted-limits", M.compile_walker3d, 0, 0.25)])
 def test_substep_on_random_contact_states(name, compile_fn, task, z):
     """Tumbling robots close to the ground: 3-12 contacts (terrain + self), limit rows, stale warm starts, the row cap.
     "-warm": the compiled blobs start every impulse from zero (Bullet's multibody contacts do not warm start); the warm-start path of
@@ -89,6 +90,8 @@ def test_substep_on_random_contact_states(name, compile_fn, task, z):
     assert m.linear_slop == 0.0
     if name.endswith("-slop"):               # Bullet's m_linearSlop (pybullet contactSlop), exaggerated 20 x so that a sign error could not hide in the tolerance
         m.linear_slop = 2e-4
+    if "-alternate" in name:                 # Bullet's alternating sweep direction of the non-contact rows (with many limit rows: predicted-gap limits)
+        m.sweep_alternate = 1
     if "-wide-caps" in name:                 # 64 rows / 20 contacts: the caps of the HIP accuracy instance (mocca_r64.hip), rows beyond 48 really solved
         m.max_rows, m.max_contacts = 64, 20
     if name.endswith("-absolute-margin"):    # 2 cm for every pair (g_margin <= 0); the compiled blobs: Bullet's relative thresholds, millimetres
@@ -216,9 +219,12 @@ def test_substep_on_the_height_field():
     assert max(rows) >= 12
 
 
-def test_substep_with_loop_closures():
-    """Cassie: two point-to-point closures (6 bilateral rows) between the limit rows and the contacts."""
+@pytest.mark.parametrize("alternate", [0, 1])
+def test_substep_with_loop_closures(alternate):
+    """Cassie: two point-to-point closures (6 bilateral rows) between the limit rows and the contacts; alternate = 1: the non-contact rows swept
+    last-to-first in the even iterations (MoccaModel.sweep_alternate)."""
     m = M.compile_cassie()
+    m.sweep_alternate = alternate
     mdl = D.Model(m)
     orc = Oracle(m.to_bytes(), M.TASK_CASSIE, 1, "f64")
     orc.reset(seed=0)
