@@ -237,6 +237,17 @@ class MoccaModel(C.Structure):
         return STATE_BASE + 2 * self.n_joints + self.n_slots
 
 
+def bullet_fidelity(m: "MoccaModel") -> "MoccaModel":
+    """The blob with the three solver details that only the 64-row ACCURACY instance of the step kernel carries, switched to Bullet's side as
+    recalled [UNVERIFIED-BULLET]: no contact / row cap within the wave's reach (64 rows, 20 contacts), the non-contact rows swept in alternating
+    direction (`sweep_alternate`), pybullet's default contact slop (1e-5 m).  Slower by design (17 KB of LDS per env, two waves per SIMD); what a
+    real PyBullet trace should be compared with first."""
+    m.max_rows, m.max_contacts = 64, 20
+    m.sweep_alternate = 1
+    m.linear_slop = 1e-5
+    return m
+
+
 def relative_margins(factor: float, groups) -> dict:
     """Bullet's relative contact breaking threshold per collision object: `groups` maps a link id to a list of
     (kind, radius, p1, p2, mass, com) geoms given in ONE frame whose axes are the link's; returns {link id: factor x getAngularMotionDisc()},

@@ -119,3 +119,12 @@ def test_table_matches_reference_xml():
     m = M.compile_walker3d()
     assert abs(m.jarm[1] - 0.01) < 1e-7 and abs(m.jdamp[1] - 0.1) < 1e-7  # fp32 blob
     assert f(d.find("geom").get("friction"))[0] == pytest.approx(m.g_friction[0])
+
+
+def test_bullet_fidelity_switches_the_accuracy_instance_fields():
+    from mocca_envs_amd import model as M
+    m = M.compile_walker3d()
+    assert (m.max_rows, m.max_contacts, m.sweep_alternate, m.linear_slop) == (48, 12, 0, 0.0)
+    M.bullet_fidelity(m)
+    assert (m.max_rows, m.max_contacts, m.sweep_alternate) == (64, 20, 1) and abs(m.linear_slop - 1e-5) < 1e-12
+    assert M.MoccaModel.from_bytes(m.to_bytes()).sweep_alternate == 1
