@@ -68,6 +68,8 @@ CASES = [("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {}), ("Walker3DStepper
          ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_alt": True}), ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_alt": True, "_predict": True}),
          ("CassieEnv-v0", M.TASK_CASSIE, {"_alt": True}), ("Cassie2DEnv-v0", M.TASK_CASSIE, {"_alt": True}),
          ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_alt": True, "_caps": (32, 10)}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_alt": True, "_caps": (64, 20)}),
+         # model.bullet_fidelity(): 64 / 20 caps + alternating sweeps + 1e-5 m slop, what a real PyBullet trace is to be read with first
+         ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_fidelity": True}), ("CassieEnv-v0", M.TASK_CASSIE, {"_fidelity": True}),
          # one absolute contact margin of 2 cm for every pair (g_margin <= 0; the compiled blobs carry Bullet's relative thresholds, millimetres)
          ("Walker3DCustomEnv-v0", M.TASK_WALKER3D_CUSTOM, {"_abs_margin": True}), ("Walker3DStepperEnv-v0", M.TASK_WALKER3D_STEPPER, {"_abs_margin": True})]
 
@@ -76,7 +78,7 @@ def _one_substep_blob(env_id, **kw):
     from mocca_envs_amd.vec_env import compile_model_for
     dump, massive, warm, cone = kw.pop("_dump", None), kw.pop("_massive", False), kw.pop("_warm", None), kw.pop("_cone", None)
     predict, abs_margin, caps = kw.pop("_predict", False), kw.pop("_abs_margin", False), kw.pop("_caps", None)
-    slop, alt = kw.pop("_slop", None), kw.pop("_alt", False)
+    slop, alt, fidelity = kw.pop("_slop", None), kw.pop("_alt", False), kw.pop("_fidelity", False)
     m = compile_model_for(env_id, **kw)
     if caps:
         m.max_rows, m.max_contacts = caps
@@ -93,6 +95,8 @@ def _one_substep_blob(env_id, **kw):
         m.linear_slop = slop
     if alt:
         m.sweep_alternate = 1
+    if fidelity:
+        M.bullet_fidelity(m)
     if warm is not None:
         m.warmstart = warm
     if cone is not None:

@@ -3,7 +3,8 @@ import os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from mocca_envs_amd.vec_env import VecEnv, TASKS
 # SOAK_MAX_ROWS=32 soaks the compact kernel instance (handles whose robot has loop closures keep the 48-row instance)
-caps = {"max_rows": 32, "max_contacts": 10} if os.environ.get("SOAK_MAX_ROWS") == "32" else {}
+# SOAK_MAX_ROWS=64 soaks the 64-row accuracy instance (20 contacts)
+caps = {"max_rows": 32, "max_contacts": 10} if os.environ.get("SOAK_MAX_ROWS") == "32" else ({"max_rows": 64} if os.environ.get("SOAK_MAX_ROWS") == "64" else {})
 for env_id in TASKS:
     n = 2048 if "Cassie" in env_id else 4096
     env = VecEnv(env_id, n, auto_reset=True, seed=123, **caps)
