@@ -259,7 +259,16 @@ class VecEnv:
         """The six index lists SymmetricRL consumes (env_locomotion.py:224-282 / :761-840); see symmetry.MirrorTransform."""
         from . import host_logic as H
         if self.task_id == M.TASK_CASSIE:
-            raise NotImplementedError("the Cassie envs publish their mirror indices through the gym classes (envs.py)")
+            # the Cassie mocap / phase envs publish a DICT of index lists as a class attribute (env_cassie.py:536-571, :627-629), not the walkers'
+            # six-tuple; CassieEnv itself publishes nothing
+            if self.model.cassie_mode == M.CASSIE_PLAIN:
+                raise NotImplementedError("CassieEnv has no mirror indices in the reference (env_cassie.py:284-479)")
+            import copy
+            from .envs import CassieMoccaEnv
+            mi = copy.deepcopy(CassieMoccaEnv.mirror_indices)
+            mi["left_obs_inds"] += [40]
+            mi["right_obs_inds"] += [41]
+            return mi
         return H.mirror_indices(self.model, stepper=self.task_id == M.TASK_WALKER3D_STEPPER)
 
     def set_param_v(self, pid: int, values, broadcast: bool = False):
