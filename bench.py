@@ -449,7 +449,10 @@ def main():
         kinfo = env.kernel_info()
         bracket = None
         if world == 1 and not args.no_physics_bracket and not subs and args.max_rows is None and "Cassie" not in args.env_id:
-            bracket = physics_bracket(args, local_rank, lo, tape)
+            try:      # (untimed extra: a failure here must not cost the line its headline)
+                bracket = physics_bracket(args, local_rank, lo, tape)
+            except Exception as e:      # noqa: BLE001
+                bracket = {"error": f"{type(e).__name__}: {e}"}
         host_io_ms = None
         if args.host_io:   # a trainer on the host: actions up, obs / reward / done down, every step, through PCIe
             h_act = tape.cpu().pin_memory()
@@ -520,7 +523,9 @@ def main():
         if not args.dry_run and host_io_ms is not None:
             out["host_io"] = {"ms_per_step": host_io_ms, "value": args.envs * world / (host_io_ms * 1e-3), "unit": "env-steps/s",
                               "note": "actions from pinned host memory, obs + reward + done copied to the host and waited for every step"}
-        if not args.dry_run and bracket:
+        if not args.dry_run and bracket and "error" in bracket:
+            out["sensitivity"] = bracket
+        elif not args.dry_run and bracket:
             worst = min(bracket.values(), key=lambda v: v["value"])
             out["sensitivity"] = {"note": "the same launch on blobs that read Bullet's unverifiable solver laws the other way (DESIGN.md section 3; 200 launches "
                                           "each after an 800-step pre-roll, kernel time by HIP events); `value` above is the as-built reading",
@@ -534,7 +539,10 @@ def main():
         if args.oversubscribe:
             out["oversubscribed"] = True
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
-            out["cpu_baseline"] = cpu_baseline(args.env_id)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.env_id)
+            except Exception as e:      # noqa: BLE001  (the reported baseline must not cost the line its GPU numbers)
+                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
