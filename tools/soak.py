@@ -1,3 +1,5 @@
+"""Stability soak: every env id, 4096 envs (Cassie ids 2048) x 3000 steps (300) of U(-1, 1) actions with in-kernel auto-reset; reports episodes ended,
+non-finite observation rows and whether the final state is finite.  SOAK_MAX_ROWS=32 / 64 soaks the compact / the 64-row accuracy instance."""
 import sys, torch
 import os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
