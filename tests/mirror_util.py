@@ -73,6 +73,9 @@ class IndexMirror:
         else:
             o[:, 0] *= -1
         o[:, 12], o[:, 13] = tk[:, 13], tk[:, 12]
+        # Stepper: which planks' covers each foot touches, 4 bits per foot (word 26, mocca_device.h cover_targets): the feet exchange their nibbles
+        cov = tk[:, 26].astype(np.int64)
+        o[:, 26] = ((cov & 0xF) << 4) | ((cov >> 4) & 0xF) | (cov & ~0xFF)
         return o
 
 

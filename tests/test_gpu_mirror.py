@@ -165,7 +165,7 @@ def test_the_reference_mirror_sets_on_hip(env_id, one_substep):
         if not one_substep:                 # a full step: "few" must hold in EVERY substep -- word 15 is the largest row count since the record was zeroed
             few &= (ga[:, 15] <= 1) | ((ga[:, 15] == 3) & (ga[:, 2] == 1) & (ga[:, 1] == 0))
         exact.append(e[fin & few]); multi.append(e[fin & ~few])
-        if task != M.TASK_WALKER3D_STEPPER:        # the Stepper's task record (feet state machine) is not mirrored here: physics only
+        if True:       # Custom AND Stepper: the Stepper's task record mirrors too (feet contact flags, cover masks, terrain: mirror_util.IndexMirror.task)
             sel = torch.from_numpy(fin & few).cuda()
             d = (mt.obs(oa) - ob).abs()[sel]
             obs_err = max(obs_err, float(d.max()) if d.numel() else 0.0)

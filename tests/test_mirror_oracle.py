@@ -140,9 +140,10 @@ def _run_index_mirror(env_id, m, mir, prec="f64", n=256, steps=160, act_mirror=N
     err = {0: [], 1: [], 2: []}
     obs_err, rew_err, done_diff = [], [], 0
     operm = osign = None
-    if task in (M.TASK_WALKER3D_CUSTOM,) and m.n_mirror_side and mir.plane == "xz":
+    if task in (M.TASK_WALKER3D_CUSTOM, M.TASK_WALKER3D_STEPPER) and m.n_mirror_side and mir.plane == "xz" and m.n_feet == 2:
+        # get_mirror_indices(): the Custom env's sets (env_locomotion.py:224-282) / the Stepper's, with the step targets' lateral entries (:761-840)
         from mocca_envs_amd import host_logic as H
-        operm, osign = obs_mirror(H.mirror_indices(m, stepper=False), A.obs_dim)
+        operm, osign = obs_mirror(H.mirror_indices(m, stepper=task == M.TASK_WALKER3D_STEPPER), A.obs_dim)
     for t in range(steps):
         s, tk = A.get_state(), A.get_task()
         if lift or shake:
