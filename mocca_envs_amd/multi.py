@@ -175,7 +175,8 @@ class SubBatchedVecEnv(_Parts):
     def step_async(self, i: int, actions: torch.Tensor, ordered: bool = True) -> None:
         """Launch one env.step of sub-batch i on ITS stream and return at once.  actions: [n_envs / k, act_dim] float32, contiguous, on
         the device.  ordered=True makes the launch wait for what torch's current stream has queued so far (the policy that produced
-        `actions`); ordered=False skips that (actions known to be ready, e.g. a pre-computed tape)."""
+        `actions`, and whatever still reads sub-batch i's rows of obs / rew / done -- the launch overwrites them); ordered=False skips that: the
+        caller vouches that the actions are ready (e.g. a pre-computed tape) AND that nothing queued on the current stream still reads those rows."""
         e = self.parts[i]
         if actions.device != e.device or actions.dtype != torch.float32 or not actions.is_contiguous():
             actions = actions.to(device=e.device, dtype=torch.float32).contiguous()     # on the current stream, ordered below
