@@ -123,3 +123,22 @@ def test_bench_as_a_torchrun_rank():
     """Under torch.distributed.run the process is one rank: WORLD_SIZE from the environment decides, a lone rank 0 of world 1."""
     out = _bench("--gpus", "1", "--steps", "2", "--dry-run", env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"))
     assert out["n_gpus"] == 1
+
+
+def test_bench_physics_variants_flip_exactly_the_documented_fields():
+    """bench.py's sensitivity bracket: each variant blob differs from the compiled one in the law it names and in nothing else."""
+    import bench
+    from mocca_envs_amd.vec_env import compile_model_for
+    base = compile_model_for(bench.ENV_ID)
+    assert (base.limit_at_violation, base.friction_cone, base.warmstart) == (1, 1, 0.0) and 0 < base.slot_margin[0] < 0.01
+    seen = {}
+    for v in bench.PHYSICS_VARIANTS:
+        m = bench.physics_variant_model(bench.ENV_ID, v)
+        seen[v] = (m.limit_at_violation, round(float(m.slot_margin[0]), 4), m.friction_cone, round(float(m.warmstart), 2))
+        assert (m.max_rows, m.max_contacts, m.n_iters, m.sweep_alternate) == (base.max_rows, base.max_contacts, base.n_iters, 0)
+    b = (1, round(float(base.slot_margin[0]), 4), 1, 0.0)
+    assert seen["limit_rows_from_predicted_gap"] == (0,) + b[1:]
+    assert seen["absolute_2cm_margins"] == (1, 0.02, 1, 0.0)
+    assert seen["pyramid_friction"] == (1, b[1], 0, 0.0)
+    assert seen["warmstart_0.85"] == (1, b[1], 1, 0.85)
+    assert seen["all_four"] == (0, 0.02, 0, 0.85)
