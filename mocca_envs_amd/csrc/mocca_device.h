@@ -2367,7 +2367,9 @@ struct TaskRegs {  // uniform across the wave
   int close, done, t, episode, draw, mirrored, nsi, trc, stop, setstop, cur, istep;
   int cover;   // Stepper: cover mask of the last step's contacts (word 26, as a float; ContactFlags / cover_targets) -- what reset() reads stale
 };
-DI void load_task(const uint32_t* tk, TaskRegs& t, bool quadruped = false) {
+// (`cassie`: words 38 / 39 -- initial_z, istep -- are Cassie's alone and sit in the third 64-byte line of the 160-byte record: the other tasks
+// neither read nor write them, which keeps that line out of a walker step's HBM traffic where it is not shared with the next env's record)
+DI void load_task(const uint32_t* tk, TaskRegs& t, bool quadruped = false, bool cassie = false) {
   auto f = [&](int i) { return __uint_as_float(tk[i]); };
   t.wt[0] = f(T_WTX); t.wt[1] = f(T_WTY); t.wt[2] = f(T_WTZ); t.linpot = f(T_LINPOT); t.angpot = f(T_ANGPOT);
   t.close = (int)tk[T_CLOSE]; t.stopf = f(T_STOPF); t.done = (int)tk[T_DONE]; t.t = (int)tk[T_T];
@@ -2376,13 +2378,13 @@ DI void load_task(const uint32_t* tk, TaskRegs& t, bool quadruped = false) {
   t.fc2 = quadruped ? f(T_FC2) : 0.0f; t.fc3 = quadruped ? f(T_FC3) : 0.0f;
   t.nsi = (int)tk[T_NSI]; t.trc = (int)tk[T_TRC]; t.stop = (int)tk[T_STOP]; t.setstop = (int)tk[T_SETSTOP];
   t.cur = (int)tk[T_CUR]; t.gain = f(T_GAIN); t.prevx = f(T_PREVX);
-  t.initz = f(T_INITZ); t.istep = (int)tk[T_ISTEP];
+  t.initz = cassie ? f(T_INITZ) : 0.0f; t.istep = cassie ? (int)tk[T_ISTEP] : 0;
   t.cover = 0;
 }
 enum : int { T_COVER = 26 };
 DI void load_task_cover(const uint32_t* tk, TaskRegs& t) { t.cover = (int)__uint_as_float(tk[T_COVER]); }
 DI void store_task_cover(uint32_t* tk, const TaskRegs& t) { tk[T_COVER] = __float_as_uint((float)t.cover); }
-DI void store_task(uint32_t* tk, const TaskRegs& t, bool quadruped = false) {
+DI void store_task(uint32_t* tk, const TaskRegs& t, bool quadruped = false, bool cassie = false) {
   auto u = [](float x) { return __float_as_uint(x); };
   tk[T_WTX] = u(t.wt[0]); tk[T_WTY] = u(t.wt[1]); tk[T_WTZ] = u(t.wt[2]); tk[T_LINPOT] = u(t.linpot); tk[T_ANGPOT] = u(t.angpot);
   tk[T_CLOSE] = (uint32_t)t.close; tk[T_STOPF] = u(t.stopf); tk[T_DONE] = (uint32_t)t.done; tk[T_T] = (uint32_t)t.t;
@@ -2391,7 +2393,7 @@ DI void store_task(uint32_t* tk, const TaskRegs& t, bool quadruped = false) {
   if (quadruped) { tk[T_FC2] = u(t.fc2); tk[T_FC3] = u(t.fc3); }
   tk[T_NSI] = (uint32_t)t.nsi; tk[T_TRC] = (uint32_t)t.trc; tk[T_STOP] = (uint32_t)t.stop; tk[T_SETSTOP] = (uint32_t)t.setstop;
   tk[T_CUR] = (uint32_t)t.cur; tk[T_GAIN] = u(t.gain); tk[T_PREVX] = u(t.prevx);
-  tk[T_INITZ] = u(t.initz); tk[T_ISTEP] = (uint32_t)t.istep;
+  if (cassie) { tk[T_INITZ] = u(t.initz); tk[T_ISTEP] = (uint32_t)t.istep; }
 }
 
 // calc_potential, env_locomotion.py:143-158

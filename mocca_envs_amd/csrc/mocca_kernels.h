@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     }
     if (!INJECT && lane == 0) tk[T_RES23] = (uint32_t)last_rows;
     TaskRegs t;
-    load_task(tk, t);
+    load_task(tk, t, false, true);
     t.istep += M->n_llc;  // pd_control counts every low-level iteration (:381); the task-layer entry replays a whole env.step
     float jv = 0.0f;
     if (lane < no) {  // :467-468 finite-difference joint velocity over the control step
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     wsync();
     flush_obs(L, obs_out, lane, a.obs_dim);
     store_dyn(st, L, lane, T::NJ, T::NSLOT, uni(__float_as_int(L[L_KEEPWARM])) != 0);
-    if (lane == 0) store_task(tk, t);
+    if (lane == 0) store_task(tk, t, false, true);
     if (!INJECT) pace_finish(a, L, lane, a.pace);
     return;
   }
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64) void mocca_reset_kernel(StepArgs a) {
   uint32_t* tk = a.task + (size_t)env * MOCCA_TASK_WORDS;
   float* ter = TASK == MOCCA_TASK_WALKER3D_STEPPER ? a.terrain + (size_t)env * TERRAIN_STRIDE : nullptr;
   TaskRegs t;
-  load_task(tk, t, T::NFEET > 2);
+  load_task(tk, t, T::NFEET > 2, TASK == MOCCA_TASK_CASSIE);
   if (TASK == MOCCA_TASK_WALKER3D_STEPPER) load_task_cover(tk, t);
   if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
   if constexpr (TASK == MOCCA_TASK_CASSIE) {
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64) void mocca_reset_kernel(StepArgs a) {
   wsync();
   flush_obs(L, a.obs + (size_t)env * a.obs_dim, lane, a.obs_dim);
   store_dyn(st, L, lane, T::NJ, T::NSLOT);
-  if (lane == 0) { store_task(tk, t, T::NFEET > 2); if (TASK == MOCCA_TASK_WALKER3D_STEPPER) store_task_cover(tk, t); }
+  if (lane == 0) { store_task(tk, t, T::NFEET > 2, TASK == MOCCA_TASK_CASSIE); if (TASK == MOCCA_TASK_WALKER3D_STEPPER) store_task_cover(tk, t); }
 }
 
 // calc_state + observation tail on the stored state (no physics, no randomness)
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
   float* obs = L + L_OBS;
   load_dyn(st, L, lane, T::NJ, T::NSLOT);
   TaskRegs t;
-  load_task(tk, t, T::NFEET > 2);
+  load_task(tk, t, T::NFEET > 2, TASK == MOCCA_TASK_CASSIE);
   if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
   wsync();
   stage_joints<T>(M, L, lane);
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64) void mocca_observe_kernel(StepArgs a) {
   }
   wsync();
   flush_obs(L, a.obs + (size_t)env * a.obs_dim, lane, a.obs_dim);
-  if (lane == 0) store_task(tk, t, T::NFEET > 2);
+  if (lane == 0) store_task(tk, t, T::NFEET > 2, TASK == MOCCA_TASK_CASSIE);
 }
 
 
