@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MOCCA_ABI_VERSION 5
+#define MOCCA_ABI_VERSION 6
 
 typedef struct mocca_ctx *mocca_handle;
 
