@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MOCCA_ABI_VERSION 6
+#define MOCCA_ABI_VERSION 7
 
 typedef struct mocca_ctx *mocca_handle;
 
@@ -93,11 +93,12 @@ enum {
                                         the share of the env.step it has done (64 units per substep + 2 per constraint row) and runs at issue
                                         priority 3 / 2 / 1 / 0 as its estimated finish lies beyond 17/16 of, beyond, within 1/16 below, or
                                         further below P: the waves of a SIMD finish together.  value > 0: P in ticks; value = -k (1 <= k <= 64):
-                                        self-calibrating, P = k/16 of the mean wave time of the previous launch (every 61st wave adds a sample;
-                                        the first launch of a handle falls back to the row-count priorities); 0: off.  Default -18; 0 for a blob that
-                                        runs the compact instance (batches beyond one generation of resident waves: measured slower with it).
-                                        The self-calibrating form and ORDER_EVERY > 0 keep HOST state per launch (sample-slot rotation, re-sort
-                                        schedule): capture mocca_step in a hipGraph only with value >= 0 and ORDER_EVERY = 0. */
+                                        self-calibrating, P = k/16 of the mean wave time of the last 64 .. 128 sampled waves (one wave in 61 adds
+                                        its time to a device-side accumulator; until the first sample a handle falls back to the row-count
+                                        priorities); 0: off.  Default -18; 0 for a blob that runs the compact instance (batches beyond one generation of
+                                        resident waves: measured slower with it).  Since ABI 7 the calibration keeps no host state: mocca_step can be
+                                        captured in a hipGraph with any pace; only ORDER_EVERY > 0 and the episode-record ring (mocca_set_episode_stats)
+                                        keep per-launch HOST state that a capture would freeze. */
 };
 
 /* words of the per-env debug record (mocca_set_debug_buffer): words 0..11 the active set of the LAST physics substep, words 12..15
@@ -206,6 +207,31 @@ int mocca_set_debug_buffer(mocca_handle h, int32_t *dbg_dev);
  * NULL detaches): on every mocca_step the row of each env whose done byte is non-zero receives that final observation -- bit-identical
  * to what the same step returns with auto-reset off; rows of the other envs are left untouched. */
 int mocca_set_terminal_obs_buffer(mocca_handle h, float *final_obs_dev);
+/* Monitor + TimeLimitMask + the PPO loop's mask columns, inside the launch.  The reference's trainers (README.md:33-39) wrap every env in
+ * baselines' Monitor (info["episode"] = {"r": return, "l": length} in the step that ends an episode) and a TimeLimitMask
+ * (info["bad_transition"] when gym's TimeLimit, /root/reference/mocca_envs/__init__.py:55, cut the episode), then build `masks` / `bad_masks`
+ * from `done` / `infos` on the host.  With any of the four pointers non-NULL every mocca_step also, per env (the handle keeps the running
+ * return itself; mocca_reset zeroes it for the envs it resets):
+ *   masks_dev     [N] f32 or NULL: 0.0 where done != 0 in this step, else 1.0
+ *   bad_masks_dev [N] f32 or NULL: 0.0 where the TimeLimit bit of done is set, else 1.0
+ *   totals_dev    [4] f32 or NULL: += {return, length, 1, TimeLimit bit} of every episode that ends (atomics; the caller zeroes it when it likes)
+ *   records       NULL, or a ring of n_slots slots, slot_stride_bytes apart, of [N] mocca_episode_rec in DEVICE-VISIBLE memory -- device memory or
+ *                 pinned host memory (hipHostMalloc / torch pin_memory: the kernel then writes the few records of a step straight into the
+ *                 host's memory and nothing is copied).  The k-th mocca_step after this call (k = 1, 2, ...; mocca_episode_serial() returns
+ *                 the NEXT k) writes slot k mod n_slots: record i only if env i finished in that step, with serial = k -- a record whose
+ *                 serial differs is left over from n_slots steps ago.  The caller reads a slot once the step's stream work has completed.
+ * All NULL detaches (synchronises the device).  The slot / serial are host state of the handle: under hipGraph replay they stay frozen,
+ * masks and totals do not. */
+typedef struct mocca_episode_rec {
+  uint32_t serial; /* which mocca_step wrote it */
+  float ret;       /* Monitor's r: sum of the episode's rewards (f32) */
+  int32_t length;  /* Monitor's l: steps */
+  uint32_t flags;  /* bits 0..1 the step's done byte (bit1: TimeLimit -> "bad_transition"), bits 8.. the step's info word (Stepper: steps_reached) */
+} mocca_episode_rec;
+int mocca_set_episode_stats(mocca_handle h, float *masks_dev, float *bad_masks_dev, float *totals_dev, void *records, int n_slots,
+                            size_t slot_stride_bytes);
+uint32_t mocca_episode_serial(mocca_handle h);
+
 /* 1 if the library was compiled with a profiling switch that makes results wrong or slow by construction
  * (MOCCA_SKIP_*, MOCCA_DUMMY_VALU, MOCCA_STAMPS); the Python binding refuses such a build unless told otherwise */
 int mocca_is_diagnostic_build(void);

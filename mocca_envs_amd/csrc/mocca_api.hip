@@ -77,8 +77,14 @@ struct mocca_ctx {
   int force_full = 0;          // MOCCA_PARAM_KERNEL_VARIANT: 1 forces the 48-row instance, 2 the 64-row one
   int persist_warm = 0;        // MOCCA_PARAM_PERSIST_IMPULSES
   int pace = -18;              // MOCCA_PARAM_PACE_TICKS: self-calibrating pace priorities, 18/16 of the previous launch's mean wave time (profiles/r04_pace_*.jsonl)
-  unsigned* d_pace_acc = nullptr;  // [3][2] self-calibration samples of the pace (StepArgs.pace_acc), owned by the handle
-  unsigned pace_step = 0;
+  unsigned long long* d_pace_acc = nullptr;  // self-calibration samples of the pace, one packed word (StepArgs.pace_acc), owned by the handle
+  // Monitor / TimeLimitMask inside the launch (mocca_set_episode_stats)
+  float* d_ep_ret = nullptr;       // [N] running episode returns, owned by the handle
+  float *ep_masks = nullptr, *ep_bad = nullptr, *ep_totals = nullptr;   // caller-owned
+  char* ep_rec = nullptr;          // caller-owned record ring: n_slots slots of [N] x 16 bytes, ep_stride bytes apart
+  int ep_slots = 0;
+  size_t ep_stride = 0;
+  uint32_t ep_serial = 1;          // stamped into the records of the next mocca_step (0 never: a zeroed ring holds no record)
   int order_every = 0;         // MOCCA_PARAM_ORDER_EVERY: re-sort the launch order every K steps (0: envs run in index order)
   int order_age = 0;           // steps since the last sort
   int32_t* d_order = nullptr;  // [N] the permutation, owned by the handle
@@ -284,8 +290,8 @@ int mocca_create(const void* model_blob, size_t nbytes, int task_id, int n_envs,
   if ((e = hipMalloc(&h->d_dyn, dyn_b)) != hipSuccess) return fail("hipMalloc(state)", e);
   if ((e = hipMalloc(&h->d_task, task_b)) != hipSuccess) return fail("hipMalloc(task)", e);
   if ((e = hipMalloc(&h->d_terrain, ter_b)) != hipSuccess) return fail("hipMalloc(terrain)", e);
-  if ((e = hipMalloc(&h->d_pace_acc, 6 * sizeof(unsigned))) != hipSuccess) return fail("hipMalloc(pace samples)", e);
-  if ((e = hipMemset(h->d_pace_acc, 0, 6 * sizeof(unsigned))) != hipSuccess) return fail("hipMemset", e);
+  if ((e = hipMalloc(&h->d_pace_acc, sizeof(unsigned long long))) != hipSuccess) return fail("hipMalloc(pace samples)", e);
+  if ((e = hipMemset(h->d_pace_acc, 0, sizeof(unsigned long long))) != hipSuccess) return fail("hipMemset", e);
   if ((e = hipMemset(h->d_dyn, 0, dyn_b)) != hipSuccess) return fail("hipMemset", e);
   if ((e = hipMemset(h->d_terrain, 0, ter_b)) != hipSuccess) return fail("hipMemset", e);
   // task records: episode = -1 so the first reset is episode 0; applied_gain = 1
@@ -323,6 +329,7 @@ int mocca_destroy(mocca_handle h) {
   if (h->d_hf) (void)hipFree(h->d_hf);
   if (h->d_order) (void)hipFree(h->d_order);
   if (h->d_pace_acc) (void)hipFree(h->d_pace_acc);
+  if (h->d_ep_ret) (void)hipFree(h->d_ep_ret);
   for (float* p : h->d_pvec) if (p) (void)hipFree(p);
   delete h;
   return MOCCA_OK;
@@ -353,6 +360,8 @@ static StepArgs make_args(mocca_handle h) {
   a.final_obs = h->final_obs;
   a.persist_warm = h->persist_warm;
   a.pace = h->pace;
+  a.pace_acc = h->d_pace_acc;
+  a.ep_ret = h->d_ep_ret; a.ep_masks = h->ep_masks; a.ep_bad = h->ep_bad; a.ep_totals = h->ep_totals;   // (ep_rec / ep_serial: mocca_step only)
   a.hf = h->d_hf; a.hf_rows = h->hf_rows; a.hf_cols = h->hf_cols; a.hf_scale = h->hf_scale;
   return a;
 }
@@ -406,13 +415,14 @@ int mocca_step(mocca_handle h, const float* act_dev, float* obs_dev, float* rew_
   a.act = act_dev; a.obs = obs_dev; a.rew = rew_dev; a.done = done_dev; a.info = info_dev;
   hipStream_t s = (hipStream_t)stream;
   if (int rc = flush_pending(h, s)) return rc;
-  // mocca_step never allocates and never synchronises.  hipGraph capture: the slot rotation below and the re-sort schedule are HOST state
-  // that a capture bakes into the kernel arguments (a replayed launch would keep writing one sample slot and reading one that is never
-  // refreshed: the pace freezes at its pre-capture value) -- capture with MOCCA_PARAM_PACE_TICKS >= 0 and MOCCA_PARAM_ORDER_EVERY = 0.
-  if (h->pace < 0) {   // self-calibrating pace priorities: three sample slots, rotated per launch (StepArgs.pace_acc; allocated by mocca_create)
-    a.pace_acc = h->d_pace_acc;
-    a.pace_slot_w = (int)(h->pace_step % 3u); a.pace_slot_r = (int)((h->pace_step + 2u) % 3u); a.pace_slot_c = (int)((h->pace_step + 1u) % 3u);
-    ++h->pace_step;
+  // mocca_step never allocates and never synchronises, and the pace calibrates itself on the device: the launch can be captured in a
+  // hipGraph.  Two optional features keep HOST state per launch that a capture bakes into the kernel arguments: the episode-record ring
+  // (slot and serial below: a replayed launch keeps writing one slot under one serial -- read ep_masks / ep_totals instead) and the
+  // re-sort schedule of MOCCA_PARAM_ORDER_EVERY > 0.
+  if (h->d_ep_ret && h->ep_rec) {
+    a.ep_rec = h->ep_rec + (size_t)(h->ep_serial % (uint32_t)h->ep_slots) * h->ep_stride;
+    a.ep_serial = h->ep_serial;
+    if (++h->ep_serial == 0u) h->ep_serial = 1u;
   }
   if (h->order_every > 0 && h->d_order) {   // heaviest envs first: the permutation is rebuilt on the caller's stream, ahead of the step that reads it
     if (h->order_age >= h->order_every) {
@@ -466,6 +476,28 @@ int mocca_set_terminal_obs_buffer(mocca_handle h, float* final_obs_dev) {
   h->final_obs = final_obs_dev;
   return MOCCA_OK;
 }
+
+int mocca_set_episode_stats(mocca_handle h, float* masks_dev, float* bad_masks_dev, float* totals_dev, void* records, int n_slots,
+                            size_t slot_stride_bytes) {
+  if (!h) return MOCCA_E_ARG;
+  const bool on = masks_dev || bad_masks_dev || totals_dev || records;
+  if (records && (n_slots < 1 || slot_stride_bytes < (size_t)h->n_envs * sizeof(mocca_episode_rec) || ((uintptr_t)records & 15u) || (slot_stride_bytes & 15u))) {
+    h->err = "episode records: n_slots >= 1 slots of n_envs 16-byte records, 16-byte aligned, slot_stride_bytes >= 16 n_envs"; return MOCCA_E_ARG;
+  }
+  DeviceGuard guard(h->device);
+  if (on && !h->d_ep_ret) {
+    HIP_TRY(h, hipMalloc(&h->d_ep_ret, (size_t)h->n_envs * sizeof(float)));
+    HIP_TRY(h, hipMemset(h->d_ep_ret, 0, (size_t)h->n_envs * sizeof(float)));
+  } else if (!on && h->d_ep_ret) {
+    HIP_TRY(h, hipDeviceSynchronize());   // a launch in flight may still add to it
+    HIP_TRY(h, hipFree(h->d_ep_ret));
+    h->d_ep_ret = nullptr;
+  }
+  h->ep_masks = masks_dev; h->ep_bad = bad_masks_dev; h->ep_totals = totals_dev;
+  h->ep_rec = (char*)records; h->ep_slots = records ? n_slots : 0; h->ep_stride = records ? slot_stride_bytes : 0;
+  return MOCCA_OK;
+}
+uint32_t mocca_episode_serial(mocca_handle h) { return h ? h->ep_serial : 0u; }
 
 int mocca_set_seed(mocca_handle h, uint64_t seed) {
   if (!h) return MOCCA_E_ARG;

@@ -254,11 +254,22 @@ struct StepArgs {
   // of `pace` shader-clock ticks per env.step (its own elapsed time against the fraction of the step it has done) raises its issue
   // priority, one that is ahead lowers it, so that the waves of a SIMD finish together instead of oldest-first
   int pace;
-  // pace < 0: self-calibrating pace = (-pace / 16) x the mean wave time of the PREVIOUS launch.  Every 64th wave adds its elapsed ticks to
-  // pace_acc[slot_w] = {sum of ticks / 16, samples}; this launch reads slot_r (written by the launch before), and its workgroup 0 clears
-  // slot_c for the launch after (three slots, rotated by the host: no launch reads or clears what another one in flight is adding to)
-  unsigned* pace_acc;
-  int pace_slot_r, pace_slot_w, pace_slot_c;
+  // pace < 0: self-calibrating pace = (-pace / 16) x the mean wave time of the last 64 .. 128 sampled waves (one wave in 61 adds its elapsed
+  // ticks at its end).  One 64-bit word in device memory, {sum of ticks / 64 : 40 bits | samples : 24 bits}, added to with ONE atomic; the wave
+  // whose add makes the count reach 128 takes half of what it saw away again (pace_finish).  No host state per launch: a captured
+  // mocca_step replays with a live pace.
+  unsigned long long* pace_acc;
+  // Monitor / TimeLimitMask inside the launch (mocca_set_episode_stats; all optional, ep_ret == null: off).  ep_ret [N]: the running return of
+  // each env's episode (handle-owned); ep_masks / ep_bad [N]: 0.0 where the episode ended in this step / ended with the TimeLimit bit set, else
+  // 1.0; ep_rec [N] x 16 bytes: {serial, return, length, done bits | info << 8} of the envs that finished, this launch's slot of the caller's
+  // ring (device-visible memory, normally pinned host memory: the kernel writes the few records straight across PCIe); ep_totals [4]: sums of
+  // return / length / episodes / truncated episodes (atomics) for a trainer that never leaves the device
+  float* ep_ret;
+  float* ep_masks;
+  float* ep_bad;
+  void* ep_rec;
+  float* ep_totals;
+  uint32_t ep_serial;
 };
 
 // ------------------------------------------------------------------ helpers
@@ -1679,13 +1690,14 @@ DI void set_issue_priority(int nr, int prio) {
 #endif
 constexpr int PACE_TICK_SHIFT = 6;   // elapsed ticks and the pace are compared in units of 64 ticks
 enum : int { L_T0 = L_BASE + 13, L_PACE = L_BASE + 14, L_KEEPWARM = L_BASE + 15 /* StepArgs.persist_warm or a warm-starting blob: same reason */ };
+constexpr unsigned PACE_CNT_BITS = 24, PACE_WINDOW = 128;
 DI void pace_start(const StepArgs& a, float* L, int lane, int pace) {
   if (lane == 0) {
     int p16 = pace >> PACE_TICK_SHIFT;
-    if (pace < 0) {   // self-calibrating: the previous launch's mean wave time (ticks / 64) x (-pace) / 16; no sample yet: row-count priorities
-      const unsigned sum = a.pace_acc[2 * a.pace_slot_r], cnt = a.pace_acc[2 * a.pace_slot_r + 1];
-      p16 = cnt > 0u ? (int)((float)sum / (float)cnt * (float)(-pace) * 0.0625f) : 0;
-      if (blockIdx.x == 0) { a.pace_acc[2 * a.pace_slot_c] = 0u; a.pace_acc[2 * a.pace_slot_c + 1] = 0u; }
+    if (pace < 0) {   // self-calibrating: the mean wave time of the last sampled waves (ticks / 64) x (-pace) / 16; no sample yet: row-count priorities
+      const unsigned long long v = __hip_atomic_load(a.pace_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned cnt = (unsigned)v & ((1u << PACE_CNT_BITS) - 1u);
+      p16 = cnt > 0u ? (int)((float)(v >> PACE_CNT_BITS) / (float)cnt * (float)(-pace) * 0.0625f) : 0;
     }
     L[L_PACE] = __int_as_float(p16);
     if (pace != 0) L[L_T0] = __uint_as_float((unsigned)__builtin_amdgcn_s_memtime());
@@ -1693,9 +1705,14 @@ DI void pace_start(const StepArgs& a, float* L, int lane, int pace) {
 }
 DI void pace_finish(const StepArgs& a, const float* L, int lane, int pace) {   // (after a barrier: lane 0's words are visible to itself anyway)
   if (pace < 0 && lane == 0 && (blockIdx.x % 61u) == 0u) {   // one wave in 61: a sample spread over the XCDs and CUs
-    const unsigned el = (unsigned)__builtin_amdgcn_s_memtime() - __float_as_uint(L[L_T0]);
-    atomicAdd(&a.pace_acc[2 * a.pace_slot_w], el >> PACE_TICK_SHIFT);
-    atomicAdd(&a.pace_acc[2 * a.pace_slot_w + 1], 1u);
+    const unsigned el = ((unsigned)__builtin_amdgcn_s_memtime() - __float_as_uint(L[L_T0])) >> PACE_TICK_SHIFT;
+    const unsigned long long old = atomicAdd(a.pace_acc, ((unsigned long long)el << PACE_CNT_BITS) | 1ull);
+    // Exactly one wave sees the count arrive at the window (every add returns another value); it halves both fields.  Count and sum only
+    // grow in between (the next halving is 64 samples away), so neither subtraction borrows: the mean is that of the last 64 .. 128 samples.
+    if (((unsigned)old & ((1u << PACE_CNT_BITS) - 1u)) + 1u == PACE_WINDOW) {
+      const unsigned long long sum = (old >> PACE_CNT_BITS) + el;
+      atomicAdd(a.pace_acc, 0ull - (((sum >> 1) << PACE_CNT_BITS) | (unsigned long long)(PACE_WINDOW / 2)));
+    }
   }
 }
 DI bool pace_on(const float* L) { return uni(__float_as_int(L[L_PACE])) > 0; }

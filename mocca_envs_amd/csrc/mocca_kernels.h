@@ -27,6 +27,29 @@ DI void keep_terminal_obs(const StepArgs& a, const float* L, int env, int lane) 
   wsync();
 }
 
+// Monitor + TimeLimitMask inside the launch (mocca_set_episode_stats, StepArgs.ep_*): what the reference's trainers wrap around every env --
+// baselines' Monitor (info["episode"] = {r, l} in the step that ends the episode) and a TimeLimitMask (info["bad_transition"] when the episode
+// was cut by max_episode_steps, /root/reference/mocca_envs/__init__.py:55) -- and the two mask columns their PPO loop builds from `done` /
+// `infos`.  Lane 0; `ret0` is the env's running return loaded by the caller ahead of the observation code (the load's latency hides there).
+DI void monitor_emit(const StepArgs& a, int env, float ret0, float rew, int dflag, int length, int info) {
+  float r = ret0 + rew;
+  if (dflag) {
+    if (a.ep_rec) {   // one 16-byte store: {serial of this launch, return, length, done bits | info << 8}
+      uint4 rec;
+      rec.x = a.ep_serial; rec.y = __float_as_uint(r); rec.z = (uint32_t)length; rec.w = (uint32_t)dflag | ((uint32_t)info << 8);
+      ((uint4*)a.ep_rec)[env] = rec;
+    }
+    if (a.ep_totals) {
+      atomicAdd(&a.ep_totals[0], r); atomicAdd(&a.ep_totals[1], (float)length); atomicAdd(&a.ep_totals[2], 1.0f);
+      if (dflag & 2) atomicAdd(&a.ep_totals[3], 1.0f);
+    }
+    r = 0.0f;
+  }
+  a.ep_ret[env] = r;
+  if (a.ep_masks) a.ep_masks[env] = dflag ? 0.0f : 1.0f;
+  if (a.ep_bad) a.ep_bad[env] = (dflag & 2) ? 0.0f : 1.0f;
+}
+
 // --------------------------------------------------------------------------------------------
 // kernels: one 64-lane workgroup (= one wavefront) per environment
 // --------------------------------------------------------------------------------------------
@@ -103,6 +126,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     if (!INJECT && lane == 0) tk[T_RES23] = (uint32_t)last_rows;
     TaskRegs t;
     load_task(tk, t, false, true);
+    const float ep_ret0 = a.ep_ret ? a.ep_ret[env] : 0.0f;
     t.istep += M->n_llc;  // pd_control counts every low-level iteration (:381); the task-layer entry replays a whole env.step
     float jv = 0.0f;
     if (lane < no) {  // :467-468 finite-difference joint velocity over the control step
@@ -133,6 +157,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
       a.rew[env] = rew;
       a.done[env] = (uint8_t)dflag;
       if (a.info) a.info[env] = 0;
+      if (a.ep_ret) monitor_emit(a, env, ep_ret0, rew, dflag, t.t, 0);
     }
     if (a.auto_reset && dflag) {
       keep_terminal_obs(a, L, env, lane);
@@ -198,6 +223,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
   STAMP(27);  // substeps done
   TaskRegs t;
   load_task(tk, t, T::NFEET > 2);
+  const float ep_ret0 = a.ep_ret ? a.ep_ret[env] : 0.0f;
   // the raw (unclipped) action enters the energy penalty (env_locomotion.py:185-188); re-read it rather than
   // hold a register across the substeps
   const float act_raw = lane < T::NJ ? a.act[(size_t)env * T::NJ + lane] : 0.0f;
@@ -374,6 +400,7 @@ __global__ __launch_bounds__(64, MOCCA_WAVES_PER_EU) void mocca_step_kernel(Step
     a.rew[env] = rew;
     a.done[env] = (uint8_t)dflag;
     if (a.info) a.info[env] = info;
+    if (a.ep_ret) monitor_emit(a, env, ep_ret0, rew, dflag, t.t, info);
   }
   STAMP(26);  // observation + reward done
   if (a.auto_reset && dflag) {
@@ -404,7 +431,7 @@ __global__ __launch_bounds__(64) void mocca_reset_kernel(StepArgs a) {
   TaskRegs t;
   load_task(tk, t, T::NFEET > 2, TASK == MOCCA_TASK_CASSIE);
   if (TASK == MOCCA_TASK_WALKER3D_STEPPER) load_task_cover(tk, t);
-  if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; }
+  if (lane == 0) { L[L_Q] = 0.0f; L[L_QD] = 0.0f; if (a.ep_ret) a.ep_ret[env] = 0.0f; }   // Monitor.reset: a new episode's return starts at 0
   if constexpr (TASK == MOCCA_TASK_CASSIE) {
     cassie_reset_env<T, INJECT>(a, M, L, env + a.env_offset, lane, t, L + L_OBS);
     if (lane < MOCCA_MAX_CTRL) tk[T_JVEL + lane] = __float_as_uint(L[L_JVEL + lane]);

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # MOCCA_LIB_PATH selects another build of the same HIP library (A/B kernel experiments); never a CPU fallback
 LIB_PATH = os.environ.get("MOCCA_LIB_PATH") or os.path.join(HERE, "libmocca_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 PARAM_AUTO_RESET, PARAM_EVAL_MODE, PARAM_CURRICULUM, PARAM_RANDOM_POSE, PARAM_HOST_RETARGET, PARAM_SEED, PARAM_ENV_OFFSET, PARAM_APPLIED_GAIN, PARAM_RANDOM_REWARD = 0, 1, 2, 3, 4, 5, 6, 7, 8
 PARAM_ISSUE_PRIORITY = 9   # timing only: row-count thresholds of the step kernel's issue priorities, t1 + 64 t2 + 4096 t3
 PARAM_PERSIST_IMPULSES = 10  # keep the last substep's normal impulses in the state record although the blob does not warm-start (diagnostic)
@@ -48,6 +48,8 @@ SYMBOLS = {
     "mocca_set_seed": (_i, [_vp, _u64]),
     "mocca_set_debug_buffer": (_i, [_vp, _vp]),
     "mocca_set_terminal_obs_buffer": (_i, [_vp, _vp]),
+    "mocca_set_episode_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz]),
+    "mocca_episode_serial": (C.c_uint32, [_vp]),
     "mocca_set_trajectory": (_i, [_vp, _vp, _i, _d, _d]),
     "mocca_set_heightfield": (_i, [_vp, _vp, _i, _i, _d]),
     "mocca_is_diagnostic_build": (_i, []),

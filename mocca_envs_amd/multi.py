@@ -167,6 +167,26 @@ class SubBatchedVecEnv(_Parts):
                 e.keep_terminal_obs(True, buffer=self.terminal_obs[sl])
         torch.cuda.synchronize(self.device)
 
+    def episode_stats(self, on: bool = True, slots: int = 4) -> Optional[dict]:
+        """`VecEnv.episode_stats` for the whole batch: one set of buffers, every sub-batch writes its rows (the sub-batches' serials advance
+        together as long as every step() / round of step_async() steps each of them once)."""
+        if not on:
+            for e in self.parts:
+                e.episode_stats(False)
+            self.ep = None
+            return None
+        f32 = dict(dtype=torch.float32, device=self.device)
+        masks, bad = torch.ones(self.n_envs, **f32), torch.ones(self.n_envs, **f32)
+        totals = torch.zeros(4, **f32)
+        records = torch.zeros(int(slots), self.n_envs, 4, dtype=torch.int32).pin_memory()
+        torch.cuda.synchronize(self.device)     # the buffers are filled on torch's current stream, the parts read them on their own
+        firsts = {e.episode_stats(True, masks=masks[sl], bad_masks=bad[sl], totals=totals, records=records, row0=sl.start)["first_serial"]
+                  for e, sl in zip(self.parts, self.slices)}
+        if len(firsts) != 1:
+            raise _lib.MoccaError("the sub-batches' episode serials differ: attach episode_stats before stepping them separately")
+        self.ep = dict(masks=masks, bad_masks=bad, totals=totals, records=records, row0=0, slots=int(slots), first_serial=firsts.pop())
+        return self.ep
+
     def reset(self, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         for e, sl in zip(self.parts, self.slices):
             e.reset(None if mask is None else mask[sl])

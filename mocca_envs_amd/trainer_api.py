@@ -5,20 +5,26 @@ SymmetricRL and ALLSTEPS / SteppingStone (/root/reference/README.md:33-39) are P
 behind baselines' `ShmemVecEnv`, wrapped in `VecPyTorch` -- and then only ever touch this surface:
 
     obs = envs.reset()                                   # float tensor [N, obs_dim] on the trainer's device
-    obs, reward, done, infos = envs.step(action)         # reward [N, 1]; done: numpy bool [N]; infos: N dicts
+    obs, reward, done, infos = envs.step(action)         # reward [N, 1]; done: bool array [N]; infos: N dicts
     for info in infos: info["episode"]["r"]              # Monitor's episode return / length, in the step that ends the episode
-    "bad_transition" in info                             # TimeLimitMask: the episode was cut by max_episode_steps, not terminated
+    "bad_transition" in info                             # TimeLimitMask: the episode was cut by max_episode_steps
     envs.observation_space / action_space / num_envs, envs.close()
     env.unwrapped.get_mirror_indices()                   # on a dummy env (SymmetricRL); set_env_params({"curriculum": k}) (ALLSTEPS)
 
-`TorchVecEnv` is that surface with the N processes replaced by ONE `VecEnv` (or `SubBatchedVecEnv`): finished envs are reset inside the
-launch and `obs` already holds the next episode's first observation (baselines' VecEnv contract); episode return and length are accumulated
-on the device; only the done flags (N bytes) and the finished envs' statistics cross to the host per step.  A trainer that wants no host
-traffic at all reads `masks` / `bad_masks` (float tensors [N, 1] on the device, what the PPO loop builds from `done` / `infos`) and skips `infos`
-(the list-like `infos` only builds dicts for the envs that finished; `infos.finished()` iterates just those).
+`TorchVecEnv` is that surface with the N processes replaced by ONE `VecEnv` (or `SubBatchedVecEnv`), and with Monitor and the TimeLimit mask
+INSIDE the step kernel (`VecEnv.episode_stats`, include/mocca.h mocca_set_episode_stats): the launch accumulates every env's episode return,
+writes the PPO loop's `masks` / `bad_masks` columns on the device and, for the few envs that finished, a 16-byte record straight into pinned
+host memory.  `step()` therefore is one kernel launch and one event record: no torch arithmetic, no copy, NO SYNCHRONISE.  `done` and `infos`
+are lazy views of that step's records -- they wait for THAT step's launch, and only when the trainer looks at them (iterate / index /
+np.asarray), and then behave like the bool array and the list of dicts of the contract above.  A loop that logs `infos` one step late
+(after it has issued the next step) never lets the GPU run dry.  A trainer that wants no host traffic at all reads `envs.masks` / `envs.bad_masks`
+([N, 1] float tensors on the device, what the PPO loop builds from `done` / `infos`), `envs.done` (uint8 [N], bit0 terminated, bit1
+TimeLimit) and `envs.episode_totals` ([4] on the device: sums of return, length, episodes, truncated episodes since it last zeroed them),
+and never touches `done` / `infos`; that loop can be captured in a `torch.cuda.CUDAGraph` (tests/test_gpu_trainer_api.py).
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -28,11 +34,122 @@ from . import gym_shim
 from .multi import make_vec_env
 
 
+class _StepRecords:
+    """The episode records of ONE step (serial k), read from the pinned ring on first use."""
+
+    __slots__ = ("_env", "serial", "_done", "_fin", "_rows", "_idx", "_term", "_stepper", "__weakref__")
+
+    def __init__(self, env: "TorchVecEnv", serial: int):
+        self._env, self.serial, self._done, self._fin, self._rows, self._idx, self._term = env, serial, None, None, None, None, None
+        self._stepper = env._stepper
+
+    def materialise(self):
+        """Wait for THIS step's launch and copy its records out of the ring slot (numpy only: no per-env Python work yet)."""
+        if self._done is not None:
+            return
+        env = self._env
+        env._events[self.serial % env._slots].synchronize()  # the launch of THIS step has completed (later ones may still be queued or running)
+        rec = env._ring[self.serial % env._slots]            # [N][4] int32 view of the pinned slot
+        self._idx = np.nonzero(rec[:, 0] == np.array(self.serial, np.uint32).view(np.int32))[0]
+        self._rows = rec[self._idx]                          # (a copy: the slot is rewritten `slots` steps from now)
+        done = np.zeros(env.num_envs, dtype=bool)
+        done[self._idx] = True
+        if env._want_terminal and self._idx.size:            # owned copies of the finished envs' terminal observations, gathered once
+            self._term = env.venv.terminal_obs.index_select(0, torch.from_numpy(self._idx).to(env.device))
+        self._done = done
+        self._env = None
+
+    def episodes(self) -> dict:
+        """The finished envs of the step as arrays: env index, Monitor's r and l, the TimeLimit flag, the step's info word."""
+        self.materialise()
+        r = self._rows
+        flags = r[:, 3].view(np.uint32) if r.size else np.zeros(0, np.uint32)
+        return {"env": self._idx, "r": np.ascontiguousarray(r[:, 1]).view(np.float32), "l": r[:, 2], "truncated": (flags & 2) != 0, "info": flags >> 8}
+
+    def fin(self) -> dict:
+        """{env index: info dict} of the finished envs, built on first use."""
+        if self._fin is None:
+            e = self.episodes()
+            self._fin = {}
+            for j, i in enumerate(e["env"].tolist()):
+                info = {"episode": {"r": float(e["r"][j]), "l": int(e["l"][j])}}
+                if e["truncated"][j]:                        # TimeLimitMask: done at max_episode_steps (whether or not it also terminated)
+                    info["bad_transition"] = True
+                    info["TimeLimit.truncated"] = True
+                if self._stepper:
+                    info["steps_reached"] = int(e["info"][j])     # Walker3DStepperEnv.step's info at done (env_locomotion.py:562-566)
+                if self._term is not None:
+                    info["terminal_observation"] = self._term[j]
+                self._fin[i] = info
+        return self._fin
+
+
+class _LazyDone:
+    """`done` of one step: a bool array [N] that is fetched when first looked at (np.asarray(done), iteration, indexing, any attribute of
+    numpy.ndarray)."""
+
+    __slots__ = ("_rec",)
+
+    def __init__(self, rec: _StepRecords):
+        self._rec = rec
+
+    def numpy(self) -> np.ndarray:
+        self._rec.materialise()
+        return self._rec._done
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __len__(self):
+        return len(self._rec._done) if self._rec._done is not None else self._rec._env.num_envs
+
+    def __iter__(self):
+        return iter(self.numpy())
+
+    def __getitem__(self, i):
+        return self.numpy()[i]
+
+    def __getattr__(self, name):        # .any(), .sum(), .dtype, .shape, .nonzero(), .astype(...), ...
+        return getattr(self.numpy(), name)
+
+    def __invert__(self):
+        return ~self.numpy()
+
+    def __and__(self, o):
+        return self.numpy() & o
+
+    def __or__(self, o):
+        return self.numpy() | o
+
+    def __eq__(self, o):
+        return self.numpy() == o
+
+    def __ne__(self, o):
+        return self.numpy() != o
+
+    __hash__ = None
+
+    def __repr__(self):
+        return f"LazyDone({self.numpy()!r})"
+
+
 class _Infos:
     """List-of-dicts view of one step's infos: {} for envs that go on, Monitor / TimeLimitMask keys for envs that finished."""
 
-    def __init__(self, n: int, finished: dict):
-        self._n, self._fin = n, finished
+    __slots__ = ("_n", "_rec")
+
+    def __init__(self, n: int, rec: _StepRecords):
+        self._n, self._rec = n, rec
+
+    def _finished(self) -> dict:
+        return self._rec.fin()
+
+    def episodes(self) -> dict:
+        """The same information without a dict per env: {"env": indices of the envs that finished in this step, "r": their episode returns,
+        "l": lengths, "truncated": ended at the TimeLimit ("bad_transition"), "info": the step's info word (Stepper: steps_reached)} as
+        numpy arrays -- what a logging loop over thousands of envs wants."""
+        return self._rec.episodes()
 
     def __len__(self):
         return self._n
@@ -44,23 +161,26 @@ class _Infos:
             i += self._n
         if not 0 <= i < self._n:
             raise IndexError(i)
-        return self._fin.get(i, {})
+        return self._finished().get(i, {})
 
     def __iter__(self):
-        fin, empty = self._fin, {}
+        fin, empty = self._finished(), {}
         return (fin.get(i, empty) for i in range(self._n))
 
     def finished(self):
         """(env index, info dict) of the envs whose episode ended in this step -- what a trainer's logging loop is after."""
-        return self._fin.items()
+        return self._finished().items()
 
 
 class TorchVecEnv:
     """`VecPyTorch`-shaped env batch on one MI355X (module docstring).  kwargs go to the env class (`plank_class=...`) / `VecEnv`
-    (`max_rows=...`); `sub_batches=k` steps the batch as k sub-batches on their own HIP streams (`multi.SubBatchedVecEnv`)."""
+    (`max_rows=...`); `sub_batches=k` steps the batch as k sub-batches on their own HIP streams (`multi.SubBatchedVecEnv`).
+    `record_slots`: how many steps' episode records the pinned ring holds; a step's `done` / `infos` that are still referenced when
+    their slot comes up for rewriting are fetched then, so they stay correct however late they are read.  `eager_done=True` returns
+    `done` as a real numpy array (one synchronise per step -- for code that insists on `isinstance(done, np.ndarray)`)."""
 
     def __init__(self, env_id: str, num_envs: int, seed: int = 0, device: Optional[int] = None, sub_batches: int = 1,
-                 terminal_observation: bool = False, **kw):
+                 terminal_observation: bool = False, record_slots: int = 8, eager_done: bool = False, **kw):
         self.venv = make_vec_env(env_id, num_envs, sub_batches=sub_batches, seed=seed, auto_reset=True, terminal_obs=terminal_observation,
                                  **({"device": device} if device is not None else {}), **kw)
         self.env_id, self.num_envs = env_id, int(num_envs)
@@ -68,51 +188,47 @@ class TorchVecEnv:
         high = np.inf * np.ones(self.venv.obs_dim, dtype=np.float32)
         self.observation_space = gym_shim.Box(-high, high, dtype=np.float32)                      # robots.py:18-29, env_locomotion.py:58-60
         self.action_space = gym_shim.Box(-np.ones(self.venv.act_dim, np.float32), np.ones(self.venv.act_dim, np.float32), dtype=np.float32)
-        self._ret = torch.zeros(num_envs, device=self.device)
-        self._len = torch.zeros(num_envs, dtype=torch.int32, device=self.device)
-        self.masks = torch.ones(num_envs, 1, device=self.device)        # 0 where the episode ended in the last step
-        self.bad_masks = torch.ones(num_envs, 1, device=self.device)    # 0 where it ended by the TimeLimit only ("bad_transition")
+        ep = self.venv.episode_stats(True, slots=int(record_slots))
+        self.masks = ep["masks"].unsqueeze(1)              # [N, 1], 0 where the episode ended in the last step; REWRITTEN IN PLACE by every step
+        self.bad_masks = ep["bad_masks"].unsqueeze(1)      # [N, 1], 0 where it ended at the TimeLimit ("bad_transition")
+        self.episode_totals = ep["totals"]                 # [4] sums of return / length / episodes / truncated episodes; zero it when you like
+        self.done = self.venv.done                         # uint8 [N] on the device: bit0 terminated, bit1 TimeLimit
+        self._ring = ep["records"].numpy()                 # [slots][N][4] int32 over the pinned host ring
+        self._slots, self._k = ep["slots"], ep["first_serial"]
+        self._live = [None] * self._slots                  # weak references to the lazy records of the last `slots` steps
+        self._events = [torch.cuda.Event() for _ in range(self._slots)]   # recorded behind each step's launch: what its lazy records wait for
+        self._rew2 = self.venv.rew.unsqueeze(1)
         self._want_terminal = bool(terminal_observation)
-        self._pack = torch.zeros(num_envs, 5, device=self.device)
-        self._pack_host = torch.zeros(num_envs, 5).pin_memory()
+        self._eager = bool(eager_done)
         from . import model as M
         self._stepper = self.venv.task_id == M.TASK_WALKER3D_STEPPER
 
+    def synchronize(self):
+        """Wait for every launch issued so far (the streams the env steps on)."""
+        if hasattr(self.venv, "synchronize"):
+            self.venv.synchronize()
+        torch.cuda.current_stream(self.device).synchronize()
+
     # ---- the VecPyTorch surface ----
     def reset(self) -> torch.Tensor:
-        self._ret.zero_(); self._len.zero_()
-        return self.venv.reset()
+        return self.venv.reset()       # (the reset kernel zeroes the envs' running returns: Monitor.reset)
 
     def step(self, actions: torch.Tensor):
-        actions = actions.to(device=self.device, dtype=torch.float32)
-        obs, rew, done, kinfo = self.venv.step(actions.contiguous())
-        self._ret += rew
-        self._len += 1
-        ended = done != 0
-        truncated_only = done == 2                                       # bit1 = TimeLimit, bit0 = terminated (include/mocca.h)
-        self.masks = (~ended).float().unsqueeze(1)
-        self.bad_masks = (~truncated_only).float().unsqueeze(1)
-        # ONE download per step: done flags + the statistics of the envs that finished, in one pinned image (N x 5 floats)
-        torch.stack([ended.float(), self._ret, self._len.float(), truncated_only.float(), kinfo.float()], dim=1, out=self._pack)
-        self._pack_host.copy_(self._pack, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
-        h = self._pack_host.numpy()
-        done_host = h[:, 0] != 0.0
-        finished = {}
-        if done_host.any():
-            self._ret *= self.masks[:, 0]                                # (after the download was queued: same stream)
-            self._len *= (~ended).to(self._len.dtype)
-            for i in np.nonzero(done_host)[0].tolist():
-                info = {"episode": {"r": float(h[i, 1]), "l": int(h[i, 2])}}
-                if h[i, 3] != 0.0:
-                    info["bad_transition"] = True
-                    info["TimeLimit.truncated"] = True
-                if self._stepper:
-                    info["steps_reached"] = int(h[i, 4])          # Walker3DStepperEnv.step's info at done (env_locomotion.py:562-566)
-                if self._want_terminal:
-                    info["terminal_observation"] = self.venv.terminal_obs[i]
-                finished[i] = info
-        return obs, rew.unsqueeze(1), done_host, _Infos(self.num_envs, finished)
+        k = self._k
+        slot = k % self._slots
+        old = self._live[slot]
+        if old is not None:
+            old = old()
+            if old is not None:
+                old.materialise()      # its slot is about to be rewritten: fetch it now (its launch finished long ago)
+        if actions.device != self.device or actions.dtype != torch.float32 or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        obs = self.venv.step(actions)[0]
+        self._events[slot].record(torch.cuda.current_stream(self.device))
+        self._k = k + 1 if k < 0xFFFFFFFF else 1
+        rec = _StepRecords(self, k)
+        self._live[slot] = weakref.ref(rec)
+        return obs, self._rew2, (_LazyDone(rec).numpy() if self._eager else _LazyDone(rec)), _Infos(self.num_envs, rec)
 
     def step_async(self, actions):      # baselines' two-phase form
         self._pending = self.step(actions)
@@ -149,7 +265,7 @@ class TorchVecEnv:
 
 def make_vec_envs(env_name: str, seed: int, num_processes: int, log_dir=None, device=None, **kw) -> TorchVecEnv:
     """Same call as the trainers' `common.envs_utils.make_vec_envs(env_name, seed, num_processes, log_dir)`; `log_dir` (Monitor's csv) is
-    accepted and ignored -- episode statistics arrive through `infos`."""
+    accepted and ignored -- episode statistics arrive through `infos` / `envs.episode_totals`."""
     dev = None
     if device is not None:
         dev = torch.device(device).index if not isinstance(device, int) else device

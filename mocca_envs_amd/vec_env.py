@@ -161,6 +161,7 @@ class VecEnv:
         self.terminal_obs = None
         if terminal_obs:
             self.keep_terminal_obs(True)
+        self.ep = None        # episode_stats(): Monitor / TimeLimitMask inside the launch
         self.height_field = None
         if self.task_id == M.TASK_WALKER3D_PLANNER:
             from .terrain import load_height_field   # self.terrain.reload(data="height_field_map_0.npy"), env_locomotion.py:1015-1021
@@ -313,6 +314,38 @@ class VecEnv:
             self.terminal_obs = torch.zeros(self.n_envs, self.obs_dim, dtype=torch.float32, device=self.device) if on else None
         _lib.check(self.lib.mocca_set_terminal_obs_buffer(self.h, C.c_void_p(self.terminal_obs.data_ptr()) if on else None), self.h)
         return self.terminal_obs
+
+    def episode_stats(self, on: bool = True, slots: int = 4, masks=None, bad_masks=None, totals=None, records=None, row0: int = 0) -> Optional[dict]:
+        """Monitor + TimeLimitMask inside the launch (include/mocca.h mocca_set_episode_stats): per step and env the PPO loop's `masks` /
+        `bad_masks` columns (float32 [N] on the device, 0.0 where the episode ended / ended with the TimeLimit bit), device-side `totals`
+        [4] (sums of return, length, episodes, truncated episodes) and, for the envs that finished, a 16-byte record {serial, return,
+        length, done bits | info << 8} written by the kernel straight into PINNED HOST memory: `records` int32 [slots][N][4], the k-th
+        step() after this call (k = 1, 2, ...) writes slot k % slots with serial k.  Nothing is copied and nothing synchronises; read a
+        slot after the stream work of its step has completed.  The four buffers are allocated here unless passed in (a sub-batch gets
+        its rows of a whole batch's buffers: `records` is then the whole ring and `row0` this handle's first row).  on=False detaches."""
+        if not on:
+            _lib.check(self.lib.mocca_set_episode_stats(self.h, None, None, None, None, 0, 0), self.h)
+            self.ep = None
+            return None
+        n = self.n_envs
+        f32 = dict(dtype=torch.float32, device=self.device)
+        masks = torch.ones(n, **f32) if masks is None else masks
+        bad_masks = torch.ones(n, **f32) if bad_masks is None else bad_masks
+        totals = torch.zeros(4, **f32) if totals is None else totals
+        if records is None:
+            records = torch.zeros(int(slots), n, 4, dtype=torch.int32).pin_memory()
+        for t, shape in ((masks, (n,)), (bad_masks, (n,)), (totals, (4,))):
+            if tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("episode_stats: masks / bad_masks must be contiguous float32 [n_envs] and totals float32 [4] on the env's device")
+        if records.dim() != 3 or records.shape[2] != 4 or records.dtype != torch.int32 or not records.is_contiguous() or \
+                row0 < 0 or row0 + n > records.shape[1] or not (records.is_cuda or records.is_pinned()):
+            raise ValueError("episode_stats: records must be a contiguous int32 [slots][rows >= row0 + n_envs][4] tensor in pinned host (or device) memory")
+        self._sync()      # no launch of this handle is in flight while its buffers change
+        _lib.check(self.lib.mocca_set_episode_stats(self.h, C.c_void_p(masks.data_ptr()), C.c_void_p(bad_masks.data_ptr()), C.c_void_p(totals.data_ptr()),
+                                                    C.c_void_p(records.data_ptr() + 16 * row0), records.shape[0], 16 * records.shape[1]), self.h)
+        self.ep = dict(masks=masks, bad_masks=bad_masks, totals=totals, records=records, row0=row0, slots=records.shape[0],
+                       first_serial=int(self.lib.mocca_episode_serial(self.h)))
+        return self.ep
 
     def set_debug(self, on: bool = True) -> Optional[torch.Tensor]:
         """Attach (or detach) the per-env debug record: [N][16] int32, words MOCCA_DBG_* (0..11 the active set of the last substep

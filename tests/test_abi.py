@@ -107,15 +107,48 @@ def test_multi_handle_envs_validate_their_arguments_before_touching_a_gpu():
         make_vec_env("Walker3DCustomEnv-v0", 128, sub_batches=2, devices=[0, 1])
 
 
-def test_trainer_infos_container_behaves_like_a_list_of_dicts():
-    """trainer_api._Infos: what `for info in infos` / `infos[i]` / `len(infos)` of the PPO trainers see, without building N dicts per step."""
-    from mocca_envs_amd.trainer_api import _Infos
-    fin = {3: {"episode": {"r": 1.5, "l": 7}}, 9: {"episode": {"r": -2.0, "l": 1000}, "bad_transition": True}}
-    infos = _Infos(12, fin)
-    assert len(infos) == 12 and infos[3]["episode"]["l"] == 7 and infos[0] == {} and infos[-3] is fin[9]
+def test_trainer_lazy_done_and_infos_read_the_record_ring():
+    """trainer_api._LazyDone / _Infos over one slot of the episode-record ring (include/mocca.h mocca_episode_rec): what `for d in done` /
+    `for info in infos` / `infos[i]` / `len(infos)` of the PPO trainers see.  Nothing is read before the first look; records whose serial is
+    another step's (left over in the slot) are not this step's."""
+    import numpy as np
+    from mocca_envs_amd.trainer_api import _Infos, _LazyDone, _StepRecords
+
+    class Ev:
+        waits = 0
+
+        def synchronize(self):
+            Ev.waits += 1
+
+    class Env:
+        num_envs, _slots, _want_terminal, _stepper = 12, 4, False, True
+        _events = [Ev() for _ in range(4)]
+        _ring = np.zeros((4, 12, 4), np.int32)
+
+    def put(slot, env, serial, ret, length, flags):
+        Env._ring[slot, env] = (serial, np.float32(ret).view(np.int32), length, flags)
+
+    serial = 6                                   # slot 6 % 4 = 2
+    put(2, 3, serial, 1.5, 7, 1 | (4 << 8))      # terminated, steps_reached 4
+    put(2, 9, serial, -2.0, 1000, 3 | (19 << 8)) # terminated AND at the TimeLimit: bad_transition (a2c-ppo-acktr's TimeLimitMask)
+    put(2, 5, serial - 4, 9.0, 3, 1)             # left over from four steps ago
+    rec = _StepRecords(Env, serial)
+    done, infos = _LazyDone(rec), _Infos(12, rec)
+    assert len(done) == 12 and len(infos) == 12 and Ev.waits == 0       # nothing fetched yet
+    fin = dict(infos.finished())
+    assert Ev.waits == 1 and sorted(fin) == [3, 9]
+    assert fin[3] == {"episode": {"r": 1.5, "l": 7}, "steps_reached": 4}
+    assert fin[9] == {"episode": {"r": -2.0, "l": 1000}, "steps_reached": 19, "bad_transition": True, "TimeLimit.truncated": True}
+    assert infos[3]["episode"]["l"] == 7 and infos[0] == {} and infos[-3] is fin[9]
     assert [("episode" in i) for i in infos] == [k in fin for k in range(12)]
-    assert sum("bad_transition" in i.keys() for i in infos) == 1 and dict(infos.finished()) == fin
-    assert [len(x) for x in infos[2:5]] == [0, 1, 0]
+    assert sum("bad_transition" in i.keys() for i in infos) == 1
+    assert [len(x) for x in infos[2:5]] == [0, 2, 0]
+    d = np.asarray(done)
+    assert d.dtype == bool and d.tolist() == [k in fin for k in range(12)] and done.sum() == 2 and bool(done[9]) and not done[5]
+    assert [[0.0] if x else [1.0] for x in done] == [[0.0] if k in fin else [1.0] for k in range(12)]     # the trainers' mask comprehension
+    assert (~done).sum() == 10 and (done == d).all() and Ev.waits == 1
+    Env._ring[2] = 0                             # the slot is rewritten later: the fetched step keeps its records
+    assert dict(infos.finished()) == fin
     import pytest
     with pytest.raises(IndexError):
         infos[12]

@@ -1,6 +1,8 @@
 """`mocca_envs_amd.trainer_api`: the VecPyTorch-shaped surface SymmetricRL / ALLSTEPS drive (/root/reference/README.md:33-39), over one VecEnv.
 Checked against a plain VecEnv stepped beside it with the same seed and actions: observations and rewards bit for bit; Monitor's episode
-return / length, TimeLimitMask's `bad_transition` and the Stepper's `steps_reached` (env_locomotion.py:562-566) against a hand-kept ledger.
+return / length, TimeLimitMask's `bad_transition` and the Stepper's `steps_reached` (env_locomotion.py:562-566) -- all produced INSIDE the
+step kernel since ABI 7 (include/mocca.h mocca_set_episode_stats) -- against a hand-kept ledger.  Then the two things the lazy surface
+promises: records read many steps late are still the right ones, and `policy -> mocca_step` replays bit-identically from a CUDA graph.
 Needs a real MI355X: -m gpu."""
 import numpy as np
 import pytest
@@ -24,31 +26,44 @@ def test_trainer_surface_matches_a_hand_kept_ledger(env_id, sub_batches):
     g = torch.Generator(device="cuda").manual_seed(9)
     ret, length = np.zeros(n), np.zeros(n, int)
     n_eps = n_bad = 0
+    tot = np.zeros(4)
     for t in range(steps):
         a = torch.rand(n, ref.act_dim, device="cuda", generator=g) * 2 - 1
         obs, rew, done, infos = envs.step(a)
         o2, r2, d2, i2 = ref.step(a)
         assert torch.equal(obs, o2) and torch.equal(rew, r2.unsqueeze(1)) and rew.shape == (n, 1)
-        assert isinstance(done, np.ndarray) and done.dtype == bool and (done == (d2.cpu().numpy() != 0)).all()
+        assert torch.equal(envs.done, d2)                                   # the device-side done byte (bit0 terminated, bit1 TimeLimit)
+        dn = np.asarray(done)
+        assert dn.dtype == bool and dn.shape == (n,) and (dn == (d2.cpu().numpy() != 0)).all() and len(done) == n
+        assert bool(done.any()) == bool(dn.any()) and [bool(x) for x in done] == dn.tolist() and done[3] == dn[3]
         assert len(infos) == n
         ret += r2.cpu().numpy(); length += 1
         d2h, i2h = d2.cpu().numpy(), i2.cpu().numpy()
         masks, bad = envs.masks.cpu().numpy()[:, 0], envs.bad_masks.cpu().numpy()[:, 0]
+        assert envs.masks.shape == (n, 1) and envs.bad_masks.shape == (n, 1)
         for i, info in enumerate(infos):            # the trainers' own loop over the N dicts
             if done[i]:
                 assert abs(info["episode"]["r"] - ret[i]) < 1e-3 * (1 + abs(ret[i])) and info["episode"]["l"] == length[i]
-                assert ("bad_transition" in info) == (d2h[i] == 2) and masks[i] == 0.0 and bad[i] == (0.0 if d2h[i] == 2 else 1.0)
+                # a2c-ppo-acktr's TimeLimitMask: bad_transition on ANY done at max_episode_steps, also when the env terminates in that very step
+                timeout = bool(d2h[i] & 2)
+                assert ("bad_transition" in info) == timeout and masks[i] == 0.0 and bad[i] == (0.0 if timeout else 1.0)
                 assert torch.equal(info["terminal_observation"], ref.terminal_obs[i])
                 if "Stepper" in env_id:
                     assert info["steps_reached"] == i2h[i]
-                n_eps += 1; n_bad += d2h[i] == 2
+                n_eps += 1; n_bad += timeout
+                tot += (ret[i], length[i], 1, timeout)
                 ret[i], length[i] = 0.0, 0
             else:
                 assert info == {} and masks[i] == 1.0 and bad[i] == 1.0
-        assert sorted(k for k, _ in infos.finished()) == list(np.nonzero(done)[0])
+        assert sorted(k for k, _ in infos.finished()) == list(np.nonzero(dn)[0])
+        e = infos.episodes()                       # the same records as arrays
+        assert e["env"].tolist() == np.nonzero(dn)[0].tolist() and e["l"].tolist() == [infos[i]["episode"]["l"] for i in e["env"]]
+        assert e["r"].tolist() == [infos[i]["episode"]["r"] for i in e["env"]] and e["truncated"].tolist() == [bool(d2h[i] & 2) for i in e["env"]]
     assert n_eps > n // 2
     if "2D" in env_id:
         assert n_bad == n_eps > 0                   # every Walker2D episode ends by the TimeLimit
+    dev_tot = envs.episode_totals.cpu().numpy()     # the on-device Monitor: sums over every episode that ended
+    assert dev_tot[2] == n_eps and dev_tot[3] == n_bad and dev_tot[1] == tot[1] and abs(dev_tot[0] - tot[0]) < 1e-3 * (1 + abs(tot[0]))
     # the curriculum and mirror calls the trainers make
     if "Stepper" in env_id:
         envs.set_env_params({"curriculum": 5})
@@ -56,3 +71,74 @@ def test_trainer_surface_matches_a_hand_kept_ledger(env_id, sub_batches):
     if "2D" not in env_id:
         assert len(envs.get_mirror_indices()) == 6
     envs.close(); ref.close()
+
+
+def test_records_read_late_are_still_the_right_ones():
+    """`done` / `infos` are lazy: nothing is fetched until the trainer looks.  Kept for 30 steps (the ring holds 4) and read afterwards they
+    must equal what an eager twin saw step by step; `eager_done=True` hands out real numpy arrays."""
+    import torch
+    from mocca_envs_amd.trainer_api import make_vec_envs
+    n, steps = 128, 90
+    lazy = make_vec_envs("Walker3DCustomEnv-v0", seed=2, num_processes=n, record_slots=4)
+    eager = make_vec_envs("Walker3DCustomEnv-v0", seed=2, num_processes=n, eager_done=True)
+    lazy.reset(); eager.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    kept, seen = [], []
+    for t in range(steps):
+        a = torch.rand(n, 21, device="cuda", generator=g) * 2 - 1
+        _, _, d1, i1 = lazy.step(a)
+        _, _, d2, i2 = eager.step(a)
+        assert isinstance(d2, np.ndarray) and d2.dtype == bool
+        seen.append((d2.copy(), {k: dict(v) for k, v in i2.finished()}))
+        kept.append((d1, i1))
+        if len(kept) == 30:
+            for (dl, il), (de, ie) in zip(kept, seen):
+                assert (np.asarray(dl) == de).all() and dict(il.finished()) == ie
+            kept, seen = [], []
+    assert sum(int(np.asarray(d).sum()) for d, _ in kept) >= 0
+    lazy.close(); eager.close()
+
+
+def test_policy_and_step_replay_from_a_cuda_graph():
+    """The collection loop without the host: `policy -> mocca_step` captured once in a torch.cuda.CUDAGraph (default parameters: the pace
+    calibrates itself on the device since ABI 7) and replayed; observations, rewards, done bytes, masks, episode totals and the
+    simulation state must equal, bit for bit, those of an eager twin that launched every kernel from Python."""
+    import torch
+    from mocca_envs_amd.vec_env import VecEnv
+    n, warm, steps = 256, 3, 120
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(5)
+    w1 = torch.randn(52, 64, device=dev, generator=g) * 0.3
+    w2 = torch.randn(64, 21, device=dev, generator=g) * 0.3
+
+    def policy(o):
+        return torch.tanh(torch.tanh(o @ w1) @ w2)
+
+    envs = []
+    for _ in range(2):
+        e = VecEnv("Walker3DCustomEnv-v0", n, auto_reset=True, seed=6)
+        e.episode_stats(True)
+        e.reset()
+        envs.append(e)
+    eager, graphed = envs
+    for _ in range(warm + steps):
+        eager.step(policy(eager.obs))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                   # torch wants the captured ops to have run once on a side stream
+        for _ in range(warm):
+            graphed.step(policy(graphed.obs))
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        graphed.step(policy(graphed.obs))           # obs is read and rewritten in place: the graph is the whole loop body
+    for _ in range(steps):                          # (capturing records the launches, it does not run them)
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(eager.obs, graphed.obs) and torch.equal(eager.rew, graphed.rew) and torch.equal(eager.done, graphed.done)
+    assert torch.equal(eager.get_state(), graphed.get_state()) and torch.equal(eager.get_task(), graphed.get_task())
+    assert torch.equal(eager.ep["masks"], graphed.ep["masks"]) and torch.equal(eager.ep["bad_masks"], graphed.ep["bad_masks"])
+    te, tg = eager.ep["totals"].cpu().numpy(), graphed.ep["totals"].cpu().numpy()
+    assert te[2] > 0 and te[1] == tg[1] and te[2] == tg[2] and te[3] == tg[3] and abs(te[0] - tg[0]) < 1e-3 * (1 + abs(te[0]))   # (atomic float sums: order differs)
+    for e in envs:
+        e.close()

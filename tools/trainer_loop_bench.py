@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
-"""What a SymmetricRL / ALLSTEPS-style PPO collection loop gets out of mocca_envs_amd.trainer_api.TorchVecEnv on one MI355X:
-(a) the trainers' own loop, verbatim habits included (a Python list comprehension over `done` for the masks, a loop over the N info dicts),
-(b) the same loop reading `envs.masks` / `envs.bad_masks` and `infos.finished()` instead.  Policy: MLP obs-64-act on the GPU.
-  python tools/trainer_loop_bench.py [--envs 4096] [--steps 300] [--env-id Walker3DCustomEnv-v0] [--sub-batches 1]"""
+"""What a SymmetricRL / ALLSTEPS-style PPO collection loop gets out of mocca_envs_amd.trainer_api.TorchVecEnv on one MI355X.
+Policy: MLP obs-64-act on the GPU; every loop writes the masked observation into a rollout buffer as the PPO storage does.
+  trainer_loop_verbatim       the trainers' own loop, habits included: a Python list comprehension over `done` for the masks, a loop over the
+                              N info dicts (both force the lazy `done` / `infos` of THIS step: one wait per step, then ~3 x N Python iterations)
+  trainer_loop_device_masks   `envs.masks` / `envs.bad_masks` from the device, episode returns from `infos.episodes()` (arrays, no dict per env)
+                              read ONE STEP LATE (after the next step has been issued: the wait never lets the GPU run dry)
+  trainer_loop_device_totals  the same without `infos`: episode statistics from `envs.episode_totals` (device) at the end
+  trainer_loop_graphed        policy -> mocca_step -> rollout write of `--chunk` consecutive steps captured in ONE torch.cuda.CUDAGraph and
+                              replayed: the collection phase without the host
+  python tools/trainer_loop_bench.py [--envs 4096] [--steps 300] [--env-id Walker3DCustomEnv-v0] [--sub-batches 1] [--chunk 10]"""
 import argparse
 import json
 import os
@@ -18,6 +24,8 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--env-id", default="Walker3DCustomEnv-v0")
     ap.add_argument("--sub-batches", type=int, default=1)
+    ap.add_argument("--chunk", type=int, default=10)
+    ap.add_argument("--skip-verbatim", action="store_true")
     args = ap.parse_args()
     import torch
     from mocca_envs_amd.trainer_api import make_vec_envs
@@ -27,7 +35,8 @@ def main():
     w1 = torch.randn(envs.observation_space.shape[0], 64, device=dev, generator=g) * 0.3
     w2 = torch.randn(64, envs.action_space.shape[0], device=dev, generator=g) * 0.3
     policy = lambda o: torch.tanh(torch.tanh(o @ w1) @ w2)
-    rollouts = torch.zeros(args.steps + 1, args.envs, envs.observation_space.shape[0], device=dev)
+    steps = (args.steps // args.chunk) * args.chunk
+    rollouts = torch.zeros(max(steps, 50) + 1, args.envs, envs.observation_space.shape[0], device=dev)
 
     def verbatim(steps):
         obs = envs.reset(); ep = []
@@ -44,20 +53,59 @@ def main():
         return len(ep)
 
     def lean(steps):
-        obs = envs.reset(); ep = []
+        obs = envs.reset(); ep = []; prev = None
         for t in range(steps):
             with torch.no_grad():
                 action = policy(obs)
             obs, reward, done, infos = envs.step(action)
-            ep += [info["episode"]["r"] for _, info in infos.finished()]
+            if prev is not None:      # logging one step late: waits for the launch BEFORE the one just issued
+                ep.append(prev.episodes()["r"])
+            prev = infos
             rollouts[t + 1].copy_(obs * envs.masks * envs.bad_masks.clamp(min=1.0))
-        return len(ep)
+        ep.append(prev.episodes()["r"])
+        return sum(len(x) for x in ep)
 
-    out = {"env_id": args.env_id, "envs": args.envs, "sub_batches": args.sub_batches, "steps": args.steps}
-    for name, fn in (("trainer_loop_verbatim", verbatim), ("trainer_loop_device_masks", lean)):
+    def totals(steps):
+        obs = envs.reset(); envs.episode_totals.zero_()
+        for t in range(steps):
+            with torch.no_grad():
+                action = policy(obs)
+            obs, reward, done, infos = envs.step(action)
+            rollouts[t + 1].copy_(obs * envs.masks * envs.bad_masks.clamp(min=1.0))
+        return int(envs.episode_totals[2].item())
+
+    graph = None
+
+    def graphed(steps):
+        nonlocal graph
+        venv, obs = envs.venv, envs.venv.obs
+        if graph is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for t in range(3):
+                    venv.step(policy(obs))
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph), torch.no_grad():
+                for t in range(args.chunk):     # (a trainer captures its whole num_steps rollout; the chunk writes rollout rows 1 .. chunk)
+                    venv.step(policy(obs))
+                    rollouts[t + 1].copy_(obs * envs.masks * envs.bad_masks.clamp(min=1.0))
+        envs.reset(); envs.episode_totals.zero_()
+        for _ in range(steps // args.chunk):
+            graph.replay()
+        return int(envs.episode_totals[2].item())
+
+    out = {"env_id": args.env_id, "envs": args.envs, "sub_batches": args.sub_batches, "steps": steps, "graph_chunk": args.chunk}
+    loops = [("trainer_loop_verbatim", verbatim), ("trainer_loop_device_masks", lean), ("trainer_loop_device_totals", totals)]
+    if args.sub_batches == 1:
+        loops.append(("trainer_loop_graphed", graphed))
+    for name, fn in loops:
+        if args.skip_verbatim and fn is verbatim:
+            continue
         fn(50); torch.cuda.synchronize()
-        t0 = time.perf_counter(); n_ep = fn(args.steps); torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / args.steps
+        t0 = time.perf_counter(); n_ep = fn(steps); torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
         out[name] = {"ms_per_step": 1e3 * dt, "env_steps_per_s": args.envs / dt, "episodes": n_ep}
     print(json.dumps(out))
     envs.close()
