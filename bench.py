@@ -143,6 +143,79 @@ def cpu_baseline(env_id: str = ENV_ID, seconds_target: float = 10.0):
     return out
 
 
+WALKER3D_GAINS = (60, 80, 60, 80, 60, 100, 90, 60, 80, 60, 100, 90, 60, 60, 60, 50, 60, 60, 60, 50, 60)   # robots.py:168,234-256
+
+
+def pybullet_baseline(n_steps: int = 1000, module=None):
+    """BASELINE.md section 3, "opportunistic PyBullet baseline": if `import pybullet` works on this box AND the reference's model assets are
+    reachable (MOCCA_REF_DATA = .../mocca_envs/data: the repo carries no copy of walker3d.xml), drive RAW pybullet with this loop -- never the
+    reference's Python files -- on one core: plane + Walker3D, fixedTimeStep 1/60, 4 substeps, 5 solver iterations, contact ERP 0.9
+    (bullet_utils.py:340-350), running-start pose at rest, n_steps of gains x U(-1,1)^21 torques from default_rng(0), and per step the eleven
+    Python->C crossings of Walker3DCustomEnv.step (set torques, stepSimulation, getJointStates, 2 x getBasePositionAndOrientation +
+    getEulerFromQuaternion, getBaseVelocity, 2 x getLinkState, 2 x getContactPoints); a fallen robot (z < 0.5) is put back.  Returns the
+    `cpu_baseline["pybullet"]` object: value in env-steps/s, kind "reference", or value None with the reason.  `module`: tests hand in
+    tests/fake_pybullet.py's stand-in."""
+    import numpy as np
+    p = module
+    if p is None:
+        try:
+            import pybullet as p            # noqa: F811
+        except ImportError:
+            return {"value": None, "unit": "env-steps/s", "cores": 1, "kind": "reference", "sample": "n/a (pybullet not installed)"}
+    data = os.environ.get("MOCCA_REF_DATA", "")
+    xml, sdf = os.path.join(data, "robots", "walker3d.xml"), os.path.join(data, "objects", "misc", "plane_stadium.sdf")
+    if module is None and not (os.path.isfile(xml) and os.path.isfile(sdf)):
+        return {"value": None, "unit": "env-steps/s", "cores": 1, "kind": "reference",
+                "sample": "n/a (pybullet is installed, but MOCCA_REF_DATA does not point at the reference's mocca_envs/data directory)"}
+    cid = p.connect(p.DIRECT)
+    try:
+        p.setGravity(0, 0, -9.8)
+        p.setDefaultContactERP(0.9)
+        p.setPhysicsEngineParameter(fixedTimeStep=1 / 60, numSolverIterations=5, numSubSteps=4)
+        plane = p.loadSDF(sdf)[0]
+        p.changeDynamics(plane, -1, lateralFriction=0.8, restitution=0.5)
+        robot = p.loadMJCF(xml, flags=p.MJCF_COLORS_FROM_FILE | p.URDF_USE_SELF_COLLISION | p.URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS)[0]
+        nj = p.getNumJoints(robot)
+        info = [p.getJointInfo(robot, j) for j in range(nj)]
+        act = [j for j in range(nj) if not info[j][1].decode().startswith(("jointfix", "ignore"))]
+        links = [ji[12].decode() for ji in info]
+        feet = [links.index(n) for n in ("right_foot", "left_foot")]
+        for j in range(nj):
+            p.setJointMotorControl2(robot, j, p.POSITION_CONTROL, positionGain=0.1, velocityGain=0.1, force=0)
+        q0 = np.zeros(21)                                        # Walker3D.set_base_pose("running_start"), robots.py:296-302
+        q0[[5, 6]] = -np.pi / 8; q0[10] = np.pi / 10; q0[[13, 17]] = np.pi / 3; q0[14] = -np.pi / 6; q0[18] = np.pi / 6; q0[[16, 20]] = np.pi / 3
+
+        def place():
+            p.resetBasePositionAndOrientation(robot, [0, 0, 1.32], [0, 0, 0, 1])
+            p.resetBaseVelocity(robot, [0, 0, 0], [0, 0, 0])
+            for k, j in enumerate(act):
+                p.resetJointState(robot, j, float(q0[k]), 0.0)
+
+        place()
+        gains = np.asarray(WALKER3D_GAINS, float)
+        actions = np.random.default_rng(0).uniform(-1, 1, (n_steps, 21))
+        restarts, sink = 0, 0.0
+        t0 = time.perf_counter()
+        for t in range(n_steps):
+            p.setJointMotorControlArray(robot, act, p.TORQUE_CONTROL, forces=list(gains * actions[t]))
+            p.stepSimulation()
+            js = p.getJointStates(robot, act)
+            pos, orn = p.getBasePositionAndOrientation(robot)
+            rpy = p.getEulerFromQuaternion(p.getBasePositionAndOrientation(robot)[1])
+            lin, _ = p.getBaseVelocity(robot)
+            fz = [p.getLinkState(robot, f)[0][2] for f in feet]
+            fc = [len(p.getContactPoints(bodyA=robot, linkIndexA=f)) for f in feet]
+            sink += js[0][0] + rpy[2] + lin[0] + min(fz) + fc[0]
+            if pos[2] < 0.5:
+                place(); restarts += 1
+        wall = time.perf_counter() - t0
+    finally:
+        p.disconnect(cid)
+    return {"value": n_steps / wall, "unit": "env-steps/s", "cores": 1, "kind": "reference",
+            "sample": f"raw pybullet, 1 env x {n_steps} steps, Walker3D on the stadium plane, U(-1,1) torques x gains, 11 C-API calls per step, "
+                      f"{restarts} restarts of a fallen robot" + (" [stand-in module: not a measurement]" if module is not None else "")}
+
+
 PHYSICS_VARIANTS = ("limit_rows_from_predicted_gap", "absolute_2cm_margins", "pyramid_friction", "warmstart_0.85", "all_four")
 
 
@@ -199,6 +272,76 @@ def physics_bracket(args, local_rank, lo, tape, steps=200, preroll=800):
     return out
 
 
+WORKLOADS = ("uniform_0.3", "zero_actions", "pd_to_t_pose")
+PD_KP, PD_KD = 2.0, 0.5     # action = clip(KP (theta_norm* - theta_norm) - KD (0.1 qdot), -1, 1): both terms in the observation's units (robots.py:46-50)
+
+
+def workload_bracket(args, local_rank, lo, tape, steps=200, preroll=800):
+    """The headline launch re-timed on OTHER BEHAVIOUR (untimed for `value`): random torques make robots that fall every ~22 steps, a trained
+    policy (env_locomotion.py:111-141 is its reward) makes robots that stay up with their feet planted.  Three stand-ins: 0.3 x U(-1,1)
+    torques; zero torques; a PD controller to the T-pose computed on the device from the observation (normalised joint angles and speeds,
+    robots.py:46-50), which keeps robots standing for longer.  Closed-loop workloads cannot come from a tape, and timing the controller's
+    torch kernels would not time the step kernel: each workload is therefore (1) pre-rolled closed-loop, (2) snapshotted (state, task
+    record, terrain), (3) run closed-loop for `steps` steps while the actions are RECORDED, (4) restored and replayed from the recorded
+    actions back to back under HIP events -- the same launches on the same states (`replay_exact`: final observations bit-identical).
+    Returns {workload: {ms_per_step, value, rows_per_substep, reset_fraction_per_step, replay_exact}}."""
+    import torch
+    from mocca_envs_amd.vec_env import VecEnv
+    out = {}
+    stepper = "Stepper" in args.env_id
+    for name in WORKLOADS:
+        if name == "pd_to_t_pose" and "Cassie" in args.env_id:
+            continue                      # (Cassie's action already is a PD target: env_cassie.py:380-393)
+        env = VecEnv(args.env_id, args.envs, device=local_rank, auto_reset=True, seed=1000, env_offset=lo)
+        if args.curriculum is not None:
+            env.set_param(2, args.curriculum)
+        obs = env.reset()
+        nj = env.act_dim
+        if name == "pd_to_t_pose":        # theta_norm of q = 0: 2 (0 - lo) / (hi - lo) - 1 (robots.py:132)
+            jlo = torch.tensor([env.model.jlo[1 + j] for j in range(nj)], device=obs.device)
+            jhi = torch.tensor([env.model.jhi[1 + j] for j in range(nj)], device=obs.device)
+            target = -(jhi + jlo) / (jhi - jlo)
+        zero = torch.zeros(args.envs, nj, device=obs.device)
+
+        def action(i):
+            if name == "uniform_0.3":
+                return 0.3 * tape[i % 64]
+            if name == "zero_actions":
+                return zero
+            return (PD_KP * (target - obs[:, 6:6 + nj]) - PD_KD * obs[:, 6 + nj:6 + 2 * nj]).clamp_(-1.0, 1.0)
+
+        for i in range(preroll):
+            env.step(action(i))
+        snap = (env.get_state(), env.get_task(), env.get_terrain() if stepper else None)
+        rec = torch.empty(steps, args.envs, nj, device=obs.device)
+        n_done = torch.zeros((), device=obs.device)
+        for i in range(steps):
+            rec[i].copy_(action(preroll + i))
+            env.step(rec[i])
+            n_done += (env.done != 0).sum()
+        final = env.obs.clone()
+        env.set_state(snap[0]); env.set_task(snap[1])
+        if stepper:
+            env.set_terrain(snap[2])
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        ev0.record()
+        for i in range(steps):
+            env.step(rec[i])
+        ev1.record()
+        torch.cuda.synchronize()
+        exact = bool(torch.equal(final, env.obs))
+        rows = torch.zeros((), device=obs.device)
+        for i in range(16):     # rows of the last substep of 16 more steps (task word 23), outside the timed loop
+            env.step(action(preroll + steps + i))
+            rows += env.get_task()[:, 23].float().mean()
+        ms = ev0.elapsed_time(ev1) / steps
+        out[name] = {"ms_per_step": ms, "value": args.envs / (ms * 1e-3), "rows_per_substep": float(rows.item()) / 16,
+                     "reset_fraction_per_step": float(n_done.item()) / (args.envs * steps), "replay_exact": exact}
+        env.close()
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -239,6 +382,9 @@ def parse_args(argv=None):
                     help="skip the sensitivity block: after the timed region the headline launch is re-timed (200 launches each, N = 1 only) on blobs "
                          "that read the unverifiable Bullet laws the other way -- limit rows from a predicted gap, 2 cm absolute margins, pyramid "
                          "friction, warm start 0.85, and all four; reported as `sensitivity`, never as `value`")
+    ap.add_argument("--no-workload-bracket", action="store_true",
+                    help="skip the workload block: after the timed region the headline launch is re-timed (N = 1 only) on other behaviour than falling "
+                         "robots -- 0.3 x U(-1,1) torques, zero torques, a PD controller to the T-pose -- reported as `workload_sensitivity`, never as `value`")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise launch / rendezvous / reporting only (CPU tests)")
     ap.add_argument("--test-barrier-delay", type=float, default=0.0,
                     help="TEST ONLY: every rank sleeps this many seconds inside each barrier (a slow rendezvous); the timed window must not see it")
@@ -249,6 +395,12 @@ def parse_args(argv=None):
                     help="TEST ONLY: let ranks share GPUs (device = rank %% visible GPUs) so the N-rank path can be exercised on a 1-GPU box; "
                          "the line is marked and is not a scaling measurement")
     args = ap.parse_args(argv)
+    # The two untimed brackets re-run the headline launch ~8000 times on variant blobs and workloads.  Under a profiler they would swamp the
+    # 25 headline launches in every per-kernel average (tools/pmc.sh averages over all launches named mocca_step), and an A/B library
+    # (MOCCA_LIB_PATH) is there to time ONE kernel: both cases skip them without being told to.
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "") \
+            or os.environ.get("MOCCA_LIB_PATH"):
+        args.no_physics_bracket = args.no_workload_bracket = True
     if args.host_io and args.stagger > 1:
         ap.error("--host-io times the synchronous host loop of ONE handle; it does not combine with --stagger")
     return args
@@ -379,13 +531,14 @@ def main():
         sub_tapes = [tape[:, env.slices[k]].contiguous() for k in subs]
         torch.cuda.synchronize()
 
-        def step_all(i):
+        def step_all(i, ordered=False):
             """one env.step of every env of this rank; returns the done flags of the batch (sub-batches: not yet ordered against the
-            current stream -- env.wait(k) does that)"""
+            current stream -- env.wait(k) does that).  ordered=True: the sub-batches' launches wait for what the current stream has queued
+            (the warm-up loop's reduction over `done` still reads the rows the next launch overwrites)"""
             if not subs:
                 return env.step(tape[i % 64])[2]
             for k in subs:      # SubBatchedVecEnv.step_async: one launch on sub-batch k's own stream; the tape is resident, nothing to order
-                env.step_async(k, sub_tapes[k][i % 64], ordered=False)
+                env.step_async(k, sub_tapes[k][i % 64], ordered=ordered)
             return env.done
 
         # First use of everything the warm-up and the timed window call besides mocca_step, BEFORE the pre-roll: torch loads the code objects
@@ -418,7 +571,7 @@ def main():
                 preroll_s = time.perf_counter() - t_pre
         n_done = torch.zeros((), device=dev)
         for i in range(args.warmup):
-            done = step_all(i)
+            done = step_all(i, ordered=True)
             for k in subs:
                 env.wait(k)
             n_done += (done != 0).sum()  # reset fraction is sampled during warm-up, outside the timed region
@@ -454,6 +607,13 @@ def main():
                 bracket = physics_bracket(args, local_rank, lo, tape, steps=40 if cassie else 200, preroll=150 if cassie else 800)
             except Exception as e:      # noqa: BLE001
                 bracket = {"error": f"{type(e).__name__}: {e}"}
+        workloads = None
+        if world == 1 and not args.no_workload_bracket and not subs and args.max_rows is None:
+            try:
+                cassie = "Cassie" in args.env_id
+                workloads = workload_bracket(args, local_rank, lo, tape, steps=40 if cassie else 200, preroll=150 if cassie else 800)
+            except Exception as e:      # noqa: BLE001
+                workloads = {"error": f"{type(e).__name__}: {e}"}
         host_io_ms = None
         if args.host_io:   # a trainer on the host: actions up, obs / reward / done down, every step, through PCIe
             h_act = tape.cpu().pin_memory()
@@ -471,6 +631,16 @@ def main():
 
     elapsed = sharding.max_over_ranks(elapsed_rank, dist)
     per_rank = sharding.gather_over_ranks([1e3 * elapsed_rank / args.steps, kern_ms], dist)   # [world][2]
+    # which GPU each rank ran on: a scaling line must prove N distinct devices (uuid / PCI bus id from the runtime, host + local index beside it)
+    ident = {"rank": rank, "host": socket.gethostname(), "local_index": local_rank, "name": None, "uuid": None, "pci_bus_id": None}
+    if not args.dry_run:
+        import torch
+        pr = torch.cuda.get_device_properties(local_rank)
+        ident["name"] = pr.name
+        ident["uuid"] = str(getattr(pr, "uuid", "")) or None
+        pci = [getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+        ident["pci_bus_id"] = "%04x:%02x:%02x" % tuple(pci) if all(isinstance(x, int) for x in pci) else None
+    devices = sharding.gather_objects(ident, dist)
     if rank == 0:
         traffic, valu, pmc_note = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -508,8 +678,13 @@ def main():
             "kernel_info": kinfo,
             # one entry per rank (rank order): wall ms per step of the rank's own K steps, and its HIP-event kernel time; `ms_per_step`
             # above is the max of the first list
-            "per_rank": {"ms_per_step": [r[0] for r in per_rank], "kernel_ms": [r[1] for r in per_rank]},
+            "per_rank": {"ms_per_step": [r[0] for r in per_rank], "kernel_ms": [r[1] for r in per_rank], "device": devices},
         }
+        keys = [(d["host"], d["uuid"] or d["pci_bus_id"] or d["local_index"]) for d in devices]
+        out["per_rank"]["distinct_devices"] = len(set(keys))
+        if not args.dry_run and not args.oversubscribe and len(set(keys)) != world:
+            print(f"bench.py: {world} ranks ran on {len(set(keys))} distinct GPU(s): {keys} -- not a scaling measurement (use --oversubscribe to rehearse)", file=sys.stderr)
+            sys.exit(3)
         if pmc_note:
             out["roofline"]["traffic_note"] = pmc_note
         if valu:
@@ -531,6 +706,16 @@ def main():
             out["sensitivity"] = {"note": "the same launch on blobs that read Bullet's unverifiable solver laws the other way (DESIGN.md section 3; 200 launches "
                                           "each after an 800-step pre-roll -- Cassie: 40 after 150 --, kernel time by HIP events); `value` above is the as-built reading",
                                   "variants": bracket, "worst_case_value": worst["value"]}
+        if not args.dry_run and workloads and "error" in workloads:
+            out["workload_sensitivity"] = workloads
+        elif not args.dry_run and workloads:
+            vals = [v["value"] for v in workloads.values()] + [value]
+            out["workload_sensitivity"] = {
+                "note": "the same launch on other behaviour than the headline's falling robots (untimed for `value`): 0.3 x U(-1,1) torques, zero torques, "
+                        f"a PD controller to the T-pose (kp {PD_KP}, kd {PD_KD} in observation units) computed on the device; closed-loop runs are recorded and "
+                        "replayed from a snapshot back to back under HIP events (bench.py workload_bracket)",
+                "headline": {"ms_per_step": kern_ms, "value": args.envs / (kern_ms * 1e-3), "reset_fraction_per_step": reset_frac},
+                "workloads": workloads, "range": [min(vals), max(vals)]}
         if args.stagger > 1:
             out["config"]["pipelined"] = True
             out["config"]["workload"] += f"; {args.stagger} sub-batches on their own streams (mocca_envs_amd.multi.SubBatchedVecEnv.step_async), their steps overlap (NOT the headline protocol)"
@@ -544,6 +729,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.env_id)
             except Exception as e:      # noqa: BLE001  (the reported baseline must not cost the line its GPU numbers)
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
+            try:      # the reference's own CPU path beside it, where this box has it
+                out["cpu_baseline"]["pybullet"] = pybullet_baseline()
+            except Exception as e:      # noqa: BLE001
+                out["cpu_baseline"]["pybullet"] = {"value": None, "unit": "env-steps/s", "cores": 1, "kind": "reference", "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

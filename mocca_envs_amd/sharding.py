@@ -35,6 +35,15 @@ def gather_over_ranks(values, dist=None):
     return [[float(x) for x in o] for o in out]
 
 
+def gather_objects(obj, dist=None):
+    """[world] picklable objects, rank order (each rank's device identity for the report)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def aggregate_throughput(envs_per_rank: int, world: int, steps: int, seconds: float) -> float:
     """Whole-job env-steps/s: all ranks' envs x steps over the slowest rank's time."""
     return envs_per_rank * world * steps / seconds

@@ -56,6 +56,79 @@ def test_rod_angles_close_the_loops():
     assert worst < 0.012
 
 
+def _mocap_fk(m, tr, f, base_R=None, base_p=None):
+    """Body frames (R, p) of frame f of the reference's walking cycle on the compiled Cassie blob: the 14 recorded joint angles, the 4
+    fitted rod angles, the pelvis at (base_R, base_p) (identity / origin by default)."""
+    def rot(axis, q):
+        a = axis / np.linalg.norm(axis)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return np.eye(3) + np.sin(q) * K + (1 - np.cos(q)) * (K @ K)
+    nb = m.n_bodies
+    q = np.zeros(nb)
+    for k in range(14):
+        q[m.ordered_body[k]] = tr.angles[f, k]
+    for k in range(4):
+        q[tr.rod_bodies[k]] = tr.rods[f, k]
+    R, p = [None] * nb, [None] * nb
+    R[0], p[0] = (np.eye(3) if base_R is None else base_R), (np.zeros(3) if base_p is None else base_p)
+    for b in range(1, nb):
+        pa = m.parent[b]
+        R[b] = R[pa] @ np.array(m.jrot[b][:]).reshape(3, 3) @ rot(np.array(m.jaxis[b][:]), q[b])
+        p[b] = p[pa] + R[pa] @ np.array(m.jpos[b][:])
+    return R, p
+
+
+def test_every_mocap_frame_closes_the_four_bars_to_a_centimetre():
+    """What the reference's Cassie data says about THIS project's compiled geometry, part 1 (env_cassie.py:114-137: the two point-to-point
+    closures tarsus <-> achilles rod).  For each of the 1 682 frames of data/robots/cassie/mocap (joint angles fitted to the URDF robot),
+    with the rod's two free angles at their least-squares optimum, the distance between the closure's two pivots on this blob is the
+    part of the four-bar the URDF tree cannot represent: the heel spring's deflection (a fixed joint in the URDF).  Bounded here over the
+    whole cycle -- tools/gen_cassie_mocap.py only printed it: worst 10.9 mm, mean 4.7 mm; a wrong link offset or joint axis in the tarsus /
+    rod chain (lengths of 0.12 .. 0.50 m) would show as centimetres."""
+    m = M.compile_cassie()
+    tr = CassieTrajectory()
+    res = np.zeros((len(tr), 2))
+    for f in range(len(tr)):
+        R, p = _mocap_fk(m, tr, f)
+        for c in range(2):
+            a, b = m.cl_body_a[c], m.cl_body_b[c]
+            res[f, c] = np.linalg.norm(p[a] + R[a] @ np.array(m.cl_point_a[c][:]) - p[b] - R[b] @ np.array(m.cl_point_b[c][:]))
+    print(f"\nclosure residual over {len(tr)} frames [mm]: worst {1e3 * res.max(0)}, mean {1e3 * res.mean(0)}")
+    assert res.max() < 0.012 and res.mean() < 0.006
+    assert abs(res[:, 0].mean() - res[:, 1].mean()) < 0.001          # left and right loops are mirror images walking the same gait
+
+
+def test_stance_foot_of_every_mocap_frame_stands_on_the_ground():
+    """Part 2: the recorded pelvis pose (stepdata.bin qpos[0:7], fixture tests/golden/cassie_mocap_base.npz made by
+    make_golden_cassie_base.py) + the recorded joint angles through THIS blob's kinematics (tree, joint frames, axes) put the lowest point
+    of the stance foot's toe hull (cassie_table.TOE_POINTS, the blob's contact geoms) on the ground plane z = 0 in every frame of the
+    walking cycle: within [-1.5 mm, +3 mm] (measured: -0.7 .. +2.1 mm, mean 0.9 mm) over a 1.0 m leg chain of seven joints.  The swing
+    foot clears 10 cm, each foot stands for about half the cycle.  These are the only reference-held numbers that reach Cassie's compiled
+    geometry; an error in any link offset, joint axis sign or toe point would break the bound by centimetres."""
+    m = M.compile_cassie()
+    tr = CassieTrajectory()
+    B = np.load(os.path.join(os.path.dirname(__file__), "golden", "cassie_mocap_base.npz"))
+    assert len(B["time"]) == len(tr) and np.abs(B["time"] - tr.time).max() == 0.0
+    low = np.full((len(tr), 2), 1e9)
+    for f in range(len(tr)):
+        w, x, y, z = B["base_quat_wxyz"][f]
+        Rb = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                       [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                       [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        R, p = _mocap_fk(m, tr, f, Rb, B["base_pos"][f])
+        for g in range(m.n_geoms):
+            b, k = m.g_body[g], m.g_foot[g]
+            assert k in (0, 1) and m.g_radius[g] == 0.0
+            low[f, k] = min(low[f, k], (p[b] + R[b] @ np.array(m.g_p1[g][:]))[2])
+    stance = low.min(1)
+    print(f"\nstance foot's lowest toe point over {len(tr)} frames [mm]: {1e3 * stance.min():.2f} .. {1e3 * stance.max():.2f}, mean {1e3 * stance.mean():.2f}; "
+          f"swing apex [mm]: {1e3 * low.max(0)}")
+    assert -0.0015 < stance.min() and stance.max() < 0.003
+    assert low.max(0).min() > 0.10                                  # both feet swing: 10.6 / 10.7 cm at the apex
+    on = low < 0.003
+    assert 0.4 < on[:, 0].mean() < 0.7 and 0.4 < on[:, 1].mean() < 0.7 and on.any(1).all()
+
+
 @pytest.mark.parametrize("tag", ["mocca", "mirror"])
 def test_blob_constants_match_the_reference_classes(tag):
     m, _ = _oracle(tag)

@@ -136,6 +136,36 @@ def test_single_process_shards_reproduce_the_unsharded_batch(gather):
     got = torch.cat([sh.wait(i)[0].to("cuda:0") for i in range(sh.n_parts)])
     assert torch.equal(one.obs, got)
     assert torch.equal(one.get_state(), sh.get_state())
+    distinct = len(set(devices))
+    print(f"\n[multi] ShardedVecEnv ran {len(devices)} shards on {distinct} distinct device(s) {sorted(set(devices))} of {ndev} visible"
+          + ("" if distinct >= 2 else " -- the cross-device copies and device switches ran between IDENTICAL devices (one-GPU box)"))
+    one.close(); sh.close()
+
+
+def test_gather_on_a_device_that_holds_no_shard():
+    """`gather_device` other than every shard's device: observations, rewards and done flags cross from each shard's GPU to a third one
+    (multi.py _collect: peer-to-peer copy_ between the devices' current streams).  Needs >= 2 GPUs to mean anything -- with one visible it
+    is reported as NOT EXERCISED rather than run between a device and itself, which the test above already does."""
+    import torch
+    from mocca_envs_amd.multi import ShardedVecEnv
+    from mocca_envs_amd.vec_env import VecEnv
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip(f"{ndev} GPU visible: cross-device gather NOT EXERCISED on this box (multi-GPU scaling is unmeasured, DESIGN.md section 7)")
+    shard_devs = list(range(1, ndev)) if ndev > 2 else [1]
+    n = 96 * len(shard_devs)
+    one = VecEnv("Walker3DCustomEnv-v0", n, device=0, auto_reset=True, seed=13)
+    sh = ShardedVecEnv("Walker3DCustomEnv-v0", n, devices=shard_devs, auto_reset=True, seed=13, gather=True, gather_device=0)
+    assert all(e.device.index != 0 for e in sh.parts) and sh.obs.device.index == 0
+    assert torch.equal(one.reset(), sh.reset())
+    policy = _policy(_weights(one.obs_dim, one.act_dim, "cuda:0", 5))
+    for t in range(80):
+        a = policy(one.obs)
+        o, r, d, i = one.step(a)
+        o2, r2, d2, i2 = sh.step(a)
+        assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(d, d2) and torch.equal(i, i2), t
+    assert torch.equal(one.get_state(), sh.get_state())
+    print(f"\n[multi] gather on device 0 from shards on devices {shard_devs}: exact")
     one.close(); sh.close()
 
 

@@ -54,6 +54,15 @@ def test_bench_two_ranks_on_this_box():
     assert len(line) == 1
     out = json.loads(line[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["envs_per_gpu"] == 512
+    # every rank names the GPU it ran on; the line counts the distinct ones (1 on a one-GPU box: marked oversubscribed, never a scaling point)
+    devs = out["per_rank"]["device"]
+    assert len(devs) == 2 and all(d["name"] and (d["uuid"] or d["pci_bus_id"]) for d in devs)
+    import torch
+    assert out["per_rank"]["distinct_devices"] == min(2, torch.cuda.device_count()) and out["oversubscribed"]
+    if torch.cuda.device_count() == 1:     # without --oversubscribe the same launch refuses to call itself a 2-GPU run
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--envs", "256",
+                            "--no-cpu-baseline", "--preroll", "10", "--preroll-seconds", "0"], capture_output=True, text=True, timeout=900)
+        assert r.returncode != 0
 
 
 @pytest.mark.gpu

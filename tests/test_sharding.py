@@ -87,6 +87,9 @@ def test_bench_launches_its_own_ranks():
     pr = out["per_rank"]
     assert len(pr["ms_per_step"]) == 2 and len(pr["kernel_ms"]) == 2 and pr["kernel_ms"] == [1.0, 2.0]
     assert 1.0 <= pr["ms_per_step"][0] < 3.0 and out["ms_per_step"] == max(pr["ms_per_step"])
+    # ... and which device each rank ran on (host, local index, name / uuid / PCI bus id where a GPU is behind it): a scaling line proves N GPUs
+    assert [d["rank"] for d in pr["device"]] == [0, 1] and [d["local_index"] for d in pr["device"]] == [0, 1] and pr["distinct_devices"] == 2
+    assert all(set(d) == {"rank", "host", "local_index", "name", "uuid", "pci_bus_id"} for d in pr["device"])
     out = _bench("--gpus", "1", "--steps", "2", "--dry-run", "--envs", "8192")
     assert out["n_gpus"] == 1 and out["config"]["envs_per_gpu"] == 8192
     # the contract's fields, and the untimed pre-roll is declared in the line (it is data preparation, not part of W or K)
@@ -142,3 +145,42 @@ def test_bench_physics_variants_flip_exactly_the_documented_fields():
     assert seen["pyramid_friction"] == (1, b[1], 0, 0.0)
     assert seen["warmstart_0.85"] == (1, b[1], 1, 0.85)
     assert seen["all_four"] == (0, 0.02, 0, 0.85)
+
+
+def test_bench_pybullet_leg_reports_the_reference_or_says_why_not(monkeypatch, tmp_path):
+    """bench.py cpu_baseline["pybullet"]: `import pybullet` is probed at run time.  Absent (this image): the row
+    says so.  Present: the raw-PyBullet loop runs -- exercised here end to end against tests/fake_pybullet.py (PyBullet's API over the f64
+    oracle), which is a stand-in and is labelled as one."""
+    import sys
+    import bench
+    sys.modules.pop("pybullet", None)
+    out = bench.pybullet_baseline()
+    assert out["value"] is None and out["kind"] == "reference" and "pybullet not installed" in out["sample"]
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fake_pybullet import make_module
+    fake = make_module()
+    calls = {"step": 0, "disconnect": 0}
+    step = fake.stepSimulation
+
+    def counted():
+        calls["step"] += 1
+        step()
+
+    fake.stepSimulation = counted
+    fake.getEulerFromQuaternion = lambda q: (0.0, 0.0, 0.0)
+    fake.disconnect = lambda *a: calls.__setitem__("disconnect", calls["disconnect"] + 1)
+    out = bench.pybullet_baseline(n_steps=30, module=fake)
+    assert calls == {"step": 30, "disconnect": 1}
+    assert out["kind"] == "reference" and out["cores"] == 1 and out["unit"] == "env-steps/s" and out["value"] > 0 and "stand-in" in out["sample"]
+    # installed but no assets: says which variable is missing instead of failing inside loadMJCF
+    monkeypatch.setitem(sys.modules, "pybullet", fake)
+    monkeypatch.setenv("MOCCA_REF_DATA", str(tmp_path))
+    out = bench.pybullet_baseline()
+    assert out["value"] is None and "MOCCA_REF_DATA" in out["sample"]
+
+
+def test_bench_workload_bracket_names_its_workloads():
+    import bench
+    assert bench.WORKLOADS == ("uniform_0.3", "zero_actions", "pd_to_t_pose") and bench.PD_KP > 0 and bench.PD_KD > 0
+    a = bench.parse_args(["--no-workload-bracket", "--no-physics-bracket"])
+    assert a.no_workload_bracket and a.no_physics_bracket
