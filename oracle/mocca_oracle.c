@@ -223,6 +223,9 @@ typedef struct {
   /* active set of the last substep, same words as the HIP path's debug record (include/mocca.h MOCCA_DBG_*) */
   int32_t dbg[DBG_WORDS]; /* words 12..15: THIS substep's cap flags / count / wanted rows, accumulated per env by dbg_commit() */
   int nc_wanted;          /* contacts within the margin before the max_contacts cap */
+  /* MoccaModel.precise_gaps: body frames in double precision whatever `real` is, for the POSITION-level gaps of the constraint rows only */
+  double Rd[MB][9], rd[MB][3];
+  int precise; /* 0 off; bit 0 closure gaps, bit 1 flat-ground contact depth, bit 2 planar rows */
 } Work;
 
 typedef struct {
@@ -286,6 +289,30 @@ static void kinematics(const MoccaModel *m, const Dyn *s, Work *w) {
     real cl[3] = {m->com[b][0], m->com[b][1], m->com[b][2]}, cw[3];
     matvec3(w->R[b], cl, cw);
     for (int k = 0; k < 3; ++k) w->comw[b][k] = w->r[b][k] + cw[k];
+  }
+}
+
+/* The same walk in double precision (experiment: orc_set_precise_gaps).  A constraint row's bias is (position gap) x erp / dt: the gap is a
+ * difference of two ~1 m chains, fp32 leaves ~1e-7 m of rounding in it, and Cassie's dt = 0.6 ms turns that into 1e-4 m/s of velocity. */
+static void kinematics_d(const MoccaModel *m, const Dyn *s, Work *w) {
+  double x = s->quat[0], y = s->quat[1], z = s->quat[2], q = s->quat[3];
+  double *R0 = w->Rd[0];
+  R0[0] = 1 - 2 * (y * y + z * z); R0[1] = 2 * (x * y - z * q); R0[2] = 2 * (x * z + y * q);
+  R0[3] = 2 * (x * y + z * q); R0[4] = 1 - 2 * (x * x + z * z); R0[5] = 2 * (y * z - x * q);
+  R0[6] = 2 * (x * z - y * q); R0[7] = 2 * (y * z + x * q); R0[8] = 1 - 2 * (x * x + y * y);
+  w->rd[0][0] = w->rd[0][1] = w->rd[0][2] = 0;
+  for (int b = 1; b < m->n_bodies; ++b) {
+    int p = m->parent[b];
+    double a[3] = {m->jaxis[b][0], m->jaxis[b][1], m->jaxis[b][2]}, th = s->q[b], c = cos(th), sn = sin(th), t = 1 - c, Rq[9], T[9];
+    Rq[0] = c + t * a[0] * a[0];         Rq[1] = t * a[0] * a[1] - sn * a[2]; Rq[2] = t * a[0] * a[2] + sn * a[1];
+    Rq[3] = t * a[0] * a[1] + sn * a[2]; Rq[4] = c + t * a[1] * a[1];         Rq[5] = t * a[1] * a[2] - sn * a[0];
+    Rq[6] = t * a[0] * a[2] - sn * a[1]; Rq[7] = t * a[1] * a[2] + sn * a[0]; Rq[8] = c + t * a[2] * a[2];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) T[3 * i + j] = w->Rd[p][3 * i] * m->jrot[b][j] + w->Rd[p][3 * i + 1] * m->jrot[b][3 + j] + w->Rd[p][3 * i + 2] * m->jrot[b][6 + j];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) w->Rd[b][3 * i + j] = T[3 * i] * Rq[j] + T[3 * i + 1] * Rq[3 + j] + T[3 * i + 2] * Rq[6 + j];
+    for (int k = 0; k < 3; ++k)
+      w->rd[b][k] = w->rd[p][k] + w->Rd[p][3 * k] * m->jpos[b][0] + w->Rd[p][3 * k + 1] * m->jpos[b][1] + w->Rd[p][3 * k + 2] * m->jpos[b][2];
   }
 }
 
@@ -693,6 +720,12 @@ static void collide(const Oracle *o, const Dyn *s, const Task *tk, const Terrain
         cfm = 1 / (dt * kk + cc) / dt;
       } else if (o->task_id != MOCCA_TASK_WALKER3D_STEPPER) {
         gap = Cw[2] - rad;
+        if (w->precise & 2) {
+          int b = m->g_body[g];
+          const float *pl = e ? m->g_p2[g] : m->g_p1[g];
+          double zd = w->rd[b][2] + w->Rd[b][6] * pl[0] + w->Rd[b][7] * pl[1] + w->Rd[b][8] * pl[2] + (double)s->pos[2];
+          gap = (real)(zd - (double)rad);
+        }
         mu = (real)m->ground_friction * (real)m->g_friction[g];
       } else {
         gap = 1e30;
@@ -877,7 +910,13 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
       int r = nr++;
       pair_jacobian(m, w, ba, Pa, bb, Pb, dir, w->J[r]);
       w->row_kind[r] = 3; w->row_normal[r] = -1; w->row_mu[r] = 0; w->row_slot[r] = -1;
-      w->bias[r] = (real)m->erp_noncontact * (Pb[ax] - Pa[ax]) * idt; /* pull pivot a onto pivot b */
+      real gap_ = Pb[ax] - Pa[ax];
+      if (w->precise & 1) {
+        double pa = w->rd[ba][ax], pb = w->rd[bb][ax];
+        for (int k = 0; k < 3; ++k) { pa += w->Rd[ba][3 * ax + k] * m->cl_point_a[c][k]; pb += w->Rd[bb][3 * ax + k] * m->cl_point_b[c][k]; }
+        gap_ = (real)(pb - pa);
+      }
+      w->bias[r] = (real)m->erp_noncontact * gap_ * idt; /* pull pivot a onto pivot b */
       w->cfm[r] = 0; w->lam[r] = 0;
     }
   }
@@ -887,6 +926,7 @@ static void solve_constraints(const MoccaModel *m, Dyn *s, Work *w, real *nu) {
   if (m->planar) {
     const real *R0 = w->R[0];
     real err[3] = {R0[7], -R0[1], s->pos[1] - (real)m->init_pos[1]};
+    if (w->precise & 4) { err[0] = (real)w->Rd[0][7]; err[1] = (real)-w->Rd[0][1]; }
     int comp[3] = {0, 2, 4};
     for (int k = 0; k < 3 && nr < m->max_rows; ++k) {
       int r = nr++;
@@ -1040,6 +1080,7 @@ static void substep(const Oracle *o, Dyn *s, const Task *tk, const Terrain *tr, 
   const MoccaModel *m = &o->m;
   real dt = m->dt;
   kinematics(m, s, w);
+  if (w->precise) kinematics_d(m, s, w);
   collide(o, s, tk, tr, w);
   aba(m, s, tau, w, 1);
   real nu[NDOF_MAX];
@@ -1979,6 +2020,7 @@ API void orc_link_velocities(void *h, int e, double *out) {
   for (int b = 0; b < o->m.n_bodies; ++b)
     for (int k = 0; k < 6; ++k) out[6 * b + k] = o->wk.v[b][k];
 }
+API void orc_set_precise_gaps(void *h, int bits) { ((Oracle *)h)->wk.precise = bits; } /* experiment, see kinematics_d */
 API int orc_last_contacts(void *h, double *out) { /* per contact: a, b, slot, P(3) n(3) depth mu */
   Oracle *o = (Oracle *)h;
   for (int i = 0; i < o->wk.nc; ++i) {
