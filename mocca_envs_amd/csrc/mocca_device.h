@@ -2294,8 +2294,15 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
 #ifdef MOCCA_DUMMY_VALU  // experiment: is the kernel VALU-issue-bound?  (tools/ab.sh variants)
   {
     float x = (float)lane;
+#ifdef MOCCA_DUMMY_ILP   // the same number of FMAs as four INDEPENDENT chains: issue slots without the dependent-issue latency
+    float y = x + 1.0f, z = x + 2.0f, u = x + 3.0f;
+#pragma unroll 1
+    for (int i = 0; i < MOCCA_DUMMY_VALU; ++i) { x = fmaf(x, 1.0001f, 0.5f); y = fmaf(y, 0.9999f, -0.5f); z = fmaf(z, 1.0001f, 0.5f); u = fmaf(u, 0.9999f, -0.5f); }
+    asm volatile("" :: "v"(y), "v"(z), "v"(u));
+#else
 #pragma unroll 1
     for (int i = 0; i < MOCCA_DUMMY_VALU; ++i) { x = fmaf(x, 1.0001f, 0.5f); x = fmaf(x, 0.9999f, -0.5f); x = fmaf(x, 1.0001f, 0.5f); x = fmaf(x, 0.9999f, -0.5f); }
+#endif
     asm volatile("" :: "v"(x));
   }
 #endif

@@ -1,9 +1,12 @@
 #!/bin/bash
-# Everything profiles/ holds for a round, in one gpurun call: usage  tools/round_artifacts.sh <tag>
+# Everything profiles/ holds for a round: usage  tools/round_artifacts.sh <tag> [1|2]   (two gpurun calls of < 20 minutes each: part 1 = the headline's
+# profile + every bench line + the trainer loops, part 2 = timelines, micro-benchmarks and the other configs' profiles; no part = both)
 tag=${1:-r02}
+part=${2:-12}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd $R
+if [[ $part == *1* ]]; then
 # 0. rocprofv3 on the headline config first: its PMC passes refresh profiles/traffic.json, which the bench lines below quote
 tools/profile_round.sh ${tag} Walker3DCustomEnv-v0 4096 > /dev/null 2>&1
 [ -s $O/${tag}_traffic.json ] && cp $O/${tag}_traffic.json profiles/traffic.json
@@ -26,13 +29,18 @@ done
 python bench.py --env-id Cassie2DEnv-v0 --envs 2048 --steps 100 --warmup 30 --no-cpu-baseline > $O/${tag}_cassie2d_bench.json 2>/dev/null
 python bench.py --env-id CassiePhaseMocca2DEnv-v0 --envs 2048 --steps 100 --warmup 30 --no-cpu-baseline > $O/${tag}_cassiephasemocca2d_bench.json 2>/dev/null
 python bench.py --env-id CassiePhaseMirror2DEnv-v0 --envs 2048 --steps 100 --warmup 30 --no-cpu-baseline > $O/${tag}_cassiephasemirror2d_bench.json 2>/dev/null
+# 3b. the trainer-facing surface (mocca_envs_amd.trainer_api): PPO collection loops at the metric's batch and at config 5's shard
+python tools/trainer_loop_bench.py --envs 4096 > $O/${tag}_trainer_loop_4096.json 2>/dev/null
+python tools/trainer_loop_bench.py --envs 8192 > $O/${tag}_trainer_loop_8192.json 2>/dev/null
+python tools/trainer_loop_bench.py --envs 4096 --env-id Walker3DStepperEnv-v0 --skip-verbatim > $O/${tag}_trainer_loop_stepper4096.json 2>/dev/null
+fi
+if [[ $part == *2* ]]; then
 # 4. per-phase timelines (diagnostic build)
 python tools/stamps.py Walker3DCustomEnv-v0 4096 > $O/${tag}_stamps_custom4096.txt 2>&1
 python tools/stamps.py Walker3DCustomEnv-v0 1024 > $O/${tag}_stamps_custom1024.txt 2>&1
 python tools/param_time.py 4096 > $O/${tag}_param_time_4096.txt 2>&1
-# 4b. cap pressure (how often the 12-contact / 48-row caps drop something) and the occupancy probe (throughput vs resident waves)
+# 4b. cap pressure (how often the 12-contact / 48-row caps drop something)
 python tools/cap_pressure.py 300 > $O/${tag}_cap_pressure.jsonl 2>/dev/null
-bash tools/occupancy_probe.sh 2>/dev/null | grep "^{" > $O/${tag}_occupancy_probe.jsonl
 # 5. record layouts
 hipcc --offload-arch=gfx950 -O3 -o /tmp/layout_bench tools/layout_bench.hip && /tmp/layout_bench 4096 > $O/${tag}_layout_bench.json && /tmp/layout_bench 65536 >> $O/${tag}_layout_bench.json
 # 5b. microbenchmarks behind DESIGN.md section 6: dependent-issue latencies, PGS visit forms, workgroup placement
@@ -48,4 +56,5 @@ tools/profile_round.sh ${tag}_custom8192 Walker3DCustomEnv-v0 8192 > /dev/null 2
 BENCH_EXTRA="--max-rows 32" tools/profile_round.sh ${tag}_custom8192compact Walker3DCustomEnv-v0 8192 > /dev/null 2>&1
 python bench.py --envs 8192 --stagger 2 --steps 400 --warmup 100 --no-cpu-baseline > $O/${tag}_custom8192_staggered_bench.json 2>/dev/null
 python bench.py --envs 8192 --stagger 2 --max-rows 32 --steps 400 --warmup 100 --no-cpu-baseline > $O/${tag}_custom8192_staggered_compact_bench.json 2>/dev/null
-ls $O | grep "^${tag}" | head -80
+fi
+ls $O | grep "^${tag}" | head -120
