@@ -12,7 +12,7 @@ present and checks every number against this table.
 Assumptions about how Bullet turns the MJCF into a multibody are listed in
 DESIGN.md ("Model assumptions"); all of them only affect numbers in the blob,
 never the kernels, so a blob dumped from a real PyBullet session
-(``tools/dump_pybullet_model.py``) can be loaded instead of this compiler's output.
+(``tools/dump_pybullet_trace.py``, loaded by ``pybullet_dump.from_pybullet_dump``) can be loaded instead of this compiler's output.
 """
 from __future__ import annotations
 

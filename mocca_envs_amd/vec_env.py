@@ -48,7 +48,7 @@ _DEFAULT_PARAMS = {"LaikagoCustomEnv-v0": {_lib.PARAM_RANDOM_POSE: 0},    # robo
 # (no pace sample yet) and handles that switch the pace off.
 # Issue-priority thresholds of the step kernel (PARAM_ISSUE_PRIORITY; timing only, results do not depend on them): constraint-row counts
 # above which a wave runs at priority 1 / 2 / 3.  The best set follows the batch's row distribution -- measured per env id with
-# tools/prio_sweep.sh on one MI355X (profiles/r03_prio_sweep_v13.txt: the blob v13 physics hold 5.7 rows per substep on the flat-ground walker
+# a threshold sweep on one MI355X (profiles/r03_prio_sweep_v13.txt: the blob v13 physics hold 5.7 rows per substep on the flat-ground walker
 # instead of 12.7, and the thresholds of round 2 had stopped selecting anything: -5.5 % on the launch for re-reading them off the new
 # distribution); ids not listed keep the library's default (4, 7, 12: the flat-ground walker).  The stepping-stone walkers carry more rows as
 # the curriculum rises: their thresholds grow with it (x 1.7 at curriculum 9).
