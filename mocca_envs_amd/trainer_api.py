@@ -48,7 +48,10 @@ class _StepRecords:
         if self._done is not None:
             return
         env = self._env
-        env._events[self.serial % env._slots].synchronize()  # the launch of THIS step has completed (later ones may still be queued or running)
+        if env._events is not None:
+            env._events[self.serial % env._slots].synchronize()  # the launch of THIS step has completed (later ones may still be queued or running)
+        else:
+            env.synchronize()                                 # (record_events=False: wait for everything issued so far)
         rec = env._ring[self.serial % env._slots]            # [N][4] int32 view of the pinned slot
         self._idx = np.nonzero(rec[:, 0] == np.array(self.serial, np.uint32).view(np.int32))[0]
         self._rows = rec[self._idx]                          # (a copy: the slot is rewritten `slots` steps from now)
@@ -177,10 +180,11 @@ class TorchVecEnv:
     (`max_rows=...`); `sub_batches=k` steps the batch as k sub-batches on their own HIP streams (`multi.SubBatchedVecEnv`).
     `record_slots`: how many steps' episode records the pinned ring holds; a step's `done` / `infos` that are still referenced when
     their slot comes up for rewriting are fetched then, so they stay correct however late they are read.  `eager_done=True` returns
-    `done` as a real numpy array (one synchronise per step -- for code that insists on `isinstance(done, np.ndarray)`)."""
+    `done` as a real numpy array (one synchronise per step -- for code that insists on `isinstance(done, np.ndarray)`); `record_events=False`
+    drops the per-step event (for loops that read `masks` / `episode_totals` only)."""
 
     def __init__(self, env_id: str, num_envs: int, seed: int = 0, device: Optional[int] = None, sub_batches: int = 1,
-                 terminal_observation: bool = False, record_slots: int = 8, eager_done: bool = False, **kw):
+                 terminal_observation: bool = False, record_slots: int = 8, eager_done: bool = False, record_events: bool = True, **kw):
         self.venv = make_vec_env(env_id, num_envs, sub_batches=sub_batches, seed=seed, auto_reset=True, terminal_obs=terminal_observation,
                                  **({"device": device} if device is not None else {}), **kw)
         self.env_id, self.num_envs = env_id, int(num_envs)
@@ -196,7 +200,9 @@ class TorchVecEnv:
         self._ring = ep["records"].numpy()                 # [slots][N][4] int32 over the pinned host ring
         self._slots, self._k = ep["slots"], ep["first_serial"]
         self._live = [None] * self._slots                  # weak references to the lazy records of the last `slots` steps
-        self._events = [torch.cuda.Event() for _ in range(self._slots)]   # recorded behind each step's launch: what its lazy records wait for
+        # an event behind each step's launch: what that step's lazy records wait for.  record_events=False saves the record (a trainer that
+        # never looks at `done` / `infos`): records then wait for everything issued so far when they are looked at
+        self._events = [torch.cuda.Event() for _ in range(self._slots)] if record_events else None
         self._rew2 = self.venv.rew.unsqueeze(1)
         self._want_terminal = bool(terminal_observation)
         self._eager = bool(eager_done)
@@ -224,7 +230,8 @@ class TorchVecEnv:
         if actions.device != self.device or actions.dtype != torch.float32 or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         obs = self.venv.step(actions)[0]
-        self._events[slot].record(torch.cuda.current_stream(self.device))
+        if self._events is not None:
+            self._events[slot].record(torch.cuda.current_stream(self.device))
         self._k = k + 1 if k < 0xFFFFFFFF else 1
         rec = _StepRecords(self, k)
         self._live[slot] = weakref.ref(rec)

@@ -73,13 +73,15 @@ def test_trainer_surface_matches_a_hand_kept_ledger(env_id, sub_batches):
     envs.close(); ref.close()
 
 
-def test_records_read_late_are_still_the_right_ones():
+@pytest.mark.parametrize("events", [True, False])
+def test_records_read_late_are_still_the_right_ones(events):
     """`done` / `infos` are lazy: nothing is fetched until the trainer looks.  Kept for 30 steps (the ring holds 4) and read afterwards they
-    must equal what an eager twin saw step by step; `eager_done=True` hands out real numpy arrays."""
+    must equal what an eager twin saw step by step; `eager_done=True` hands out real numpy arrays.  With `record_events=False` a look waits for
+    everything issued so far instead of for its own step's event: same answers."""
     import torch
     from mocca_envs_amd.trainer_api import make_vec_envs
     n, steps = 128, 90
-    lazy = make_vec_envs("Walker3DCustomEnv-v0", seed=2, num_processes=n, record_slots=4)
+    lazy = make_vec_envs("Walker3DCustomEnv-v0", seed=2, num_processes=n, record_slots=4, record_events=events)
     eager = make_vec_envs("Walker3DCustomEnv-v0", seed=2, num_processes=n, eager_done=True)
     lazy.reset(); eager.reset()
     g = torch.Generator(device="cuda").manual_seed(3)

@@ -5,7 +5,8 @@ Policy: MLP obs-64-act on the GPU; every loop writes the masked observation into
                               N info dicts (both force the lazy `done` / `infos` of THIS step: one wait per step, then ~3 x N Python iterations)
   trainer_loop_device_masks   `envs.masks` / `envs.bad_masks` from the device, episode returns from `infos.episodes()` (arrays, no dict per env)
                               read ONE STEP LATE (after the next step has been issued: the wait never lets the GPU run dry)
-  trainer_loop_device_totals  the same without `infos`: episode statistics from `envs.episode_totals` (device) at the end
+  trainer_loop_device_totals  the same without `infos`: episode statistics from `envs.episode_totals` (device) at the end; built with
+                              `record_events=False` (no per-step event record: nothing ever waits for a step)
   trainer_loop_graphed        policy -> mocca_step -> rollout write of `--chunk` consecutive steps captured in ONE torch.cuda.CUDAGraph and
                               replayed: the collection phase without the host
   python tools/trainer_loop_bench.py [--envs 4096] [--steps 300] [--env-id Walker3DCustomEnv-v0] [--sub-batches 1] [--chunk 10]"""
@@ -30,6 +31,8 @@ def main():
     import torch
     from mocca_envs_amd.trainer_api import make_vec_envs
     envs = make_vec_envs(args.env_id, seed=0, num_processes=args.envs, sub_batches=args.sub_batches)
+    # the totals loop never looks at `done` / `infos`: its envs are built without the per-step event record (1 us of GPU time per step)
+    envs_totals = make_vec_envs(args.env_id, seed=0, num_processes=args.envs, sub_batches=args.sub_batches, record_events=False)
     dev = envs.device
     g = torch.Generator(device=dev).manual_seed(1)
     w1 = torch.randn(envs.observation_space.shape[0], 64, device=dev, generator=g) * 0.3
@@ -66,13 +69,14 @@ def main():
         return sum(len(x) for x in ep)
 
     def totals(steps):
-        obs = envs.reset(); envs.episode_totals.zero_()
+        e = envs_totals
+        obs = e.reset(); e.episode_totals.zero_()
         for t in range(steps):
             with torch.no_grad():
                 action = policy(obs)
-            obs, reward, done, infos = envs.step(action)
-            rollouts[t + 1].copy_(obs * envs.masks * envs.bad_masks.clamp(min=1.0))
-        return int(envs.episode_totals[2].item())
+            obs, reward, done, infos = e.step(action)
+            rollouts[t + 1].copy_(obs * e.masks * e.bad_masks.clamp(min=1.0))
+        return int(e.episode_totals[2].item())
 
     graph = None
 
@@ -108,7 +112,7 @@ def main():
         dt = (time.perf_counter() - t0) / steps
         out[name] = {"ms_per_step": 1e3 * dt, "env_steps_per_s": args.envs / dt, "episodes": n_ep}
     print(json.dumps(out))
-    envs.close()
+    envs.close(); envs_totals.close()
 
 
 if __name__ == "__main__":
