@@ -3,7 +3,10 @@
  * same episode stepped through the Python binding, bit for bit -- the drop-in boundary is the C ABI, PyTorch is one of its users.
  *
  *   abi_client <model blob file> <task id> <n_envs> <steps> <seed>
- * prints one line per env: the reward and done flag of the last step and the FNV-1a hash of its observation row's bytes. */
+ * prints one line per env: the reward and done flag of the last step and the FNV-1a hash of its observation row's bytes; then one line
+ * "episodes <count> <sum of lengths> <truncated> | totals <episodes> <lengths> <truncated>": Monitor's statistics as the step kernel wrote them
+ * (ABI 7, mocca_set_episode_stats) -- read record by record from a ring in pinned HOST memory (hipHostMalloc; one slot per step here), and the
+ * device-side totals beside them. */
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -42,6 +45,15 @@ int main(int argc, char **argv) {
   uint8_t *h_done = (uint8_t *)malloc((size_t)n);
   CHECK_MOCCA(mocca_set_param(h, MOCCA_PARAM_AUTO_RESET, 1.0));
   CHECK_MOCCA(mocca_set_terminal_obs_buffer(h, d_term));
+  /* Monitor / TimeLimitMask inside the launch: masks and totals on the device, the finished envs' records straight into host memory */
+  float *d_masks, *d_bad, *d_tot;
+  mocca_episode_rec *ring;
+  CHECK_HIP(hipMalloc((void **)&d_masks, (size_t)n * 4)); CHECK_HIP(hipMalloc((void **)&d_bad, (size_t)n * 4)); CHECK_HIP(hipMalloc((void **)&d_tot, 16));
+  CHECK_HIP(hipMemset(d_tot, 0, 16));
+  CHECK_HIP(hipHostMalloc((void **)&ring, (size_t)(steps + 1) * n * sizeof(mocca_episode_rec), 0));
+  memset(ring, 0, (size_t)(steps + 1) * n * sizeof(mocca_episode_rec));
+  CHECK_MOCCA(mocca_set_episode_stats(h, d_masks, d_bad, d_tot, ring, steps + 1, (size_t)n * sizeof(mocca_episode_rec)));
+  const uint32_t first_serial = mocca_episode_serial(h);
   CHECK_MOCCA(mocca_reset(h, NULL, seed, d_obs, s));
   uint32_t lcg = 12345u;   /* the same actions the Python side generates: a 24-bit LCG mapped to [-1, 1) */
   for (int t = 0; t < steps; ++t) {
@@ -61,6 +73,19 @@ int main(int argc, char **argv) {
     memcpy(&rb, &h_rew[e], 4);
     printf("%d %08x %d %08x\n", e, rb, (int)h_done[e], hash);
   }
+  {
+    long episodes = 0, lengths = 0, truncated = 0;
+    for (int t = 0; t < steps; ++t) {          /* step t stamped its records with serial first_serial + t and wrote slot serial mod (steps + 1) */
+      const uint32_t serial = first_serial + (uint32_t)t;
+      const mocca_episode_rec *slot = ring + (size_t)(serial % (uint32_t)(steps + 1)) * n;
+      for (int e = 0; e < n; ++e)
+        if (slot[e].serial == serial) { ++episodes; lengths += slot[e].length; truncated += (slot[e].flags & 2u) ? 1 : 0; }
+    }
+    float tot[4];
+    CHECK_HIP(hipMemcpy(tot, d_tot, 16, hipMemcpyDeviceToHost));
+    printf("episodes %ld %ld %ld | totals %.0f %.0f %.0f\n", episodes, lengths, truncated, tot[2], tot[1], tot[3]);
+  }
+  CHECK_MOCCA(mocca_set_episode_stats(h, NULL, NULL, NULL, NULL, 0, 0));
   CHECK_MOCCA(mocca_destroy(h));
   return 0;
 }

@@ -35,11 +35,14 @@ def test_a_plain_c_caller_gets_the_same_bits(tmp_path, env_id, task):
     (tmp_path / "model.blob").write_bytes(blob)
     out = subprocess.run([exe, str(tmp_path / "model.blob"), str(task), str(n), str(steps), str(seed)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    rows = [l.split() for l in out.stdout.strip().splitlines()]
-    assert len(rows) == n
+    lines = out.stdout.strip().splitlines()
+    rows, stats = [l.split() for l in lines[:-1]], lines[-1].split()
+    assert len(rows) == n and stats[0] == "episodes" and stats[5] == "totals"
     # the same episodes through the Python binding
     env = VecEnv(env_id, n, auto_reset=True, seed=seed)
     env.reset()
+    ep_count = ep_len = 0
+    length = np.zeros(n, int)
     lcg = np.uint32(12345)
     for t in range(steps):
         a = np.empty(n * env.act_dim, np.float32)
@@ -48,6 +51,11 @@ def test_a_plain_c_caller_gets_the_same_bits(tmp_path, env_id, task):
                 lcg = np.uint32(lcg * np.uint32(1664525) + np.uint32(1013904223))
                 a[i] = np.float32(int(lcg) >> 8) * np.float32(2.0 / 16777216.0) - np.float32(1.0)
         obs, rew, done, _ = env.step(torch.from_numpy(a.reshape(n, env.act_dim)).cuda())
+        length += 1
+        fin = done.cpu().numpy() != 0
+        ep_count += int(fin.sum()); ep_len += int(length[fin].sum()); length[fin] = 0
+    # Monitor's statistics as the C client read them out of the pinned record ring, and the device totals: the same episodes, counted here by hand
+    assert [int(x) for x in stats[1:4]] == [ep_count, ep_len, 0] and [int(x) for x in stats[6:9]] == [ep_count, ep_len, 0] and ep_count > 0
     obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
     n_done = 0
     for e, (idx, rbits, d, h) in enumerate(rows):
