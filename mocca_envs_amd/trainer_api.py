@@ -237,6 +237,38 @@ class TorchVecEnv:
         self._live[slot] = weakref.ref(rec)
         return obs, self._rew2, (_LazyDone(rec).numpy() if self._eager else _LazyDone(rec)), _Infos(self.num_envs, rec)
 
+    def capture_rollout(self, policy, num_steps: int, sink=None, warmup: int = 2):
+        """The collection phase as ONE CUDA graph: `num_steps` x { action = policy(obs); env.step(action); sink(t, obs, reward, masks, bad_masks,
+        action) } captured once, replayed with `.replay()` (returns the `torch.cuda.CUDAGraph`).  `policy` maps the observation tensor [N, obs_dim] to
+        actions [N, act_dim] with torch ops only (no host reads); `sink` copies what the trainer keeps into ITS pre-allocated rollout storage
+        (`rollouts.obs[t + 1].copy_(obs)` ...: `obs`, `reward` [N, 1], `masks` / `bad_masks` [N, 1] are this env's persistent buffers, rewritten
+        by every step).  `mocca_step` keeps no host state per launch (ABI 7), so a replay advances the envs exactly as `num_steps` calls of
+        `step()` would -- bit for bit (tests/test_gpu_trainer_api.py).  Episode statistics of a replayed rollout: `episode_totals` (the lazy
+        `done` / `infos` of `step()` do not exist inside a graph).  `warmup` eager iterations run first on a side stream, as torch requires before a
+        capture: they advance the envs too."""
+        if not hasattr(self.venv, "lib"):
+            raise NotImplementedError("capture_rollout needs one handle (sub_batches=1): sub-batches step on streams of their own")
+        venv, dev = self.venv, self.device
+        obs, rew = venv.obs, self._rew2
+
+        def body(t):
+            action = policy(obs)
+            venv.step(action)
+            if sink is not None:
+                sink(t, obs, rew, self.masks, self.bad_masks, action)
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for t in range(warmup):
+                body(t)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph), torch.no_grad():
+            for t in range(num_steps):
+                body(t)
+        return graph
+
     def step_async(self, actions):      # baselines' two-phase form
         self._pending = self.step(actions)
 

@@ -144,3 +144,37 @@ def test_policy_and_step_replay_from_a_cuda_graph():
     assert te[2] > 0 and te[1] == tg[1] and te[2] == tg[2] and te[3] == tg[3] and abs(te[0] - tg[0]) < 1e-3 * (1 + abs(te[0]))   # (atomic float sums: order differs)
     for e in envs:
         e.close()
+
+
+def test_capture_rollout_is_the_eager_rollout():
+    """`TorchVecEnv.capture_rollout`: 16 x {policy, step, sink} as one graph; three replays fill the trainer's storage with exactly what 48 eager
+    steps of a twin produce, and the device totals count the same episodes."""
+    import torch
+    from mocca_envs_amd.trainer_api import make_vec_envs
+    n, T, warm = 192, 16, 2
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(8)
+    w = torch.randn(52, 21, device=dev, generator=g) * 0.4
+    policy = lambda o: torch.tanh(o @ w)
+    a, b = (make_vec_envs("Walker3DCustomEnv-v0", seed=12, num_processes=n, record_events=False) for _ in range(2))
+    store = {k: torch.zeros(T, n, d, device=dev) for k, d in (("obs", 52), ("rew", 1), ("masks", 1), ("bad", 1), ("act", 21))}
+
+    def sink(t, obs, rew, masks, bad, act):
+        store["obs"][t].copy_(obs); store["rew"][t].copy_(rew); store["masks"][t].copy_(masks); store["bad"][t].copy_(bad); store["act"][t].copy_(act)
+
+    a.reset(); b.reset()
+    graph = a.capture_rollout(policy, T, sink=sink, warmup=warm)
+    obs = b.venv.obs
+    for _ in range(warm):
+        b.step(policy(obs))
+    for r in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        for t in range(T):
+            act = policy(obs)
+            o, rw, _, _ = b.step(act)
+            assert torch.equal(store["act"][t], act) and torch.equal(store["obs"][t], o) and torch.equal(store["rew"][t], rw), (r, t)
+            assert torch.equal(store["masks"][t], b.masks) and torch.equal(store["bad"][t], b.bad_masks), (r, t)
+    ta, tb = a.episode_totals.cpu().numpy(), b.episode_totals.cpu().numpy()
+    assert tb[2] > 0 and ta[1] == tb[1] and ta[2] == tb[2] and abs(ta[0] - tb[0]) < 1e-3 * (1 + abs(tb[0]))
+    a.close(); b.close()

@@ -7,8 +7,8 @@ Policy: MLP obs-64-act on the GPU; every loop writes the masked observation into
                               read ONE STEP LATE (after the next step has been issued: the wait never lets the GPU run dry)
   trainer_loop_device_totals  the same without `infos`: episode statistics from `envs.episode_totals` (device) at the end; built with
                               `record_events=False` (no per-step event record: nothing ever waits for a step)
-  trainer_loop_graphed        policy -> mocca_step -> rollout write of `--chunk` consecutive steps captured in ONE torch.cuda.CUDAGraph and
-                              replayed: the collection phase without the host
+  trainer_loop_graphed        policy -> mocca_step -> rollout write of `--chunk` consecutive steps captured in ONE torch.cuda.CUDAGraph
+                              (`TorchVecEnv.capture_rollout`) and replayed: the collection phase without the host
   python tools/trainer_loop_bench.py [--envs 4096] [--steps 300] [--env-id Walker3DCustomEnv-v0] [--sub-batches 1] [--chunk 10]"""
 import argparse
 import json
@@ -82,19 +82,8 @@ def main():
 
     def graphed(steps):
         nonlocal graph
-        venv, obs = envs.venv, envs.venv.obs
-        if graph is None:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side), torch.no_grad():
-                for t in range(3):
-                    venv.step(policy(obs))
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph), torch.no_grad():
-                for t in range(args.chunk):     # (a trainer captures its whole num_steps rollout; the chunk writes rollout rows 1 .. chunk)
-                    venv.step(policy(obs))
-                    rollouts[t + 1].copy_(obs * envs.masks * envs.bad_masks.clamp(min=1.0))
+        if graph is None:       # (a trainer captures its whole num_steps rollout; the chunk writes rollout rows 1 .. chunk)
+            graph = envs.capture_rollout(policy, args.chunk, sink=lambda t, obs, rew, masks, bad, act: rollouts[t + 1].copy_(obs * masks * bad.clamp(min=1.0)))
         envs.reset(); envs.episode_totals.zero_()
         for _ in range(steps // args.chunk):
             graph.replay()
