@@ -6,7 +6,8 @@ actions of step t + 1 really depend on the observations of step t and every orde
   python tools/subbatch_loop_bench.py [--envs 8192] [--sub-batches 2] [--max-rows 32] [--steps 400] [--env-id ...] [--hidden 64]
 
 Prints one JSON line per protocol: tape (pre-computed actions, step_async(ordered=False): what bench.py --stagger times),
-policy_sync (one handle: policy -> step), policy_double_buffered (wait(i) -> policy -> step_async(i))."""
+policy_sync (one handle: policy -> step), policy_double_buffered (wait(i) -> policy -> step_async(i)), trainer_loop_double_buffered (the same
+with the in-kernel masks and the rollout write of tools/trainer_loop_bench.py: the pipelined counterpart of its device-totals loop)."""
 import argparse
 import json
 import os
@@ -65,9 +66,23 @@ def main():
             obs, _, _, _ = sub.wait(i)
             sub.step_async(i, policy(obs))
 
+    # the PPO collection loop of tools/trainer_loop_bench.py (masked observation into a rollout buffer every step; Monitor / TimeLimitMask inside
+    # the launch, ABI 7), double-buffered: while sub-batch i steps, the policy and the rollout write of the other one run
+    ep = sub.episode_stats(True)
+    masks, bad = ep["masks"].unsqueeze(1), ep["bad_masks"].unsqueeze(1)
+    rollouts = torch.zeros(64, args.envs, one.obs_dim, device=dev)
+
+    def sub_trainer(t):
+        for i in range(k):
+            sl = sub.slices[i]
+            obs, _, _, _ = sub.wait(i)
+            act = policy(obs)
+            rollouts[t % 64, sl].copy_(obs * masks[sl] * bad[sl].clamp(min=1.0))
+            sub.step_async(i, act)          # ordered after the policy AND the rollout write (both read rows the launch rewrites)
+
     results = {}
     for name, fn in (("tape_one_handle", sync_tape), ("tape_sub_batches", sub_tape), ("policy_one_handle", sync_policy),
-                     ("policy_double_buffered", sub_policy)):
+                     ("policy_double_buffered", sub_policy), ("trainer_loop_double_buffered", sub_trainer)):
         timed(fn, args.preroll)          # age the batch, warm the clocks (and torch's GEMM kernels)
         s = min(timed(fn, args.steps) for _ in range(3))
         results[name] = {"ms_per_step": 1e3 * s, "env_steps_per_s": args.envs / s}
