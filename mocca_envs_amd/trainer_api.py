@@ -24,6 +24,7 @@ and never touches `done` / `infos`; that loop can be captured in a `torch.cuda.C
 """
 from __future__ import annotations
 
+import inspect
 import weakref
 from typing import Optional
 
@@ -219,7 +220,11 @@ class TorchVecEnv:
     def reset(self) -> torch.Tensor:
         return self.venv.reset()       # (the reset kernel zeroes the envs' running returns: Monitor.reset)
 
-    def step(self, actions: torch.Tensor):
+    def step(self, actions: torch.Tensor, into: Optional[dict] = None):
+        """`into` (one handle only): {"obs": [N, obs_dim], "reward": [N, 1], "masks": [N, 1], "bad_masks": [N, 1]} -- any subset -- tensors of the
+        TRAINER's storage that this step's launch writes directly (row t + 1 of the rollout buffers: PPO reads its next policy input from
+        there anyway), instead of this object's own buffers: no copy kernels between the env and the storage.  The returned `obs` / `reward`
+        are those tensors; `envs.masks` / `envs.bad_masks` keep pointing at the last buffers handed in."""
         k = self._k
         slot = k % self._slots
         old = self._live[slot]
@@ -229,39 +234,67 @@ class TorchVecEnv:
                 old.materialise()      # its slot is about to be rewritten: fetch it now (its launch finished long ago)
         if actions.device != self.device or actions.dtype != torch.float32 or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
-        obs = self.venv.step(actions)[0]
+        rew = self._rew2
+        if into:
+            if "masks" in into or "bad_masks" in into:
+                self.masks, self.bad_masks = into.get("masks", self.masks), into.get("bad_masks", self.bad_masks)
+                self.venv.episode_masks_into(self.masks, self.bad_masks)
+            rew = into.get("reward", rew)
+            obs = self.venv.step(actions, obs_out=into.get("obs"), rew_out=into.get("reward"))[0]
+        else:
+            obs = self.venv.step(actions)[0]
         if self._events is not None:
             self._events[slot].record(torch.cuda.current_stream(self.device))
         self._k = k + 1 if k < 0xFFFFFFFF else 1
         rec = _StepRecords(self, k)
         self._live[slot] = weakref.ref(rec)
-        return obs, self._rew2, (_LazyDone(rec).numpy() if self._eager else _LazyDone(rec)), _Infos(self.num_envs, rec)
+        return obs, rew, (_LazyDone(rec).numpy() if self._eager else _LazyDone(rec)), _Infos(self.num_envs, rec)
 
-    def capture_rollout(self, policy, num_steps: int, sink=None, warmup: int = 2):
+    def capture_rollout(self, policy, num_steps: int, sink=None, warmup: int = 2, into=None):
         """The collection phase as ONE CUDA graph: `num_steps` x { action = policy(obs); env.step(action); sink(t, obs, reward, masks, bad_masks,
         action) } captured once, replayed with `.replay()` (returns the `torch.cuda.CUDAGraph`).  `policy` maps the observation tensor [N, obs_dim] to
-        actions [N, act_dim] with torch ops only (no host reads); `sink` copies what the trainer keeps into ITS pre-allocated rollout storage
+        actions [N, act_dim] with torch ops only (no host reads; `policy(obs, t)` is called with the step index if it takes two arguments); `sink` copies what the trainer keeps into ITS pre-allocated rollout storage
         (`rollouts.obs[t + 1].copy_(obs)` ...: `obs`, `reward` [N, 1], `masks` / `bad_masks` [N, 1] are this env's persistent buffers, rewritten
         by every step).  `mocca_step` keeps no host state per launch (ABI 7), so a replay advances the envs exactly as `num_steps` calls of
         `step()` would -- bit for bit (tests/test_gpu_trainer_api.py).  Episode statistics of a replayed rollout: `episode_totals` (the lazy
         `done` / `infos` of `step()` do not exist inside a graph).  `warmup` eager iterations run first on a side stream, as torch requires before a
-        capture: they advance the envs too."""
+        capture: they advance the envs too.  `into`: a callable t -> the `into` dict of `step()`, each with an "obs" entry -- launch t of the
+        graph writes its observations / rewards / masks straight into those tensors (row t + 1 of the trainer's storage) and `policy` reads
+        `into(t - 1)["obs"]`; `into(-1)["obs"]` is the storage's row 0, which must hold the current observation before every replay (PPO's
+        `rollouts.after_update()` copies the last row there; this call leaves it filled): the rollout needs no copy kernels at all."""
         if not hasattr(self.venv, "lib"):
             raise NotImplementedError("capture_rollout needs one handle (sub_batches=1): sub-batches step on streams of their own")
         venv, dev = self.venv, self.device
         obs, rew = venv.obs, self._rew2
+        if len(inspect.signature(policy).parameters) >= 2:        # policy(obs, t): e.g. to write its action into the storage's row t
+            act_of = policy
+        else:
+            act_of = lambda o, t: policy(o)
 
         def body(t):
-            action = policy(obs)
-            venv.step(action)
+            if into is None:
+                action = act_of(obs, t)
+                venv.step(action)
+                o, r = obs, rew
+            else:
+                action = act_of(into(t - 1)["obs"], t)
+                d = into(t)
+                if "masks" in d or "bad_masks" in d:
+                    self.masks, self.bad_masks = d.get("masks", self.masks), d.get("bad_masks", self.bad_masks)
+                    venv.episode_masks_into(self.masks, self.bad_masks)
+                o, r = venv.step(action, obs_out=d.get("obs"), rew_out=d.get("reward"))[:2]
             if sink is not None:
-                sink(t, obs, rew, self.masks, self.bad_masks, action)
+                sink(t, o, r, self.masks, self.bad_masks, action)
 
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), torch.no_grad():
+            if into is not None:
+                into(-1)["obs"].copy_(obs)
             for t in range(warmup):
                 body(t)
+            if into is not None and warmup > 0:
+                into(-1)["obs"].copy_(into(warmup - 1)["obs"])      # row 0 <- the observation the warm-up ended on
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph), torch.no_grad():

@@ -378,17 +378,39 @@ class VecEnv:
         self._out()
         return self.obs
 
-    def step(self, actions: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    def step(self, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None,
+             rew_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
         """One env.step of all envs: one kernel launch on torch's current stream (or on `self.stream`, unordered against the current
-        stream: see _in / _out above)."""
+        stream: see _in / _out above).  `obs_out` / `rew_out`: where THIS launch writes its observations [N, obs_dim] / rewards [N] (or
+        [N, 1]) instead of `self.obs` / `self.rew` -- e.g. row t + 1 of a trainer's rollout storage, which PPO reads the next policy input
+        from anyway: the kernel's outputs need no copy (mocca_step takes the pointers per call).  Contiguous float32 on the env's device."""
         if actions.device != self.device or actions.dtype != torch.float32 or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         if actions.shape != (self.n_envs, self.act_dim):
             raise ValueError(f"actions must be [{self.n_envs}, {self.act_dim}]")
-        _lib.check(self.lib.mocca_step(self.h, C.c_void_p(actions.data_ptr()), C.c_void_p(self.obs.data_ptr()),
-                                       C.c_void_p(self.rew.data_ptr()), C.c_void_p(self.done.data_ptr()),
+        obs, rew = self.obs if obs_out is None else obs_out, self.rew if rew_out is None else rew_out
+        if obs_out is not None or rew_out is not None:
+            if obs.shape != (self.n_envs, self.obs_dim) or rew.numel() != self.n_envs or obs.dtype != torch.float32 or rew.dtype != torch.float32 \
+                    or not obs.is_contiguous() or not rew.is_contiguous() or obs.device != self.device or rew.device != self.device:
+                raise ValueError("obs_out / rew_out must be contiguous float32 [n_envs, obs_dim] / [n_envs] tensors on the env's device")
+        _lib.check(self.lib.mocca_step(self.h, C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()),
+                                       C.c_void_p(rew.data_ptr()), C.c_void_p(self.done.data_ptr()),
                                        C.c_void_p(self.info.data_ptr()), self._stream()), self.h)
-        return self.obs, self.rew, self.done, self.info
+        return obs, rew, self.done, self.info
+
+    def episode_masks_into(self, masks: torch.Tensor, bad_masks: torch.Tensor) -> None:
+        """Point the in-kernel `masks` / `bad_masks` columns of episode_stats() at other buffers FROM THE NEXT LAUNCH ON (e.g. row t + 1 of a
+        trainer's rollout storage); totals and records stay where they are.  No synchronisation: launches in flight keep the pointers they
+        were issued with.  Contiguous float32, n_envs elements each, on the env's device."""
+        if self.ep is None:
+            raise _lib.MoccaError("episode_masks_into needs episode_stats(True) first")
+        for t in (masks, bad_masks):
+            if t.numel() != self.n_envs or t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("masks / bad_masks must be contiguous float32 tensors of n_envs elements on the env's device")
+        r = self.ep["records"]
+        _lib.check(self.lib.mocca_set_episode_stats(self.h, C.c_void_p(masks.data_ptr()), C.c_void_p(bad_masks.data_ptr()),
+                                                    C.c_void_p(self.ep["totals"].data_ptr()), C.c_void_p(r.data_ptr() + 16 * self.ep["row0"]),
+                                                    r.shape[0], 16 * r.shape[1]), self.h)
 
     # ---- host-side callers (the single-env gym classes; a trainer that lives on the host) ----
     def host_mirror(self) -> dict:

@@ -178,3 +178,40 @@ def test_capture_rollout_is_the_eager_rollout():
     ta, tb = a.episode_totals.cpu().numpy(), b.episode_totals.cpu().numpy()
     assert tb[2] > 0 and ta[1] == tb[1] and ta[2] == tb[2] and abs(ta[0] - tb[0]) < 1e-3 * (1 + abs(tb[0]))
     a.close(); b.close()
+
+
+def test_step_into_the_trainers_storage_is_the_same_step():
+    """`step(action, into=...)`: the launch writes observation, reward, masks and bad_masks straight into rows of the trainer's rollout storage
+    (PPO's `rollouts.insert` without copy kernels) -- the same bits a twin leaves in its own buffers; and the same from one CUDA graph
+    (`capture_rollout(into=...)`), whose policy reads row t and writes its action into the storage too."""
+    import torch
+    from mocca_envs_amd.trainer_api import make_vec_envs
+    n, T = 160, 12
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(21)
+    w = torch.randn(52, 21, device=dev, generator=g) * 0.4
+    a, b, c = (make_vec_envs("Walker3DCustomEnv-v0", seed=5, num_processes=n, record_events=False) for _ in range(3))
+    S = {"obs": torch.zeros(T + 1, n, 52, device=dev), "reward": torch.zeros(T, n, 1, device=dev), "masks": torch.ones(T + 1, n, 1, device=dev),
+         "bad_masks": torch.ones(T + 1, n, 1, device=dev), "act": torch.zeros(T, n, 21, device=dev)}
+    G = {k: torch.zeros_like(v) for k, v in S.items()}
+    row = lambda st: (lambda t: {"obs": st["obs"][t + 1], "reward": st["reward"][t], "masks": st["masks"][t + 1], "bad_masks": st["bad_masks"][t + 1]}
+                      if t >= 0 else {"obs": st["obs"][0]})
+    S["obs"][0].copy_(a.reset()); obs_b = b.reset(); c.reset()
+    graph = c.capture_rollout(lambda o, t: torch.tanh(o @ w, out=G["act"][t]), T, into=row(G), warmup=0)
+    for r in range(3):
+        graph.replay()
+        for t in range(T):
+            act = torch.tanh(S["obs"][t] @ w)
+            o, rw, d, infos = a.step(act, into=row(S)(t))
+            assert o.data_ptr() == S["obs"][t + 1].data_ptr() and rw.data_ptr() == S["reward"][t].data_ptr()
+            o2, r2, _, _ = b.step(torch.tanh(obs_b @ w))
+            assert torch.equal(o, o2) and torch.equal(rw, r2) and torch.equal(S["masks"][t + 1], b.masks) and torch.equal(S["bad_masks"][t + 1], b.bad_masks), (r, t)
+            assert (np.asarray(d) == (S["masks"][t + 1][:, 0].cpu().numpy() == 0.0)).all()        # the lazy records still work beside it
+            obs_b = o2
+        torch.cuda.synchronize()
+        for k in ("obs", "reward", "masks", "bad_masks"):
+            assert torch.equal(G[k][1:] if k in ("obs", "masks", "bad_masks") else G[k], S[k][1:] if k in ("obs", "masks", "bad_masks") else S[k]), (r, k)
+        for st in (S, G):                                            # rollouts.after_update()
+            st["obs"][0].copy_(st["obs"][T])
+    for e in (a, b, c):
+        e.close()

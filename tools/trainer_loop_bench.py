@@ -9,6 +9,9 @@ Policy: MLP obs-64-act on the GPU; every loop writes the masked observation into
                               `record_events=False` (no per-step event record: nothing ever waits for a step)
   trainer_loop_graphed        policy -> mocca_step -> rollout write of `--chunk` consecutive steps captured in ONE torch.cuda.CUDAGraph
                               (`TorchVecEnv.capture_rollout`) and replayed: the collection phase without the host
+  trainer_loop_in_place       PPO's own structure: the policy reads rollouts.obs[t]; the step kernel writes observation, reward, masks and
+                              bad_masks of step t STRAIGHT into rows t + 1 / t of the storage (`step(action, into=...)`), the policy its action
+                              into rollouts.actions[t]: `rollouts.insert` without a copy kernel; `_graphed`: the same from one CUDA graph
   python tools/trainer_loop_bench.py [--envs 4096] [--steps 300] [--env-id Walker3DCustomEnv-v0] [--sub-batches 1] [--chunk 10]"""
 import argparse
 import json
@@ -89,10 +92,44 @@ def main():
             graph.replay()
         return int(envs.episode_totals[2].item())
 
+    # ---- the kernel writes straight into the trainer's storage (TorchVecEnv.step(into=...)): PPO's rollouts.insert without copy kernels.
+    # Storage like a2c-ppo-acktr's RolloutStorage: obs [T + 1], rewards [T], masks / bad_masks [T + 1], actions [T]; the policy reads obs[t].
+    T = args.chunk
+    od, ad = envs.observation_space.shape[0], envs.action_space.shape[0]
+    S = {"obs": torch.zeros(T + 1, args.envs, od, device=dev), "reward": torch.zeros(T, args.envs, 1, device=dev),
+         "masks": torch.ones(T + 1, args.envs, 1, device=dev), "bad_masks": torch.ones(T + 1, args.envs, 1, device=dev),
+         "act": torch.zeros(T, args.envs, ad, device=dev)}
+    row = lambda t: {"obs": S["obs"][t + 1], "reward": S["reward"][t], "masks": S["masks"][t + 1], "bad_masks": S["bad_masks"][t + 1]} if t >= 0 else {"obs": S["obs"][0]}
+    policy_into = lambda o, t: torch.tanh(torch.tanh(o @ w1) @ w2, out=S["act"][t])
+
+    def in_place(steps):
+        e = envs_totals
+        S["obs"][0].copy_(e.reset()); e.episode_totals.zero_()
+        for r in range(steps // T):
+            for t in range(T):
+                with torch.no_grad():
+                    action = policy_into(S["obs"][t], t)
+                e.step(action, into=row(t))
+            S["obs"][0].copy_(S["obs"][T]); S["masks"][0].copy_(S["masks"][T]); S["bad_masks"][0].copy_(S["bad_masks"][T])   # rollouts.after_update()
+        return int(e.episode_totals[2].item())
+
+    graph_ip = None
+
+    def in_place_graphed(steps):
+        nonlocal graph_ip
+        e = envs_totals
+        if graph_ip is None:
+            graph_ip = e.capture_rollout(policy_into, T, into=row)
+        S["obs"][0].copy_(e.reset()); e.episode_totals.zero_()
+        for r in range(steps // T):
+            graph_ip.replay()
+            S["obs"][0].copy_(S["obs"][T]); S["masks"][0].copy_(S["masks"][T]); S["bad_masks"][0].copy_(S["bad_masks"][T])
+        return int(e.episode_totals[2].item())
+
     out = {"env_id": args.env_id, "envs": args.envs, "sub_batches": args.sub_batches, "steps": steps, "graph_chunk": args.chunk}
     loops = [("trainer_loop_verbatim", verbatim), ("trainer_loop_device_masks", lean), ("trainer_loop_device_totals", totals)]
     if args.sub_batches == 1:
-        loops.append(("trainer_loop_graphed", graphed))
+        loops += [("trainer_loop_graphed", graphed), ("trainer_loop_in_place", in_place), ("trainer_loop_in_place_graphed", in_place_graphed)]
     for name, fn in loops:
         if args.skip_verbatim and fn is verbatim:
             continue
