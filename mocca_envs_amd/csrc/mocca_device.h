@@ -91,7 +91,7 @@ constexpr int DYN_STRIDE = 96;      // floats per env in the dynamic-state buffe
 constexpr int TERRAIN_STRIDE = 128; // floats per env in the terrain buffer
 
 #ifndef MOCCA_LDS_PAD
-#define MOCCA_LDS_PAD 0   // diagnostic builds only (tools/occupancy_probe.sh): extra floats of LDS per wave, to run the same code at fewer waves per SIMD
+#define MOCCA_LDS_PAD 0   // diagnostic builds only (the occupancy probe of round 3, profiles/r03_occupancy_probe.jsonl): extra floats of LDS per wave, to run the same code at fewer waves per SIMD
 #endif
 // ---- LDS layout, float offsets (one wave = one env) ----
 // [0, L_V)      survives the whole step (state, torques, new velocity, warm-start impulses)
@@ -1356,7 +1356,7 @@ DI ContactFlags collide(ModelP M, float* L, int lane, const float* ter, int next
     const int k = base + lane;
     bool near = false;
     if (k < npairs) {
-#ifdef MOCCA_ABL_PAIRLOAD   // ablation (tools/r05_l2chain_ab.sh; results WRONG by construction): the broad phase's pair record made up from the lane
+#ifdef MOCCA_ABL_PAIRLOAD   // ablation (round 5's A/B, profiles/r05_l2chain_ab.txt; results WRONG by construction): the broad phase's pair record made up from the lane
       f4_t pt;              // instead of loaded -- what ANY staging of the pair table could save at most (measured: 0.2 % of the launch)
       pt.x = __int_as_float((k % T::NG) | (((k * 7 + 3) % T::NG) << 5) | (24 << 20)); pt.y = 0.05f; pt.z = 0.05f; pt.w = 0.04f;
 #else
@@ -1561,7 +1561,7 @@ constexpr int fric_lane(int i, int s) { return MAXR - 2 - 2 * i + s; }
 // the first PGS_REG_CONTACTS contacts' friction rows -- already multiplied by the lane's 1 / (A_cc + cfm) -- are fetched ONCE per
 // substep into registers (static indices: the visits are unrolled); a typical env (12 rows) then runs its five iterations without a
 // single LDS read, and a visit loses its multiply.  Rows past the window keep the per-iteration LDS reads, requested a group ahead.
-// Window sizes by topology (tools/flag_sweep_env.sh): 16 rows + 4 contacts for the walkers (mean 12 rows; larger windows measure the
+// Window sizes by topology (tools/flag_sweep.sh): 16 rows + 4 contacts for the walkers (mean 12 rows; larger windows measure the
 // same), 24 + 12 for Cassie, whose closures, planar rows and a dozen toe points put ~45 rows in every substep (-1.8 %).
 #ifdef MOCCA_PGS_REG_ROWS   // override for sweeps
 template <class T> struct PgsWin { static constexpr int ROWS = MOCCA_PGS_REG_ROWS, CONTACTS = MOCCA_PGS_REG_CONTACTS; };
@@ -1899,7 +1899,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
   // the walker, and a merged two-path variant twice the arithmetic per step.)
   // Rows that act on two bodies (self contacts, loop closures) sweep the second body's path separately (the recursion is
   // linear in the applied force; both meet in the base's right-hand side); without such a row in the wave that pass is skipped.
-#ifdef MOCCA_NO_TWO_PATHS  // diagnostic build (tools/icache_probe.py): code-size experiment, wrong with self contacts / closures
+#ifdef MOCCA_NO_TWO_PATHS  // diagnostic build (round 4's code-size probe, profiles/r04_icache_counters.txt): code-size experiment, wrong with self contacts / closures
   const bool two_paths = false;
 #else
   const bool two_paths = T::NCLOS > 0 || __ballot(kind >= 1 && bb >= 0) != 0ull;  // wave-uniform
@@ -2275,7 +2275,7 @@ DI ContactFlags substep(ModelP M, float* L, int lane, const float* ter, int next
     geom_points<T>(M, L, lane);
     wsync();
     STAMP(15);
-#ifndef MOCCA_SKIP_COLLIDE  // profiling builds only (tools/ablate.sh): results are wrong by construction
+#ifndef MOCCA_SKIP_COLLIDE  // profiling builds only (tools/ablate_time.sh): results are wrong by construction
     fl = collide<T, TASK>(M, L, lane, ter, next_step_index, &nc, dbg, &nc_wanted, hfa, cover_out);
 #endif
   }
