@@ -354,12 +354,12 @@ def parse_args(argv=None):
                     help="data preparation, before the W warm-up steps: env-steps that age the freshly reset batch into the steady-state mix of "
                          "episode ages and contact counts (SURVEY 8d config 2 asks for >= 200; 1000 = one max_episode_steps, so TimeLimit truncations "
                          "are in the mix) and bring the GPU to its operating clocks -- after idling the first ~50 ms of launches run 9 %% slow "
-                         "(profiles/r02_ramp_probe.txt); untimed, reported in config.preroll_steps")
+                         "(profiles/archive/r02_ramp_probe.txt); untimed, reported in config.preroll_steps")
     ap.add_argument("--preroll-seconds", type=float, default=0.5,
                     help="keep pre-rolling (same launches, untimed) until the GPU has been busy this long.  A 20-launch window that follows a "
                          "synchronize samples the power management's recovery as much as the kernel: after 3 s of idling it runs 108 us per "
                          "launch, with >= 0.1 s of launches behind it 100 - 102 us, although 1000 launches back to back take 100 us either way "
-                         "(profiles/r04_short_window.txt).  0 = steps only; reported in config.preroll_seconds")
+                         "(profiles/archive/r04_short_window.txt).  0 = steps only; reported in config.preroll_seconds")
     ap.add_argument("--curriculum", type=int, default=None, help="Stepper envs: curriculum 0..9 (SURVEY 8d config 3)")
     ap.add_argument("--prio", default=None,
                     help="TUNING ONLY: t1,t2,t3 row-count thresholds of the step kernel's issue priorities (MOCCA_PARAM_ISSUE_PRIORITY) in place of "
@@ -543,7 +543,7 @@ def main():
 
         # First use of everything the warm-up and the timed window call besides mocca_step, BEFORE the pre-roll: torch loads the code objects
         # of its reduction kernels on first use (40 - 150 ms on the host, the GPU idle meanwhile).  With that gap between the pre-roll and
-        # the timed window, all K = 20 launches of the window run 7 - 14 % slow (profiles/r04_short_window4.txt).
+        # the timed window, all K = 20 launches of the window run 7 - 14 % slow (profiles/archive/r04_short_window4.txt).
         n_done = torch.zeros((), device=dev)
         n_done += (env.done != 0).sum()
         n_done.item()
@@ -558,7 +558,7 @@ def main():
         if args.preroll_seconds > 0:
             # N > 1: every rank's timed pre-roll ends preroll_seconds after its release from this barrier, in chunks of 8 launches, so the
             # ranks reach the start barrier of the timed window within ~1 ms of each other.  A rank that waits there with an idle GPU for
-            # 5 ms runs its whole 20-launch window 4 % slow, for >= 10 ms 9 % slow (profiles/r04_idle_gap.txt),
+            # 5 ms runs its whole 20-launch window 4 % slow, for >= 10 ms 9 % slow (profiles/archive/r04_idle_gap.txt),
             # and the job's time is the slowest rank's.
             torch.cuda.synchronize()
             barrier()

@@ -76,7 +76,7 @@ struct mocca_ctx {
   bool wide = false;           // the blob's caps exceed 48 rows / 12 contacts: the 64-row accuracy instance (mocca_r64.hip)
   int force_full = 0;          // MOCCA_PARAM_KERNEL_VARIANT: 1 forces the 48-row instance, 2 the 64-row one
   int persist_warm = 0;        // MOCCA_PARAM_PERSIST_IMPULSES
-  int pace = -18;              // MOCCA_PARAM_PACE_TICKS: self-calibrating pace priorities, 18/16 of the previous launch's mean wave time (profiles/r04_pace_*.jsonl)
+  int pace = -18;              // MOCCA_PARAM_PACE_TICKS: self-calibrating pace priorities, 18/16 of the previous launch's mean wave time (profiles/archive/r04_pace_*.jsonl)
   unsigned long long* d_pace_acc = nullptr;  // self-calibration samples of the pace, one packed word (StepArgs.pace_acc), owned by the handle
   // Monitor / TimeLimitMask inside the launch (mocca_set_episode_stats)
   float* d_ep_ret = nullptr;       // [N] running episode returns, owned by the handle

@@ -80,7 +80,7 @@ typedef const MOCCA_AS_CONST f4_t* CF4P;
 
 #ifndef MOCCA_PRIO_T3  // default row-count thresholds of the issue priorities 3 / 2 / 1 (solve_constraints; MOCCA_PARAM_ISSUE_PRIORITY)
 #define MOCCA_PRIO_T3 12   // re-tuned for the blob v13 physics (5.7 rows per substep, p99 17): 28 / 20 / 14 of the 12.7-row days had stopped
-#define MOCCA_PRIO_T2 7    // selecting anything -- 110.0 -> 104.3 us (profiles/r03_prio_sweep_v13.txt); no priorities at all: +13 % in round 2
+#define MOCCA_PRIO_T2 7    // selecting anything -- 110.0 -> 104.3 us (profiles/archive/r03_prio_sweep_v13.txt); no priorities at all: +13 % in round 2
 #define MOCCA_PRIO_T1 4
 #endif
 constexpr int MAXR = MOCCA_MAXR;                  // rows held by one wave (MoccaModel.max_rows must be <= MAXR)
@@ -91,7 +91,7 @@ constexpr int DYN_STRIDE = 96;      // floats per env in the dynamic-state buffe
 constexpr int TERRAIN_STRIDE = 128; // floats per env in the terrain buffer
 
 #ifndef MOCCA_LDS_PAD
-#define MOCCA_LDS_PAD 0   // diagnostic builds only (the occupancy probe of round 3, profiles/r03_occupancy_probe.jsonl): extra floats of LDS per wave, to run the same code at fewer waves per SIMD
+#define MOCCA_LDS_PAD 0   // diagnostic builds only (the occupancy probe of round 3, profiles/archive/r03_occupancy_probe.jsonl): extra floats of LDS per wave, to run the same code at fewer waves per SIMD
 #endif
 // ---- LDS layout, float offsets (one wave = one env) ----
 // [0, L_V)      survives the whole step (state, torques, new velocity, warm-start impulses)
@@ -1683,7 +1683,7 @@ DI void set_issue_priority(int nr, int prio) {
 // (The pace travels in LDS next to the start time, not in scalar registers: the kernel holds all 102 of them already, and one more value
 // that lives across the substeps is spilled to a VGPR lane, which in turn is spilled to scratch.)
 #ifndef MOCCA_PACE_ROWUNIT
-#define MOCCA_PACE_ROWUNIT 2   // pace units per constraint row (a substep without rows: 64); 0 .. 4 measured: profiles/r04_pace_probe_ru*.jsonl
+#define MOCCA_PACE_ROWUNIT 2   // pace units per constraint row (a substep without rows: 64); 0 .. 4 measured: profiles/archive/r04_pace_probe_ru*.jsonl
 #endif
 #ifndef MOCCA_PACE_SHIFT
 #define MOCCA_PACE_SHIFT 4   // width of the priority bands around the pace: 2^-4
@@ -1899,7 +1899,7 @@ DI void solve_constraints(ModelP M, float* L, int lane, int nc_found, int nc_wan
   // the walker, and a merged two-path variant twice the arithmetic per step.)
   // Rows that act on two bodies (self contacts, loop closures) sweep the second body's path separately (the recursion is
   // linear in the applied force; both meet in the base's right-hand side); without such a row in the wave that pass is skipped.
-#ifdef MOCCA_NO_TWO_PATHS  // diagnostic build (round 4's code-size probe, profiles/r04_icache_counters.txt): code-size experiment, wrong with self contacts / closures
+#ifdef MOCCA_NO_TWO_PATHS  // diagnostic build (round 4's code-size probe, profiles/archive/r04_icache_counters.txt): code-size experiment, wrong with self contacts / closures
   const bool two_paths = false;
 #else
   const bool two_paths = T::NCLOS > 0 || __ballot(kind >= 1 && bb >= 0) != 0ull;  // wave-uniform

@@ -1,7 +1,7 @@
 // mocca_r64.hip -- the ACCURACY instance of the step kernel: the same device source (mocca_device.h, mocca_kernels.h) compiled with
 // MAXR = 64 rows / 20 contacts per env -- every lane of the wave a constraint row, the most the lane = row solver can hold -- in its own
 // namespace.  Bullet caps neither contacts nor rows; the product's 48 / 12 bind in 11 % of the envs of Stepper curriculum 9 at least once
-// (up to 61 rows wanted, profiles/r04_cap_pressure.jsonl).  17.4 KB of LDS and a two-waves-per-SIMD register budget per env: speed is not
+// (up to 61 rows wanted, profiles/archive/r04_cap_pressure.jsonl).  17.4 KB of LDS and a two-waves-per-SIMD register budget per env: speed is not
 // this instance's job.  mocca_create picks it for a blob with max_rows > 48 or max_contacts > 12 (VecEnv(..., max_rows=64, max_contacts=20));
 // MOCCA_PARAM_KERNEL_VARIANT = 2 forces it for any blob (A/B runs: on the same blob it is bit-identical to the 48-row instance).
 #define MOCCA_NS mocca_r64

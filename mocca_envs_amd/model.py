@@ -1104,7 +1104,7 @@ def compile_cassie(planar: bool = False, power_coef: float = 1.0, residual_contr
     m.limit_slack, m.max_contacts, m.max_rows = 0.05, 12, 48
     # each toe is ONE convex mesh in cassie_collide.urdf: Bullet keeps at most 4 contact points per pair of collision objects
     # (btPersistentManifold)  [UNVERIFIED-BULLET] -- of the twelve hull points of a toe on the ground four make contacts, not twelve
-    # (which also overran the solver's 12-contact cap in 84 % of the substeps of a standing robot, profiles/r03_cap_pressure.jsonl)
+    # (which also overran the solver's 12-contact cap in 84 % of the substeps of a standing robot, profiles/archive/r03_cap_pressure.jsonl)
     m.manifold_max = 4
     m.init_pos[0], m.init_pos[1], m.init_pos[2] = 0.0, 0.0, 1.085            # env_cassie.py:17
     m.init_quat[3] = 1.0

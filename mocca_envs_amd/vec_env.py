@@ -44,11 +44,11 @@ _DEFAULT_PARAMS = {"LaikagoCustomEnv-v0": {_lib.PARAM_RANDOM_POSE: 0},    # robo
                    "LaikagoStepperEnv-v0": {_lib.PARAM_RANDOM_POSE: 0}}   # :899
 
 # Since round 4 the step kernel sets its issue priorities from each wave's PACE (PARAM_PACE_TICKS, default: self-calibrating -- 2.6 % to 8.7 %
-# faster than the tables below on every env id, profiles/r04_pace_envs.jsonl); the row-count thresholds only serve a handle's first launch
+# faster than the tables below on every env id, profiles/archive/r04_pace_envs.jsonl); the row-count thresholds only serve a handle's first launch
 # (no pace sample yet) and handles that switch the pace off.
 # Issue-priority thresholds of the step kernel (PARAM_ISSUE_PRIORITY; timing only, results do not depend on them): constraint-row counts
 # above which a wave runs at priority 1 / 2 / 3.  The best set follows the batch's row distribution -- measured per env id with
-# a threshold sweep on one MI355X (profiles/r03_prio_sweep_v13.txt: the blob v13 physics hold 5.7 rows per substep on the flat-ground walker
+# a threshold sweep on one MI355X (profiles/archive/r03_prio_sweep_v13.txt: the blob v13 physics hold 5.7 rows per substep on the flat-ground walker
 # instead of 12.7, and the thresholds of round 2 had stopped selecting anything: -5.5 % on the launch for re-reading them off the new
 # distribution); ids not listed keep the library's default (4, 7, 12: the flat-ground walker).  The stepping-stone walkers carry more rows as
 # the curriculum rises: their thresholds grow with it (x 1.7 at curriculum 9).

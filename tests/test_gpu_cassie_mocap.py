@@ -76,7 +76,7 @@ def test_recorded_episodes_replay_on_the_gpu(tag):
     print(f"\n{tag}: GPU vs reference-code-over-f64-oracle, one env.step: median {np.median(e):.3g} p99 {np.percentile(e, 99):.3g} "
           f"max {e.max():.3g} units of 1e-3 (1 + |x|)")
     # The typical step is 3e-5 absolute (0.03 units).  In a rare step fp32 rounding flips one clamp of one of the 50 solves, on EITHER
-    # implementation (profiles/r03_mocap_step_probe.txt: one step of 42 where the f32 oracle AND the kernel are 3e-2 from the f64 recording
+    # implementation (profiles/archive/r03_mocap_step_probe.txt: one step of 42 where the f32 oracle AND the kernel are 3e-2 from the f64 recording
     # and 2e-5 from each other; earlier blobs showed such a step on one side only).  So: median and count of outlier steps bounded
     # absolutely, the worst step against 3 x the fp32 yardstick's worst step.
     per_step, y = np.array([x.max() for x in errs]), np.array([x.max() for x in yard])

@@ -82,7 +82,7 @@ def test_wide_and_full_instances_agree_bit_for_bit(env_id):
 
 def test_the_wide_instance_holds_what_the_product_caps_drop():
     """Stepper curriculum 9 (BASELINE config 3's hard end): with 64 rows / 20 contacts the cap-pressure counters of the debug record stay at
-    zero where the 48 / 12 caps drop contacts or rows (profiles/r04_cap_pressure.jsonl: 11 % of the envs at least once in 1000 steps), and
+    zero where the 48 / 12 caps drop contacts or rows (profiles/archive/r04_cap_pressure.jsonl: 11 % of the envs at least once in 1000 steps), and
     row counts above 48 are really solved."""
     import torch
     from mocca_envs_amd import lib as L

@@ -2,7 +2,7 @@
   Runs each env id with the debug record attached (MOCCA_DBG_CAP_*: cumulative per (env, substep)) after an
 untimed pre-roll, and prints one JSON line per env id: fraction of substeps in which contacts / rows were dropped, fraction of envs
 that ever hit a cap, the largest row count an uncapped solver would have held, and the row-count distribution of the last substeps.
-usage: python tools/cap_pressure.py [steps [env_id]] > profiles/r03_cap_pressure.jsonl"""
+usage: python tools/cap_pressure.py [steps [env_id]] > profiles/archive/r03_cap_pressure.jsonl"""
 import json
 import os
 import sys
