@@ -100,3 +100,26 @@ def test_sub_batches_on_their_own_streams_reproduce_the_single_batch():
         assert torch.equal(one.obs, torch.cat([halves[0].obs, halves[1].obs])) and torch.equal(one.done, torch.cat([halves[0].done, halves[1].done]))
         for e in halves + [one]:
             e.close()
+
+
+@pytest.mark.gpu
+def test_default_bench_line_carries_both_brackets_and_the_baselines():
+    """`python bench.py` as the driver runs it (smaller batch here): ONE JSON line with `roofline`, `cpu_baseline` (incl. the `pybullet` leg's
+    answer), the physics-law `sensitivity` bracket and the behaviour `workload_sensitivity` bracket, whose closed-loop workloads must replay
+    exactly from their snapshots."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--envs", "512", "--steps", "10", "--warmup", "3", "--preroll", "50",
+                        "--preroll-seconds", "0"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["pybullet"]["kind"] == "reference" and ("n/a" in cb["pybullet"]["sample"] or cb["pybullet"]["value"] > 0)
+    assert set(out["sensitivity"]["variants"]) == {"as_built", "limit_rows_from_predicted_gap", "absolute_2cm_margins", "pyramid_friction", "warmstart_0.85", "all_four"}
+    ws = out["workload_sensitivity"]
+    assert set(ws["workloads"]) == {"uniform_0.3", "zero_actions", "pd_to_t_pose"} and ws["range"][0] <= ws["range"][1]
+    for name, w in ws["workloads"].items():
+        assert w["replay_exact"] and w["value"] > 0 and 0 <= w["reset_fraction_per_step"] < 0.2, name
+    assert ws["workloads"]["pd_to_t_pose"]["reset_fraction_per_step"] < ws["headline"]["reset_fraction_per_step"]      # the controller keeps robots up longer
+    assert out["per_rank"]["device"][0]["name"] and out["per_rank"]["distinct_devices"] == 1
