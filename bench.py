@@ -272,7 +272,8 @@ def physics_bracket(args, local_rank, lo, tape, steps=200, preroll=800):
     return out
 
 
-WORKLOADS = ("uniform_0.3", "zero_actions", "pd_to_t_pose")
+WORKLOADS = ("uniform_0.3", "zero_actions", "pd_to_t_pose", "ppo_policy")
+PPO_POLICY = os.path.join(ROOT, "profiles", "ppo_policy_walker3d.npz")   # tools/ppo_demo.py: 1.05 G env-steps of plain PPO on this stepper (7 minutes on one MI355X)
 PD_KP, PD_KD = 2.0, 0.5     # action = clip(KP (theta_norm* - theta_norm) - KD (0.1 qdot), -1, 1): both terms in the observation's units (robots.py:46-50)
 
 
@@ -284,6 +285,9 @@ def workload_bracket(args, local_rank, lo, tape, steps=200, preroll=800):
     torch kernels would not time the step kernel: each workload is therefore (1) pre-rolled closed-loop, (2) snapshotted (state, task
     record, terrain), (3) run closed-loop for `steps` steps while the actions are RECORDED, (4) restored and replayed from the recorded
     actions back to back under HIP events -- the same launches on the same states (`replay_exact`: final observations bit-identical).
+    A fourth workload, Walker3DCustomEnv-v0 only: `ppo_policy` -- the policy `tools/ppo_demo.py` trained on this very stepper (weights in
+    profiles/ppo_policy_walker3d.npz: MLP 52-256-256-21 on normalised observations, with its training-time action noise): robots that WALK
+    to their targets for the full 1000 steps, what the batch looks like late in a trainer's run (env_locomotion.py:111-141 is its reward).
     Returns {workload: {ms_per_step, value, rows_per_substep, reset_fraction_per_step, replay_exact}}."""
     import torch
     from mocca_envs_amd.vec_env import VecEnv
@@ -292,6 +296,8 @@ def workload_bracket(args, local_rank, lo, tape, steps=200, preroll=800):
     for name in WORKLOADS:
         if name == "pd_to_t_pose" and "Cassie" in args.env_id:
             continue                      # (Cassie's action already is a PD target: env_cassie.py:380-393)
+        if name == "ppo_policy" and (args.env_id != ENV_ID or not os.path.exists(PPO_POLICY)):
+            continue
         env = VecEnv(args.env_id, args.envs, device=local_rank, auto_reset=True, seed=1000, env_offset=lo)
         if args.curriculum is not None:
             env.set_param(2, args.curriculum)
@@ -302,12 +308,24 @@ def workload_bracket(args, local_rank, lo, tape, steps=200, preroll=800):
             jhi = torch.tensor([env.model.jhi[1 + j] for j in range(nj)], device=obs.device)
             target = -(jhi + jlo) / (jhi - jlo)
         zero = torch.zeros(args.envs, nj, device=obs.device)
+        if name == "ppo_policy":
+            import numpy as np
+            w = {k: torch.from_numpy(v).to(obs.device) for k, v in np.load(PPO_POLICY).items() if v.dtype.kind == "f"}
+            std, gen = w["log_std"].exp(), torch.Generator(device=obs.device).manual_seed(7)
+
+            def ppo_action():
+                o = ((obs - w["obs_mean"]) / torch.sqrt(w["obs_var"] + 1e-8)).clamp(-10.0, 10.0)
+                h = torch.tanh(torch.tanh(o @ w["pi_0_weight"].T + w["pi_0_bias"]) @ w["pi_2_weight"].T + w["pi_2_bias"])
+                mu = h @ w["pi_4_weight"].T + w["pi_4_bias"]
+                return mu + std * torch.randn(mu.shape, device=mu.device, generator=gen)
 
         def action(i):
             if name == "uniform_0.3":
                 return 0.3 * tape[i % 64]
             if name == "zero_actions":
                 return zero
+            if name == "ppo_policy":
+                return ppo_action()
             return (PD_KP * (target - obs[:, 6:6 + nj]) - PD_KD * obs[:, 6 + nj:6 + 2 * nj]).clamp_(-1.0, 1.0)
 
         for i in range(preroll):
@@ -712,7 +730,8 @@ def main():
             vals = [v["value"] for v in workloads.values()] + [value]
             out["workload_sensitivity"] = {
                 "note": "the same launch on other behaviour than the headline's falling robots (untimed for `value`): 0.3 x U(-1,1) torques, zero torques, "
-                        f"a PD controller to the T-pose (kp {PD_KP}, kd {PD_KD} in observation units) computed on the device; closed-loop runs are recorded and "
+                        f"a PD controller to the T-pose (kp {PD_KP}, kd {PD_KD} in observation units) computed on the device, and -- headline env only -- the "
+                        "walking policy tools/ppo_demo.py trained on this stepper (profiles/ppo_policy_walker3d.npz); closed-loop runs are recorded and "
                         "replayed from a snapshot back to back under HIP events (bench.py workload_bracket)",
                 "headline": {"ms_per_step": kern_ms, "value": args.envs / (kern_ms * 1e-3), "reset_fraction_per_step": reset_frac},
                 "workloads": workloads, "range": [min(vals), max(vals)]}

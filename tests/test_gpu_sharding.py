@@ -118,7 +118,8 @@ def test_default_bench_line_carries_both_brackets_and_the_baselines():
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["pybullet"]["kind"] == "reference" and ("n/a" in cb["pybullet"]["sample"] or cb["pybullet"]["value"] > 0)
     assert set(out["sensitivity"]["variants"]) == {"as_built", "limit_rows_from_predicted_gap", "absolute_2cm_margins", "pyramid_friction", "warmstart_0.85", "all_four"}
     ws = out["workload_sensitivity"]
-    assert set(ws["workloads"]) == {"uniform_0.3", "zero_actions", "pd_to_t_pose"} and ws["range"][0] <= ws["range"][1]
+    assert set(ws["workloads"]) == {"uniform_0.3", "zero_actions", "pd_to_t_pose", "ppo_policy"} and ws["range"][0] <= ws["range"][1]
+    assert ws["workloads"]["ppo_policy"]["reset_fraction_per_step"] < 0.01           # the trained policy walks: episodes run into the TimeLimit (which falls on the window's last step: 1 / 200)
     for name, w in ws["workloads"].items():
         assert w["replay_exact"] and w["value"] > 0 and 0 <= w["reset_fraction_per_step"] < 0.2, name
     assert ws["workloads"]["pd_to_t_pose"]["reset_fraction_per_step"] < ws["headline"]["reset_fraction_per_step"]      # the controller keeps robots up longer

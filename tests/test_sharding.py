@@ -181,6 +181,9 @@ def test_bench_pybullet_leg_reports_the_reference_or_says_why_not(monkeypatch, t
 
 def test_bench_workload_bracket_names_its_workloads():
     import bench
-    assert bench.WORKLOADS == ("uniform_0.3", "zero_actions", "pd_to_t_pose") and bench.PD_KP > 0 and bench.PD_KD > 0
+    assert bench.WORKLOADS == ("uniform_0.3", "zero_actions", "pd_to_t_pose", "ppo_policy") and bench.PD_KP > 0 and bench.PD_KD > 0
+    import numpy as np
+    w = np.load(bench.PPO_POLICY)       # the trained policy the fourth workload runs: MLP 52-256-256-21 + observation statistics
+    assert w["pi_0_weight"].shape == (256, 52) and w["pi_4_weight"].shape == (21, 256) and w["obs_mean"].shape == (52,) and str(w["env_id"]) == bench.ENV_ID
     a = bench.parse_args(["--no-workload-bracket", "--no-physics-bracket"])
     assert a.no_workload_bracket and a.no_physics_bracket
