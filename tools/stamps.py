@@ -1,5 +1,7 @@
 """Per-phase timeline of one wave's last physics substep (diagnostic build -DMOCCA_STAMPS: raw s_memtime marks, plain
-stores, no waits).  Reports the mean over waves that executed every phase.  usage: stamps.py [env-id] [n_envs]"""
+stores, no waits).  Reports the mean over waves that executed every phase.  usage: stamps.py [env-id] [n_envs] [ppo]
+`ppo` (Walker3DCustomEnv-v0 only): the batch is driven by the trained policy of profiles/ppo_policy_walker3d.npz (tools/ppo_demo.py) after a
+600-step closed-loop pre-roll -- the per-phase timeline of bench.py's `ppo_policy` workload instead of the headline's random torques."""
 import ctypes as C, os, subprocess, sys
 import numpy as np
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -15,6 +17,17 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 env = VecEnv(env_id, n, auto_reset=True, seed=1000)
 env.reset()
 tape = torch.rand(64, n, env.act_dim, device="cuda") * 2 - 1
+act = lambda rep: tape[rep % 64]
+if len(sys.argv) > 3 and sys.argv[3] == "ppo":
+    w = {k: torch.from_numpy(v).cuda() for k, v in np.load(os.path.join(R, "profiles", "ppo_policy_walker3d.npz")).items() if v.dtype.kind == "f"}
+
+    def act(rep):
+        o = ((env.obs - w["obs_mean"]) / torch.sqrt(w["obs_var"] + 1e-8)).clamp(-10.0, 10.0)
+        h = torch.tanh(torch.tanh(o @ w["pi_0_weight"].T + w["pi_0_bias"]) @ w["pi_2_weight"].T + w["pi_2_bias"])
+        return (h @ w["pi_4_weight"].T + w["pi_4_bias"] + w["log_std"].exp() * torch.randn(n, env.act_dim, device="cuda")).contiguous()
+    for rep in range(600):
+        env.step(act(rep))
+    env_id += " under the trained PPO policy"
 lib = C.CDLL(so)
 SEQ = [(30, "substep start"), (29, "stage joints"), (0, "kinematics walk"), (15, "geom points"), (13, "collide: terrain"),
        (14, "collide: self pairs"), (1, "collide: epilogue"), (10, "aba: inward levels"), (11, "aba: base 6x6"),
@@ -24,7 +37,7 @@ SEQ = [(30, "substep start"), (29, "stage joints"), (0, "kinematics walk"), (15,
 acc = np.zeros(len(SEQ) - 1); cnt = 0; tot_all = []; slow = np.zeros(len(SEQ) - 1); nslow = 0
 nw = min(n, 8192)
 for rep in range(40):
-    env.step(tape[rep % 64])
+    env.step(act(rep))
     torch.cuda.synchronize()
     if rep < 20: continue
     buf = np.zeros((nw, 32), np.uint64)
