@@ -236,6 +236,8 @@ class TorchVecEnv:
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         rew = self._rew2
         if into:
+            if not hasattr(self.venv, "lib"):
+                raise NotImplementedError("step(into=...) needs one handle (sub_batches=1)")
             if "masks" in into or "bad_masks" in into:
                 self.masks, self.bad_masks = into.get("masks", self.masks), into.get("bad_masks", self.bad_masks)
                 self.venv.episode_masks_into(self.masks, self.bad_masks)
@@ -253,8 +255,8 @@ class TorchVecEnv:
     def capture_rollout(self, policy, num_steps: int, sink=None, warmup: int = 2, into=None):
         """The collection phase as ONE CUDA graph: `num_steps` x { action = policy(obs); env.step(action); sink(t, obs, reward, masks, bad_masks,
         action) } captured once, replayed with `.replay()` (returns the `torch.cuda.CUDAGraph`).  `policy` maps the observation tensor [N, obs_dim] to
-        actions [N, act_dim] with torch ops only (no host reads; `policy(obs, t)` is called with the step index if it takes two arguments); `sink` copies what the trainer keeps into ITS pre-allocated rollout storage
-        (`rollouts.obs[t + 1].copy_(obs)` ...: `obs`, `reward` [N, 1], `masks` / `bad_masks` [N, 1] are this env's persistent buffers, rewritten
+        actions [N, act_dim] with torch ops only (no host reads; `policy(obs, t)` is called with the step index if it takes two arguments);
+        `sink` copies what the trainer keeps into ITS pre-allocated rollout storage (`rollouts.obs[t + 1].copy_(obs)` ...: `obs`, `reward` [N, 1], `masks` / `bad_masks` [N, 1] are this env's persistent buffers, rewritten
         by every step).  `mocca_step` keeps no host state per launch (ABI 7), so a replay advances the envs exactly as `num_steps` calls of
         `step()` would -- bit for bit (tests/test_gpu_trainer_api.py).  Episode statistics of a replayed rollout: `episode_totals` (the lazy
         `done` / `infos` of `step()` do not exist inside a graph).  `warmup` eager iterations run first on a side stream, as torch requires before a
