@@ -273,7 +273,10 @@ def physics_bracket(args, local_rank, lo, tape, steps=200, preroll=800):
 
 
 WORKLOADS = ("uniform_0.3", "zero_actions", "pd_to_t_pose", "ppo_policy")
-PPO_POLICY = os.path.join(ROOT, "profiles", "ppo_policy_walker3d.npz")   # tools/ppo_demo.py: 1.05 G env-steps of plain PPO on this stepper (7 minutes on one MI355X)
+# tools/ppo_demo.py: plain PPO on this stepper (1.05 G env-steps = 7 minutes on one MI355X for the walker, 0.9 G = 6 minutes for the Stepper at curriculum 0)
+PPO_POLICIES = {ENV_ID: os.path.join(ROOT, "profiles", "ppo_policy_walker3d.npz"),
+                "Walker3DStepperEnv-v0": os.path.join(ROOT, "profiles", "ppo_policy_stepper.npz")}
+PPO_POLICY = PPO_POLICIES[ENV_ID]
 PD_KP, PD_KD = 2.0, 0.5     # action = clip(KP (theta_norm* - theta_norm) - KD (0.1 qdot), -1, 1): both terms in the observation's units (robots.py:46-50)
 
 
@@ -285,9 +288,10 @@ def workload_bracket(args, local_rank, lo, tape, steps=200, preroll=800):
     torch kernels would not time the step kernel: each workload is therefore (1) pre-rolled closed-loop, (2) snapshotted (state, task
     record, terrain), (3) run closed-loop for `steps` steps while the actions are RECORDED, (4) restored and replayed from the recorded
     actions back to back under HIP events -- the same launches on the same states (`replay_exact`: final observations bit-identical).
-    A fourth workload, Walker3DCustomEnv-v0 only: `ppo_policy` -- the policy `tools/ppo_demo.py` trained on this very stepper (weights in
-    profiles/ppo_policy_walker3d.npz: MLP 52-256-256-21 on normalised observations, with its training-time action noise): robots that WALK
-    to their targets for the full 1000 steps, what the batch looks like late in a trainer's run (env_locomotion.py:111-141 is its reward).
+    A fourth workload, Walker3DCustomEnv-v0 and Walker3DStepperEnv-v0: `ppo_policy` -- the policy `tools/ppo_demo.py` trained on this very stepper
+    (weights in profiles/ppo_policy_*.npz: MLP obs-256-256-21 on normalised observations, with its training-time action noise): robots that
+    WALK to their targets / over the planks for the full 1000 steps, what the batch looks like late in a trainer's run
+    (env_locomotion.py:111-141 / :515-568 are its reward; the Stepper's policy was trained at curriculum 0).
     Returns {workload: {ms_per_step, value, rows_per_substep, reset_fraction_per_step, replay_exact}}."""
     import torch
     from mocca_envs_amd.vec_env import VecEnv
@@ -296,7 +300,7 @@ def workload_bracket(args, local_rank, lo, tape, steps=200, preroll=800):
     for name in WORKLOADS:
         if name == "pd_to_t_pose" and "Cassie" in args.env_id:
             continue                      # (Cassie's action already is a PD target: env_cassie.py:380-393)
-        if name == "ppo_policy" and (args.env_id != ENV_ID or not os.path.exists(PPO_POLICY)):
+        if name == "ppo_policy" and not os.path.exists(PPO_POLICIES.get(args.env_id, "")):
             continue
         env = VecEnv(args.env_id, args.envs, device=local_rank, auto_reset=True, seed=1000, env_offset=lo)
         if args.curriculum is not None:
@@ -310,7 +314,7 @@ def workload_bracket(args, local_rank, lo, tape, steps=200, preroll=800):
         zero = torch.zeros(args.envs, nj, device=obs.device)
         if name == "ppo_policy":
             import numpy as np
-            w = {k: torch.from_numpy(v).to(obs.device) for k, v in np.load(PPO_POLICY).items() if v.dtype.kind == "f"}
+            w = {k: torch.from_numpy(v).to(obs.device) for k, v in np.load(PPO_POLICIES[args.env_id]).items() if v.dtype.kind == "f"}
             std, gen = w["log_std"].exp(), torch.Generator(device=obs.device).manual_seed(7)
 
             def ppo_action():
@@ -730,8 +734,8 @@ def main():
             vals = [v["value"] for v in workloads.values()] + [value]
             out["workload_sensitivity"] = {
                 "note": "the same launch on other behaviour than the headline's falling robots (untimed for `value`): 0.3 x U(-1,1) torques, zero torques, "
-                        f"a PD controller to the T-pose (kp {PD_KP}, kd {PD_KD} in observation units) computed on the device, and -- headline env only -- the "
-                        "walking policy tools/ppo_demo.py trained on this stepper (profiles/ppo_policy_walker3d.npz); closed-loop runs are recorded and "
+                        f"a PD controller to the T-pose (kp {PD_KP}, kd {PD_KD} in observation units) computed on the device, and -- Walker3D Custom / Stepper -- the "
+                        "walking policy tools/ppo_demo.py trained on this stepper (profiles/ppo_policy_*.npz); closed-loop runs are recorded and "
                         "replayed from a snapshot back to back under HIP events (bench.py workload_bracket)",
                 "headline": {"ms_per_step": kern_ms, "value": args.envs / (kern_ms * 1e-3), "reset_fraction_per_step": reset_frac},
                 "workloads": workloads, "range": [min(vals), max(vals)]}

@@ -126,6 +126,8 @@ def main():
             line = {"iter": it + 1, "env_steps": total_steps, "wall_s": round(wall, 1), "env_steps_per_s_incl_learning": round(total_steps / wall),
                     "episodes": int(dlt[2]), "mean_return": float(dlt[0] / max(dlt[2], 1)), "mean_length": float(dlt[1] / max(dlt[2], 1)),
                     "truncated_fraction": float(dlt[3] / max(dlt[2], 1)), "log_std": float(log_std.mean().item())}
+            if "Stepper" in args.env_id:      # next_step_index of the running episodes (the step's info word): how far along the 20 planks the batch is
+                line["mean_next_step_index"] = float(envs.venv.info.float().mean().item())
             log.write(json.dumps(line) + "\n"); log.flush()
             print(json.dumps(line), flush=True)
             if wall > 60.0 * args.minutes:
