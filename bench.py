@@ -273,9 +273,10 @@ def physics_bracket(args, local_rank, lo, tape, steps=200, preroll=800):
 
 
 WORKLOADS = ("uniform_0.3", "zero_actions", "pd_to_t_pose", "ppo_policy")
-# tools/ppo_demo.py: plain PPO on this stepper (1.05 G env-steps = 7 minutes on one MI355X for the walker, 0.9 G = 6 minutes for the Stepper at curriculum 0)
+# tools/ppo_demo.py: plain PPO on this stepper (1.05 G env-steps = 7 minutes on one MI355X for the walker, 0.9 G = 6 minutes for the Stepper at curriculum 0, CassieEnv)
 PPO_POLICIES = {ENV_ID: os.path.join(ROOT, "profiles", "ppo_policy_walker3d.npz"),
-                "Walker3DStepperEnv-v0": os.path.join(ROOT, "profiles", "ppo_policy_stepper.npz")}
+                "Walker3DStepperEnv-v0": os.path.join(ROOT, "profiles", "ppo_policy_stepper.npz"),
+                "CassieEnv-v0": os.path.join(ROOT, "profiles", "ppo_policy_cassie.npz")}   # 0.6 G env-steps at 4096 envs, 6 minutes
 PPO_POLICY = PPO_POLICIES[ENV_ID]
 PD_KP, PD_KD = 2.0, 0.5     # action = clip(KP (theta_norm* - theta_norm) - KD (0.1 qdot), -1, 1): both terms in the observation's units (robots.py:46-50)
 
@@ -288,7 +289,7 @@ def workload_bracket(args, local_rank, lo, tape, steps=200, preroll=800):
     torch kernels would not time the step kernel: each workload is therefore (1) pre-rolled closed-loop, (2) snapshotted (state, task
     record, terrain), (3) run closed-loop for `steps` steps while the actions are RECORDED, (4) restored and replayed from the recorded
     actions back to back under HIP events -- the same launches on the same states (`replay_exact`: final observations bit-identical).
-    A fourth workload, Walker3DCustomEnv-v0 and Walker3DStepperEnv-v0: `ppo_policy` -- the policy `tools/ppo_demo.py` trained on this very stepper
+    A fourth workload, Walker3DCustomEnv-v0, Walker3DStepperEnv-v0 and CassieEnv-v0: `ppo_policy` -- the policy `tools/ppo_demo.py` trained on this very stepper
     (weights in profiles/ppo_policy_*.npz: MLP obs-256-256-21 on normalised observations, with its training-time action noise): robots that
     WALK to their targets / over the planks for the full 1000 steps, what the batch looks like late in a trainer's run
     (env_locomotion.py:111-141 / :515-568 are its reward; the Stepper's policy was trained at curriculum 0).
