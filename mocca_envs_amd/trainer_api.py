@@ -109,7 +109,7 @@ class _LazyDone:
         return len(self._rec._done) if self._rec._done is not None else self._rec._env.num_envs
 
     def __iter__(self):
-        return iter(self.numpy())
+        return iter(self.numpy().tolist())      # Python bools: a trainer's `for d in done` comprehension runs twice as fast over them
 
     def __getitem__(self, i):
         return self.numpy()[i]
@@ -168,8 +168,10 @@ class _Infos:
         return self._finished().get(i, {})
 
     def __iter__(self):
-        fin, empty = self._finished(), {}
-        return (fin.get(i, empty) for i in range(self._n))
+        out = [{}] * self._n                    # ONE shared empty dict for the envs that go on (the verbatim loops only read it)
+        for i, info in self._finished().items():
+            out[i] = info
+        return iter(out)
 
     def finished(self):
         """(env index, info dict) of the envs whose episode ended in this step -- what a trainer's logging loop is after."""
