@@ -113,3 +113,36 @@ def test_cassie_task_logic_matches_the_reference_code():
             assert abs(rew[0] - g[f"ep{ep}_rew"][t]) < 2e-2, (ep, t, rew[0], g[f"ep{ep}_rew"][t])
             assert bool(done[0] & 1) == bool(g[f"ep{ep}_done"][t])
         np.testing.assert_allclose(o.get_state()[0][:49], g[f"ep{ep}_final_state"][:49], atol=2e-3, rtol=2e-3)
+
+
+def test_exact_position_gaps_buy_less_than_half_of_cassies_fp32_error():
+    """Round 6's conditioning A/B as a test (tools/fp32_yardstick.py at full size: 9.3 -> 5.5 units): the f32 oracle's distance from the f64 oracle
+    over single teacher-forced substeps, with and without the oracle's experiment switch that forms the closure gaps and the toe depths in DOUBLE
+    precision (orc_set_precise_gaps; everything else stays fp32).  The exact gaps help -- and leave more than a third of the error: the rest is the
+    fp32 solve of stiff rows at dt = 0.6 ms, which is why the kernel was not given a second, double-precision kinematics walk."""
+    import ctypes
+    from mocca_envs_amd.vec_env import compile_model_for
+    m = compile_model_for("CassieEnv-v0")
+    m.n_substeps, m.n_llc = 1, 1
+    blob, n = m.to_bytes(), 96
+    nd = 13 + 2 * m.n_joints
+    med = {}
+    for bits in (0, 3):
+        o32, o64 = Oracle(blob, M.TASK_CASSIE, n, "f32"), Oracle(blob, M.TASK_CASSIE, n, "f64")
+        o32.lib.orc_set_precise_gaps.argtypes, o32.lib.orc_set_precise_gaps.restype = [ctypes.c_void_p, ctypes.c_int], None
+        o32.lib.orc_set_precise_gaps(o32.h, bits)
+        o32.reset(seed=4); o64.reset(seed=4)
+        rng = np.random.default_rng(2)
+        errs = []
+        for t in range(60):
+            o64.set_state(o32.get_state()); o64.set_task(o32.get_task())
+            a = ((1.0 if t % 3 else 0.3) * rng.uniform(-1, 1, (n, o32.act_dim))).astype(np.float32)
+            _, _, done, _ = o32.step(a); o64.step(a)
+            s32, s64 = o32.get_state(), o64.get_state()
+            same = (o32.get_debug()[:, :12] == o64.get_debug()[:, :12]).all(1) & np.isfinite(s32).all(1) & np.isfinite(s64).all(1)
+            errs.append((np.abs(s32[same][:, :nd] - s64[same][:, :nd]) / (1e-5 * (1 + np.abs(s64[same][:, :nd])))).max(1))
+            if t % 8 == 7 and (done != 0).any():
+                o32.reset(seed=4, mask=(done != 0).astype(np.uint8))
+        med[bits] = float(np.median(np.concatenate(errs)))
+    print(f"\nCassie, one substep, f32 vs f64 oracle, units of 1e-5 (1 + |x|): median {med[0]:.2f}, with exact closure gaps and toe depths {med[3]:.2f}")
+    assert med[3] < 0.95 * med[0] and med[3] > 0.35 * med[0] and med[0] > 3.0
